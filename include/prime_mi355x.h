@@ -1,0 +1,295 @@
+/*
+ * prime_mi355x.h — C ABI of libprime_mi355x.so, the MI355X (gfx950 / CDNA4) kernels behind the
+ * prime-rl GRPO policy-update hot path.
+ *
+ * The reference (PrimeIntellect-ai/prime-rl) has NO native boundary on this path:
+ * its seams are Python (lm_head.py, loss.py, attn.py, norms.py, ...).  This header is the boundary a
+ * maintainer would bind from those seams (ctypes stubs: INTEGRATION.md).  Every entry point cites the
+ * reference interface (file:line under src/prime_rl/) whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void*; kernels are only ENQUEUED on it: no allocation,
+ *     no host synchronisation, no hidden device-to-host copies.
+ *   - return 0 on success, a negative PM_ERR_* otherwise; pm_last_error() gives the message
+ *     (thread-local).  No exception crosses the ABI.
+ *   - index tensors: labels / token ids int64 (torch.long), segment offsets int32.
+ *   - dtype arguments take PM_DTYPE_*.
+ *   - re-entrant; no mutable globals beyond a once-initialised device-property cache.
+ */
+#ifndef PRIME_MI355X_H
+#define PRIME_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+
+enum { PM_DTYPE_F32 = 0, PM_DTYPE_BF16 = 1 };
+
+enum {
+  PM_OK = 0,
+  PM_ERR_INVALID_ARG = -1,   /* null pointer, negative size, unsupported dtype/shape */
+  PM_ERR_UNSUPPORTED = -2,   /* shape outside what the kernel was built for (e.g. head_dim != 128) */
+  PM_ERR_LAUNCH = -3,        /* hipGetLastError() after enqueue was not hipSuccess */
+  PM_ERR_WORKSPACE = -4      /* workspace too small */
+};
+
+/* loss types of the rl component: trainer/rl/loss.py:262-282 (setup_rl_loss_fn) */
+enum { PM_LOSS_DEFAULT = 0 /* default_loss_fn, loss.py:109-161 */, PM_LOSS_IPO = 1 /* ipo_loss_fn, loss.py:164-196 */ };
+
+/* advantage rules sharing the score_group hook: orchestrator/algo/grpo.py:25-45, algo/max_rl.py:22-28 */
+enum { PM_ADV_GRPO = 0, PM_ADV_MAXRL = 1 };
+
+int pm_abi_version(void);
+const char* pm_last_error(void);
+/* Name of the device the library sees (rocminfo gcnArchName, e.g. "gfx950:sramecc+:xnack-"); writes into buf. */
+int pm_device_arch(char* buf_host, int buf_len);
+
+/* --------------------------------------------------------------------------------------------
+ * K1. Per-token log-prob gather over the vocab + entropy, on materialised logits.
+ *     Replaces selective_log_softmax + compute_entropy + the temperature divide
+ *     (trainer/rl/loss.py:48-63, trainer/rl/train.py:436-443) and the inner epilogue of
+ *     _SequenceChunkedLogProbEntropyFn.forward (trainer/models/layers/lm_head.py:89-156).
+ *
+ *       l[n,v]     = float(logits[n,v]) * inv_temp[n]
+ *       logz[n]    = logsumexp_v l[n,v]
+ *       logprob[n] = l[n,label[n]] - logz[n]            (label gather is an exact indexed load)
+ *       entropy[n] = logz[n] - sum_v softmax(l)[v]*l[n,v]
+ *
+ *     logits: [n_rows, row_stride] row-major, dtype f32 or bf16, vocab = first `vocab` columns.
+ *     workspace: pm_logprob_workspace_bytes(n_rows, vocab) bytes (split-vocab partials for small n_rows).
+ * ------------------------------------------------------------------------------------------ */
+int64_t pm_logprob_workspace_bytes(int64_t n_rows, int64_t vocab);
+int pm_logprob_entropy_fwd(const void* logits, int dtype, int64_t n_rows, int64_t vocab, int64_t row_stride,
+                           const int64_t* labels, const float* inv_temp,
+                           float* logprobs, float* entropy, float* logz,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Backward of K1 w.r.t. logits (entropy has no backward: lm_head.py:160-161 asserts grad_entropy is None):
+ *   dlogits[n,v] = grad_logprobs[n] * inv_temp[n] * ( [v==label[n]] - exp(l[n,v]-logz[n]) )
+ * lm_head.py:184-191.  dlogits may alias logits when dtypes match (in-place). */
+int pm_logprob_bwd(const void* logits, int dtype, int64_t n_rows, int64_t vocab, int64_t row_stride,
+                   const int64_t* labels, const float* inv_temp, const float* logz,
+                   const float* grad_logprobs, void* dlogits, int dlogits_dtype, int64_t dlogits_stride,
+                   void* stream);
+
+/* Vocab-chunked form (logits chunk = hidden @ W[vocab_start:vocab_start+chunk_vocab].T, never the full [N,V]):
+ * online (m, s, t, target) state update per chunk then finalize — lm_head.py:76-86,118-148.
+ * state_* are [n_rows] f32; initialise with pm_logprob_chunk_init. */
+int pm_logprob_chunk_init(float* state_m, float* state_s, float* state_t, float* state_target, int64_t n_rows, void* stream);
+int pm_logprob_chunk_update(const void* logits_chunk, int dtype, int64_t n_rows, int64_t chunk_vocab, int64_t row_stride,
+                            int64_t vocab_start, const int64_t* labels, const float* inv_temp,
+                            float* state_m, float* state_s, float* state_t, float* state_target, void* stream);
+int pm_logprob_chunk_finalize(const float* state_m, const float* state_s, const float* state_t, const float* state_target,
+                              int64_t n_rows, float* logprobs, float* entropy, float* logz, void* stream);
+/* chunk backward: same formula as pm_logprob_bwd with labels offset by vocab_start (lm_head.py:184-191). */
+int pm_logprob_chunk_bwd(const void* logits_chunk, int dtype, int64_t n_rows, int64_t chunk_vocab, int64_t row_stride,
+                         int64_t vocab_start, const int64_t* labels, const float* inv_temp, const float* logz,
+                         const float* grad_logprobs, void* dlogits, int dlogits_dtype, int64_t dlogits_stride, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K3. Group-relative advantage — GRPOAlgorithm.score_group (orchestrator/algo/grpo.py:25-45),
+ *     MaxRLAlgorithm.score_group (algo/max_rl.py:22-28).
+ *     rewards: flat [n_rollouts]; group g owns rollouts [group_offsets[g], group_offsets[g+1]).
+ *       GRPO : adv = r - mean(r)       (no std division)
+ *       length penalty (optional, all three pointers non-null): grpo.py:32-43
+ *         frac = w_out*out/max(max(out),1) + w_in*(tot-out)/max(max(tot-out),1) + w_turn*turns/max(max(turns),1)
+ *         shaped = r - mean(r)*frac ; adv = shaped - mean(shaped)
+ *       MaxRL: adv = mean<=0 ? 0 : (r-mean)/mean
+ * ------------------------------------------------------------------------------------------ */
+int pm_grpo_advantage(const float* rewards, const int32_t* group_offsets, int32_t n_groups, int mode,
+                      const float* num_output_tokens, const float* num_total_tokens, const float* num_turns,
+                      float w_output, float w_input, float w_turns,
+                      float* advantages, void* stream);
+
+/* Broadcast one scalar per rollout over its mask-True tokens — assign_advantages (algo/routing.py:11-34)
+ * + the per-token stream of trace_to_samples (orchestrator/trajectories.py:111-160).
+ * token t of rollout r (tokens [rollout_offsets[r], rollout_offsets[r+1])) gets adv[r] if mask[t] else 0. */
+int pm_advantage_broadcast(const float* rollout_adv, const int32_t* rollout_offsets, int32_t n_rollouts,
+                           const uint8_t* token_mask, float* token_adv, int64_t n_tokens, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K2. GRPO loss over a packed micro-batch (or several concatenated ones), forward AND backward in one pass.
+ *     Replaces compute_loss (trainer/rl/loss.py:285-403) with default_loss_fn (:109-161) / ipo_loss_fn (:164-196)
+ *     for the rl component, ce_loss_fn (:246-259), ref_kl_loss_fn (:199-243), and the two shift_tensor_right
+ *     calls of train.py:450-457.
+ *
+ *     Tokens are flat [n_tokens]; sample s owns [cu_samples[s], cu_samples[s+1]).
+ *     trainer_logprobs are the UNSHIFTED head outputs (logprob of token i+1 at position i).  With
+ *     shift=1 the kernel reads lp_shifted[i] = (i is the first token of a micro-batch) ? pad_logprob : lp[i-1]
+ *     (sample_starts_mb[s] != 0 marks samples that open a micro-batch; null = only sample 0) and writes
+ *     the gradient back in unshifted indexing (grad_logprobs[i-1] += dL/dlp_shifted[i]; the last position of a
+ *     micro-batch gets 0).
+ *
+ *     loss_out[0]  = rl/rl_scale + ce/ce_scale + ref_kl/ref_kl_scale        (the scaled loss, loss.py:394)
+ *     grad_logprobs[n_tokens] = d loss_out / d trainer_logprobs              (f32)
+ *     sample_stats[n_samples][PM_LOSS_NSTATS] raw per-sample sums (see enum) from which the wrapper forms the
+ *     reference's metrics dict (loss.py:151-159, 186-194, 234-241, 255-258) without device-host syncs.
+ *     scales are max(global_count,1) computed by the caller (train.py:307-323).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  PM_STAT_RL_LOSS = 0,        /* un-normalised rl loss sum of the sample */
+  PM_STAT_RL_N_MASK,          /* count(mask_rl) */
+  PM_STAT_RL_N_DROP,          /* count(mask_rl & is_masked) */
+  PM_STAT_RL_N_KEEP,          /* count(mask_rl & ~is_masked) */
+  PM_STAT_RL_MKL_DROP,        /* sum mismatch_kl over drop */
+  PM_STAT_RL_MKL_KEEP,        /* sum mismatch_kl over keep */
+  PM_STAT_RL_N_LOW,           /* count(mask_rl & is_masked_low)  (default loss only) */
+  PM_STAT_RL_N_HIGH,          /* count(mask_rl & is_masked_high) (default loss only) */
+  PM_STAT_RL_N_DROP_POS,      /* count(drop & adv>0) */
+  PM_STAT_RL_N_DROP_NEG,      /* count(drop & adv<0) */
+  PM_STAT_CE_LOSS,            /* un-normalised ce loss sum */
+  PM_STAT_CE_N,               /* count(ce_w != 0) */
+  PM_STAT_CE_NLL,             /* sum(-lp) over ce mask (unweighted) */
+  PM_STAT_REFKL_LOSS,         /* un-normalised ref_kl loss sum */
+  PM_STAT_REFKL_N,            /* count(ref_kl_w != 0) */
+  PM_STAT_REFKL_N_DROP,
+  PM_STAT_REFKL_N_KEEP,
+  PM_STAT_REFKL_MKL_DROP,
+  PM_STAT_REFKL_MKL_KEEP,
+  PM_STAT_REFKL_SUM,          /* sum(ref_lp - lp) over ref_kl mask */
+  PM_LOSS_NSTATS
+};
+
+typedef struct {
+  int32_t loss_type;        /* PM_LOSS_DEFAULT | PM_LOSS_IPO */
+  float dppo_mask_low;      /* DefaultLossConfig, configs/trainer.py:494-507 (0.2) */
+  float dppo_mask_high;     /* 0.2 */
+  float adv_tau;            /* 1.0 */
+  float kl_tau;             /* 1e-3 */
+  float ipo_threshold;      /* IPOLossConfig (0.1) */
+  float rl_scale;           /* max(global rl token count,1) as float (train.py:307-323); the kernel divides by it */
+  float ce_scale;
+  float ref_kl_scale;
+  int32_t shift;            /* 1: apply shift_tensor_right inside the kernel */
+  float pad_logprob;        /* log(1/vocab) (train.py:452) */
+} pm_loss_params;
+
+/* per-sample metrics written by the kernel (NaN-free: _safe_mean semantics, loss.py:94-97) */
+enum {
+  PM_MET_MASKED_MISMATCH_KL = 0, PM_MET_UNMASKED_MISMATCH_KL, PM_MET_IS_MASKED, PM_MET_IS_MASKED_LOW, PM_MET_IS_MASKED_HIGH,
+  PM_MET_MASKED_ADV_POS, PM_MET_MASKED_ADV_NEG,                                   /* default/ipo rl metrics, loss.py:151-159 */
+  PM_MET_NLL,                                                                     /* ce, loss.py:255-258 */
+  PM_MET_REFKL_MASKED_MISMATCH_KL, PM_MET_REFKL_UNMASKED_MISMATCH_KL, PM_MET_REFKL_IS_MASKED, PM_MET_REFKL,  /* loss.py:234-241 */
+  PM_LOSS_NMETRICS
+};
+
+int pm_grpo_loss_fwd_bwd(const float* trainer_logprobs, const float* inference_logprobs,
+                         const float* ref_logprobs /* nullable */, const float* advantages,
+                         const uint8_t* loss_mask,
+                         const float* rl_weights /* nullable */, const float* ce_weights /* nullable */,
+                         const float* ref_kl_weights /* nullable */,
+                         const int32_t* cu_samples, const uint8_t* sample_starts_mb /* nullable */,
+                         int32_t n_samples, int64_t n_tokens, const pm_loss_params* params_host,
+                         float* loss_out, float* grad_logprobs, float* sample_stats /* [n_samples][PM_LOSS_NSTATS] */,
+                         float* sample_metrics /* [n_samples][PM_LOSS_NMETRICS] */, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Packed-sequence scoring forward/backward (Qwen3 dense), bf16 activations, f32 accumulation.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Embedding gather / deterministic scatter-add — nn.Embedding (models/qwen3/modeling_qwen3.py:139,174). */
+int pm_embedding_fwd(const void* table_bf16, const int64_t* ids, int64_t n_tokens, int64_t hidden, int64_t vocab,
+                     void* out_bf16, void* stream);
+/* grad_table_f32[id] += sum of grad_out rows with that id.  `order` = argsort(ids) (stable), ids_sorted = ids[order]. */
+int pm_embedding_bwd(const void* grad_out_bf16, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens,
+                     int64_t hidden, float* grad_table_f32, void* stream);
+
+/* RMSNorm — RMSNorm.forward (models/layers/norms.py:36-44): y = w * bf16(x*rsqrt(mean(x^2)+eps)); fp32 math.
+ * Optional fused residual: if residual != null, x_in = x + residual is written to sum_out (bf16) and normalised. */
+int pm_rmsnorm_fwd(const void* x_bf16, const void* residual_bf16 /* nullable */, const void* weight_bf16,
+                   int64_t n_rows, int64_t hidden, float eps,
+                   void* y_bf16, void* sum_out_bf16 /* nullable unless residual */, float* rstd, void* stream);
+/* dx = rstd*(g*w - xhat*mean(g*w*xhat)) (+ dresidual if non-null, fused residual-gradient add);
+ * dweight_f32[h] += sum_rows g*xhat  (two-stage deterministic reduction through workspace). */
+int64_t pm_rmsnorm_bwd_workspace_bytes(int64_t n_rows, int64_t hidden);
+int pm_rmsnorm_bwd(const void* grad_y_bf16, const void* x_bf16, const void* weight_bf16, const float* rstd,
+                   const void* dresidual_bf16 /* nullable */, int64_t n_rows, int64_t hidden,
+                   void* grad_x_bf16, float* grad_weight_f32 /* accumulated into */,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* cos/sin table — RotaryEmbedding.forward (models/layers/rotary_emb.py:60-73): angle = pos*inv_freq[j] in f32
+ * (inv_freq is the module's registered buffer, rotary_emb.py:24,55), cos/sin rounded to bf16;
+ * table[n][0:d/2] (the reference's cat(f,f) duplicates it). */
+int pm_rope_table(const int64_t* position_ids, int64_t n_tokens, const float* inv_freq, int32_t half_dim,
+                  void* cos_bf16, void* sin_bf16, void* stream);
+
+/* Per-head q/k RMSNorm + RoPE (half-split) fused, no transposes — FlashAttention.attn_projections
+ * (models/layers/attn.py:123-160) + apply_rotary_pos_emb (rotary_emb.py:83-118).
+ * qkv: [n_tokens, (hq+2*hkv)*128] bf16 (fused q|k|v projection output).  Writes q_out [n,hq,128], k_out [n,hkv,128]
+ * (normed+roped), and keeps per-(token,head) rstd for backward.  bf16 rounding points follow the reference
+ * (norm -> bf16, *w -> bf16, *cos -> bf16, *sin -> bf16, add -> bf16). */
+int pm_qknorm_rope_fwd(const void* qkv_bf16, const void* q_norm_w_bf16, const void* k_norm_w_bf16,
+                       const void* cos_bf16, const void* sin_bf16,
+                       int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float eps,
+                       void* q_out_bf16, void* k_out_bf16, float* rstd /* [n, hq+hkv] */, void* stream);
+int64_t pm_qknorm_rope_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads);
+/* grad wrt the raw q/k slices of qkv, written into grad_qkv[:, 0:(hq+hkv)*128]; dweights accumulated (f32). */
+int pm_qknorm_rope_bwd(const void* grad_q_bf16, const void* grad_k_bf16, const void* qkv_bf16,
+                       const void* q_norm_w_bf16, const void* k_norm_w_bf16,
+                       const void* cos_bf16, const void* sin_bf16, const float* rstd,
+                       int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                       void* grad_qkv_bf16, float* grad_q_norm_w_f32, float* grad_k_norm_w_f32,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* token -> start index of its document; cu_seqlens from get_cu_seqlens_from_seq_lens (utils/sequence.py:38-52)
+ * without its three host syncs. */
+int pm_seq_start_from_cu(const int32_t* cu_seqlens, int32_t n_seqs, int64_t n_tokens, int32_t* seq_start, void* stream);
+
+/* Varlen causal attention with GQA over packed documents — FlashAttention._compute_attention
+ * (models/layers/attn.py:94-110; flash_attn_varlen_func(q,k,v,cu,cu,max,max,causal=True)).
+ * q [n,hq,128], k,v [n,hkv,128] bf16 (v may be a strided view of qkv: v_row_stride in elements);
+ * out [n,hq,128] bf16; lse [hq,n] f32 (natural-log logsumexp of scaled scores).
+ * Row i attends to j in [seq_start[i], i].  head_dim must be 128. */
+int64_t pm_attn_fwd_workspace_bytes(int64_t n_tokens, int32_t n_kv_heads, int32_t head_dim);
+int pm_attn_varlen_fwd(const void* q_bf16, const void* k_bf16, const void* v_bf16, int64_t v_row_stride,
+                       const int32_t* seq_start, int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads,
+                       int32_t head_dim, float softmax_scale,
+                       void* out_bf16, float* lse, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pm_attn_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim);
+/* grad_v is written with row stride grad_v_row_stride (so it can land in the v slice of grad_qkv). Deterministic. */
+int pm_attn_varlen_bwd(const void* grad_out_bf16, const void* q_bf16, const void* k_bf16, const void* v_bf16,
+                       int64_t v_row_stride, const void* out_bf16, const float* lse, const int32_t* seq_start,
+                       int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale,
+                       void* grad_q_bf16, void* grad_k_bf16, void* grad_v_bf16, int64_t grad_v_row_stride,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* SwiGLU — MLP.forward (models/layers/mlp.py:27-29): act = bf16(silu(gate)) * up, on the fused [n, 2*inter] gate|up. */
+int pm_swiglu_fwd(const void* gate_up_bf16, int64_t n_rows, int64_t inter, void* act_bf16, void* stream);
+int pm_swiglu_bwd(const void* grad_act_bf16, const void* gate_up_bf16, int64_t n_rows, int64_t inter,
+                  void* grad_gate_up_bf16, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Gradient post-processing + optimizer on flat f32 shards (train.py:557-570,
+ * trainer/utils.py:78-98, optim/__init__.py:101-108 AdamW(lr, wd, betas, fused)).
+ * ------------------------------------------------------------------------------------------ */
+/* main_grad_f32 += float(grad_bf16) */
+int pm_grad_accumulate(float* main_grad_f32, const void* grad_bf16, int64_t n, void* stream);
+/* partial sums of squares of a flat f32 buffer; out_sumsq[0] += sum(x^2) (deterministic two-stage). */
+int64_t pm_sumsq_workspace_bytes(int64_t n);
+int pm_sumsq(const float* x, int64_t n, float* out_sumsq /* device scalar, accumulated into */,
+             void* workspace, int64_t workspace_bytes, void* stream);
+/* clip_coef[0] = min(1, max_norm/(sqrt(total_sumsq*grad_scale^2)+1e-6)); grad_norm_out[0] = sqrt(total_sumsq)*grad_scale
+ * (torch clip_grad_norm_ semantics, trainer/utils.py:88-98). */
+int pm_clip_coef(const float* total_sumsq, float grad_scale, float max_norm, float* clip_coef, float* grad_norm_out, void* stream);
+/* Fused AdamW step on a flat shard: g = grad*grad_scale*clip_coef[0]; decoupled weight decay; bias correction from
+ * `step` (1-based); writes the bf16 compute copy and (zero_grad) clears the gradient. */
+int pm_adamw_step(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, float* grad_f32,
+                  void* param_bf16 /* nullable */, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */,
+                  int32_t zero_grad, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
+ * C[16,16] = A[16,32] @ B[32,16]^T-free form: c = sum_k a[i][k]*b[j][k]  (both operands K-contiguous, bf16). */
+int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIME_MI355X_H */

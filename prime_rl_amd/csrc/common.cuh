@@ -1,0 +1,96 @@
+// common.cuh — shared device/host helpers for libprime_mi355x (gfx950 only; wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/prime_mi355x.h"
+
+namespace pm {
+
+constexpr int kWave = 64;  // CDNA wavefront; hard-coded on purpose (guide §1)
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define PM_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::pm::set_error(__VA_ARGS__);            \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+#define PM_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) {                                                     \
+      ::pm::set_error("%s: launch failed: %s", name, hipGetErrorString(_e));    \
+      return PM_ERR_LAUNCH;                                                     \
+    }                                                                           \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 (raw bits; RNE, NaN preserved) --------------------------------------------
+typedef uint16_t bf16_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-byte vector (clang ext vector: usable with nontemporal builtins)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// round an f32 to the nearest bf16 and return it as f32 (emulates a bf16 torch op's output rounding)
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+// low / high halves of a packed pair
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 16-lane group a lane belongs to
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x = NWAVES*64; `smem` needs NWAVES floats. Result valid in every thread.
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWAVES; ++i) r += smem[i];
+  return r;
+}
+
+}  // namespace pm

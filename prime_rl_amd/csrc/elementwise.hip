@@ -1,0 +1,308 @@
+// elementwise.hip — SwiGLU fwd/bwd, embedding gather / deterministic scatter-add, gradient accumulation,
+// sum-of-squares, clip coefficient and fused AdamW on flat f32 shards.  All HBM-bound streaming kernels with
+// 16-byte accesses per lane and capped grids (guide G11/G13).
+//
+// Reference arithmetic (src/prime_rl/): MLP.forward (trainer/models/layers/mlp.py:27-29), nn.Embedding
+// (trainer/models/qwen3/modeling_qwen3.py:139,174), scale_gradients_ / clip_grad_norm_ (trainer/utils.py:78-98),
+// AdamW (trainer/optim/__init__.py:101-108; torch.optim.AdamW semantics: decoupled decay, bias correction).
+#include "common.cuh"
+
+namespace pm {
+
+__device__ __forceinline__ void unpack8e(const u32x4& v, float* o) {
+  o[0] = bf16lo(v.x); o[1] = bf16hi(v.x); o[2] = bf16lo(v.y); o[3] = bf16hi(v.y);
+  o[4] = bf16lo(v.z); o[5] = bf16hi(v.z); o[6] = bf16lo(v.w); o[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8e(const float* o) {
+  u32x4 v;
+  v.x = pack_bf16(o[0], o[1]); v.y = pack_bf16(o[2], o[3]); v.z = pack_bf16(o[4], o[5]); v.w = pack_bf16(o[6], o[7]);
+  return v;
+}
+
+static inline unsigned capped_grid(int64_t work_items, int block) {
+  int64_t g = cdiv(work_items, block);
+  const int64_t cap = 256 * 16;  // 256 CUs x 16 workgroups
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// ---------------------------------- SwiGLU -------------------------------------------------------
+// act = bf16( bf16(silu(gate)) * up ): torch computes silu on bf16 in f32 and rounds, then a bf16 multiply.
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, int64_t n_rows, int64_t inter, bf16_t* __restrict__ act) {
+  const int64_t vec_per_row = inter >> 3;
+  const int64_t total = n_rows * vec_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vec_per_row, c = i - r * vec_per_row;
+    const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
+    float g[8], u[8], o[8];
+    unpack8e(gp[c], g);
+    unpack8e(gp[vec_per_row + c], u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float s = g[k] / (1.0f + __expf(-g[k]));
+      o[k] = round_bf16(s) * u[k];
+    }
+    reinterpret_cast<u32x4*>(act + r * inter)[c] = pack8e(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ ga, const bf16_t* __restrict__ gu, int64_t n_rows,
+                                                        int64_t inter, bf16_t* __restrict__ ggu) {
+  const int64_t vec_per_row = inter >> 3;
+  const int64_t total = n_rows * vec_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vec_per_row, c = i - r * vec_per_row;
+    const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
+    float g[8], u[8], d[8], dg[8], du[8];
+    unpack8e(gp[c], g);
+    unpack8e(gp[vec_per_row + c], u);
+    unpack8e(reinterpret_cast<const u32x4*>(ga + r * inter)[c], d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sig = 1.0f / (1.0f + __expf(-g[k]));
+      const float s = g[k] * sig;
+      du[k] = d[k] * s;
+      dg[k] = d[k] * u[k] * (sig * (1.0f + g[k] * (1.0f - sig)));
+    }
+    u32x4* op = reinterpret_cast<u32x4*>(ggu + r * 2 * inter);
+    op[c] = pack8e(dg);
+    op[vec_per_row + c] = pack8e(du);
+  }
+}
+
+// ---------------------------------- embedding ----------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ ids, int64_t n_tokens,
+                                                           int64_t hidden, int64_t vocab, bf16_t* __restrict__ out) {
+  const int64_t vec_per_row = hidden >> 3;
+  const int64_t total = n_tokens * vec_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / vec_per_row, c = i - t * vec_per_row;
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    reinterpret_cast<u32x4*>(out + t * hidden)[c] = reinterpret_cast<const u32x4*>(table + id * hidden)[c];
+  }
+}
+
+// one workgroup per sorted position; only the first position of each run of equal ids does work, summing the run in order.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ ids_sorted,
+                                                           const int64_t* __restrict__ order, int64_t n_tokens, int64_t hidden,
+                                                           float* __restrict__ gtable) {
+  const int64_t p = blockIdx.x;
+  const int64_t id = ids_sorted[p];
+  if (p > 0 && ids_sorted[p - 1] == id) return;
+  int64_t e = p + 1;
+  while (e < n_tokens && ids_sorted[e] == id) ++e;
+  const int64_t vec_per_row = hidden >> 3;
+  for (int64_t c = threadIdx.x; c < vec_per_row; c += 256) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int64_t q = p; q < e; ++q) {
+      float g[8];
+      unpack8e(reinterpret_cast<const u32x4*>(gout + order[q] * hidden)[c], g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += g[k];
+    }
+    float4* dst = reinterpret_cast<float4*>(gtable + id * hidden + c * 8);
+    float4 a = dst[0], b = dst[1];
+    a.x += acc[0]; a.y += acc[1]; a.z += acc[2]; a.w += acc[3];
+    b.x += acc[4]; b.y += acc[5]; b.z += acc[6]; b.w += acc[7];
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+// ---------------------------------- gradients / optimizer ---------------------------------------
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(float* __restrict__ mg, const bf16_t* __restrict__ g, int64_t n) {
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float gf[8];
+    unpack8e(reinterpret_cast<const u32x4*>(g)[i], gf);
+    float4* dst = reinterpret_cast<float4*>(mg + i * 8);
+    float4 a = dst[0], b = dst[1];
+    a.x += gf[0]; a.y += gf[1]; a.z += gf[2]; a.w += gf[3];
+    b.x += gf[4]; b.y += gf[5]; b.z += gf[6]; b.w += gf[7];
+    dst[0] = a;
+    dst[1] = b;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += 256) mg[i] += bf16_to_f32(g[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
+  __shared__ float smem[4];
+  const int64_t nvec = n >> 2;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    s0 = fmaf(v.x, v.x, s0);
+    s1 = fmaf(v.y, v.y, s1);
+    s2 = fmaf(v.z, v.z, s2);
+    s3 = fmaf(v.w, v.w, s3);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) s0 = fmaf(x[i], x[i], s0);
+  }
+  const float tot = block_sum<4>((s0 + s1) + (s2 + s3), smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int n_partials, float* __restrict__ out) {
+  __shared__ float smem[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
+  const float tot = block_sum<4>(s, smem);
+  if (threadIdx.x == 0) out[0] += tot;
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ total_sumsq, float grad_scale, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+  const float norm = sqrtf(total_sumsq[0]) * grad_scale;
+  if (norm_out) norm_out[0] = norm;
+  // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1.0
+  float c = (max_norm > 0.f) ? max_norm / (norm + 1e-6f) : 1.0f;
+  coef[0] = c > 1.0f ? 1.0f : c;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g,
+                                                   bf16_t* __restrict__ pb, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2_sqrt, float grad_scale, const float* __restrict__ clip_coef,
+                                                   int zero_grad) {
+  const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
+  const float step_size = lr / bc1;
+  const int64_t nvec = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i],
+           G = reinterpret_cast<float4*>(g)[i];
+    float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w}, gg[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gs;
+      pp[k] = pp[k] * (1.0f - lr * wd);                 // param.mul_(1 - lr*wd)
+      mm[k] = mm[k] + (gr - mm[k]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1-beta1)
+      vv[k] = vv[k] * b2 + (1.0f - b2) * gr * gr;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+      pp[k] = pp[k] - step_size * (mm[k] / denom);      // param.addcdiv_(exp_avg, denom, -step_size)
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pb) {
+      u32x2 o;
+      o.x = pack_bf16(pp[0], pp[1]);
+      o.y = pack_bf16(pp[2], pp[3]);
+      reinterpret_cast<u32x2*>(pb)[i] = o;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) {
+      const float gr = g[i] * gs;
+      float pp = p[i] * (1.0f - lr * wd);
+      const float mm = m[i] + (gr - m[i]) * (1.0f - b1);
+      const float vv = v[i] * b2 + (1.0f - b2) * gr * gr;
+      pp = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+      p[i] = pp; m[i] = mm; v[i] = vv;
+      if (zero_grad) g[i] = 0.f;
+      if (pb) pb[i] = f32_to_bf16(pp);
+    }
+  }
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_swiglu_fwd(const void* gate_up, int64_t n_rows, int64_t inter, void* act, void* stream) {
+  PM_REQUIRE(gate_up && act, PM_ERR_INVALID_ARG, "pm_swiglu_fwd: null pointer");
+  PM_REQUIRE(n_rows >= 0 && inter > 0 && inter % 8 == 0, PM_ERR_UNSUPPORTED, "pm_swiglu_fwd: inter=%lld must be a multiple of 8", (long long)inter);
+  if (n_rows == 0) return PM_OK;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(capped_grid(n_rows * (inter >> 3), 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)gate_up,
+                     n_rows, inter, (bf16_t*)act);
+  PM_CHECK_LAUNCH("pm_swiglu_fwd");
+  return PM_OK;
+}
+
+extern "C" int pm_swiglu_bwd(const void* grad_act, const void* gate_up, int64_t n_rows, int64_t inter, void* grad_gate_up, void* stream) {
+  PM_REQUIRE(grad_act && gate_up && grad_gate_up, PM_ERR_INVALID_ARG, "pm_swiglu_bwd: null pointer");
+  PM_REQUIRE(n_rows >= 0 && inter > 0 && inter % 8 == 0, PM_ERR_UNSUPPORTED, "pm_swiglu_bwd: inter=%lld must be a multiple of 8", (long long)inter);
+  if (n_rows == 0) return PM_OK;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(capped_grid(n_rows * (inter >> 3), 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_act,
+                     (const bf16_t*)gate_up, n_rows, inter, (bf16_t*)grad_gate_up);
+  PM_CHECK_LAUNCH("pm_swiglu_bwd");
+  return PM_OK;
+}
+
+extern "C" int pm_embedding_fwd(const void* table, const int64_t* ids, int64_t n_tokens, int64_t hidden, int64_t vocab, void* out, void* stream) {
+  PM_REQUIRE(table && ids && out, PM_ERR_INVALID_ARG, "pm_embedding_fwd: null pointer");
+  PM_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden % 8 == 0 && vocab > 0, PM_ERR_UNSUPPORTED, "pm_embedding_fwd: bad sizes");
+  if (n_tokens == 0) return PM_OK;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(capped_grid(n_tokens * (hidden >> 3), 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)table,
+                     ids, n_tokens, hidden, vocab, (bf16_t*)out);
+  PM_CHECK_LAUNCH("pm_embedding_fwd");
+  return PM_OK;
+}
+
+extern "C" int pm_embedding_bwd(const void* grad_out, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens, int64_t hidden,
+                                float* grad_table, void* stream) {
+  PM_REQUIRE(grad_out && ids_sorted && order && grad_table, PM_ERR_INVALID_ARG, "pm_embedding_bwd: null pointer");
+  PM_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden % 8 == 0, PM_ERR_UNSUPPORTED, "pm_embedding_bwd: bad sizes");
+  if (n_tokens == 0) return PM_OK;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_out, ids_sorted, order,
+                     n_tokens, hidden, grad_table);
+  PM_CHECK_LAUNCH("pm_embedding_bwd");
+  return PM_OK;
+}
+
+extern "C" int pm_grad_accumulate(float* main_grad, const void* grad_bf16, int64_t n, void* stream) {
+  PM_REQUIRE(main_grad && grad_bf16 && n >= 0, PM_ERR_INVALID_ARG, "pm_grad_accumulate: bad args");
+  PM_REQUIRE((reinterpret_cast<uintptr_t>(main_grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_bf16) & 15) == 0, PM_ERR_INVALID_ARG,
+             "pm_grad_accumulate: buffers must be 16-byte aligned");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(grad_accumulate_kernel, dim3(capped_grid(n >> 3, 256)), dim3(256), 0, as_stream(stream), main_grad, (const bf16_t*)grad_bf16, n);
+  PM_CHECK_LAUNCH("pm_grad_accumulate");
+  return PM_OK;
+}
+
+static int sumsq_grid(int64_t n) { return (int)capped_grid(n >> 2, 256); }
+
+extern "C" int64_t pm_sumsq_workspace_bytes(int64_t n) { return n <= 0 ? 0 : (int64_t)sumsq_grid(n) * (int64_t)sizeof(float); }
+
+extern "C" int pm_sumsq(const float* x, int64_t n, float* out_sumsq, void* workspace, int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(x && out_sumsq && n >= 0, PM_ERR_INVALID_ARG, "pm_sumsq: bad args");
+  PM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, PM_ERR_INVALID_ARG, "pm_sumsq: x must be 16-byte aligned");
+  if (n == 0) return PM_OK;
+  const int grid = sumsq_grid(n);
+  PM_REQUIRE(workspace && workspace_bytes >= (int64_t)grid * 4, PM_ERR_WORKSPACE, "pm_sumsq: workspace too small");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, n, (float*)workspace);
+  PM_CHECK_LAUNCH("pm_sumsq");
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, out_sumsq);
+  PM_CHECK_LAUNCH("pm_sumsq(final)");
+  return PM_OK;
+}
+
+extern "C" int pm_clip_coef(const float* total_sumsq, float grad_scale, float max_norm, float* clip_coef, float* grad_norm_out, void* stream) {
+  PM_REQUIRE(total_sumsq && clip_coef, PM_ERR_INVALID_ARG, "pm_clip_coef: null pointer");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), total_sumsq, grad_scale, max_norm, clip_coef, grad_norm_out);
+  PM_CHECK_LAUNCH("pm_clip_coef");
+  return PM_OK;
+}
+
+extern "C" int pm_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, float* grad, void* param_bf16, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, float grad_scale, const float* clip_coef, int32_t zero_grad,
+                             void* stream) {
+  PM_REQUIRE(master && exp_avg && exp_avg_sq && grad && n >= 0 && step >= 1, PM_ERR_INVALID_ARG, "pm_adamw_step: bad args");
+  PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
+               reinterpret_cast<uintptr_t>(grad)) & 15) == 0 && (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
+             PM_ERR_INVALID_ARG, "pm_adamw_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
+  if (n == 0) return PM_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
+                     (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, clip_coef, zero_grad);
+  PM_CHECK_LAUNCH("pm_adamw_step");
+  return PM_OK;
+}

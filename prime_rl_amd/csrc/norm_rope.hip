@@ -1,0 +1,462 @@
+// norm_rope.hip — RMSNorm (fwd/bwd, optional fused residual add), RoPE table, fused per-head q/k RMSNorm + RoPE
+// (fwd/bwd), and token->document-start map.  All HBM-bound; 16-byte (8 x bf16) accesses per lane (guide G13).
+//
+// Reference arithmetic (src/prime_rl/trainer/models/layers/): RMSNorm.forward (norms.py:36-44),
+// RotaryEmbedding.forward (rotary_emb.py:60-73), apply_rotary_pos_emb / rotate_half (rotary_emb.py:76-118),
+// FlashAttention.attn_projections (attn.py:123-160); get_cu_seqlens_from_seq_lens (utils/sequence.py:38-52).
+// bf16 rounding points follow the reference's eager bf16 ops so forward values match it bit-for-bit up to the
+// reduction order of the sum of squares.
+#include "common.cuh"
+
+namespace pm {
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* o) {
+  o[0] = bf16lo(v.x); o[1] = bf16hi(v.x); o[2] = bf16lo(v.y); o[3] = bf16hi(v.y);
+  o[4] = bf16lo(v.z); o[5] = bf16hi(v.z); o[6] = bf16lo(v.w); o[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* o) {
+  u32x4 v;
+  v.x = pack_bf16(o[0], o[1]); v.y = pack_bf16(o[2], o[3]); v.z = pack_bf16(o[4], o[5]); v.w = pack_bf16(o[6], o[7]);
+  return v;
+}
+
+// ================================= RMSNorm =====================================================
+// one wave64 per row; lane l owns 8-element vectors {v*64 + l}; MAXV*512 >= hidden.
+template <int MAXV, bool HAS_RES>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                         const bf16_t* __restrict__ w, int64_t n_rows, int H, float eps,
+                                                         bf16_t* __restrict__ y, bf16_t* __restrict__ sum_out, float* __restrict__ rstd) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= n_rows) return;
+  const int nvec = H >> 3;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * H);
+  const u32x4* rr = HAS_RES ? reinterpret_cast<const u32x4*>(res + row * H) : nullptr;
+  u32x4* sr = HAS_RES ? reinterpret_cast<u32x4*>(sum_out + row * H) : nullptr;
+  float xf[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int idx = v * 64 + lane;
+    if (idx < nvec) {
+      unpack8(xr[idx], xf[v]);
+      if (HAS_RES) {
+        float rf[8];
+        unpack8(rr[idx], rf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xf[v][k] = round_bf16(xf[v][k] + rf[k]);  // bf16 residual add (modeling_qwen3.py:80,84)
+        sr[idx] = pack8(xf[v]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss = fmaf(xf[v][k], xf[v][k], ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)H + eps);
+  if (lane == 0) rstd[row] = r;
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+  u32x4* yr = reinterpret_cast<u32x4*>(y + row * H);
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int idx = v * 64 + lane;
+    if (idx < nvec) {
+      float wf[8], o[8];
+      unpack8(wr[idx], wf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = wf[k] * round_bf16(xf[v][k] * r);  // weight * hidden.to(bf16); pack8 rounds the product
+      yr[idx] = pack8(o);
+    }
+  }
+}
+
+// backward: each wave walks rows {first + 4*k + wave}, keeps dweight partials in registers, writes one partial row per wave.
+template <int MAXV, bool HAS_DRES>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                         const bf16_t* __restrict__ dres, int64_t n_rows, int H, int64_t rows_per_wg,
+                                                         bf16_t* __restrict__ gx, float* __restrict__ dw_partials) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nvec = H >> 3;
+  const int64_t first = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t last = first + rows_per_wg;
+  if (last > n_rows) last = n_rows;
+  float dw[MAXV][8];
+  float wf[MAXV][8];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int idx = v * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dw[v][k] = 0.f;
+    if (idx < nvec) unpack8(reinterpret_cast<const u32x4*>(w)[idx], wf[v]);
+  }
+  for (int64_t row = first + wave; row < last; row += 4) {
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * H);
+    const u32x4* gr = reinterpret_cast<const u32x4*>(gy + row * H);
+    const float r = rstd[row];
+    float xh[MAXV][8], gw[MAXV][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int idx = v * 64 + lane;
+      if (idx < nvec) {
+        float gf[8];
+        unpack8(xr[idx], xh[v]);
+        unpack8(gr[idx], gf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xh[v][k] *= r;
+          dw[v][k] = fmaf(gf[k], xh[v][k], dw[v][k]);
+          gw[v][k] = gf[k] * wf[v][k];
+          dot = fmaf(gw[v][k], xh[v][k], dot);
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)H;
+    u32x4* ox = reinterpret_cast<u32x4*>(gx + row * H);
+    const u32x4* dr = HAS_DRES ? reinterpret_cast<const u32x4*>(dres + row * H) : nullptr;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int idx = v * 64 + lane;
+      if (idx < nvec) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = r * (gw[v][k] - xh[v][k] * dot);
+        if (HAS_DRES) {
+          float df[8];
+          unpack8(dr[idx], df);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] += df[k];
+        }
+        ox[idx] = pack8(o);
+      }
+    }
+  }
+  float* pw = dw_partials + ((int64_t)blockIdx.x * 4 + wave) * H;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int idx = v * 64 + lane;
+    if (idx < nvec) {
+      float4* p4 = reinterpret_cast<float4*>(pw + (int64_t)idx * 8);
+      p4[0] = make_float4(dw[v][0], dw[v][1], dw[v][2], dw[v][3]);
+      p4[1] = make_float4(dw[v][4], dw[v][5], dw[v][6], dw[v][7]);
+    }
+  }
+}
+
+// out[c] += sum_p partials[p][c]  (deterministic: fixed order over p)
+__global__ void column_reduce_accum_kernel(const float* __restrict__ partials, int64_t n_partials, int64_t ncols, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t p = 0;
+  for (; p + 3 < n_partials; p += 4) {
+    s0 += partials[(p + 0) * ncols + c];
+    s1 += partials[(p + 1) * ncols + c];
+    s2 += partials[(p + 2) * ncols + c];
+    s3 += partials[(p + 3) * ncols + c];
+  }
+  for (; p < n_partials; ++p) s0 += partials[p * ncols + c];
+  out[c] += (s0 + s1) + (s2 + s3);
+}
+
+static int64_t rms_bwd_num_wg(int64_t n_rows) {
+  int64_t g = cdiv(n_rows, 32);
+  if (g < 1) g = 1;
+  if (g > 512) g = 512;
+  return g;
+}
+
+// ================================= RoPE table ==================================================
+// angle = inv_freq[j] * pos in f32 (rotary_emb.py:66: a K=1 matmul, i.e. the exact product), cos/sin rounded to bf16 (:73).
+__global__ void rope_table_kernel(const int64_t* __restrict__ pos, int64_t n_tokens, int half, const float* __restrict__ inv_freq,
+                                  bf16_t* __restrict__ cosb, bf16_t* __restrict__ sinb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens * half) return;
+  const int64_t t = i / half;
+  const int j = (int)(i - t * half);
+  const float ang = inv_freq[j] * (float)pos[t];
+  cosb[i] = f32_to_bf16(cosf(ang));
+  sinb[i] = f32_to_bf16(sinf(ang));
+}
+
+// ================================= q/k norm + RoPE =============================================
+// 16 lanes per (token, head) item, 8 contiguous elements per lane (head_dim = 128).
+// lanes 0-7 of a group hold elements [0,64), lanes 8-15 hold [64,128): the rotate_half partner is lane ^ 8.
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
+                                                             const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
+                                                             const bf16_t* __restrict__ sinb, int64_t n_tokens, int hq, int hkv, float eps,
+                                                             bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, float* __restrict__ rstd) {
+  const int nh = hq + hkv;
+  const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const bool valid = item < n_tokens * nh;
+  const int64_t it = valid ? item : 0;
+  const int64_t tok = it / nh;
+  const int h = (int)(it - tok * nh);
+  const int64_t row_stride = (int64_t)(hq + 2 * hkv) * 128;
+  float xf[8];
+  unpack8(*reinterpret_cast<const u32x4*>(qkv + tok * row_stride + (int64_t)h * 128 + sub * 8), xf);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ss = fmaf(xf[k], xf[k], ss);
+  ss = group16_sum(ss);
+  const float r = rsqrtf(ss / 128.0f + eps);
+  float wf[8], cf[8], sf[8], yv[8], yp[8];
+  unpack8(*reinterpret_cast<const u32x4*>((h < hq ? qw : kw) + sub * 8), wf);
+  const int cs = (sub & 7) * 8;
+  unpack8(*reinterpret_cast<const u32x4*>(cosb + tok * 64 + cs), cf);
+  unpack8(*reinterpret_cast<const u32x4*>(sinb + tok * 64 + cs), sf);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) yv[k] = round_bf16(wf[k] * round_bf16(xf[k] * r));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) yp[k] = __shfl_xor(yv[k], 8, 64);
+  const float sgn = (sub < 8) ? -1.0f : 1.0f;  // rotate_half: first half gets -x2, second half gets +x1
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = round_bf16(yv[k] * cf[k]) + round_bf16((sgn * yp[k]) * sf[k]);
+  if (valid) {
+    bf16_t* dst = (h < hq) ? (qo + (tok * hq + h) * 128 + sub * 8) : (ko + (tok * hkv + (h - hq)) * 128 + sub * 8);
+    *reinterpret_cast<u32x4*>(dst) = pack8(o);
+    if (sub == 0) rstd[item] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __restrict__ gq, const bf16_t* __restrict__ gk,
+                                                             const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
+                                                             const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
+                                                             const bf16_t* __restrict__ sinb, const float* __restrict__ rstd,
+                                                             int64_t n_tokens, int hq, int hkv, bf16_t* __restrict__ gqkv,
+                                                             float* __restrict__ dw_partials /* [grid*4][2][128] */) {
+  const int nh = hq + hkv;
+  const int64_t n_items = n_tokens * nh;
+  const int sub = threadIdx.x & 15;
+  const int64_t row_stride = (int64_t)(hq + 2 * hkv) * 128;
+  float dwq[8], dwk[8], wq[8], wk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dwq[k] = dwk[k] = 0.f;
+  unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
+  unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+  const int64_t stride_items = (int64_t)gridDim.x * 16;
+  // all 16 lanes of a group iterate together; loop bound is uniform per group, shuffles stay inside the group
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < n_items; base += stride_items) {
+    const int64_t item = base + (threadIdx.x >> 4);
+    const bool valid = item < n_items;
+    const int64_t it = valid ? item : 0;
+    const int64_t tok = it / nh;
+    const int h = (int)(it - tok * nh);
+    const bool is_q = h < hq;
+    float g[8], gp[8], cf[8], sf[8], xf[8];
+    const bf16_t* gsrc = is_q ? (gq + (tok * hq + h) * 128 + sub * 8) : (gk + (tok * hkv + (h - hq)) * 128 + sub * 8);
+    unpack8(*reinterpret_cast<const u32x4*>(gsrc), g);
+    const int cs = (sub & 7) * 8;
+    unpack8(*reinterpret_cast<const u32x4*>(cosb + tok * 64 + cs), cf);
+    unpack8(*reinterpret_cast<const u32x4*>(sinb + tok * 64 + cs), sf);
+    unpack8(*reinterpret_cast<const u32x4*>(qkv + tok * row_stride + (int64_t)h * 128 + sub * 8), xf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gp[k] = __shfl_xor(g[k], 8, 64);
+    // transpose of out = y*cos + rotate_half(y)*sin :  dy[j] = g[j]*cos[j] + (j<64 ? g[j+64] : -g[j-64]) * sin[j mod 64]
+    const float sgn = (sub < 8) ? 1.0f : -1.0f;
+    const float r = rstd[it];
+    const float* wv = is_q ? wq : wk;
+    float dn[8], nh_[8];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dy = g[k] * cf[k] + (sgn * gp[k]) * sf[k];
+      nh_[k] = xf[k] * r;
+      if (valid) {
+        if (is_q) dwq[k] = fmaf(dy, nh_[k], dwq[k]);
+        else dwk[k] = fmaf(dy, nh_[k], dwk[k]);
+      }
+      dn[k] = dy * wv[k];
+      dot = fmaf(dn[k], nh_[k], dot);
+    }
+    dot = group16_sum(dot) / 128.0f;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = r * (dn[k] - nh_[k] * dot);
+    if (valid) *reinterpret_cast<u32x4*>(gqkv + tok * row_stride + (int64_t)h * 128 + sub * 8) = pack8(o);
+  }
+  // reduce the 4 groups of a wave, then one partial row per wave
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    dwq[k] += __shfl_xor(dwq[k], 16, 64);
+    dwq[k] += __shfl_xor(dwq[k], 32, 64);
+    dwk[k] += __shfl_xor(dwk[k], 16, 64);
+    dwk[k] += __shfl_xor(dwk[k], 32, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 16) {
+    float* p = dw_partials + ((int64_t)blockIdx.x * 4 + wave) * 256;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      p[lane * 8 + k] = dwq[k];
+      p[128 + lane * 8 + k] = dwk[k];
+    }
+  }
+}
+
+__global__ void qk_dw_reduce_kernel(const float* __restrict__ partials, int64_t n_partials, float* __restrict__ gqw, float* __restrict__ gkw) {
+  const int c = threadIdx.x;  // 256 threads: [0,128) q, [128,256) k
+  float s = 0.f;
+  for (int64_t p = 0; p < n_partials; ++p) s += partials[p * 256 + c];
+  if (c < 128) gqw[c] += s;
+  else gkw[c - 128] += s;
+}
+
+static int64_t qk_bwd_grid(int64_t n_tokens, int nh) {
+  int64_t g = cdiv(n_tokens * nh, 16);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// ================================= token -> document start =====================================
+__global__ void seq_start_kernel(const int32_t* __restrict__ cu, int n_seqs, int64_t n_tokens, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  int lo = 0, hi = n_seqs;  // largest s in [0, n_seqs] with cu[s] <= i
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)cu[mid] <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  out[i] = cu[lo];
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+template <bool HAS_RES>
+static int rms_fwd_launch(const bf16_t* x, const bf16_t* res, const bf16_t* w, int64_t n_rows, int H, float eps, bf16_t* y, bf16_t* so,
+                          float* rstd, hipStream_t st) {
+  const dim3 grid((unsigned)cdiv(n_rows, 4)), block(256);
+  const int nv = (int)cdiv(H, 512);
+  if (nv <= 2) hipLaunchKernelGGL((rmsnorm_fwd_kernel<2, HAS_RES>), grid, block, 0, st, x, res, w, n_rows, H, eps, y, so, rstd);
+  else if (nv <= 4) hipLaunchKernelGGL((rmsnorm_fwd_kernel<4, HAS_RES>), grid, block, 0, st, x, res, w, n_rows, H, eps, y, so, rstd);
+  else if (nv <= 8) hipLaunchKernelGGL((rmsnorm_fwd_kernel<8, HAS_RES>), grid, block, 0, st, x, res, w, n_rows, H, eps, y, so, rstd);
+  else hipLaunchKernelGGL((rmsnorm_fwd_kernel<16, HAS_RES>), grid, block, 0, st, x, res, w, n_rows, H, eps, y, so, rstd);
+  PM_CHECK_LAUNCH("pm_rmsnorm_fwd");
+  return PM_OK;
+}
+
+extern "C" int pm_rmsnorm_fwd(const void* x, const void* residual, const void* weight, int64_t n_rows, int64_t hidden, float eps, void* y,
+                              void* sum_out, float* rstd, void* stream) {
+  PM_REQUIRE(x && weight && y && rstd, PM_ERR_INVALID_ARG, "pm_rmsnorm_fwd: null pointer");
+  PM_REQUIRE(!(residual && !sum_out), PM_ERR_INVALID_ARG, "pm_rmsnorm_fwd: residual given without sum_out");
+  PM_REQUIRE(n_rows >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8192, PM_ERR_UNSUPPORTED,
+             "pm_rmsnorm_fwd: hidden=%lld must be a multiple of 8 and <= 8192", (long long)hidden);
+  if (n_rows == 0) return PM_OK;
+  if (residual)
+    return rms_fwd_launch<true>((const bf16_t*)x, (const bf16_t*)residual, (const bf16_t*)weight, n_rows, (int)hidden, eps, (bf16_t*)y,
+                                (bf16_t*)sum_out, rstd, as_stream(stream));
+  return rms_fwd_launch<false>((const bf16_t*)x, nullptr, (const bf16_t*)weight, n_rows, (int)hidden, eps, (bf16_t*)y, nullptr, rstd,
+                               as_stream(stream));
+}
+
+extern "C" int64_t pm_rmsnorm_bwd_workspace_bytes(int64_t n_rows, int64_t hidden) {
+  if (n_rows <= 0 || hidden <= 0) return 0;
+  return rms_bwd_num_wg(n_rows) * 4 * hidden * (int64_t)sizeof(float);
+}
+
+template <bool HAS_DRES>
+static int rms_bwd_launch(const bf16_t* gy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres, int64_t n_rows, int H,
+                          bf16_t* gx, float* partials, int64_t num_wg, hipStream_t st) {
+  const int64_t rows_per_wg = cdiv(n_rows, num_wg);
+  const dim3 grid((unsigned)num_wg), block(256);
+  const int nv = (int)cdiv(H, 512);
+  if (nv <= 2) hipLaunchKernelGGL((rmsnorm_bwd_kernel<2, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else if (nv <= 4) hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else if (nv <= 8) hipLaunchKernelGGL((rmsnorm_bwd_kernel<8, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else hipLaunchKernelGGL((rmsnorm_bwd_kernel<16, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  PM_CHECK_LAUNCH("pm_rmsnorm_bwd");
+  return PM_OK;
+}
+
+extern "C" int pm_rmsnorm_bwd(const void* grad_y, const void* x, const void* weight, const float* rstd, const void* dresidual, int64_t n_rows,
+                              int64_t hidden, void* grad_x, float* grad_weight, void* workspace, int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(grad_y && x && weight && rstd && grad_x && grad_weight, PM_ERR_INVALID_ARG, "pm_rmsnorm_bwd: null pointer");
+  PM_REQUIRE(n_rows >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8192, PM_ERR_UNSUPPORTED, "pm_rmsnorm_bwd: hidden=%lld unsupported",
+             (long long)hidden);
+  if (n_rows == 0) return PM_OK;
+  const int64_t need = pm_rmsnorm_bwd_workspace_bytes(n_rows, hidden);
+  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_rmsnorm_bwd: workspace %lld < %lld", (long long)workspace_bytes,
+             (long long)need);
+  hipStream_t st = as_stream(stream);
+  const int64_t num_wg = rms_bwd_num_wg(n_rows);
+  int rc;
+  if (dresidual)
+    rc = rms_bwd_launch<true>((const bf16_t*)grad_y, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dresidual, n_rows, (int)hidden,
+                              (bf16_t*)grad_x, (float*)workspace, num_wg, st);
+  else
+    rc = rms_bwd_launch<false>((const bf16_t*)grad_y, (const bf16_t*)x, (const bf16_t*)weight, rstd, nullptr, n_rows, (int)hidden,
+                               (bf16_t*)grad_x, (float*)workspace, num_wg, st);
+  if (rc != PM_OK) return rc;
+  hipLaunchKernelGGL(column_reduce_accum_kernel, dim3((unsigned)cdiv(hidden, 256)), dim3(256), 0, st, (const float*)workspace, num_wg * 4, hidden,
+                     grad_weight);
+  PM_CHECK_LAUNCH("pm_rmsnorm_bwd(reduce)");
+  return PM_OK;
+}
+
+extern "C" int pm_rope_table(const int64_t* position_ids, int64_t n_tokens, const float* inv_freq, int32_t half_dim, void* cos_bf16,
+                             void* sin_bf16, void* stream) {
+  PM_REQUIRE(position_ids && inv_freq && cos_bf16 && sin_bf16, PM_ERR_INVALID_ARG, "pm_rope_table: null pointer");
+  PM_REQUIRE(n_tokens >= 0 && half_dim > 0, PM_ERR_INVALID_ARG, "pm_rope_table: bad sizes");
+  if (n_tokens == 0) return PM_OK;
+  const int half = half_dim;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)cdiv(n_tokens * half, 256)), dim3(256), 0, as_stream(stream), position_ids, n_tokens, half,
+                     inv_freq, (bf16_t*)cos_bf16, (bf16_t*)sin_bf16);
+  PM_CHECK_LAUNCH("pm_rope_table");
+  return PM_OK;
+}
+
+extern "C" int pm_qknorm_rope_fwd(const void* qkv, const void* q_norm_w, const void* k_norm_w, const void* cosb, const void* sinb,
+                                  int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float eps, void* q_out, void* k_out,
+                                  float* rstd, void* stream) {
+  PM_REQUIRE(qkv && q_norm_w && k_norm_w && cosb && sinb && q_out && k_out && rstd, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: null pointer");
+  PM_REQUIRE(head_dim == 128, PM_ERR_UNSUPPORTED, "pm_qknorm_rope_fwd: head_dim=%d (only 128 is built)", head_dim);
+  PM_REQUIRE(n_tokens >= 0 && n_q_heads > 0 && n_kv_heads > 0, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: bad sizes");
+  if (n_tokens == 0) return PM_OK;
+  const int64_t items = n_tokens * (n_q_heads + n_kv_heads);
+  hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)cdiv(items, 16)), dim3(256), 0, as_stream(stream), (const bf16_t*)qkv,
+                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, n_tokens, n_q_heads, n_kv_heads,
+                     eps, (bf16_t*)q_out, (bf16_t*)k_out, rstd);
+  PM_CHECK_LAUNCH("pm_qknorm_rope_fwd");
+  return PM_OK;
+}
+
+extern "C" int64_t pm_qknorm_rope_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads) {
+  if (n_tokens <= 0) return 0;
+  return qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads) * 4 * 256 * (int64_t)sizeof(float);
+}
+
+extern "C" int pm_qknorm_rope_bwd(const void* grad_q, const void* grad_k, const void* qkv, const void* q_norm_w, const void* k_norm_w,
+                                  const void* cosb, const void* sinb, const float* rstd, int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads,
+                                  int32_t head_dim, void* grad_qkv, float* grad_q_norm_w, float* grad_k_norm_w, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(grad_q && grad_k && qkv && q_norm_w && k_norm_w && cosb && sinb && rstd && grad_qkv && grad_q_norm_w && grad_k_norm_w,
+             PM_ERR_INVALID_ARG, "pm_qknorm_rope_bwd: null pointer");
+  PM_REQUIRE(head_dim == 128, PM_ERR_UNSUPPORTED, "pm_qknorm_rope_bwd: head_dim=%d (only 128 is built)", head_dim);
+  if (n_tokens == 0) return PM_OK;
+  const int64_t need = pm_qknorm_rope_bwd_workspace_bytes(n_tokens, n_q_heads, n_kv_heads);
+  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_qknorm_rope_bwd: workspace %lld < %lld", (long long)workspace_bytes,
+             (long long)need);
+  hipStream_t st = as_stream(stream);
+  const int64_t grid = qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads);
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)grad_q, (const bf16_t*)grad_k,
+                     (const bf16_t*)qkv, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, rstd, n_tokens,
+                     n_q_heads, n_kv_heads, (bf16_t*)grad_qkv, (float*)workspace);
+  PM_CHECK_LAUNCH("pm_qknorm_rope_bwd");
+  hipLaunchKernelGGL(qk_dw_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid * 4, grad_q_norm_w, grad_k_norm_w);
+  PM_CHECK_LAUNCH("pm_qknorm_rope_bwd(reduce)");
+  return PM_OK;
+}
+
+extern "C" int pm_seq_start_from_cu(const int32_t* cu_seqlens, int32_t n_seqs, int64_t n_tokens, int32_t* seq_start, void* stream) {
+  PM_REQUIRE(cu_seqlens && seq_start && n_seqs > 0 && n_tokens >= 0, PM_ERR_INVALID_ARG, "pm_seq_start_from_cu: bad args");
+  if (n_tokens == 0) return PM_OK;
+  hipLaunchKernelGGL(seq_start_kernel, dim3((unsigned)cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), cu_seqlens, n_seqs, n_tokens, seq_start);
+  PM_CHECK_LAUNCH("pm_seq_start_from_cu");
+  return PM_OK;
+}

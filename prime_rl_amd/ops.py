@@ -1,0 +1,419 @@
+"""Tensor-level wrappers over the C ABI (include/prime_mi355x.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic step of the hot path is a
+kernel in libprime_mi355x.so.  Each function validates dtypes/contiguity, passes raw device pointers + the current
+stream, and raises `PrimeMI355XError` on any non-zero return.  No function here falls back to eager PyTorch.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import LossParams, PrimeMI355XError, check
+
+_DT = {torch.float32: _lib.PM_DTYPE_F32, torch.bfloat16: _lib.PM_DTYPE_BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: Tensor, dtype: torch.dtype | None, name: str, contiguous: bool = True) -> Tensor:
+    if not t.is_cuda:
+        raise PrimeMI355XError(f"{name}: expected a GPU tensor (prime_rl_amd kernels run on MI355X only), got {t.device}")
+    if dtype is not None and t.dtype != dtype:
+        raise PrimeMI355XError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise PrimeMI355XError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+_workspaces: dict[tuple, Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device, tag: str) -> Tensor:
+    """Growable per-(device, stream, tag) scratch buffer; reuse is ordered by the stream."""
+    key = (device.index, _stream(), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _rows2d(logits: Tensor, name: str) -> tuple[int, int, int]:
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise PrimeMI355XError(f"{name}: expected [rows, vocab] with unit stride on the vocab axis, got {tuple(logits.shape)} / {logits.stride()}")
+    return logits.shape[0], logits.shape[1], logits.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def logprob_entropy_fwd(logits: Tensor, labels: Tensor, inv_temp: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """logprob / entropy / logz per row of `logits` ([N, V] f32|bf16); replaces trainer/rl/loss.py:48-63 + train.py:441."""
+    lib = _lib.load()
+    _req(logits, None, "logits", contiguous=False)
+    if logits.dtype not in _DT:
+        raise PrimeMI355XError(f"logits dtype {logits.dtype} unsupported (f32 | bf16)")
+    n, v, stride = _rows2d(logits, "logits")
+    _req(labels, torch.int64, "labels")
+    _req(inv_temp, torch.float32, "inv_temp")
+    if labels.numel() != n or inv_temp.numel() != n:
+        raise PrimeMI355XError("labels / inv_temp length must equal the number of logits rows")
+    out = torch.empty((3, n), dtype=torch.float32, device=logits.device)
+    wsb = lib.pm_logprob_workspace_bytes(n, v)
+    ws = workspace(wsb, logits.device, "logprob")
+    check(
+        lib.pm_logprob_entropy_fwd(_p(logits), _DT[logits.dtype], n, v, stride, _p(labels), _p(inv_temp), _p(out[0]), _p(out[1]), _p(out[2]),
+                                   _p(ws), ws.numel(), _stream()),
+        "pm_logprob_entropy_fwd",
+    )
+    return out[0], out[1], out[2]
+
+
+def logprob_bwd(logits: Tensor, labels: Tensor, inv_temp: Tensor, logz: Tensor, grad_logprobs: Tensor,
+                out: Tensor | None = None, out_dtype: torch.dtype | None = None, vocab_start: int = 0) -> Tensor:
+    """dlogits = g*inv_T*(onehot - softmax); `out` may be `logits` itself (in place) when dtypes match."""
+    lib = _lib.load()
+    n, v, stride = _rows2d(_req(logits, None, "logits", contiguous=False), "logits")
+    if out is None:
+        out = torch.empty((n, v), dtype=out_dtype or logits.dtype, device=logits.device)
+    on, ov, ostride = _rows2d(_req(out, None, "dlogits", contiguous=False), "dlogits")
+    if (on, ov) != (n, v):
+        raise PrimeMI355XError("dlogits shape mismatch")
+    _req(labels, torch.int64, "labels"); _req(inv_temp, torch.float32, "inv_temp"); _req(logz, torch.float32, "logz")
+    _req(grad_logprobs, torch.float32, "grad_logprobs")
+    if vocab_start == 0:
+        rc = lib.pm_logprob_bwd(_p(logits), _DT[logits.dtype], n, v, stride, _p(labels), _p(inv_temp), _p(logz), _p(grad_logprobs), _p(out),
+                                _DT[out.dtype], ostride, _stream())
+    else:
+        rc = lib.pm_logprob_chunk_bwd(_p(logits), _DT[logits.dtype], n, v, stride, vocab_start, _p(labels), _p(inv_temp), _p(logz),
+                                      _p(grad_logprobs), _p(out), _DT[out.dtype], ostride, _stream())
+    check(rc, "pm_logprob_bwd")
+    return out
+
+
+class ChunkedLogprobState:
+    """Online (m, s, t, target) state across vocab chunks (trainer/models/layers/lm_head.py:118-148)."""
+
+    def __init__(self, n_rows: int, device: torch.device):
+        self.n = n_rows
+        self.buf = torch.empty((4, n_rows), dtype=torch.float32, device=device)
+        lib = _lib.load()
+        check(lib.pm_logprob_chunk_init(_p(self.buf[0]), _p(self.buf[1]), _p(self.buf[2]), _p(self.buf[3]), n_rows, _stream()), "pm_logprob_chunk_init")
+
+    def update(self, logits_chunk: Tensor, vocab_start: int, labels: Tensor, inv_temp: Tensor) -> None:
+        lib = _lib.load()
+        n, v, stride = _rows2d(_req(logits_chunk, None, "logits_chunk", contiguous=False), "logits_chunk")
+        b = self.buf
+        check(
+            lib.pm_logprob_chunk_update(_p(logits_chunk), _DT[logits_chunk.dtype], n, v, stride, vocab_start, _p(labels), _p(inv_temp), _p(b[0]),
+                                        _p(b[1]), _p(b[2]), _p(b[3]), _stream()),
+            "pm_logprob_chunk_update",
+        )
+
+    def finalize(self) -> tuple[Tensor, Tensor, Tensor]:
+        lib = _lib.load()
+        out = torch.empty((3, self.n), dtype=torch.float32, device=self.buf.device)
+        b = self.buf
+        check(lib.pm_logprob_chunk_finalize(_p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), self.n, _p(out[0]), _p(out[1]), _p(out[2]), _stream()),
+              "pm_logprob_chunk_finalize")
+        return out[0], out[1], out[2]
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def grpo_advantage(rewards: Tensor, group_offsets: Tensor, mode: int = _lib.PM_ADV_GRPO, num_output_tokens: Tensor | None = None,
+                   num_total_tokens: Tensor | None = None, num_turns: Tensor | None = None,
+                   weights: tuple[float, float, float] = (0.0, 0.0, 0.0)) -> Tensor:
+    lib = _lib.load()
+    _req(rewards, torch.float32, "rewards"); _req(group_offsets, torch.int32, "group_offsets")
+    for t, nm in ((num_output_tokens, "num_output_tokens"), (num_total_tokens, "num_total_tokens"), (num_turns, "num_turns")):
+        if t is not None:
+            _req(t, torch.float32, nm)
+    adv = torch.empty_like(rewards)
+    check(
+        lib.pm_grpo_advantage(_p(rewards), _p(group_offsets), group_offsets.numel() - 1, mode, _p(num_output_tokens), _p(num_total_tokens),
+                              _p(num_turns), weights[0], weights[1], weights[2], _p(adv), _stream()),
+        "pm_grpo_advantage",
+    )
+    return adv
+
+
+def advantage_broadcast(rollout_adv: Tensor, rollout_offsets: Tensor, token_mask: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(rollout_adv, torch.float32, "rollout_adv"); _req(rollout_offsets, torch.int32, "rollout_offsets")
+    mask_u8 = _req(token_mask, None, "token_mask")
+    if mask_u8.dtype == torch.bool:
+        mask_u8 = mask_u8.view(torch.uint8)
+    out = torch.empty(mask_u8.numel(), dtype=torch.float32, device=rollout_adv.device)
+    check(lib.pm_advantage_broadcast(_p(rollout_adv), _p(rollout_offsets), rollout_adv.numel(), _p(mask_u8), _p(out), out.numel(), _stream()),
+          "pm_advantage_broadcast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K2
+def grpo_loss_fwd_bwd(trainer_logprobs: Tensor, inference_logprobs: Tensor, advantages: Tensor, loss_mask: Tensor, cu_samples: Tensor,
+                      params: LossParams, ref_logprobs: Tensor | None = None, rl_weights: Tensor | None = None,
+                      ce_weights: Tensor | None = None, ref_kl_weights: Tensor | None = None,
+                      sample_starts_mb: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Returns (loss[1], grad_logprobs[N], sample_stats[S,20], sample_metrics[S,12]); see pm_grpo_loss_fwd_bwd."""
+    lib = _lib.load()
+    n = trainer_logprobs.numel()
+    for t, nm in ((trainer_logprobs, "trainer_logprobs"), (inference_logprobs, "inference_logprobs"), (advantages, "advantages")):
+        _req(t, torch.float32, nm)
+        if t.numel() != n:
+            raise PrimeMI355XError(f"{nm}: length {t.numel()} != {n}")
+    for t, nm in ((ref_logprobs, "ref_logprobs"), (rl_weights, "rl_weights"), (ce_weights, "ce_weights"), (ref_kl_weights, "ref_kl_weights")):
+        if t is not None:
+            _req(t, torch.float32, nm)
+            if t.numel() != n:
+                raise PrimeMI355XError(f"{nm}: length {t.numel()} != {n}")
+    mask_u8 = _req(loss_mask, None, "loss_mask")
+    if mask_u8.dtype == torch.bool:
+        mask_u8 = mask_u8.view(torch.uint8)
+    elif mask_u8.dtype != torch.uint8:
+        raise PrimeMI355XError("loss_mask must be bool or uint8")
+    _req(cu_samples, torch.int32, "cu_samples")
+    s = cu_samples.numel() - 1
+    if sample_starts_mb is not None:
+        _req(sample_starts_mb, torch.uint8, "sample_starts_mb")
+    dev = trainer_logprobs.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grad = torch.empty(n, dtype=torch.float32, device=dev)
+    stats = torch.empty((s, _lib.PM_LOSS_NSTATS), dtype=torch.float32, device=dev)
+    metrics = torch.empty((s, _lib.PM_LOSS_NMETRICS), dtype=torch.float32, device=dev)
+    check(
+        lib.pm_grpo_loss_fwd_bwd(_p(trainer_logprobs), _p(inference_logprobs), _p(ref_logprobs), _p(advantages), _p(mask_u8), _p(rl_weights),
+                                 _p(ce_weights), _p(ref_kl_weights), _p(cu_samples), _p(sample_starts_mb), s, n, ctypes.byref(params), _p(loss),
+                                 _p(grad), _p(stats), _p(metrics), _stream()),
+        "pm_grpo_loss_fwd_bwd",
+    )
+    return loss, grad, stats, metrics
+
+
+# ------------------------------------------------------------------------------------------------ model ops
+def embedding_fwd(table: Tensor, ids: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(table, torch.bfloat16, "embedding table"); _req(ids, torch.int64, "ids")
+    n, (v, h) = ids.numel(), table.shape
+    out = torch.empty((n, h), dtype=torch.bfloat16, device=table.device)
+    check(lib.pm_embedding_fwd(_p(table), _p(ids), n, h, v, _p(out), _stream()), "pm_embedding_fwd")
+    return out
+
+
+def embedding_bwd(grad_out: Tensor, ids: Tensor, grad_table_f32: Tensor) -> None:
+    """grad_table_f32[id] += rows of grad_out; deterministic (sorted run reduction)."""
+    lib = _lib.load()
+    _req(grad_out, torch.bfloat16, "grad_out"); _req(ids, torch.int64, "ids"); _req(grad_table_f32, torch.float32, "grad_table")
+    ids_sorted, order = torch.sort(ids.reshape(-1), stable=True)  # plumbing: index sort only
+    n, h = grad_out.shape
+    check(lib.pm_embedding_bwd(_p(grad_out), _p(ids_sorted), _p(order), n, h, _p(grad_table_f32), _stream()), "pm_embedding_bwd")
+
+
+def rmsnorm_fwd(x: Tensor, weight: Tensor, eps: float, residual: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor | None]:
+    """Returns (y, rstd, x_plus_residual | None)."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x"); _req(weight, torch.bfloat16, "weight")
+    h = x.shape[-1]
+    n = x.numel() // h
+    y = torch.empty_like(x)
+    rstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    so = None
+    if residual is not None:
+        _req(residual, torch.bfloat16, "residual")
+        so = torch.empty_like(x)
+    check(lib.pm_rmsnorm_fwd(_p(x), _p(residual), _p(weight), n, h, eps, _p(y), _p(so), _p(rstd), _stream()), "pm_rmsnorm_fwd")
+    return y, rstd, so
+
+
+def rmsnorm_bwd(grad_y: Tensor, x: Tensor, weight: Tensor, rstd: Tensor, grad_weight_f32: Tensor, dresidual: Tensor | None = None) -> Tensor:
+    lib = _lib.load()
+    _req(grad_y, torch.bfloat16, "grad_y"); _req(x, torch.bfloat16, "x"); _req(weight, torch.bfloat16, "weight")
+    _req(rstd, torch.float32, "rstd"); _req(grad_weight_f32, torch.float32, "grad_weight")
+    if dresidual is not None:
+        _req(dresidual, torch.bfloat16, "dresidual")
+    h = x.shape[-1]
+    n = x.numel() // h
+    gx = torch.empty_like(x)
+    wsb = lib.pm_rmsnorm_bwd_workspace_bytes(n, h)
+    ws = workspace(wsb, x.device, "rmsnorm_bwd")
+    check(lib.pm_rmsnorm_bwd(_p(grad_y), _p(x), _p(weight), _p(rstd), _p(dresidual), n, h, _p(gx), _p(grad_weight_f32), _p(ws), ws.numel(), _stream()),
+          "pm_rmsnorm_bwd")
+    return gx
+
+
+def rope_inv_freq(head_dim: int, theta: float, device) -> Tensor:
+    """inv_freq exactly as _compute_default_rope_parameters builds it (trainer/models/layers/rotary_emb.py:24): host f32, once per model."""
+    return (1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))).to(device)
+
+
+def rope_table(position_ids: Tensor, inv_freq: Tensor) -> tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    _req(position_ids, torch.int64, "position_ids"); _req(inv_freq, torch.float32, "inv_freq")
+    n, half = position_ids.numel(), inv_freq.numel()
+    cs = torch.empty((2, n, half), dtype=torch.bfloat16, device=position_ids.device)
+    check(lib.pm_rope_table(_p(position_ids), n, _p(inv_freq), half, _p(cs[0]), _p(cs[1]), _stream()), "pm_rope_table")
+    return cs[0], cs[1]
+
+
+def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, n_q_heads: int, n_kv_heads: int,
+                    head_dim: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
+    lib = _lib.load()
+    _req(qkv, torch.bfloat16, "qkv")
+    n = qkv.shape[0]
+    if qkv.shape[1] != (n_q_heads + 2 * n_kv_heads) * head_dim:
+        raise PrimeMI355XError("qkv: wrong width")
+    q = torch.empty((n, n_q_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty((n, n_kv_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
+    rstd = torch.empty((n, n_q_heads + n_kv_heads), dtype=torch.float32, device=qkv.device)
+    check(
+        lib.pm_qknorm_rope_fwd(_p(qkv), _p(q_norm_w), _p(k_norm_w), _p(cos), _p(sin), n, n_q_heads, n_kv_heads, head_dim, eps, _p(q), _p(k),
+                               _p(rstd), _stream()),
+        "pm_qknorm_rope_fwd",
+    )
+    return q, k, rstd
+
+
+def qknorm_rope_bwd(grad_q: Tensor, grad_k: Tensor, qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, rstd: Tensor,
+                    grad_qkv: Tensor, grad_q_norm_w_f32: Tensor, grad_k_norm_w_f32: Tensor, n_q_heads: int, n_kv_heads: int, head_dim: int) -> None:
+    """Writes the q|k columns of grad_qkv (the v columns are written by attention backward)."""
+    lib = _lib.load()
+    for t, nm in ((grad_q, "grad_q"), (grad_k, "grad_k"), (qkv, "qkv"), (grad_qkv, "grad_qkv")):
+        _req(t, torch.bfloat16, nm)
+    n = qkv.shape[0]
+    wsb = lib.pm_qknorm_rope_bwd_workspace_bytes(n, n_q_heads, n_kv_heads)
+    ws = workspace(wsb, qkv.device, "qknorm_bwd")
+    check(
+        lib.pm_qknorm_rope_bwd(_p(grad_q), _p(grad_k), _p(qkv), _p(q_norm_w), _p(k_norm_w), _p(cos), _p(sin), _p(rstd), n, n_q_heads, n_kv_heads,
+                               head_dim, _p(grad_qkv), _p(grad_q_norm_w_f32), _p(grad_k_norm_w_f32), _p(ws), ws.numel(), _stream()),
+        "pm_qknorm_rope_bwd",
+    )
+
+
+def seq_start_from_cu(cu_seqlens: Tensor, n_tokens: int) -> Tensor:
+    lib = _lib.load()
+    _req(cu_seqlens, torch.int32, "cu_seqlens")
+    out = torch.empty(n_tokens, dtype=torch.int32, device=cu_seqlens.device)
+    check(lib.pm_seq_start_from_cu(_p(cu_seqlens), cu_seqlens.numel() - 1, n_tokens, _p(out), _stream()), "pm_seq_start_from_cu")
+    return out
+
+
+def attn_varlen_fwd(q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, softmax_scale: float) -> tuple[Tensor, Tensor]:
+    """q [N,Hq,128], k [N,Hkv,128] contiguous; v [N,Hkv,128] may be a row-strided view (e.g. the v slice of qkv)."""
+    lib = _lib.load()
+    _req(q, torch.bfloat16, "q"); _req(k, torch.bfloat16, "k"); _req(v, torch.bfloat16, "v", contiguous=False)
+    _req(seq_start, torch.int32, "seq_start")
+    n, hq, d = q.shape
+    hkv = k.shape[1]
+    if v.stride(2) != 1 or v.stride(1) != d:
+        raise PrimeMI355XError("v: heads must be contiguous within a row")
+    out = torch.empty_like(q)
+    lse = torch.empty((hq, n), dtype=torch.float32, device=q.device)
+    wsb = lib.pm_attn_fwd_workspace_bytes(n, hkv, d)
+    ws = workspace(wsb, q.device, "attn_fwd")
+    check(
+        lib.pm_attn_varlen_fwd(_p(q), _p(k), _p(v), v.stride(0), _p(seq_start), n, hq, hkv, d, softmax_scale, _p(out), _p(lse), _p(ws), ws.numel(),
+                               _stream()),
+        "pm_attn_varlen_fwd",
+    )
+    return out, lse
+
+
+def attn_varlen_bwd(grad_out: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor, seq_start: Tensor, softmax_scale: float,
+                    grad_v_out: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
+    lib = _lib.load()
+    for t, nm in ((grad_out, "grad_out"), (q, "q"), (k, "k"), (out, "out")):
+        _req(t, torch.bfloat16, nm)
+    _req(v, torch.bfloat16, "v", contiguous=False)
+    n, hq, d = q.shape
+    hkv = k.shape[1]
+    gq = torch.empty_like(q)
+    gk = torch.empty_like(k)
+    gv = grad_v_out if grad_v_out is not None else torch.empty((n, hkv, d), dtype=torch.bfloat16, device=q.device)
+    if gv.stride(2) != 1 or gv.stride(1) != d:
+        raise PrimeMI355XError("grad_v: heads must be contiguous within a row")
+    wsb = lib.pm_attn_bwd_workspace_bytes(n, hq, hkv, d)
+    ws = workspace(wsb, q.device, "attn_bwd")
+    check(
+        lib.pm_attn_varlen_bwd(_p(grad_out), _p(q), _p(k), _p(v), v.stride(0), _p(out), _p(lse), _p(seq_start), n, hq, hkv, d, softmax_scale,
+                               _p(gq), _p(gk), _p(gv), gv.stride(0), _p(ws), ws.numel(), _stream()),
+        "pm_attn_varlen_bwd",
+    )
+    return gq, gk, gv
+
+
+def swiglu_fwd(gate_up: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(gate_up, torch.bfloat16, "gate_up")
+    n, two_i = gate_up.shape
+    act = torch.empty((n, two_i // 2), dtype=torch.bfloat16, device=gate_up.device)
+    check(lib.pm_swiglu_fwd(_p(gate_up), n, two_i // 2, _p(act), _stream()), "pm_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(grad_act: Tensor, gate_up: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(grad_act, torch.bfloat16, "grad_act"); _req(gate_up, torch.bfloat16, "gate_up")
+    n, two_i = gate_up.shape
+    g = torch.empty_like(gate_up)
+    check(lib.pm_swiglu_bwd(_p(grad_act), _p(gate_up), n, two_i // 2, _p(g), _stream()), "pm_swiglu_bwd")
+    return g
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def grad_accumulate(main_grad_f32: Tensor, grad_bf16: Tensor) -> None:
+    lib = _lib.load()
+    _req(main_grad_f32, torch.float32, "main_grad"); _req(grad_bf16, torch.bfloat16, "grad")
+    check(lib.pm_grad_accumulate(_p(main_grad_f32), _p(grad_bf16), main_grad_f32.numel(), _stream()), "pm_grad_accumulate")
+
+
+def sumsq_accumulate(x: Tensor, out_scalar: Tensor) -> None:
+    """out_scalar[0] += sum(x^2)."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(out_scalar, torch.float32, "out")
+    ws = workspace(lib.pm_sumsq_workspace_bytes(x.numel()), x.device, "sumsq")
+    check(lib.pm_sumsq(_p(x), x.numel(), _p(out_scalar), _p(ws), ws.numel(), _stream()), "pm_sumsq")
+
+
+def clip_coef(total_sumsq: Tensor, grad_scale: float, max_norm: float) -> tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    out = torch.empty(2, dtype=torch.float32, device=total_sumsq.device)
+    check(lib.pm_clip_coef(_p(total_sumsq), grad_scale, max_norm, _p(out[0:1]), _p(out[1:2]), _stream()), "pm_clip_coef")
+    return out[0:1], out[1:2]
+
+
+def adamw_step(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor, param_bf16: Tensor | None, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int, grad_scale: float = 1.0, clip: Tensor | None = None, zero_grad: bool = True) -> None:
+    lib = _lib.load()
+    for t, nm in ((master, "master"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grad, "grad")):
+        _req(t, torch.float32, nm)
+    if param_bf16 is not None:
+        _req(param_bf16, torch.bfloat16, "param_bf16")
+    check(
+        lib.pm_adamw_step(_p(master), _p(exp_avg), _p(exp_avg_sq), _p(grad), _p(param_bf16), master.numel(), lr, beta1, beta2, eps, weight_decay,
+                          step, grad_scale, _p(clip), 1 if zero_grad else 0, _stream()),
+        "pm_adamw_step",
+    )
+
+
+def mfma_probe(a: Tensor, b: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    c = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    check(lib.pm_mfma_probe_16x16x32(_p(a), _p(b), _p(c), _stream()), "pm_mfma_probe_16x16x32")
+    return c
+
+
+def device_arch() -> str:
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(128)
+    check(lib.pm_device_arch(buf, 128), "pm_device_arch")
+    return buf.value.decode()

@@ -1,0 +1,36 @@
+"""pytest configuration: `gpu` marker = needs a real MI355X (run with `-m gpu`); everything else runs on CPU."""
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs an AMD MI355X GPU (HIP kernels through the C ABI)")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

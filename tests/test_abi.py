@@ -1,0 +1,55 @@
+"""CPU suite: the C-ABI library builds, loads, and exports exactly the symbols include/prime_mi355x.h declares."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from prime_rl_amd import _lib
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_symbols() -> set[str]:
+    text = (ROOT / "include" / "prime_mi355x.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not _lib.LIB_PATH.exists():
+        _lib.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == set(_lib.SIGNATURES), _declared_symbols() ^ set(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in _declared_symbols():
+        assert hasattr(raw, name), f"{name} is declared in the header but not exported"
+
+
+def test_abi_version_and_error_plumbing(lib):
+    assert lib.pm_abi_version() == 1
+    # argument validation happens before any device work, so it is safe without a GPU
+    rc = lib.pm_logprob_entropy_fwd(None, 0, 4, 8, 8, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.pm_last_error()
+    assert lib.pm_logprob_workspace_bytes(8, 151936) == 8 * 18 * 3 * 4  # 8 rows -> 18 vocab splits
+    assert lib.pm_logprob_workspace_bytes(2048, 151936) == 2048 * 3 * 4
+
+
+def test_loss_params_struct_layout():
+    # pm_loss_params is 11 x 4 bytes, no padding
+    assert ctypes.sizeof(_lib.LossParams) == 44
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.PrimeMI355XError, match="no CPU or eager-PyTorch fallback"):
+        _lib.load()

@@ -1,0 +1,455 @@
+"""GPU suite (`-m gpu`): every HIP kernel, called through the C ABI, against the oracle / the golden fixtures.
+
+Tolerances: bit-exact for the label gather and integer work; f32 kernels 1e-5 (the reference's own bound,
+tests/unit/train/rl/test_fused_lm_head.py:58-61); bf16 kernels rtol 1e-3 / atol 1e-4 on log-probs (ibid. :160-161) and
+bf16-resolution bounds (stated per test) on activations.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import grpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from prime_rl_amd import ops as _ops
+
+    return _ops
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def _close(got, want, rtol, atol, what):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().float().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()}/{bad.size} outside tol; max abs err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)} (got {got.flat[err.argmax()]:.6g}, want {want.flat[err.argmax()]:.6g})"
+
+
+def test_device_is_gfx950(ops):
+    arch = ops.device_arch()
+    assert arch.startswith("gfx950"), arch
+
+
+def test_mfma_fragment_layout(ops):
+    torch.manual_seed(0)
+    a = torch.randn(16, 32).to(torch.bfloat16)
+    b = (torch.randn(16, 32) + torch.arange(16)[:, None] * 0.25).to(torch.bfloat16)  # asymmetric on purpose (guide §3)
+    c = ops.mfma_probe(a.to(DEV), b.to(DEV))
+    _close(c, a.float() @ b.float().T, 1e-6, 1e-5, "mfma 16x16x32 layout")
+
+
+# ================================================================================================ K1
+def test_logprob_vanilla_golden_unaligned(ops, golden_dir):
+    g = dict(np.load(golden_dir / "logprob_vanilla.npz"))
+    inv_t = _t(1.0 / g["temperature"], torch.float32)
+    lp, ent, _ = ops.logprob_entropy_fwd(_t(g["logits"]), _t(g["labels"]), inv_t)
+    _close(lp, g["logprobs"], 0, 1e-5, "logprobs")
+    _close(ent, g["entropy"], 0, 1e-5, "entropy")
+
+
+def test_logprob_fp32_head_golden(ops, golden_dir):
+    g = dict(np.load(golden_dir / "lm_head_fp32.npz"))
+    hidden = g["hidden"].reshape(-1, g["hidden"].shape[-1])
+    logits = _t(hidden @ g["weight"].T)
+    inv_t = _t(1.0 / g["temperature"].reshape(-1), torch.float32)
+    lp, ent, logz = ops.logprob_entropy_fwd(logits, _t(g["labels"].reshape(-1)), inv_t)
+    _close(lp, g["logprobs"].reshape(-1), 0, 1e-5, "logprobs")
+    _close(ent, g["entropy"].reshape(-1), 0, 1e-5, "entropy")
+    gl = _t(g["grad_logprobs"].reshape(-1))
+    dl = ops.logprob_bwd(logits, _t(g["labels"].reshape(-1)), inv_t, logz, gl)
+    dl_ref, gh_ref, gw_ref = O.fused_head_backward(hidden, g["weight"], g["labels"].reshape(-1), (1.0 / g["temperature"].reshape(-1)).astype(np.float32),
+                                                   logz.cpu().numpy(), g["grad_logprobs"].reshape(-1))
+    _close(dl, dl_ref, 0, 1e-5, "dlogits")
+    # the two GEMMs of lm_head.py:194-197 on the kernel's dlogits reproduce the reference's gradients
+    _close(dl.cpu() @ torch.from_numpy(g["weight"]), g["grad_hidden"].reshape(hidden.shape), 0, 1e-5, "grad_hidden")
+    _close(dl.cpu().T @ torch.from_numpy(hidden), g["grad_weight"], 0, 1e-5, "grad_weight")
+
+
+def test_logprob_bf16_head_golden(ops, golden_dir):
+    g = dict(np.load(golden_dir / "lm_head_bf16.npz"))
+    hidden = _t(g["hidden"][0], torch.bfloat16)
+    weight = _t(g["weight"], torch.bfloat16)
+    logits = hidden @ weight.T  # bf16 logits, as the reference's chunk GEMM produces them (lm_head.py:133)
+    inv_t = _t(1.0 / g["temperature"][0], torch.float32)
+    lp, ent, _ = ops.logprob_entropy_fwd(logits, _t(g["labels"][0]), inv_t)
+    _close(lp, g["logprobs"][0], 1e-3, 1e-4, "logprobs bf16")
+    _close(ent, g["entropy"][0], 1e-3, 1e-4, "entropy bf16")
+    # vocab-chunked form: two chunks of the same logits give the same answer
+    st = ops.ChunkedLogprobState(logits.shape[0], logits.device)
+    st.update(logits[:, :8192], 0, _t(g["labels"][0]), inv_t)
+    st.update(logits[:, 8192:], 8192, _t(g["labels"][0]), inv_t)
+    lp2, ent2, _ = st.finalize()
+    _close(lp2, lp, 0, 2e-6, "chunked == one-shot (logprobs)")
+    _close(ent2, ent, 0, 2e-6, "chunked == one-shot (entropy)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_rows", [2048, 8])
+def test_logprob_full_vocab(ops, dtype, n_rows):
+    """BASELINE shape (V = 151936): label gather bit-exact, values vs the oracle on a row sample, size-independent properties."""
+    v = 151936
+    g = torch.Generator(device=DEV).manual_seed(n_rows)
+    logits = (torch.randn(n_rows, v, device=DEV, generator=g) * 4.0).to(dtype)
+    labels = torch.randint(0, v, (n_rows,), device=DEV, generator=g)
+    temp = torch.where(torch.rand(n_rows, device=DEV, generator=g) < 0.5, 0.7, 1.0).float()
+    inv_t = 1.0 / temp
+    lp, ent, logz = ops.logprob_entropy_fwd(logits, labels, inv_t)
+    # bit-exact token-index gather: logprob + logz is exactly the label logit times inv_T
+    tl = logits[torch.arange(n_rows, device=DEV), labels].float() * inv_t
+    assert torch.equal(lp, tl - logz), "label gather is not bit-exact"
+    rows = np.linspace(0, n_rows - 1, num=min(n_rows, 6)).astype(int)
+    lp_o, ent_o, logz_o = O.logprob_entropy_from_logits(logits[rows].float().cpu().numpy(), labels[rows].cpu().numpy(), temp[rows].cpu().numpy())
+    _close(lp[rows], lp_o, 0, 2e-5, "logprobs vs oracle")
+    _close(ent[rows], ent_o, 0, 2e-5, "entropy vs oracle")
+    # properties over ALL rows: agreement with an independent f32 implementation, bounds, shift invariance
+    ref = torch.log_softmax(logits.float() * inv_t[:, None], dim=-1)
+    _close(lp, ref[torch.arange(n_rows, device=DEV), labels], 0, 2e-5, "logprobs vs torch.log_softmax (all rows)")
+    assert (lp <= 0).all() and (ent >= 0).all() and (ent <= math.log(v) + 1e-4).all()
+    if dtype == torch.float32:
+        lp_s, ent_s, logz_s = ops.logprob_entropy_fwd(logits + 3.0, labels, inv_t)
+        _close(lp_s, lp, 0, 3e-5, "shift invariance of logprobs")
+        _close(logz_s - logz, 3.0 * inv_t, 0, 3e-5, "logz shifts by c/T")
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16),
+                                          (torch.bfloat16, torch.float32)])
+def test_logprob_bwd(ops, in_dt, out_dt):
+    n, v = 64, 151936
+    g = torch.Generator(device=DEV).manual_seed(7)
+    logits = (torch.randn(n, v, device=DEV, generator=g) * 3.0).to(in_dt)
+    labels = torch.randint(0, v, (n,), device=DEV, generator=g)
+    inv_t = (1.0 / torch.where(torch.rand(n, device=DEV, generator=g) < 0.5, 0.7, 1.0)).float()
+    grad = torch.randn(n, device=DEV, generator=g)
+    grad[::5] = 0.0  # masked tokens: rows of exact zeros
+    _, _, logz = ops.logprob_entropy_fwd(logits, labels, inv_t)
+    dl = ops.logprob_bwd(logits, labels, inv_t, logz, grad, out_dtype=out_dt)
+    assert dl.dtype == out_dt
+    l = logits.float() * inv_t[:, None]
+    want = (grad * inv_t)[:, None] * (torch.nn.functional.one_hot(labels, v).float() - torch.exp(l - logz[:, None]))
+    tol = 1e-6 if out_dt == torch.float32 else 4e-3
+    _close(dl, want, tol if out_dt == torch.bfloat16 else 1e-4, 1e-6 if out_dt == torch.float32 else 1e-6, "dlogits")
+    assert not dl[::5].float().any(), "masked rows must be exactly zero"
+    _close(dl.float().sum(-1), torch.zeros(n), 0, 2e-3 if out_dt == torch.bfloat16 else 1e-4, "rows of dlogits sum to zero")
+    if in_dt == out_dt:  # in place
+        buf = logits.clone()
+        ops.logprob_bwd(buf, labels, inv_t, logz, grad, out=buf)
+        assert torch.equal(buf, dl), "in-place backward differs"
+
+
+# ================================================================================================ K3
+def test_grpo_advantage(ops):
+    rng = np.random.default_rng(0)
+    sizes = [16] * 8 + [1, 3, 70, 130]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rewards = (rng.random(offs[-1]) < 0.5).astype(np.float32)
+    rewards[offs[-2]:] = rng.standard_normal(130).astype(np.float32)
+    adv = ops.grpo_advantage(_t(rewards), _t(offs)).cpu().numpy()
+    for a, b in zip(offs[:-1], offs[1:]):
+        np.testing.assert_allclose(adv[a:b], O.grpo_advantages(rewards[a:b]), rtol=0, atol=1e-6)
+        assert abs(adv[a:b].sum()) < 1e-4
+    assert adv[offs[8]] == 0.0  # singleton group
+    from prime_rl_amd import _lib
+    mx = ops.grpo_advantage(_t(np.array([1, 0, 0, 0, 0, 0, 0], dtype=np.float32)), _t(np.array([0, 4, 7], dtype=np.int32)), mode=_lib.PM_ADV_MAXRL)
+    np.testing.assert_allclose(mx.cpu().numpy(), [3, -1, -1, -1, 0, 0, 0], atol=1e-6)
+    out, tot, turns = (rng.integers(1, 500, offs[-1]).astype(np.float32) for _ in range(3))
+    tot = tot + out
+    w = (0.25, 0.1, 0.1)
+    sh = ops.grpo_advantage(_t(rewards), _t(offs), num_output_tokens=_t(out), num_total_tokens=_t(tot), num_turns=_t(turns), weights=w).cpu().numpy()
+    for a, b in zip(offs[:-1], offs[1:]):
+        want = O.grpo_advantages(rewards[a:b], dict(output=out[a:b], total=tot[a:b], turns=turns[a:b], w_output=w[0], w_input=w[1], w_turns=w[2]))
+        np.testing.assert_allclose(sh[a:b], want, rtol=0, atol=2e-6)
+
+
+def test_advantage_broadcast(ops):
+    radv = np.array([0.7, -0.25, 0.0], dtype=np.float32)
+    roffs = np.array([0, 3, 300, 1000], dtype=np.int32)
+    mask = np.random.default_rng(0).random(1000) < 0.7
+    mask[:3] = [False, True, True]
+    got = ops.advantage_broadcast(_t(radv), _t(roffs), _t(mask)).cpu().numpy()
+    want = np.concatenate([O.broadcast_advantage(radv[r], mask[roffs[r]:roffs[r + 1]]) for r in range(3)])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(got[:3], [0.0, 0.7, 0.7])
+
+
+# ================================================================================================ K2
+def _loss_params(cfg: O.LossConfig, scales, shift=0, vocab=151936):
+    from prime_rl_amd import _lib
+
+    return _lib.LossParams(loss_type=_lib.PM_LOSS_IPO if cfg.type == "ipo" else _lib.PM_LOSS_DEFAULT, dppo_mask_low=cfg.dppo_mask_low,
+                           dppo_mask_high=cfg.dppo_mask_high, adv_tau=cfg.adv_tau, kl_tau=cfg.kl_tau, ipo_threshold=cfg.ipo_threshold,
+                           rl_scale=float(scales[0]), ce_scale=float(scales[1]), ref_kl_scale=float(scales[2]), shift=shift,
+                           pad_logprob=math.log(1.0 / vocab))
+
+
+@pytest.mark.parametrize("name,cfg", [("loss_default.npz", O.LossConfig()), ("loss_default_weights.npz", O.LossConfig()),
+                                      ("loss_ipo.npz", O.LossConfig(type="ipo"))])
+def test_grpo_loss_golden(ops, golden_dir, name, cfg):
+    from prime_rl_amd import _lib
+
+    g = dict(np.load(golden_dir / name))
+    cu = _t(np.concatenate([[0], np.cumsum(g["lens"])]).astype(np.int32))
+    kw = {}
+    if "rl_weights" in g:
+        kw = dict(ref_logprobs=_t(g["ref_logprobs"]), rl_weights=_t(g["rl_weights"]), ce_weights=_t(g["ce_weights"]), ref_kl_weights=_t(g["ref_kl_weights"]))
+    loss, grad, stats, metrics = ops.grpo_loss_fwd_bwd(_t(g["trainer_logprobs"]), _t(g["inference_logprobs"]), _t(g["advantages"]), _t(g["loss_mask"]), cu,
+                                                       _loss_params(cfg, g["scales"]), **kw)
+    _close(loss[0], g["loss"], 1e-5, 1e-6, "loss")
+    _close(grad, g["grad"], 1e-5, 1e-7, "dloss/dlogprob")
+    stats, metrics = stats.cpu().numpy(), metrics.cpu().numpy()
+    comp_count = {"rl": stats[:, _lib.STAT["RL_N_MASK"]], "ce": stats[:, _lib.STAT["CE_N"]], "ref_kl": stats[:, _lib.STAT["REFKL_N"]]}
+    for k in [k for k in g if k.startswith("metric__")]:
+        key = k[len("metric__"):].replace("__", "/")
+        col = _lib.METRIC_KEYS.index(key)
+        comp = "ce" if key == "nll" else ("ref_kl" if key.startswith("ref_kl") else "rl")
+        keep = comp_count[comp] > 0 if ("rl_weights" in g or comp != "rl") else np.ones(len(stats), bool)  # loss.py:367-380 appends only non-empty components
+        _close(metrics[keep, col], g[k], 1e-5, 1e-6, key)
+
+
+def test_grpo_loss_known_answers_and_edge_cases(ops):
+    lp = _t(np.array([-0.1, -0.5, -0.2], dtype=np.float32))
+    z = _t(np.zeros(3, dtype=np.float32))
+    mask = _t(np.array([True, False, True]))
+    cu = _t(np.array([0, 3], dtype=np.int32))
+    loss, grad, _, _ = ops.grpo_loss_fwd_bwd(lp, z, z, mask, cu, _loss_params(O.LossConfig(), (1, 2, 1)), rl_weights=z,
+                                             ce_weights=_t(np.array([1, 0, 1], dtype=np.float32)))
+    assert abs(loss.item() - 0.15) < 1e-6  # reference tests/unit/train/rl/test_loss.py:88-115
+    np.testing.assert_allclose(grad.cpu().numpy(), [-0.5, 0.0, -0.5], atol=1e-7)
+    loss, _, _, _ = ops.grpo_loss_fwd_bwd(lp, z, z, mask, cu, _loss_params(O.LossConfig(), (1, 1, 1)), rl_weights=z,
+                                          ce_weights=_t(np.array([0.1, 0, 0.1], dtype=np.float32)))
+    assert abs(loss.item() - 0.03) < 1e-6  # :118-144
+    # explicit all-ones rl stream is bitwise the absent stream (:147-172)
+    rng = np.random.default_rng(0)
+    a, b, c = (_t(rng.standard_normal(50).astype(np.float32)) for _ in range(3))
+    m = _t(rng.random(50) > 0.3)
+    cu50 = _t(np.array([0, 50], dtype=np.int32))
+    p = _loss_params(O.LossConfig(), (1, 1, 1))
+    l1, g1, _, _ = ops.grpo_loss_fwd_bwd(a, b, c, m, cu50, p)
+    l2, g2, _, _ = ops.grpo_loss_fwd_bwd(a, b, c, m, cu50, p, rl_weights=torch.ones(50, device=DEV))
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    # empty components: exact zero loss and exact zero gradient (:213-242)
+    z6 = torch.zeros(6, device=DEV)
+    l0, g0, _, _ = ops.grpo_loss_fwd_bwd(torch.randn(6, device=DEV), z6, z6, torch.zeros(6, dtype=torch.bool, device=DEV),
+                                         _t(np.array([0, 6], dtype=np.int32)), p, rl_weights=z6, ce_weights=z6)
+    assert l0.item() == 0.0 and not g0.any()
+
+
+def test_grpo_loss_fused_shift_and_microbatch_concat(ops):
+    """shift_tensor_right fused in the kernel (loss.py:76-91 / train.py:450-457), two micro-batches concatenated in one launch."""
+    rng = np.random.default_rng(3)
+    vocab = 151936
+    lens_a, lens_b = [40, 24], [30, 34]
+    n = 128
+    raw = rng.standard_normal(n).astype(np.float32) * 0.3 - 1.0
+    inf = raw + rng.standard_normal(n).astype(np.float32) * 0.2
+    adv = rng.standard_normal(n).astype(np.float32)
+    mask = rng.random(n) > 0.3
+    pad = math.log(1.0 / vocab)
+    cfg = O.LossConfig()
+    shifted = np.concatenate([O.shift_right(raw[:64][None], pad)[0], O.shift_right(raw[64:][None], pad)[0]])
+    scale = max(int(mask.sum()), 1)
+    la, _, ga = O.compute_loss(shifted[:64], inf[:64], adv[:64], mask[:64], lens_a, cfg, scale)
+    lb, _, gb = O.compute_loss(shifted[64:], inf[64:], adv[64:], mask[64:], lens_b, cfg, scale)
+    want_grad = np.zeros(n, dtype=np.float32)  # un-shift: gradient of position i lands on head position i-1, per micro-batch
+    want_grad[0:63] = ga[1:]
+    want_grad[64:127] = gb[1:]
+    cu = _t(np.array([0, 40, 64, 94, 128], dtype=np.int32))
+    starts = _t(np.array([1, 0, 1, 0], dtype=np.uint8))
+    loss, grad, _, _ = ops.grpo_loss_fwd_bwd(_t(raw), _t(inf), _t(adv), _t(mask), cu, _loss_params(cfg, (scale, 1, 1), shift=1, vocab=vocab),
+                                             sample_starts_mb=starts)
+    _close(loss[0], np.float32(la + lb), 1e-5, 1e-6, "loss of two concatenated micro-batches")
+    _close(grad, want_grad, 1e-5, 1e-7, "gradient in head indexing")
+
+
+# ================================================================================================ elementwise / norms
+@pytest.mark.parametrize("h", [4096, 1024, 256])
+def test_rmsnorm(ops, h):
+    torch.manual_seed(h)
+    n = 300
+    x = torch.randn(n, h).to(torch.bfloat16)
+    res = torch.randn(n, h).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(h)).to(torch.bfloat16)
+    y, rstd, _ = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6)
+    want = O.rmsnorm(x, w, 1e-6)
+    mism = (y.cpu() != want).float().mean().item()
+    assert mism < 2e-3, f"rmsnorm fwd: {mism:.4%} of outputs differ from the reference rounding"  # reduction-order ulps only
+    _close(y, want, 8e-3, 1e-6, "rmsnorm fwd")
+    y2, _, so = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6, residual=res.to(DEV))
+    assert torch.equal(so.cpu(), x + res)
+    _close(y2, O.rmsnorm(x + res, w, 1e-6), 8e-3, 1e-6, "rmsnorm fwd (fused residual)")
+    # backward vs f32 autograd of the same formula
+    gy = torch.randn(n, h).to(torch.bfloat16)
+    dres = torch.randn(n, h).to(torch.bfloat16)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * wf * gy.float()).sum().backward()
+    gw = torch.zeros(h, device=DEV)
+    gx = ops.rmsnorm_bwd(gy.to(DEV), x.to(DEV), w.to(DEV), rstd, gw, dresidual=dres.to(DEV))
+    _close(gx, xf.grad + dres.float(), 8e-3, 2e-3, "rmsnorm dx (+dresidual)")
+    _close(gw, wf.grad, 2e-3, 2e-3, "rmsnorm dweight")
+    gw2 = gw.clone()
+    ops.rmsnorm_bwd(gy.to(DEV), x.to(DEV), w.to(DEV), rstd, gw2)
+    _close(gw2, 2 * wf.grad, 2e-3, 4e-3, "rmsnorm dweight accumulates")
+
+
+def test_rope_table_and_qknorm_rope(ops):
+    torch.manual_seed(0)
+    n, hq, hkv, d = 77, 8, 2, 128
+    pos = torch.cat([torch.arange(50), torch.arange(27)]) + 1000
+    cos, sin = ops.rope_table(pos.to(DEV), ops.rope_inv_freq(d, 1_000_000.0, DEV))
+    cos_o, sin_o = O.rope_cos_sin(pos, d, 1_000_000.0, torch.bfloat16)
+    assert (cos.cpu() != cos_o[:, :64]).float().mean() < 5e-3 and (sin.cpu() != sin_o[:, :64]).float().mean() < 5e-3
+    _close(cos, cos_o[:, :64], 8e-3, 1e-6, "cos table")
+    qkv = torch.randn(n, (hq + 2 * hkv) * d).to(torch.bfloat16)
+    qw = (1 + 0.1 * torch.randn(d)).to(torch.bfloat16)
+    kw = (1 + 0.1 * torch.randn(d)).to(torch.bfloat16)
+    q, k, rstd = ops.qknorm_rope_fwd(qkv.to(DEV), qw.to(DEV), kw.to(DEV), cos, sin, hq, hkv, d, 1e-6)
+    cos_f = torch.cat([cos.cpu(), cos.cpu()], -1)
+    sin_f = torch.cat([sin.cpu(), sin.cpu()], -1)
+    q_raw = qkv[:, : hq * d].view(n, hq, d)
+    k_raw = qkv[:, hq * d: (hq + hkv) * d].view(n, hkv, d)
+    q_o = O.apply_rope(O.rmsnorm(q_raw, qw, 1e-6), cos_f, sin_f)
+    k_o = O.apply_rope(O.rmsnorm(k_raw, kw, 1e-6), cos_f, sin_f)
+    assert (q.cpu() != q_o).float().mean() < 3e-3, "q differs from the reference's bf16 rounding sequence"
+    _close(q, q_o, 1.6e-2, 1e-6, "q norm+rope")
+    _close(k, k_o, 1.6e-2, 1e-6, "k norm+rope")
+    # backward vs f32 autograd
+    gq = torch.randn(n, hq, d).to(torch.bfloat16)
+    gk = torch.randn(n, hkv, d).to(torch.bfloat16)
+    qr = q_raw.float().requires_grad_(True)
+    kr = k_raw.float().requires_grad_(True)
+    qwf = qw.float().requires_grad_(True)
+    kwf = kw.float().requires_grad_(True)
+
+    def f(x, w):
+        xn = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+        return O.apply_rope(xn, cos_f.float(), sin_f.float())
+
+    ((f(qr, qwf) * gq.float()).sum() + (f(kr, kwf) * gk.float()).sum()).backward()
+    gqkv = torch.zeros_like(qkv).to(DEV)
+    gqw = torch.zeros(d, device=DEV)
+    gkw = torch.zeros(d, device=DEV)
+    ops.qknorm_rope_bwd(gq.to(DEV), gk.to(DEV), qkv.to(DEV), qw.to(DEV), kw.to(DEV), cos, sin, rstd, gqkv, gqw, gkw, hq, hkv, d)
+    _close(gqkv[:, : hq * d].view(n, hq, d), qr.grad, 1e-2, 4e-3, "dq_raw")
+    _close(gqkv[:, hq * d: (hq + hkv) * d].view(n, hkv, d), kr.grad, 1e-2, 4e-3, "dk_raw")
+    assert not gqkv[:, (hq + hkv) * d:].any(), "v columns must be left untouched"
+    _close(gqw, qwf.grad, 3e-3, 3e-2, "d q_norm.weight")
+    _close(gkw, kwf.grad, 3e-3, 3e-2, "d k_norm.weight")
+
+
+def test_swiglu(ops):
+    torch.manual_seed(1)
+    n, inter = 130, 1536
+    gu = (torch.randn(n, 2 * inter) * 2).to(torch.bfloat16)
+    act = ops.swiglu_fwd(gu.to(DEV))
+    want = O.swiglu(gu[:, :inter], gu[:, inter:])
+    assert (act.cpu() != want).float().mean() < 2e-3
+    _close(act, want, 8e-3, 1e-6, "swiglu fwd")
+    ga = torch.randn(n, inter).to(torch.bfloat16)
+    gf = gu.float().requires_grad_(True)
+    (torch.nn.functional.silu(gf[:, :inter]) * gf[:, inter:] * ga.float()).sum().backward()
+    _close(ops.swiglu_bwd(ga.to(DEV), gu.to(DEV)), gf.grad, 8e-3, 1e-3, "swiglu bwd")
+
+
+def test_embedding(ops):
+    torch.manual_seed(2)
+    v, h, n = 1000, 256, 500
+    table = torch.randn(v, h).to(torch.bfloat16)
+    ids = torch.randint(0, 40, (n,))  # heavy duplication, like FakeDataLoader ids < 100
+    out = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
+    assert torch.equal(out.cpu(), table[ids])  # integer gather: bit-exact
+    go = torch.randn(n, h).to(torch.bfloat16)
+    gt = torch.zeros(v, h, device=DEV)
+    ops.embedding_bwd(go.to(DEV), ids.to(DEV), gt)
+    want = torch.zeros(v, h).index_add_(0, ids, go.float())
+    _close(gt, want, 1e-5, 1e-5, "embedding bwd")
+    gt2 = gt.clone()
+    ops.embedding_bwd(go.to(DEV), ids.to(DEV), gt2)
+    assert torch.equal(gt2, 2 * gt), "embedding bwd is not deterministic/accumulating"
+
+
+# ================================================================================================ attention
+def _attn_case(n, seq_lens, hq, hkv, seed):
+    torch.manual_seed(seed)
+    d = 128
+    q = torch.randn(n, hq, d).to(torch.bfloat16)
+    k = torch.randn(n, hkv, d).to(torch.bfloat16)
+    v = torch.randn(n, hkv, d).to(torch.bfloat16)
+    return q, k, v
+
+
+@pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([300, 212], 8, 8), ([5], 2, 1)])
+def test_attention_forward_backward(ops, seq_lens, hq, hkv):
+    n, d = sum(seq_lens), 128
+    q, k, v = _attn_case(n, seq_lens, hq, hkv, n)
+    scale = d**-0.5
+    cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    want_ss = np.repeat(np.cumsum([0] + seq_lens[:-1]), seq_lens)
+    assert np.array_equal(ss.cpu().numpy(), want_ss)  # integer work: exact
+    # v handed over as the strided v-slice of a fused qkv buffer, like the engine does
+    qkv = torch.zeros(n, (hq + 2 * hkv) * d, dtype=torch.bfloat16, device=DEV)
+    qkv[:, (hq + hkv) * d:] = v.reshape(n, -1).to(DEV)
+    v_view = qkv[:, (hq + hkv) * d:].view(n, hkv, d)
+    out, lse = ops.attn_varlen_fwd(q.to(DEV), k.to(DEV), v_view, ss, scale)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    want = O.varlen_causal_attention(qf, kf, vf, seq_lens, scale)
+    _close(out, want, 1e-2, 1e-2, "attention forward")  # bf16 P and bf16 output
+    go = torch.randn(n, hq, d).to(torch.bfloat16)
+    (want * go.float()).sum().backward()
+    gq, gk, gv = ops.attn_varlen_bwd(go.to(DEV), q.to(DEV), k.to(DEV), v_view, out, lse, ss, scale)
+    _close(gq, qf.grad, 2e-2, 3e-2, "dq")
+    _close(gk, kf.grad, 2e-2, 3e-2, "dk")
+    _close(gv, vf.grad, 2e-2, 3e-2, "dv")
+    gq2, gk2, gv2 = ops.attn_varlen_bwd(go.to(DEV), q.to(DEV), k.to(DEV), v_view, out, lse, ss, scale)
+    assert torch.equal(gq, gq2) and torch.equal(gk, gk2) and torch.equal(gv, gv2), "backward must be bitwise reproducible"
+
+
+# ================================================================================================ optimizer
+def test_adamw_sumsq_clip(ops):
+    torch.manual_seed(0)
+    n = 100_003
+    p0 = torch.randn(n)
+    g = torch.randn(n) * 3
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    pad = (-n) % 4
+    master = torch.cat([p0, torch.zeros(pad)]).to(DEV)
+    m = torch.zeros_like(master)
+    v = torch.zeros_like(master)
+    grad = torch.cat([g, torch.zeros(pad)]).to(DEV)
+    pb = torch.zeros(n + pad, dtype=torch.bfloat16, device=DEV)
+    ssq = torch.zeros(1, device=DEV)
+    ops.sumsq_accumulate(grad, ssq)
+    _close(ssq[0], (g.double() ** 2).sum().float(), 1e-5, 0, "sum of squares")
+    coef, norm = ops.clip_coef(ssq, 1.0, 1.0)
+    want_norm = g.double().norm().item()
+    assert abs(norm.item() - want_norm) / want_norm < 1e-5 and abs(coef.item() - 1.0 / (want_norm + 1e-6)) < 1e-7
+    for step in range(1, 4):
+        p.grad = g.clone() * coef.item()
+        opt.step()
+        grad_step = torch.cat([g, torch.zeros(pad)]).to(DEV)
+        ops.adamw_step(master, m, v, grad_step, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=1.0, clip=coef, zero_grad=True)
+        assert not grad_step.any(), "zero_grad"
+    _close(master[:n], p.detach(), 1e-6, 1e-7, "AdamW master weights")  # reference bound tests/unit/train/test_cpu_adam.py:34-134
+    assert torch.equal(pb[:n].cpu(), p.detach().to(torch.bfloat16)) or (pb[:n].cpu().float() - p.detach()).abs().max() < 1e-2
+    mg = torch.zeros(4096 + 8, device=DEV)
+    gb = torch.randn(4096 + 8).to(torch.bfloat16).to(DEV)
+    ops.grad_accumulate(mg, gb)
+    ops.grad_accumulate(mg, gb)
+    assert torch.equal(mg, 2 * gb.float())
