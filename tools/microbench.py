@@ -1,0 +1,110 @@
+"""Per-kernel microbenchmarks on one MI355X (HIP events on the launch stream).  Not the graded bench (that is bench.py);
+used while iterating on kernels:  python tools/microbench.py [k1|attn|norm|all]"""
+
+from __future__ import annotations
+
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from prime_rl_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters=20, warmup=3, flush_mb=0):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    flush = torch.empty(flush_mb * 1024 * 1024, dtype=torch.uint8, device=DEV) if flush_mb else None
+    ts = []
+    for _ in range(iters):
+        if flush is not None:
+            flush.zero_()  # evict L2 / Infinity Cache between iterations
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def bench_k1(out):
+    n, v = 2048, 151936
+    for dt in (torch.float32, torch.bfloat16):
+        logits = (torch.randn(n, v, device=DEV) * 4).to(dt)
+        labels = torch.randint(0, v, (n,), device=DEV)
+        inv_t = torch.ones(n, device=DEV)
+        med, best = timeit(lambda: ops.logprob_entropy_fwd(logits, labels, inv_t), flush_mb=512)
+        nbytes = n * (logits.element_size() * v + 20)
+        out.append(dict(kernel=f"logprob_entropy_fwd[{dt}]", ms=med * 1e3, best_ms=best * 1e3, GBps=nbytes / med / 1e9, frac_hbm=nbytes / med / HBM_PEAK))
+        _, _, logz = ops.logprob_entropy_fwd(logits, labels, inv_t)
+        g = torch.randn(n, device=DEV)
+        buf = logits.clone()
+        med, best = timeit(lambda: ops.logprob_bwd(buf, labels, inv_t, logz, g, out=buf), flush_mb=512)
+        nbytes = n * 2 * logits.element_size() * v
+        out.append(dict(kernel=f"logprob_bwd[{dt} in place]", ms=med * 1e3, best_ms=best * 1e3, GBps=nbytes / med / 1e9, frac_hbm=nbytes / med / HBM_PEAK))
+        del logits, buf
+
+
+def bench_attn(out):
+    hq, hkv, d = 32, 8, 128
+    for n, seqs in ((2048, [2048]), (16384, [2048] * 8)):
+        q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+        k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+        v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+        cu = torch.tensor([0] + list(torch.tensor(seqs).cumsum(0)), dtype=torch.int32, device=DEV)
+        ss = ops.seq_start_from_cu(cu, n)
+        med, best = timeit(lambda: ops.attn_varlen_fwd(q, k, v, ss, d**-0.5), iters=10)
+        flops = sum(2 * s * s * hq * d for s in seqs)  # causal: 2 matmuls x 2 flop x s^2/2
+        out.append(dict(kernel=f"attn_fwd[n={n}]", ms=med * 1e3, TFLOPs=flops / med / 1e12))
+        o, lse = ops.attn_varlen_fwd(q, k, v, ss, d**-0.5)
+        go = torch.randn_like(o)
+        med, best = timeit(lambda: ops.attn_varlen_bwd(go, q, k, v, o, lse, ss, d**-0.5), iters=10)
+        out.append(dict(kernel=f"attn_bwd[n={n}]", ms=med * 1e3, TFLOPs=2.5 * flops / med / 1e12))
+
+
+def bench_norm(out):
+    n, h = 16384, 4096
+    x = torch.randn(n, h, device=DEV).to(torch.bfloat16)
+    w = torch.ones(h, device=DEV, dtype=torch.bfloat16)
+    med, _ = timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6), flush_mb=512)
+    out.append(dict(kernel="rmsnorm_fwd[16384x4096]", ms=med * 1e3, GBps=n * h * 4 / med / 1e9))
+    y, rstd, _ = ops.rmsnorm_fwd(x, w, 1e-6)
+    gw = torch.zeros(h, device=DEV)
+    med, _ = timeit(lambda: ops.rmsnorm_bwd(y, x, w, rstd, gw), flush_mb=512)
+    out.append(dict(kernel="rmsnorm_bwd[16384x4096]", ms=med * 1e3, GBps=n * h * 6 / med / 1e9))
+    gu = torch.randn(n, 2 * 12288, device=DEV).to(torch.bfloat16)
+    med, _ = timeit(lambda: ops.swiglu_fwd(gu), flush_mb=512)
+    out.append(dict(kernel="swiglu_fwd[16384x12288]", ms=med * 1e3, GBps=n * 12288 * 6 / med / 1e9))
+    a = torch.randn(n, 4096, device=DEV).to(torch.bfloat16)
+    wt = torch.randn(24576, 4096, device=DEV).to(torch.bfloat16)
+    med, _ = timeit(lambda: a @ wt.T, iters=10)
+    out.append(dict(kernel="hipBLASLt gemm 16384x4096x24576 bf16", ms=med * 1e3, TFLOPs=2 * n * 4096 * 24576 / med / 1e12))
+    a2 = a[:2048]
+    med, _ = timeit(lambda: a2 @ wt.T, iters=10)
+    out.append(dict(kernel="hipBLASLt gemm 2048x4096x24576 bf16", ms=med * 1e3, TFLOPs=2 * 2048 * 4096 * 24576 / med / 1e12))
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    out = []
+    if which in ("k1", "all"):
+        bench_k1(out)
+    if which in ("attn", "all"):
+        bench_attn(out)
+    if which in ("norm", "all"):
+        bench_norm(out)
+    for r in out:
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
+
+
+if __name__ == "__main__":
+    main()
