@@ -1,0 +1,607 @@
+"""The MI355X-native GRPO policy-update engine: one process per GPU, flat parameter/gradient buffers, explicit forward
+and backward schedules over the C-ABI kernels (no autograd graph, no tracing compiler), RCCL collectives on a side stream.
+
+What it replaces in the reference (src/prime_rl/): the body of the training step in trainer/rl/train.py:307-570 —
+scale all-reduce (:307-323), the micro-batch loop (:337-480: forward() of trainer/model.py:1431-1482 through
+Qwen3ForCausalLM, the LM-head log-probs, shift_tensor_right, compute_loss, loss.backward()), scale_gradients_ (:557-558),
+clip_grad_norm_ (:561-565) and optimizer.step() (:566-570) — and the FSDP2 sharding of trainer/model.py:823-960.
+
+MI355X-first choices (DESIGN.md has the numbers):
+  * 288 GB HBM: no activation checkpointing, no activation/optimizer offload, no per-layer parameter resharding.
+    All micro-batches of a step are concatenated into ONE packed pass (varlen attention + segmented loss keep the
+    reference's per-micro-batch semantics), so every weight-gradient GEMM reduces over the whole step in f32 inside the
+    MFMA accumulators and gradients are written once.
+  * ZeRO-2 style data parallelism instead of ZeRO-3: bf16 parameters are replicated (16 GB of 288 GB for Qwen3-8B), f32
+    gradients are reduce-scattered per layer bucket while backward is still running, master weights + Adam moments are
+    sharded, updated bf16 shards are all-gathered in place.  One reduce-scatter + one all-gather of the model per step
+    instead of two all-gathers per layer per micro-batch (xGMI is per-link bound: fewer, larger collectives).
+  * GEMMs are plain library calls (hipBLASLt through torch.mm); everything else on the path is a kernel in
+    libprime_mi355x.so.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .. import _lib, ops
+from .._lib import LossParams, PrimeMI355XError
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class ModelDims:
+    """Dense Qwen3 / Llama-style dimensions (HF config names)."""
+
+    vocab_size: int
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1_000_000.0
+    tie_word_embeddings: bool = False
+    name: str = "custom"
+
+    @classmethod
+    def qwen3_8b(cls) -> "ModelDims":  # public HF config
+        return cls(151936, 4096, 12288, 36, 32, 8, 128, name="Qwen3-8B")
+
+    @classmethod
+    def qwen3_0_6b(cls) -> "ModelDims":
+        return cls(151936, 1024, 3072, 28, 16, 8, 128, tie_word_embeddings=True, name="Qwen3-0.6B")
+
+    @classmethod
+    def tiny(cls, layers: int = 2, vocab: int = 512) -> "ModelDims":
+        return cls(vocab, 256, 512, layers, 4, 2, 128, name="tiny")
+
+    @property
+    def q_dim(self) -> int:
+        return self.num_attention_heads * self.head_dim
+
+    @property
+    def kv_dim(self) -> int:
+        return self.num_key_value_heads * self.head_dim
+
+    def num_params(self) -> int:
+        h, i, v = self.hidden_size, self.intermediate_size, self.vocab_size
+        per_layer = 2 * h + (self.q_dim + 2 * self.kv_dim) * h + 2 * self.head_dim + h * self.q_dim + 3 * i * h
+        return v * h * (1 if self.tie_word_embeddings else 2) + self.num_hidden_layers * per_layer + h
+
+    def flops_per_token(self, seq_len: int) -> int:
+        """PerfCounter._get_num_flop_per_token (trainer/perf.py:177-213): 6 * matmul params + 12*L*H*Dh*T."""
+        h, i = self.hidden_size, self.intermediate_size
+        mm = self.num_hidden_layers * ((self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h) + self.vocab_size * h
+        return 6 * mm + 12 * self.num_hidden_layers * self.num_attention_heads * self.head_dim * seq_len
+
+
+@dataclass
+class OptimConfig:
+    """AdamWConfig defaults (packages/prime-rl-configs/src/prime_rl/configs/trainer.py:415-443)."""
+
+    lr: float = 1e-6
+    weight_decay: float = 0.01
+    betas1: float = 0.9
+    betas2: float = 0.999
+    eps: float = 1e-8
+    max_norm: float = 1.0
+
+
+@dataclass
+class LossConfig:
+    """DefaultLossConfig / IPOLossConfig (configs/trainer.py:494-520)."""
+
+    type: str = "default"
+    dppo_mask_low: float = 0.2
+    dppo_mask_high: float = 0.2
+    adv_tau: float = 1.0
+    kl_tau: float = 1e-3
+    ipo_threshold: float = 0.1
+
+
+@dataclass
+class PackedBatch:
+    """All micro-batches of one rank for one step, concatenated along the token axis (device tensors)."""
+
+    input_ids: Tensor  # i64 [n]
+    position_ids: Tensor  # i64 [n]
+    labels: Tensor  # i64 [n]   shift_tensor_left per micro-batch (loss.py:66-73)
+    inv_temp: Tensor  # f32 [n]  1/temperature (lm_head.py:54)
+    advantages: Tensor  # f32 [n]
+    inference_logprobs: Tensor  # f32 [n]
+    loss_mask: Tensor  # bool [n]
+    cu_seqlens: Tensor  # i32 [docs+1]     attention documents (MicroBatch.seq_lens)
+    cu_samples: Tensor  # i32 [samples+1]  loss samples (MicroBatch.sequence_lengths)
+    sample_starts_mb: Tensor  # u8 [samples]
+    n_micro_batches: int
+    ref_logprobs: Tensor | None = None
+    rl_weights: Tensor | None = None
+    ce_weights: Tensor | None = None
+    ref_kl_weights: Tensor | None = None
+    local_counts: tuple[int, int, int] = (0, 0, 0)  # rl / ce / ref_kl member tokens on this rank (train.py:307-317)
+
+    @property
+    def n_tokens(self) -> int:
+        return self.input_ids.numel()
+
+
+def pack_micro_batches(micro_batches: list[dict], device: torch.device | str) -> PackedBatch:
+    """Concatenate TensorMicroBatch dicts (trainer/rl/data.py:18-52 layout, CPU tensors [1, seq]) into one PackedBatch.
+    Token counts per loss component are taken on the host tensors exactly like train.py:307-317."""
+    if not micro_batches:
+        raise ValueError("empty step")
+
+    def cat(key, dtype):
+        return torch.cat([mb[key].reshape(-1).to(dtype) for mb in micro_batches])
+
+    ids = cat("input_ids", torch.int64)
+    labels = torch.cat([torch.cat([mb["input_ids"].reshape(-1)[1:], mb["input_ids"].new_zeros(1)]).to(torch.int64) for mb in micro_batches])
+    temps = cat("temperatures", torch.float32)
+    mask = cat("loss_mask", torch.bool)
+
+    def opt(key):
+        present = [mb.get(key) is not None for mb in micro_batches]
+        if not any(present):
+            return None
+        parts = []
+        for mb in micro_batches:
+            t = mb.get(key)
+            if t is None:  # a stream materialises as soon as one packed micro-batch carries it (types.py:96-99)
+                n = mb["input_ids"].numel()
+                fill = 1.0 if key == "rl_weights" else 0.0
+                t = torch.full((n,), fill, dtype=torch.float32)
+            parts.append(t.reshape(-1).to(torch.float32))
+        return torch.cat(parts)
+
+    rl_w, ce_w, rk_w, ref = opt("rl_weights"), opt("ce_weights"), opt("ref_kl_weights"), opt("ref_logprobs")
+    n_rl = int((mask & (rl_w != 0)).sum()) if rl_w is not None else int(mask.sum())
+    n_ce = int((ce_w != 0).sum()) if ce_w is not None else 0
+    n_rk = int((rk_w != 0).sum()) if rk_w is not None else 0
+    seq_lens = torch.cat([mb["seq_lens"].reshape(-1).to(torch.int64) for mb in micro_batches])
+    sample_lens, starts = [], []
+    for mb in micro_batches:
+        sl = list(mb["sequence_lengths"])
+        sample_lens += sl
+        starts += [1] + [0] * (len(sl) - 1)
+    cu_seq = torch.zeros(seq_lens.numel() + 1, dtype=torch.int32)
+    cu_seq[1:] = seq_lens.cumsum(0)
+    cu_smp = torch.zeros(len(sample_lens) + 1, dtype=torch.int32)
+    cu_smp[1:] = torch.tensor(sample_lens, dtype=torch.int64).cumsum(0)
+    if int(cu_seq[-1]) != ids.numel() or int(cu_smp[-1]) != ids.numel():
+        raise ValueError("seq_lens / sequence_lengths must sum to the packed length (trainer/batch.py:_assert_token_arrays_aligned)")
+
+    def dev(t):
+        return None if t is None else t.to(device, non_blocking=True)
+
+    return PackedBatch(
+        input_ids=dev(ids), position_ids=dev(cat("position_ids", torch.int64)), labels=dev(labels), inv_temp=dev(1.0 / temps),
+        advantages=dev(cat("advantages", torch.float32)), inference_logprobs=dev(cat("inference_logprobs", torch.float32)), loss_mask=dev(mask),
+        cu_seqlens=dev(cu_seq), cu_samples=dev(cu_smp), sample_starts_mb=dev(torch.tensor(starts, dtype=torch.uint8)),
+        n_micro_batches=len(micro_batches), ref_logprobs=dev(ref), rl_weights=dev(rl_w), ce_weights=dev(ce_w), ref_kl_weights=dev(rk_w),
+        local_counts=(n_rl, n_ce, n_rk),
+    )
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class _Bucket:
+    name: str
+    offset: int  # element offset in the flat buffers
+    size: int  # padded size (multiple of 256 * dp)
+    params: list[tuple[str, int, tuple[int, ...]]] = field(default_factory=list)  # (name, offset within flat, shape)
+
+
+def _align(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+class ParamStore:
+    """Flat bf16 parameters + flat f32 gradients, bucketed per decoder layer; f32 master/Adam state sharded over dp.
+
+    Fused storage: q|k|v projections are one [(Hq+2Hkv)*D, H] matrix and gate|up one [2I, H] matrix (one GEMM each);
+    `state_dict()` exposes HF-named views (q_proj.weight, k_proj.weight, ...) so checkpoints and the weight push keep the
+    reference's names (trainer/models/qwen3/modeling_qwen3.py parameter names)."""
+
+    def __init__(self, dims: ModelDims, device, dp_rank: int = 0, dp_size: int = 1):
+        self.dims, self.device, self.dp_rank, self.dp_size = dims, torch.device(device), dp_rank, dp_size
+        d = dims
+        buckets: list[_Bucket] = []
+        cursor = 0
+
+        def new_bucket(name, plist):
+            nonlocal cursor
+            b = _Bucket(name, cursor, 0)
+            off = cursor
+            for pname, shape in plist:
+                b.params.append((pname, off, shape))
+                off = _align(off + math.prod(shape), 128)
+            b.size = _align(off - cursor, 256 * dp_size)
+            cursor += b.size
+            buckets.append(b)
+
+        new_bucket("embed", [("model.embed_tokens.weight", (d.vocab_size, d.hidden_size))])
+        for i in range(d.num_hidden_layers):
+            p = f"model.layers.{i}."
+            new_bucket(
+                f"layer{i}",
+                [
+                    (p + "input_layernorm.weight", (d.hidden_size,)),
+                    (p + "self_attn.qkv_proj.weight", (d.q_dim + 2 * d.kv_dim, d.hidden_size)),
+                    (p + "self_attn.q_norm.weight", (d.head_dim,)),
+                    (p + "self_attn.k_norm.weight", (d.head_dim,)),
+                    (p + "self_attn.o_proj.weight", (d.hidden_size, d.q_dim)),
+                    (p + "post_attention_layernorm.weight", (d.hidden_size,)),
+                    (p + "mlp.gate_up_proj.weight", (2 * d.intermediate_size, d.hidden_size)),
+                    (p + "mlp.down_proj.weight", (d.hidden_size, d.intermediate_size)),
+                ],
+            )
+        head = [("model.norm.weight", (d.hidden_size,))]
+        if not d.tie_word_embeddings:
+            head.append(("lm_head.weight", (d.vocab_size, d.hidden_size)))
+        new_bucket("head", head)
+        self.buckets = buckets
+        self.total = cursor
+        self.shard_total = cursor // dp_size
+        self.params = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+        self.main_grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.master = torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
+        self.grad_shard = self.main_grad if dp_size == 1 else torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
+        self.w: dict[str, Tensor] = {}
+        self.g: dict[str, Tensor] = {}
+        for b in buckets:
+            for pname, off, shape in b.params:
+                n = math.prod(shape)
+                self.w[pname] = self.params[off:off + n].view(shape)
+                self.g[pname] = self.main_grad[off:off + n].view(shape)
+
+    # -- init ------------------------------------------------------------------------------------------------------
+    def random_init(self, seed: int = 0, std: float = 0.02) -> None:
+        """`config.debug.random_init`-style init (no checkpoints offline): N(0, std) matrices, ones for norms; identical on every rank."""
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.params.zero_()
+        for name, w in self.w.items():
+            if w.dim() == 1:
+                w.fill_(1.0)
+            else:
+                chunk = 1 << 26  # generate in f32 chunks, round to bf16
+                flat = w.view(-1)
+                for s in range(0, flat.numel(), chunk):
+                    e = min(s + chunk, flat.numel())
+                    flat[s:e] = (torch.randn(e - s, device=self.device, generator=gen) * std).to(torch.bfloat16)
+        self.sync_master_from_params()
+
+    def load_state_dict(self, sd: dict[str, Tensor]) -> None:
+        """HF-named tensors (q_proj/k_proj/v_proj, gate_proj/up_proj separate) -> fused flat storage."""
+        d = self.dims
+        for i in range(d.num_hidden_layers):
+            p = f"model.layers.{i}."
+            sd = dict(sd)
+            if p + "self_attn.q_proj.weight" in sd:
+                sd[p + "self_attn.qkv_proj.weight"] = torch.cat([sd.pop(p + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+            if p + "mlp.gate_proj.weight" in sd:
+                sd[p + "mlp.gate_up_proj.weight"] = torch.cat([sd.pop(p + "mlp.gate_proj.weight"), sd.pop(p + "mlp.up_proj.weight")], 0)
+        if d.tie_word_embeddings:
+            sd.pop("lm_head.weight", None)
+        missing = set(self.w) - set(sd)
+        if missing:
+            raise KeyError(f"missing parameters: {sorted(missing)[:4]}...")
+        self.params.zero_()
+        for name, w in self.w.items():
+            w.copy_(sd[name].to(torch.bfloat16))
+        self.sync_master_from_params()
+
+    def state_dict(self) -> dict[str, Tensor]:
+        """HF-named views of the bf16 parameters (no copies)."""
+        d, out = self.dims, {}
+        for name, w in self.w.items():
+            if name.endswith("qkv_proj.weight"):
+                base = name[: -len("qkv_proj.weight")]
+                out[base + "q_proj.weight"] = w[: d.q_dim]
+                out[base + "k_proj.weight"] = w[d.q_dim: d.q_dim + d.kv_dim]
+                out[base + "v_proj.weight"] = w[d.q_dim + d.kv_dim:]
+            elif name.endswith("gate_up_proj.weight"):
+                base = name[: -len("gate_up_proj.weight")]
+                out[base + "gate_proj.weight"] = w[: d.intermediate_size]
+                out[base + "up_proj.weight"] = w[d.intermediate_size:]
+            else:
+                out[name] = w
+        if d.tie_word_embeddings:
+            out["lm_head.weight"] = self.w["model.embed_tokens.weight"]
+        return out
+
+    def shard_slices(self, b: _Bucket) -> tuple[slice, slice]:
+        """(slice of this rank's shard inside the full flat buffers, slice inside the shard-sized buffers) for bucket b."""
+        per = b.size // self.dp_size
+        full = slice(b.offset + self.dp_rank * per, b.offset + (self.dp_rank + 1) * per)
+        local = slice(b.offset // self.dp_size, b.offset // self.dp_size + per)
+        return full, local
+
+    def sync_master_from_params(self) -> None:
+        for b in self.buckets:
+            full, local = self.shard_slices(b)
+            self.master[local].copy_(self.params[full])
+
+    def head_weight(self) -> Tensor:
+        return self.w["model.embed_tokens.weight"] if self.dims.tie_word_embeddings else self.w["lm_head.weight"]
+
+    def head_grad(self) -> Tensor:
+        return self.g["model.embed_tokens.weight"] if self.dims.tie_word_embeddings else self.g["lm_head.weight"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class GRPOEngine:
+    """forward -> log-probs -> GRPO loss -> backward -> (reduce-scatter) -> clip -> AdamW -> (all-gather) for one rank."""
+
+    def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
+                 dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False):
+        self.dims, self.device = dims, torch.device(device)
+        self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
+        self.dp_group = dp_group
+        self.dp_size = dist.get_world_size(dp_group) if (dp_group is not None or dist.is_initialized()) else 1
+        self.dp_rank = dist.get_rank(dp_group) if self.dp_size > 1 else 0
+        if dims.head_dim != 128:
+            raise PrimeMI355XError("attention kernels are built for head_dim 128")
+        self.store = ParamStore(dims, self.device, self.dp_rank, self.dp_size)
+        self.store.random_init(seed)
+        self.inv_freq = ops.rope_inv_freq(dims.head_dim, dims.rope_theta, self.device)
+        self.lm_head_token_chunk = lm_head_token_chunk
+        self.recompute_act = recompute_act
+        self.step_count = 0
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.dp_size > 1 else None
+        self._gather_events: dict[str, torch.cuda.Event] = {}
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._wgrad_direct = self._probe_wgrad_direct()
+        self.k1_events: list | None = None
+
+    # -- GEMM helpers (library calls: hipBLASLt via torch) ------------------------------------------------------------
+    def _probe_wgrad_direct(self) -> bool:
+        """Can the weight-gradient GEMM write/accumulate straight into the f32 gradient buffer (bf16 x bf16 -> f32)?"""
+        try:
+            a = torch.randn(64, 32, device=self.device).to(torch.bfloat16)
+            b = torch.randn(64, 48, device=self.device).to(torch.bfloat16)
+            out = torch.zeros(32, 48, dtype=torch.float32, device=self.device)
+            torch.mm(a.t(), b, out_dtype=torch.float32, out=out)
+            ref = a.float().t() @ b.float()
+            ok = torch.allclose(out, ref, rtol=1e-3, atol=1e-3)
+            torch.addmm(out, a.t(), b, out_dtype=torch.float32, out=out)
+            ok = ok and torch.allclose(out, 2 * ref, rtol=1e-3, atol=2e-3)
+            return bool(ok)
+        except Exception:
+            return False
+
+    def _wgrad(self, dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool) -> None:
+        """gview[out,in] (+)= dy[n,out]^T @ x[n,in] with f32 accumulation."""
+        if self._wgrad_direct:
+            if accumulate:
+                torch.addmm(gview, dy.t(), x, out_dtype=torch.float32, out=gview)
+            else:
+                torch.mm(dy.t(), x, out_dtype=torch.float32, out=gview)
+        else:
+            tmp = torch.mm(dy.t(), x)
+            if not accumulate:
+                gview.zero_()
+            ops.grad_accumulate(gview.view(-1), tmp.view(-1))
+
+    # -- forward ----------------------------------------------------------------------------------------------------
+    def forward(self, b: PackedBatch) -> dict:
+        d, w = self.dims, self.store.w
+        n = b.n_tokens
+        ctx: dict = {"batch": b, "layers": []}
+        self._wait_gather("embed")
+        x = ops.embedding_fwd(w["model.embed_tokens.weight"], b.input_ids)
+        cos, sin = ops.rope_table(b.position_ids, self.inv_freq)
+        seq_start = ops.seq_start_from_cu(b.cu_seqlens, n)
+        ctx.update(cos=cos, sin=sin, seq_start=seq_start)
+        scale = d.head_dim**-0.5
+        pending = None  # mlp output whose residual add is fused into the next RMSNorm
+        for i in range(d.num_hidden_layers):
+            p = f"model.layers.{i}."
+            self._wait_gather(f"layer{i}")
+            if pending is None:
+                h1, rstd1, _ = ops.rmsnorm_fwd(x, w[p + "input_layernorm.weight"], d.rms_norm_eps)
+            else:
+                h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
+            qkv = torch.mm(h1, w[p + "self_attn.qkv_proj.weight"].t())
+            q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], cos, sin,
+                                                 d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.rms_norm_eps)
+            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+            o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+            attn_out = torch.mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"].t())
+            h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
+            gu = torch.mm(h2, w[p + "mlp.gate_up_proj.weight"].t())
+            act = ops.swiglu_fwd(gu)
+            pending = torch.mm(act, w[p + "mlp.down_proj.weight"].t())
+            ctx["layers"].append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2,
+                                      gu=gu, act=None if self.recompute_act else act))
+            x = x2
+        self._wait_gather("head")
+        hf, rstd_f, x_last = ops.rmsnorm_fwd(pending, w["model.norm.weight"], d.rms_norm_eps, residual=x)
+        ctx.update(x_last=x_last, rstd_f=rstd_f, hf=hf)
+        # LM head: materialised bf16 logits per token chunk (kept for backward; 288 GB makes the recompute GEMM unnecessary)
+        wh = self.store.head_weight()
+        logprobs = torch.empty(n, dtype=torch.float32, device=self.device)
+        entropy = torch.empty_like(logprobs)
+        logz = torch.empty_like(logprobs)
+        chunks = []
+        for s in range(0, n, self.lm_head_token_chunk):
+            e = min(s + self.lm_head_token_chunk, n)
+            logits = torch.mm(hf[s:e], wh.t())
+            if self.k1_events is not None:  # HIP events on the launch stream around the log-prob kernel (bench.py roofline)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            lp, en, lz = ops.logprob_entropy_fwd(logits, b.labels[s:e], b.inv_temp[s:e])
+            if self.k1_events is not None:
+                ev1.record()
+                self.k1_events.append((ev0, ev1, e - s, logits.element_size()))
+            logprobs[s:e], entropy[s:e], logz[s:e] = lp, en, lz
+            chunks.append((s, e, logits))
+        ctx.update(logits_chunks=chunks, logprobs=logprobs, entropy=entropy, logz=logz)
+        return ctx
+
+    # -- loss -------------------------------------------------------------------------------------------------------
+    def loss(self, ctx: dict, scales: tuple[int, int, int]) -> dict:
+        b: PackedBatch = ctx["batch"]
+        c = self.loss_cfg
+        params = LossParams(loss_type=_lib.PM_LOSS_IPO if c.type == "ipo" else _lib.PM_LOSS_DEFAULT, dppo_mask_low=c.dppo_mask_low,
+                            dppo_mask_high=c.dppo_mask_high, adv_tau=c.adv_tau, kl_tau=c.kl_tau, ipo_threshold=c.ipo_threshold,
+                            rl_scale=float(max(scales[0], 1)), ce_scale=float(max(scales[1], 1)), ref_kl_scale=float(max(scales[2], 1)), shift=1,
+                            pad_logprob=math.log(1.0 / self.dims.vocab_size))
+        loss, grad, stats, metrics = ops.grpo_loss_fwd_bwd(ctx["logprobs"], b.inference_logprobs, b.advantages, b.loss_mask, b.cu_samples, params,
+                                                           ref_logprobs=b.ref_logprobs, rl_weights=b.rl_weights, ce_weights=b.ce_weights,
+                                                           ref_kl_weights=b.ref_kl_weights, sample_starts_mb=b.sample_starts_mb)
+        ctx.update(loss=loss, grad_logprobs=grad, sample_stats=stats, sample_metrics=metrics)
+        return ctx
+
+    # -- backward ---------------------------------------------------------------------------------------------------
+    def backward(self, ctx: dict, accumulate: bool, last_pass: bool = True) -> None:
+        d, w, g = self.dims, self.store.w, self.store.g
+        b: PackedBatch = ctx["batch"]
+        n = b.n_tokens
+        wh, gh = self.store.head_weight(), self.store.head_grad()
+        hf = ctx["hf"]
+        dhf = torch.empty_like(hf)
+        acc_head = accumulate
+        for s, e, logits in ctx["logits_chunks"]:
+            dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
+            torch.mm(dl, wh, out=dhf[s:e])
+            self._wgrad(dl, hf[s:e], gh, acc_head)
+            acc_head = True
+        ctx["logits_chunks"] = None
+        # tied embeddings: the embedding backward below must accumulate on top of the head gradient
+        emb_accumulate = accumulate or d.tie_word_embeddings
+        dpend = ops.rmsnorm_bwd(dhf, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], self._norm_grad(g["model.norm.weight"], accumulate))
+        self._bucket_done("head", last_pass)
+        # dpend = gradient w.r.t. (x + mlp_out) of the last layer = gradient of both the residual stream and the mlp output
+        dx = dpend
+        scale = d.head_dim**-0.5
+        for i in reversed(range(d.num_hidden_layers)):
+            p = f"model.layers.{i}."
+            L = ctx["layers"][i]
+            act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
+            dact = torch.mm(dx, w[p + "mlp.down_proj.weight"])
+            self._wgrad(dx, act, g[p + "mlp.down_proj.weight"], accumulate)
+            del act
+            dgu = ops.swiglu_bwd(dact, L["gu"])
+            dh2 = torch.mm(dgu, w[p + "mlp.gate_up_proj.weight"])
+            self._wgrad(dgu, L["h2"], g[p + "mlp.gate_up_proj.weight"], accumulate)
+            dx2 = ops.rmsnorm_bwd(dh2, L["x2"], w[p + "post_attention_layernorm.weight"], L["rstd2"],
+                                  self._norm_grad(g[p + "post_attention_layernorm.weight"], accumulate), dresidual=dx)
+            do = torch.mm(dx2, w[p + "self_attn.o_proj.weight"]).view(n, d.num_attention_heads, d.head_dim)
+            self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate)
+            qkv = L["qkv"]
+            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+            dqkv = torch.empty_like(qkv)
+            dv_view = dqkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+            dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
+            ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
+                                L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),
+                                self._norm_grad(g[p + "self_attn.k_norm.weight"], accumulate), d.num_attention_heads, d.num_key_value_heads,
+                                d.head_dim)
+            dh1 = torch.mm(dqkv, w[p + "self_attn.qkv_proj.weight"])
+            self._wgrad(dqkv, L["h1"], g[p + "self_attn.qkv_proj.weight"], accumulate)
+            dx = ops.rmsnorm_bwd(dh1, L["x"], w[p + "input_layernorm.weight"], L["rstd1"],
+                                 self._norm_grad(g[p + "input_layernorm.weight"], accumulate), dresidual=dx2)
+            ctx["layers"][i] = None
+            self._bucket_done(f"layer{i}", last_pass)
+        if not emb_accumulate:
+            g["model.embed_tokens.weight"].zero_()
+        ops.embedding_bwd(dx, b.input_ids, g["model.embed_tokens.weight"])
+        self._bucket_done("embed", last_pass)
+
+    @staticmethod
+    def _norm_grad(gview: Tensor, accumulate: bool) -> Tensor:
+        if not accumulate:
+            gview.zero_()  # the norm-weight kernels accumulate (+=); tiny vectors
+        return gview
+
+    # -- data-parallel plumbing (RCCL on a side stream) ----------------------------------------------------------------
+    def _bucket_done(self, name: str, last_pass: bool) -> None:
+        if self.dp_size == 1 or not last_pass:
+            return
+        b = next(bk for bk in self.store.buckets if bk.name == name)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        _, local = self.store.shard_slices(b)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            dist.reduce_scatter_tensor(self.store.grad_shard[local], self.store.main_grad[b.offset:b.offset + b.size], op=dist.ReduceOp.SUM,
+                                       group=self.dp_group)
+
+    def _wait_gather(self, name: str) -> None:
+        ev = self._gather_events.pop(name, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    # -- optimizer ---------------------------------------------------------------------------------------------------
+    def optimizer_step(self) -> Tensor:
+        """scale_gradients_ + clip_grad_norm_ + AdamW (train.py:557-570) on this rank's shard; returns the global grad norm (device scalar).
+
+        The loss is already divided by the GLOBAL token counts, so summed (not averaged) gradients across ranks are the
+        global per-token mean: the reference's `FSDP mean` followed by `scale_gradients_(x dp)` (train.py:557-558) is the
+        same sum, here done in one reduce-scatter(SUM)."""
+        st, o = self.store, self.optim
+        self.step_count += 1
+        cur = torch.cuda.current_stream()
+        if self.dp_size > 1:
+            cur.wait_stream(self.comm_stream)
+        self._sumsq.zero_()
+        if self.dp_size == 1:
+            ops.sumsq_accumulate(st.main_grad, self._sumsq)
+        else:
+            ops.sumsq_accumulate(st.grad_shard, self._sumsq)
+            dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.dp_group)
+        coef, norm = ops.clip_coef(self._sumsq, 1.0, o.max_norm if o.max_norm else 0.0)
+        if self.dp_size == 1:
+            ops.adamw_step(st.master, st.exp_avg, st.exp_avg_sq, st.main_grad, st.params, o.lr, o.betas1, o.betas2, o.eps, o.weight_decay,
+                           self.step_count, 1.0, coef, zero_grad=False)
+            return norm
+        for b in st.buckets:
+            full, local = st.shard_slices(b)
+            ops.adamw_step(st.master[local], st.exp_avg[local], st.exp_avg_sq[local], st.grad_shard[local], st.params[full], o.lr, o.betas1,
+                           o.betas2, o.eps, o.weight_decay, self.step_count, 1.0, coef, zero_grad=False)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_gather_into_tensor(st.params[b.offset:b.offset + b.size], st.params[full], group=self.dp_group)
+                gev = torch.cuda.Event()
+                gev.record(self.comm_stream)
+            self._gather_events[b.name] = gev  # the next forward waits per bucket, so the all-gather overlaps with it
+        return norm
+
+    # -- one full trainer step -------------------------------------------------------------------------------------------
+    def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:
+        """dist.all_reduce of the i64[3] token counts (train.py:318-323)."""
+        if self.dp_size == 1:
+            return tuple(max(c, 1) for c in local_counts)
+        t = torch.tensor(local_counts, dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp_group)
+        return tuple(max(int(c), 1) for c in t.tolist())
+
+    def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:
+        """One optimizer step over one or more packed passes (a list accumulates gradients across passes)."""
+        passes = batch if isinstance(batch, list) else [batch]
+        counts = tuple(sum(p.local_counts[k] for p in passes) for k in range(3))
+        scales = self.global_scales(counts)
+        out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": []}
+        for idx, p in enumerate(passes):
+            ctx = self.forward(p)
+            self.loss(ctx, scales)
+            out["loss"].append(ctx["loss"])
+            out["entropy"].append(ctx["entropy"])
+            out["logprobs"].append(ctx["logprobs"])
+            out["sample_metrics"].append(ctx["sample_metrics"])
+            out["sample_stats"].append(ctx["sample_stats"])
+            self.backward(ctx, accumulate=idx > 0, last_pass=idx == len(passes) - 1)
+            del ctx
+        out["grad_norm"] = self.optimizer_step()
+        out["scales"] = scales
+        return out

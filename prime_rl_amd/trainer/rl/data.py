@@ -1,0 +1,93 @@
+"""Micro-batch sources for the trainer — mirrors `prime_rl.trainer.rl.data` (src/prime_rl/trainer/rl/data.py).
+
+`TensorMicroBatch` keeps the reference's field names and shapes ([1, seq] CPU tensors; data.py:18-52) so the engine consumes
+what `DataLoader.get_batch()` hands over.  `FakeDataLoader` reproduces the reference's synthetic batches value-for-value
+(same torch.Generator seeds and draw order, data.py:55-159): it is the input of the benchmark and of the parity tests
+("identical rollout batches").
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import TypedDict
+
+import torch
+from torch import Tensor
+
+
+class TensorMicroBatch(TypedDict, total=False):
+    input_ids: Tensor  # i64 [1, seq]
+    position_ids: Tensor  # i64 [1, seq]
+    advantages: Tensor  # f32 [1, seq]
+    inference_logprobs: Tensor  # f32 [1, seq]
+    ref_logprobs: Tensor | None
+    loss_mask: Tensor  # bool [1, seq]
+    temperatures: Tensor  # f32 [1, seq]
+    env_names: list[str]
+    sequence_lengths: list[int]
+    lora_num_tokens: Tensor
+    seq_lens: Tensor  # i64 [docs]
+    routed_experts: Tensor | None
+    mm_kwargs: dict | None
+    mm_token_type_ids: Tensor | None
+    rl_weights: Tensor | None
+    ce_weights: Tensor | None
+    ref_kl_weights: Tensor | None
+
+
+@dataclass
+class FakeDataLoaderConfig:
+    """FakeDataLoaderConfig (packages/prime-rl-configs/src/prime_rl/configs/trainer.py): global batch size in micro-batches."""
+
+    batch_size: int = 2
+    generate_samples: bool = False
+
+
+class FakeDataLoader:
+    """Deterministic synthetic micro-batches; seed = dp_rank*1_000_000 + batch_counter*1000 + micro_idx (data.py:79-82)."""
+
+    def __init__(self, config: FakeDataLoaderConfig, seq_len: int, dp_world_size: int = 1, dp_rank: int = 0):
+        self.dp_rank = dp_rank
+        self.num_micro_batches = config.batch_size // dp_world_size
+        self.seq_len = seq_len
+        self.generate_samples = config.generate_samples
+        self.batch_counter = 0
+
+    def wait_for_batch(self) -> None:
+        return
+
+    def get_batch(self) -> list[TensorMicroBatch]:
+        make = self._packed_documents if self.generate_samples else self._single_document
+        out = []
+        for micro_idx in range(self.num_micro_batches):
+            gen = torch.Generator().manual_seed(self.dp_rank * 1_000_000 + self.batch_counter * 1000 + micro_idx)
+            out.append(make(gen))
+        self.batch_counter += 1
+        return out
+
+    @staticmethod
+    def _finish(ids: Tensor, pos: Tensor, doc_lens: list[int], gen: torch.Generator) -> TensorMicroBatch:
+        n = ids.numel()
+        adv = torch.randn(n, generator=gen)  # draw order matters: advantages before inference_logprobs
+        inf = torch.randn(n, generator=gen)
+        return TensorMicroBatch(
+            input_ids=ids.view(1, n), position_ids=pos.view(1, n), advantages=adv.view(1, n), inference_logprobs=inf.view(1, n), ref_logprobs=None,
+            temperatures=torch.ones(1, n), env_names=["fake"] * n, sequence_lengths=list(doc_lens), loss_mask=torch.ones(1, n, dtype=torch.bool),
+            lora_num_tokens=torch.tensor([n], dtype=torch.int32), seq_lens=torch.tensor(doc_lens, dtype=torch.long), routed_experts=None,
+            mm_kwargs=None, mm_token_type_ids=None, rl_weights=None, ce_weights=None, ref_kl_weights=None,
+        )
+
+    def _single_document(self, gen: torch.Generator) -> TensorMicroBatch:
+        ids = torch.randint(0, 100, (1, self.seq_len), generator=gen).view(-1)
+        return self._finish(ids, torch.arange(self.seq_len), [self.seq_len], gen)
+
+    def _packed_documents(self, gen: torch.Generator) -> TensorMicroBatch:
+        total, ids, pos, lens = 0, [], [], []
+        while total < self.seq_len:
+            ln = int(torch.randint(1, self.seq_len // 8, (1,), generator=gen).item())
+            ln = min(ln, self.seq_len - total)
+            total += ln
+            lens.append(ln)
+            ids.append(torch.randint(0, 120000, (ln,), generator=gen).long())
+            pos.append(torch.arange(ln))
+        return self._finish(torch.cat(ids), torch.cat(pos), lens, gen)

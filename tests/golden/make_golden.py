@@ -183,6 +183,28 @@ def main() -> None:
     run_loss("default", 3, [50, 30, 17], cfgm.DefaultLossConfig(), False)
     run_loss("default_weights", 4, [40, 25, 9, 31], cfgm.DefaultLossConfig(), True)
     run_loss("ipo", 5, [64, 33], cfgm.IPOLossConfig(), False)
+
+    # ---- 5. FakeDataLoader micro-batches (trainer/rl/data.py:55-159): the synthetic rollout batches of the benchmark
+    world = types.ModuleType("prime_rl.trainer.world")
+    world.get_world = lambda: types.SimpleNamespace(world_size=2, rank=1)
+    sys.modules["prime_rl.trainer.world"] = world
+    tr = types.ModuleType("prime_rl.transports.rollouts")
+    tr.MicroBatch = tr.MicroBatchReceiver = tr.TransportConfig = object
+    tr.setup_micro_batch_receiver = lambda *a, **k: None
+    sys.modules["prime_rl.transports"] = types.ModuleType("prime_rl.transports")
+    sys.modules["prime_rl.transports.rollouts"] = tr
+    cfgm.FakeDataLoaderConfig = object
+    data = _load("ref_data", "prime_rl/trainer/rl/data.py")
+    arrs = {}
+    for gen_samples in (False, True):
+        dl = data.FakeDataLoader(types.SimpleNamespace(batch_size=4, generate_samples=gen_samples), seq_len=96, dp_world_size=2)
+        for step in range(2):
+            for mi, mb in enumerate(dl.get_batch()):
+                tag = f"g{int(gen_samples)}_s{step}_m{mi}_"
+                for k in ("input_ids", "position_ids", "advantages", "inference_logprobs", "temperatures", "loss_mask", "seq_lens"):
+                    arrs[tag + k] = mb[k].numpy()
+                arrs[tag + "sequence_lengths"] = np.asarray(mb["sequence_lengths"])
+    np.savez_compressed(OUT / "fake_data.npz", **arrs)
     print("golden fixtures written to", OUT)
 
 

@@ -145,7 +145,8 @@ def test_logprob_bwd(ops, in_dt, out_dt):
     tol = 1e-6 if out_dt == torch.float32 else 4e-3
     _close(dl, want, tol if out_dt == torch.bfloat16 else 1e-4, 1e-6 if out_dt == torch.float32 else 1e-6, "dlogits")
     assert not dl[::5].float().any(), "masked rows must be exactly zero"
-    _close(dl.float().sum(-1), torch.zeros(n), 0, 2e-3 if out_dt == torch.bfloat16 else 1e-4, "rows of dlogits sum to zero")
+    # sum_v dlogits = a*(1 - sum softmax) = 0; with bf16 outputs each of the 151936 terms carries up to 2^-9 relative rounding
+    _close(dl.float().sum(-1), torch.zeros(n), 0, 5e-2 if out_dt == torch.bfloat16 else 1e-4, "rows of dlogits sum to zero")
     if in_dt == out_dt:  # in place
         buf = logits.clone()
         ops.logprob_bwd(buf, labels, inv_t, logz, grad, out=buf)
@@ -447,7 +448,7 @@ def test_adamw_sumsq_clip(ops):
         ops.adamw_step(master, m, v, grad_step, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=1.0, clip=coef, zero_grad=True)
         assert not grad_step.any(), "zero_grad"
     _close(master[:n], p.detach(), 1e-6, 1e-7, "AdamW master weights")  # reference bound tests/unit/train/test_cpu_adam.py:34-134
-    assert torch.equal(pb[:n].cpu(), p.detach().to(torch.bfloat16)) or (pb[:n].cpu().float() - p.detach()).abs().max() < 1e-2
+    assert torch.equal(pb, master.to(torch.bfloat16)), "bf16 compute copy must be the RNE rounding of the updated master weights"
     mg = torch.zeros(4096 + 8, device=DEV)
     gb = torch.randn(4096 + 8).to(torch.bfloat16).to(DEV)
     ops.grad_accumulate(mg, gb)
