@@ -137,7 +137,7 @@ def main() -> None:
                 "step_includes": "scale all-reduce, forward, log-prob, GRPO loss, backward, grad reduce-scatter, clip, AdamW, param all-gather",
                 "mfu_vs_2.5PF_bf16": round(value * flops_per_sample / (world * MFMA_BF16_PEAK), 4),
                 "tflop_per_sample": round(flops_per_sample / 1e12, 2),
-                "loss_last": float(losses[-1].item()),
+                "loss_last": float(sum(l.item() for l in losses[-1])),
             },
             "roofline": {
                 "kernel": f"logprob_fwd_row_kernel<{'bf16' if esz == 2 else 'f32'}> (selective log-softmax + entropy)",
