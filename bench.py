@@ -156,15 +156,16 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_trainer import time_cpu_baseline
 
-            cpu = time_cpu_baseline(dims, seq_len=args.seq_len, layers_timed=1)
+            cpu = time_cpu_baseline(dims, seq_len=args.seq_len)
             result["cpu_baseline"] = {
                 "value": round(1.0 / cpu["seconds_per_sample"], 6),
                 "unit": "samples/s",
                 "cores": cpu["threads"],
                 "kind": "port",
-                "sample": f"oracle/cpu_trainer.py f32 torch-CPU port on one {args.seq_len}-token rollout: 1 of {dims.num_hidden_layers} decoder layers fwd+bwd "
-                          f"({cpu['t_layers']:.2f}s) x{dims.num_hidden_layers}, full-vocab LM head + loss ({cpu['t_head_loss']:.2f}s), AdamW scaled by parameter count "
-                          f"({cpu['t_opt']:.2f}s on the slice); extrapolated",
+                "sample": f"oracle/cpu_trainer.py (f32 torch-CPU port of the reference step) on a {cpu['sample_tokens']}-token rollout prefix: one decoder layer fwd+bwd "
+                          f"{cpu['t_layer']:.2f}s (x{dims.num_hidden_layers} layers), full-vocab LM head + log-probs + loss fwd+bwd {cpu['t_head_loss']:.2f}s, AdamW on "
+                          f"{cpu['opt_params'] >> 20}Mi params {cpu['t_opt']:.2f}s (x params/{cpu['opt_params'] >> 20}Mi); scaled linearly to {args.seq_len} tokens "
+                          f"(ignores quadratic attention: favours the CPU)",
             }
         print(json.dumps(result), flush=True)
     if world > 1:

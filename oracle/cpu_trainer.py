@@ -70,41 +70,54 @@ def train_step(params: dict, cfg, micro_batches: list[dict], opt: torch.optim.Op
     return loss.detach(), norm, lps, ents
 
 
-def time_cpu_baseline(dims, seq_len: int = 2048, layers_timed: int = 1, threads: int | None = None) -> dict:
-    """Bounded CPU sample of the Qwen3 GRPO step: `layers_timed` decoder layers + the full-vocab LM head + loss + AdamW on one
-    `seq_len`-token rollout, f32, all host cores.  Extrapolated to the full depth: t = t_layers*(L/layers_timed) + t_head + t_opt*(P/P_timed)."""
+def time_cpu_baseline(dims, seq_len: int = 2048, sample_tokens: int = 512, opt_params: int = 64 * 1024 * 1024, threads: int | None = None) -> dict:
+    """Bounded CPU sample (~10-30 s of host work) of the Qwen3 GRPO step, f32, all host cores:
+      (a) ONE decoder layer forward+backward on a `sample_tokens`-token rollout prefix,
+      (b) the full-vocab LM head + log-probs + loss forward+backward on the same tokens,
+      (c) AdamW on `opt_params` parameters.
+    Extrapolation to one `seq_len`-token sample of the full model (linear in tokens — this ignores the quadratic attention
+    term and therefore FAVOURS the CPU): t = (a*L + b) * seq_len/sample_tokens + c * P/opt_params."""
     import os
 
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
-    cfg = O.TinyQwen3Config(hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=layers_timed,
+    cfg = O.TinyQwen3Config(hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=1,
                             num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=dims.head_dim,
                             vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta)
     params = {k: v.float().requires_grad_(True) for k, v in O.init_qwen3_params(cfg, seed=0, dtype=torch.float32).items()}
+    n = sample_tokens
     g = torch.Generator().manual_seed(0)
-    ids = torch.randint(0, 100, (1, seq_len), generator=g)
-    mb = dict(input_ids=ids, position_ids=torch.arange(seq_len)[None], advantages=torch.randn(1, seq_len, generator=g),
-              inference_logprobs=torch.randn(1, seq_len, generator=g), temperatures=torch.ones(1, seq_len), loss_mask=torch.ones(1, seq_len, dtype=torch.bool),
-              seq_lens=torch.tensor([seq_len]))
-    layer_keys = [k for k in params if k.startswith("model.layers.")]
-    n_layer_params = sum(params[k].numel() for k in layer_keys)
-    n_other = sum(v.numel() for k, v in params.items() if k not in layer_keys)
-    opt = torch.optim.AdamW(list(params.values()), lr=1e-6, weight_decay=0.01)
-
-    # (a) decoder layers only: forward+backward of the hidden-state path
+    ids = torch.randint(0, 100, (1, n), generator=g)
+    mb = dict(input_ids=ids, position_ids=torch.arange(n)[None], advantages=torch.randn(1, n, generator=g), inference_logprobs=torch.randn(1, n, generator=g),
+              temperatures=torch.ones(1, n), loss_mask=torch.ones(1, n, dtype=torch.bool), seq_lens=torch.tensor([n]))
+    # (a) decoder layer: forward + backward of the hidden-state path
     t0 = time.perf_counter()
-    h = O.qwen3_forward(params, cfg, ids[0], mb["position_ids"][0], [seq_len])
+    h = O.qwen3_forward(params, cfg, ids[0], mb["position_ids"][0], [n])
     h.float().square().mean().backward()
-    t_layers = time.perf_counter() - t0
-    opt.zero_grad(set_to_none=True)
-    # (b) full step on the slice: layers + head + loss + clip + AdamW
+    t_layer = time.perf_counter() - t0
+    for p in params.values():
+        p.grad = None
+    # (b) LM head + log-probs + loss on detached hidden states
+    hd = h.detach().requires_grad_(True)
     t0 = time.perf_counter()
-    train_step(params, cfg, [mb], opt)
-    t_full = time.perf_counter() - t0
+    labels = torch.cat([ids[0, 1:], ids.new_zeros(1)])
+    logits = (hd @ params["lm_head.weight"].T).float() / mb["temperatures"][0][:, None]
+    lp = torch.log_softmax(logits, dim=-1).gather(-1, labels[:, None])[:, 0]
+    with torch.no_grad():
+        _ = torch.logsumexp(logits, -1) - (torch.softmax(logits, -1) * logits).sum(-1)
+    lp_s = torch.cat([lp.new_full((1,), math.log(1.0 / dims.vocab_size)), lp[:-1]])
+    loss = default_loss_torch(lp_s, mb["inference_logprobs"][0], mb["advantages"][0], mb["loss_mask"][0], O.LossConfig()) / n
+    loss.backward()
+    t_head = time.perf_counter() - t0
+    # (c) AdamW on a fixed-size flat parameter
+    flat = torch.randn(opt_params).requires_grad_(True)
+    flat.grad = torch.randn(opt_params)
+    opt = torch.optim.AdamW([flat], lr=1e-6, weight_decay=0.01)
+    opt.step()  # state init
     t0 = time.perf_counter()
-    opt.step()  # (c) optimizer alone on the slice (grads still present)
+    opt.step()
     t_opt = time.perf_counter() - t0
-    t_head = max(t_full - t_layers - t_opt, 0.0)
-    n_total = dims.num_params()
-    est = t_layers * (dims.num_hidden_layers / layers_timed) + t_head + t_opt * (n_total / (n_layer_params + n_other))
-    return dict(seconds_per_sample=est, t_layers=t_layers, t_head_loss=t_head, t_opt=t_opt, threads=threads, layers_timed=layers_timed, seq_len=seq_len)
+    scale = seq_len / sample_tokens
+    est = (t_layer * dims.num_hidden_layers + t_head) * scale + t_opt * (dims.num_params() / opt_params)
+    return dict(seconds_per_sample=est, t_layer=t_layer, t_head_loss=t_head, t_opt=t_opt, threads=threads, sample_tokens=sample_tokens, opt_params=opt_params,
+                seq_len=seq_len)

@@ -21,6 +21,7 @@
 //     q tiles are issued heaviest-first (causal imbalance).
 //   * backward is two kernels (dK/dV per kv tile, dQ per q tile): no atomics, bitwise reproducible.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace pm {
 
@@ -437,7 +438,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   }
 }
 
+#include "attention_v2.cuh"
+
 static inline int64_t pad64(int64_t n) { return cdiv(n, 64) * 64; }
+static bool use_v1() {
+  static const bool v1 = getenv("PM_ATTN_V1") != nullptr;  // A/B switch for the correct-first v1 kernels
+  return v1;
+}
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 
 static int launch_transpose(const bf16_t* src, int64_t row_stride, int64_t n, int64_t n_pad, int heads, bf16_t* dst, hipStream_t st) {
@@ -479,8 +486,15 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   int rc = launch_transpose((const bf16_t*)v, v_row_stride, n_tokens, n_pad, n_kv_heads, vt, st);
   if (rc != PM_OK) return rc;
   const int64_t tiles = cdiv(n_tokens, 128);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
-                     n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  if (use_v1())
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
+                       n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  else if (getenv("PM_ATTN_FWD_OCC2") != nullptr)  // A/B: 2 workgroups per CU with spills vs 1 without
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<2>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
+                       n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  else
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<1>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
+                       n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
   PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
   return PM_OK;
 }
@@ -522,13 +536,23 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, n,
                      n_q_heads, delta);
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(delta)");
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                     (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
-                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
-  PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(cdiv(n, 64) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                     (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
-                     softmax_scale, (bf16_t*)grad_q);
+  if (use_v1()) {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                       softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(cdiv(n, 64) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                       softmax_scale, (bf16_t*)grad_q);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_v2_kernel, dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                       softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
+    hipLaunchKernelGGL(attn_bwd_dq_v2_kernel, dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                       softmax_scale, (bf16_t*)grad_q);
+  }
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dq)");
   return PM_OK;
 }

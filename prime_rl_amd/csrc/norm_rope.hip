@@ -285,28 +285,39 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     dwk[k] += __shfl_xor(dwk[k], 16, 64);
     dwk[k] += __shfl_xor(dwk[k], 32, 64);
   }
+  // ... then the 4 waves of the block through LDS: one partial row [q 128 | k 128] per block
+  __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane < 16) {
-    float* p = dw_partials + ((int64_t)blockIdx.x * 4 + wave) * 256;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      p[lane * 8 + k] = dwq[k];
-      p[128 + lane * 8 + k] = dwk[k];
+      red[wave][lane * 8 + k] = dwq[k];
+      red[wave][128 + lane * 8 + k] = dwk[k];
     }
   }
+  __syncthreads();
+  dw_partials[(int64_t)blockIdx.x * 256 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void qk_dw_reduce_kernel(const float* __restrict__ partials, int64_t n_partials, float* __restrict__ gqw, float* __restrict__ gkw) {
-  const int c = threadIdx.x;  // 256 threads: [0,128) q, [128,256) k
-  float s = 0.f;
-  for (int64_t p = 0; p < n_partials; ++p) s += partials[p * 256 + c];
+  const int c = threadIdx.x;  // 256 threads: [0,128) q, [128,256) k; coalesced rows, 4 independent chains
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t p = 0;
+  for (; p + 3 < n_partials; p += 4) {
+    s0 += partials[(p + 0) * 256 + c];
+    s1 += partials[(p + 1) * 256 + c];
+    s2 += partials[(p + 2) * 256 + c];
+    s3 += partials[(p + 3) * 256 + c];
+  }
+  for (; p < n_partials; ++p) s0 += partials[p * 256 + c];
+  const float s = (s0 + s1) + (s2 + s3);
   if (c < 128) gqw[c] += s;
   else gkw[c - 128] += s;
 }
 
 static int64_t qk_bwd_grid(int64_t n_tokens, int nh) {
   int64_t g = cdiv(n_tokens * nh, 16);
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   if (g < 1) g = 1;
   return g;
 }
@@ -448,7 +459,7 @@ extern "C" int pm_qknorm_rope_bwd(const void* grad_q, const void* grad_k, const 
                      (const bf16_t*)qkv, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, rstd, n_tokens,
                      n_q_heads, n_kv_heads, (bf16_t*)grad_qkv, (float*)workspace);
   PM_CHECK_LAUNCH("pm_qknorm_rope_bwd");
-  hipLaunchKernelGGL(qk_dw_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid * 4, grad_q_norm_w, grad_k_norm_w);
+  hipLaunchKernelGGL(qk_dw_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, grad_q_norm_w, grad_k_norm_w);
   PM_CHECK_LAUNCH("pm_qknorm_rope_bwd(reduce)");
   return PM_OK;
 }

@@ -29,6 +29,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .. import _lib, ops
+from . import zero
 from .._lib import LossParams, PrimeMI355XError
 
 
@@ -522,18 +523,12 @@ class GRPOEngine:
             gview.zero_()  # the norm-weight kernels accumulate (+=); tiny vectors
         return gview
 
-    # -- data-parallel plumbing (RCCL on a side stream) ----------------------------------------------------------------
+    # -- data-parallel plumbing (RCCL on a side stream; trainer/zero.py) -------------------------------------------------
     def _bucket_done(self, name: str, last_pass: bool) -> None:
         if self.dp_size == 1 or not last_pass:
             return
         b = next(bk for bk in self.store.buckets if bk.name == name)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        _, local = self.store.shard_slices(b)
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ev)
-            dist.reduce_scatter_tensor(self.store.grad_shard[local], self.store.main_grad[b.offset:b.offset + b.size], op=dist.ReduceOp.SUM,
-                                       group=self.dp_group)
+        zero.reduce_scatter_bucket(self.store, b, self.dp_group, self.comm_stream)
 
     def _wait_gather(self, name: str) -> None:
         ev = self._gather_events.pop(name, None)
@@ -547,44 +542,13 @@ class GRPOEngine:
         The loss is already divided by the GLOBAL token counts, so summed (not averaged) gradients across ranks are the
         global per-token mean: the reference's `FSDP mean` followed by `scale_gradients_(x dp)` (train.py:557-558) is the
         same sum, here done in one reduce-scatter(SUM)."""
-        st, o = self.store, self.optim
         self.step_count += 1
-        cur = torch.cuda.current_stream()
-        if self.dp_size > 1:
-            cur.wait_stream(self.comm_stream)
-        self._sumsq.zero_()
-        if self.dp_size == 1:
-            ops.sumsq_accumulate(st.main_grad, self._sumsq)
-        else:
-            ops.sumsq_accumulate(st.grad_shard, self._sumsq)
-            dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.dp_group)
-        coef, norm = ops.clip_coef(self._sumsq, 1.0, o.max_norm if o.max_norm else 0.0)
-        if self.dp_size == 1:
-            ops.adamw_step(st.master, st.exp_avg, st.exp_avg_sq, st.main_grad, st.params, o.lr, o.betas1, o.betas2, o.eps, o.weight_decay,
-                           self.step_count, 1.0, coef, zero_grad=False)
-            return norm
-        for b in st.buckets:
-            full, local = st.shard_slices(b)
-            ops.adamw_step(st.master[local], st.exp_avg[local], st.exp_avg_sq[local], st.grad_shard[local], st.params[full], o.lr, o.betas1,
-                           o.betas2, o.eps, o.weight_decay, self.step_count, 1.0, coef, zero_grad=False)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                dist.all_gather_into_tensor(st.params[b.offset:b.offset + b.size], st.params[full], group=self.dp_group)
-                gev = torch.cuda.Event()
-                gev.record(self.comm_stream)
-            self._gather_events[b.name] = gev  # the next forward waits per bucket, so the all-gather overlaps with it
-        return norm
+        return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.dp_group, ops, self.comm_stream, self._gather_events, self._sumsq)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:
         """dist.all_reduce of the i64[3] token counts (train.py:318-323)."""
-        if self.dp_size == 1:
-            return tuple(max(c, 1) for c in local_counts)
-        t = torch.tensor(local_counts, dtype=torch.int64, device=self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp_group)
-        return tuple(max(int(c), 1) for c in t.tolist())
+        return zero.all_reduce_counts(local_counts, self.dp_group, self.device)
 
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:
         """One optimizer step over one or more packed passes (a list accumulates gradients across passes)."""

@@ -1,0 +1,156 @@
+"""LM-head seam — mirrors `prime_rl.trainer.models.layers.lm_head` (src/prime_rl/trainer/models/layers/lm_head.py).
+
+Same names and call contract: `PrimeLmOutput` (a TypedDict so pytree hooks see tensors, lm_head.py:14-20),
+`FusedOutputLinear(in, out, chunk_size)(hidden[b,s,h], labels[b,s], temperature=[b,s]) -> {logprobs, entropy}`,
+`VanillaOutputLinear`, `inject_prime_lm_head(model, chunk_size)`.  The per-chunk epilogue of the reference
+(~10 eager passes over a 64 MiB f32 chunk, lm_head.py:118-148 and :184-191) is one HIP kernel per chunk:
+`pm_logprob_chunk_update` forward, `pm_logprob_chunk_bwd` backward (in place on the chunk).  The chunk GEMMs stay library
+calls.  Vocab chunks default to 32768 columns: a [8192 x 32768] bf16 chunk is 512 MiB... so the token chunk is what bounds
+memory; with 2k-16k tokens the chunk lives in HBM/Infinity Cache between the GEMM and the epilogue.
+"""
+
+from __future__ import annotations
+
+import types
+from typing import TypedDict
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .... import ops
+
+VOCAB_CHUNK = 8192  # the reference's vocab_chunk_size = min(vocab, 8192) (lm_head.py:112)
+
+
+class PrimeLmOutput(TypedDict, total=False):
+    logits: Tensor | None
+    logprobs: Tensor | None
+    entropy: Tensor | None
+    loss: Tensor | None
+
+
+def cast_float_and_contiguous(output: PrimeLmOutput) -> PrimeLmOutput:
+    """lm_head.py:23-34."""
+
+    def f(t):
+        return t.float().contiguous() if t is not None else None
+
+    return PrimeLmOutput(logits=f(output.get("logits")), logprobs=f(output.get("logprobs")), entropy=f(output.get("entropy")), loss=output.get("loss"))
+
+
+class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
+    """Token-chunk x vocab-chunk log-prob / entropy without materialising [N, V] (lm_head.py:89-202)."""
+
+    @staticmethod
+    def forward(ctx, hidden: Tensor, weight: Tensor, labels: Tensor, inv_temperature: Tensor, chunk_size: int):
+        assert hidden.dim() == 2, f"expected hidden [N,H], got {tuple(hidden.shape)}"
+        assert weight.dim() == 2, f"expected weight [V,H], got {tuple(weight.shape)}"
+        assert labels.dim() == 1, f"expected labels [N], got {tuple(labels.shape)}"
+        assert inv_temperature.dim() == 1, f"expected inv_temperature [N], got {tuple(inv_temperature.shape)}"
+        assert hidden.shape[0] == labels.shape[0], "hidden/labels N mismatch"
+        assert hidden.shape[1] == weight.shape[1], "hidden/weight H mismatch"
+        assert hidden.shape[0] == inv_temperature.shape[0], "hidden/inv_temperature N mismatch"
+        assert chunk_size > 0
+        n, vocab = hidden.shape[0], weight.shape[0]
+        vchunk = min(vocab, VOCAB_CHUNK)
+        dev = hidden.device
+        logprobs = torch.empty(n, dtype=torch.float32, device=dev)
+        entropy = torch.empty_like(logprobs)
+        logz = torch.empty_like(logprobs)
+        labels = labels.contiguous()
+        inv_t = inv_temperature.contiguous().float()
+        for start in range(0, n, chunk_size):
+            end = min(start + chunk_size, n)
+            state = ops.ChunkedLogprobState(end - start, dev)
+            lab, it = labels[start:end], inv_t[start:end]
+            for v0 in range(0, vocab, vchunk):
+                v1 = min(v0 + vchunk, vocab)
+                logits = hidden[start:end] @ weight[v0:v1].t()
+                state.update(logits, v0, lab, it)
+            lp, en, lz = state.finalize()
+            logprobs[start:end], entropy[start:end], logz[start:end] = lp, en, lz
+        ctx.set_materialize_grads(False)  # unused entropy output -> grad None, no sync (lm_head.py:150-152)
+        ctx.save_for_backward(hidden, weight, labels, inv_t, logz)
+        ctx.chunk_size = chunk_size
+        return logprobs, entropy
+
+    @staticmethod
+    def backward(ctx, grad_logprobs: Tensor, grad_entropy: Tensor | None):
+        assert grad_entropy is None, "Backward through entropy is not implemented in FusedOutputLinear"
+        assert grad_logprobs is not None, "FusedOutputLinear backward requires logprobs gradients"
+        hidden, weight, labels, inv_t, logz = ctx.saved_tensors
+        chunk_size = ctx.chunk_size
+        n, vocab = hidden.shape[0], weight.shape[0]
+        vchunk = min(vocab, VOCAB_CHUNK)
+        needs_hidden, needs_weight = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_hidden = torch.zeros_like(hidden) if needs_hidden else None
+        grad_weight = torch.zeros_like(weight) if needs_weight else None
+        g = grad_logprobs.contiguous().float()
+        for start in range(0, n, chunk_size):
+            end = min(start + chunk_size, n)
+            h = hidden[start:end]
+            for v0 in range(0, vocab, vchunk):
+                v1 = min(v0 + vchunk, vocab)
+                w = weight[v0:v1]
+                logits = h @ w.t()
+                dl = ops.logprob_bwd(logits, labels[start:end], inv_t[start:end], logz[start:end], g[start:end], out=logits, vocab_start=v0)
+                if needs_hidden:
+                    grad_hidden[start:end].addmm_(dl, w)
+                if needs_weight:
+                    grad_weight[v0:v1].addmm_(dl.t(), h)
+        return grad_hidden, grad_weight, None, None, None
+
+
+class FusedOutputLinear(torch.nn.Linear):
+    def __init__(self, in_features: int, out_features: int, chunk_size: int):
+        super().__init__(in_features, out_features, bias=False)
+        self.chunk_size = chunk_size
+
+    def forward(self, hidden_states: Tensor, labels: Tensor | None = None, temperature: Tensor | None = None) -> PrimeLmOutput:
+        assert labels is not None, "FusedOutputLinear requires labels for chunked logprob computation"
+        assert temperature is not None, "FusedOutputLinear requires per-token temperatures"
+        b, s, h = hidden_states.shape
+        hidden_states = hidden_states.reshape(b * s, h).contiguous()
+        labels = labels.reshape(b * s).contiguous()
+        inv_t = 1.0 / temperature.reshape(b * s).contiguous()
+        logprobs, entropy = _SequenceChunkedLogProbEntropyFn.apply(hidden_states, self.weight, labels, inv_t, self.chunk_size)
+        return PrimeLmOutput(logprobs=logprobs.reshape(b, s), entropy=entropy.reshape(b, s))
+
+
+class VanillaOutputLinear(torch.nn.Linear):
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__(in_features, out_features, bias=False)
+
+    def forward(self, hidden_states: Tensor, labels: Tensor | None = None, temperature: Tensor | None = None) -> PrimeLmOutput:
+        return PrimeLmOutput(logits=super().forward(hidden_states))  # temperature scaling happens in the train loop (train.py:436-443)
+
+
+def inject_prime_lm_head(model: nn.Module, chunk_size: int | None = None) -> None:
+    """Replace `model.lm_head` by a PrimeRL head sharing the same weight Parameter and rebind `model.forward` so labels and
+    temperature reach it (lm_head.py:205-291).  Gemma soft-capping heads are outside this path."""
+    assert hasattr(model, "model"), f"model doesnt have backbone in model.model:\n{model}"
+    assert isinstance(model.model, nn.Module), f"model.model is not a nn.Module: {type(model.model)}\n{model}"
+    assert hasattr(model, "lm_head"), f"model doesnt have lm_head in model.lm_head:\n{model}"
+    assert isinstance(model.lm_head, nn.Linear), f"model.lm_head is not a nn.Linear: {type(model.lm_head)}\n{model}"
+    assert not hasattr(model.lm_head, "bias") or model.lm_head.bias is None, f"model.lm_head.bias is not supported: {model.lm_head}\n{model}"
+    old = model.lm_head
+    if isinstance(chunk_size, int):
+        model.lm_head = FusedOutputLinear(in_features=old.in_features, out_features=old.out_features, chunk_size=chunk_size)
+    else:
+        model.lm_head = VanillaOutputLinear(in_features=old.in_features, out_features=old.out_features)
+    model.lm_head.weight = old.weight
+    del old
+
+    def new_forward(self, input_ids=None, position_ids=None, inputs_embeds=None, labels=None, logits_to_keep: int = 0, temperature=None, **kwargs):
+        if position_ids is None and kwargs.get("pixel_values") is None:
+            ref = input_ids if input_ids is not None else inputs_embeds
+            position_ids = torch.arange(1, ref.shape[1] + 1, device=ref.device).unsqueeze(0)
+        mk = {"input_ids": input_ids, "position_ids": position_ids, **kwargs}
+        if inputs_embeds is not None:
+            mk["inputs_embeds"] = inputs_embeds
+        hs = self.model(**mk).last_hidden_state
+        sl = slice(-logits_to_keep, None) if isinstance(logits_to_keep, int) and logits_to_keep > 0 else slice(None)
+        return self.lm_head(hs[:, sl, :], labels[:, sl] if labels is not None else None, temperature=temperature[:, sl] if temperature is not None else None)
+
+    model.forward = types.MethodType(new_forward, model)

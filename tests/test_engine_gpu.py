@@ -78,9 +78,19 @@ def test_engine_step_matches_oracle(packed):
     mask = torch.cat([mb["loss_mask"][0] for mb in mbs])
     d_lp = (lp_shift - lp_ref).abs()[mask]
     print(f"logprob max|d|={d_lp.max():.3e} mean|d|={d_lp.mean():.3e}; loss engine={ctx['loss'].item():.6f} oracle={loss_o.item():.6f}")
-    assert d_lp.max() < 2e-2 and d_lp.mean() < 2e-3
+    # Both bf16 backbones (engine on the GPU, oracle's bf16 CPU port) are compared with the SAME model in f32: the engine must
+    # be as close to the f32 truth as the reference-style bf16 computation is (GEMM accumulation order is the only difference).
+    params32 = {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        _, lps32, ents32 = C.step_logprobs_and_loss(params32, cfg, mbs, O.LossConfig(), rl_scale)
+    lp32 = torch.cat(lps32)
+    e_eng, e_ora = (lp_shift - lp32).abs()[mask], (lp_ref - lp32).abs()[mask]
+    print(f"vs f32 truth: engine mean {e_eng.mean():.3e} max {e_eng.max():.3e} | bf16 CPU port mean {e_ora.mean():.3e} max {e_ora.max():.3e}")
+    assert e_eng.mean() <= 1.5 * e_ora.mean() + 1e-4 and e_eng.max() <= 2.0 * e_ora.max() + 2e-3
+    assert d_lp.mean() < 2e-3
     ent_shift = torch.cat([torch.cat([torch.tensor([math.log(dims.vocab_size)]), ctx["entropy"].cpu()[i * n:(i + 1) * n - 1]]) for i in range(2)])
-    assert (ent_shift - torch.cat(ents_o)).abs().max() < 2e-2
+    ent32 = torch.cat(ents32)
+    assert (ent_shift - ent32).abs().max() <= 2.0 * (torch.cat(ents_o) - ent32).abs().max() + 2e-3
     # DPPO trust-region mask flips between the two backbones, reported separately from the smooth error
     inf = torch.cat([mb["inference_logprobs"][0] for mb in mbs])
     adv = torch.cat([mb["advantages"][0] for mb in mbs])
