@@ -439,8 +439,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 #include "attention_v2.cuh"
+#include "attention_v3.cuh"
 
 static inline int64_t pad64(int64_t n) { return cdiv(n, 64) * 64; }
+static bool use_v2() {
+  static const bool v2 = getenv("PM_ATTN_V2") != nullptr;  // A/B switch: LDS round-trip kernels
+  return v2;
+}
+static bool occ1() {
+  static const bool o = getenv("PM_ATTN_OCC1") != nullptr;  // A/B switch: 1 workgroup per CU (no register cap)
+  return o;
+}
 static bool use_v1() {
   static const bool v1 = getenv("PM_ATTN_V1") != nullptr;  // A/B switch for the correct-first v1 kernels
   return v1;
@@ -475,7 +484,8 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   PM_REQUIRE(q && k && v && seq_start && out && lse, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: null pointer");
   PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "pm_attn_varlen_fwd: head_dim=%d (only 128 is built)", head_dim);
   PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: bad head counts");
-  PM_REQUIRE(n_tokens >= 0 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: bad sizes");
+  PM_REQUIRE(n_tokens >= 0 && n_tokens < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
+             "pm_attn_varlen_fwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
   const int64_t need = pm_attn_fwd_workspace_bytes(n_tokens, n_kv_heads, head_dim);
   PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_attn_varlen_fwd: workspace %lld < %lld", (long long)workspace_bytes,
@@ -488,6 +498,12 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   const int64_t tiles = cdiv(n_tokens, 128);
   if (use_v1())
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
+                       n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  else if (!use_v2() && occ1())
+    hipLaunchKernelGGL((attn_fwd_v3_kernel<1>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
+                       n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  else if (!use_v2())
+    hipLaunchKernelGGL((attn_fwd_v3_kernel<2>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
                        n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
   else if (getenv("PM_ATTN_FWD_OCC2") != nullptr)  // A/B: 2 workgroups per CU with spills vs 1 without
     hipLaunchKernelGGL((attn_fwd_v2_kernel<2>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
@@ -544,6 +560,19 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(cdiv(n, 64) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                        softmax_scale, (bf16_t*)grad_q);
+  } else if (!use_v2()) {
+    hipLaunchKernelGGL(attn_bwd_dkdv_v3_kernel, dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                       softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
+    if (occ1())
+      hipLaunchKernelGGL((attn_bwd_dq_v3_kernel<1>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_q);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_v3_kernel<2>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_q);
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_v2_kernel, dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,

@@ -125,18 +125,18 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v2_kernel(const bf16_t* __
           s[rb][nb][r] = v;
           mx = fmaxf(mx, v);
         }
-        mx = group16_max(mx);
+        mx = row16_max(mx);
         const float m_new = fmaxf(m[rb][r], mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m[rb][r] - m_use);
+        const float alpha = fast_exp2(m[rb][r] - m_use);
         float sum = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-          const float p = exp2f(s[rb][nb][r] - m_use);
+          const float p = fast_exp2(s[rb][nb][r] - m_use);
           s[rb][nb][r] = p;
           sum += p;
         }
-        sum = group16_sum(sum);
+        sum = row16_sum(sum);
         l[rb][r] = l[rb][r] * alpha + sum;
         m[rb][r] = m_new;
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v2_kernel(const bf16_t* __
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ps[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16(s[rb][nb][r]);
+        for (int r = 0; r < 4; ++r) Ps[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16_hw(s[rb][nb][r]);
     lds_fence();
 #pragma unroll
     for (int kk2 = 0; kk2 < 2; ++kk2) {
@@ -294,10 +294,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_v2_kernel(const bf16_t* __r
           for (int r = 0; r < 4; ++r) {
             const int64_t kvr = kvb + rb * 16 + lq * 4 + r;
             const bool ok = (qcol < n) && (kvr <= qcol) && (kvr >= lo);
-            const float p = ok ? exp2f(st[rb][nb][r] * sc2 - L2) : 0.f;
+            const float p = ok ? fast_exp2(st[rb][nb][r] * sc2 - L2) : 0.f;
             const float ds = p * (dpt[rb][nb][r] - Dl) * scale;
-            Pt[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16(p);
-            dSt[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16(ds);
+            Pt[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16_hw(p);
+            dSt[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16_hw(ds);
           }
         }
       }
@@ -437,9 +437,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_v2_kernel(const bf16_t* __
         for (int r = 0; r < 4; ++r) {
           const int64_t row = q0 + rb * 16 + lq * 4 + r;
           const bool ok = (col <= row) && (col >= (int64_t)lo[rb][r]) && (row < n);
-          const float p = ok ? exp2f(s[rb][nb][r] * sc2 - L2[rb][r]) : 0.f;
+          const float p = ok ? fast_exp2(s[rb][nb][r] * sc2 - L2[rb][r]) : 0.f;
           const float ds = p * (dp[rb][nb][r] - Dl[rb][r]) * scale;
-          dSs[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16(ds);
+          dSs[w][rb * 16 + lq * 4 + r][nb * 16 + lr] = f32_to_bf16_hw(ds);
         }
       }
     lds_fence();

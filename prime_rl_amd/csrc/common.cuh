@@ -79,6 +79,36 @@ __device__ __forceinline__ float group16_max(float v) {
   return v;
 }
 
+// 16-lane row reductions on the DPP path (VALU speed; __shfl_xor is an LDS-pipe ds_bpermute with ~100-cycle latency).
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_ror:4 = 0x124, row_ror:8 = 0x128: every lane of a row gets the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x124>(v));
+  v = fmaxf(v, dpp_f32<0x128>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x124>(v);
+  v += dpp_f32<0x128>(v);
+  return v;
+}
+// hardware conversions: v_cvt_pk_bf16_f32 (RNE) and raw v_exp_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf16_hw(float lo, float hi) {
+  hw_f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hw_bf16x2_t));
+}
+__device__ __forceinline__ bf16_t f32_to_bf16_hw(float f) { return (bf16_t)(pack_bf16_hw(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // block-wide sum for blockDim.x = NWAVES*64; `smem` needs NWAVES floats. Result valid in every thread.
 template <int NWAVES>
 __device__ __forceinline__ float block_sum(float v, float* smem) {
