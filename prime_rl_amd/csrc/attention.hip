@@ -561,7 +561,28 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
                        (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                        softmax_scale, (bf16_t*)grad_q);
   } else if (!use_v2()) {
-    hipLaunchKernelGGL(attn_bwd_dkdv_v3_kernel, dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+    static const bool smem_ok = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
+      bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v3_kernel<8, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvSmemBytes) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v3_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvSmemBytes) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v3_kernel<8, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvSmemBytes) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v3_kernel<4, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvSmemBytes) == hipSuccess;
+      return ok;
+    }();
+    PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (getenv("PM_ATTN_DKDV_CB2") != nullptr)  // A/B: 4 waves x 32 kv rows (register-starved) vs 8 waves x 16
+      hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<4, 2>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), kDkdvSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    else if (getenv("PM_ATTN_ABL1") != nullptr)
+      hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<8, 1, 1>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kDkdvSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    else if (getenv("PM_ATTN_ABL2") != nullptr)
+      hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<8, 1, 2>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kDkdvSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    else
+    hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<8, 1>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kDkdvSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                        softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
     PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");

@@ -17,8 +17,17 @@
 // S = Q . K^T with the kv rows of the wave as the B operand).
 #pragma once
 
-__device__ __forceinline__ u32x2 lds8(const bf16_t* p) { return *reinterpret_cast<const u32x2*>(p); }
-__device__ __forceinline__ u32x4 join8(const u32x2& a, const u32x2& b) { return u32x4{a.x, a.y, b.x, b.y}; }
+// Column permutation of the transposed tiles ([d][token] with 32-token groups): the in-register B fragment of lane (lr, lq)
+// carries tokens {lq*4..lq*4+3} u {16+lq*4..16+lq*4+3} of a group, so the tile is STORED with those 8 tokens contiguous at
+// position lq*8 and the matching A fragment is ONE conflict-free ds_read_b128 (the unpermuted layout needed two 8-byte reads
+// that hipcc fuses into ds_read2_b64, which is served in 16-lane groups on 32 banks: 2-way conflicts at any 16-byte-aligned
+// row stride).  A 16-byte global chunk c8 (tokens 8*c8..8*c8+7) therefore lands as two 8-byte LDS stores.
+__device__ __forceinline__ void sts_perm(bf16_t* row_base, int c8, const u32x4& v) {
+  const int c = c8 & 3;
+  const int p0 = 32 * (c8 >> 2) + 16 * (c & 1) + 4 * (c >> 1);
+  *reinterpret_cast<u32x2*>(row_base + p0) = u32x2{v.x, v.y};
+  *reinterpret_cast<u32x2*>(row_base + p0 + 8) = u32x2{v.z, v.w};
+}
 __device__ __forceinline__ u32x4 pack_c_pair(const f32x4& c0, const f32x4& c1) {
   return u32x4{pack_bf16_hw(c0[0], c0[1]), pack_bf16_hw(c0[2], c0[3]), pack_bf16_hw(c1[0], c1[1]), pack_bf16_hw(c1[2], c1[3])};
 }
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v3_kernel(const bf16_t* __
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       sts16(&Ks[kr + 16 * i][kc], kreg[i]);
-      sts16(&Vs[vr + 32 * i][vc], vreg[i]);
+      sts_perm(&Vs[vr + 32 * i][0], t & 7, vreg[i]);
     }
     __syncthreads();
     if (kv0 + 64 <= tile_last) issue(kv0 + 64);
@@ -112,13 +121,21 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v3_kernel(const bf16_t* __
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) st[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      u32x4 ka[2][4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+      for (int kk = 0; kk < 4; ++kk) ka[0][kk] = lds16(&Ks[lr][kk * 32 + lq * 8]);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const u32x4 ka = lds16(&Ks[nb * 16 + lr][kk * 32 + lq * 8]);
-        st[0][nb] = mfma16(ka, qf[0][kk], st[0][nb]);
-        st[1][nb] = mfma16(ka, qf[1][kk], st[1][nb]);
+      for (int nb = 0; nb < 4; ++nb) {
+        if (nb < 3) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ka[(nb + 1) & 1][kk] = lds16(&Ks[(nb + 1) * 16 + lr][kk * 32 + lq * 8]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          st[0][nb] = mfma16(ka[nb & 1][kk], qf[0][kk], st[0][nb]);
+          st[1][nb] = mfma16(ka[nb & 1][kk], qf[1][kk], st[1][nb]);
+        }
       }
     }
     const bool need_mask = (kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]);  // per lane; cheap and exact either way
@@ -166,10 +183,20 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v3_kernel(const bf16_t* __
       const u32x4 pb0 = pack_c_pair(st[0][2 * kk2], st[0][2 * kk2 + 1]);
       const u32x4 pb1 = pack_c_pair(st[1][2 * kk2], st[1][2 * kk2 + 1]);
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const u32x4 va = join8(lds8(&Vs[nb * 16 + lr][(2 * kk2) * 16 + lq * 4]), lds8(&Vs[nb * 16 + lr][(2 * kk2 + 1) * 16 + lq * 4]));
-        ot[0][nb] = mfma16(va, pb0, ot[0][nb]);
-        ot[1][nb] = mfma16(va, pb1, ot[1][nb]);
+      for (int h4 = 0; h4 < 2; ++h4) {
+        u32x4 va[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nb = h4 * 4 + i;
+          va[i] = lds16(&Vs[nb * 16 + lr][kk2 * 32 + lq * 8]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nb = h4 * 4 + i;
+          ot[0][nb] = mfma16(va[i], pb0, ot[0][nb]);
+          ot[1][nb] = mfma16(va[i], pb1, ot[1][nb]);
+        }
       }
     }
   }
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v3_kernel(const bf16_t*
     for (int i = 0; i < 2; ++i) {
       sts16(&Ks[rr + 16 * i][rc], rk[i]);
       sts16(&Vr[rr + 16 * i][rc], rv[i]);
-      sts16(&Kts[tr + 64 * i][tc], rkt[i]);
+      sts_perm(&Kts[tr + 64 * i][0], t & 3, rkt[i]);
     }
     __syncthreads();
     if (kv0 + 32 <= tile_last) issue(kv0 + 32);
@@ -269,14 +296,19 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v3_kernel(const bf16_t*
       for (int nb = 0; nb < 2; ++nb) st[cb][nb] = dpt[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
+      u32x4 ka[4], va[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const u32x4 ka = lds16(&Ks[nb * 16 + lr][kk * 32 + lq * 8]);
-        const u32x4 va = lds16(&Vr[nb * 16 + lr][kk * 32 + lq * 8]);
-        st[0][nb] = mfma16(ka, qf[0][kk], st[0][nb]);
-        st[1][nb] = mfma16(ka, qf[1][kk], st[1][nb]);
-        dpt[0][nb] = mfma16(va, dof[0][kk], dpt[0][nb]);
-        dpt[1][nb] = mfma16(va, dof[1][kk], dpt[1][nb]);
+        ka[kk] = lds16(&Ks[nb * 16 + lr][kk * 32 + lq * 8]);
+        va[kk] = lds16(&Vr[nb * 16 + lr][kk * 32 + lq * 8]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        st[0][nb] = mfma16(ka[kk], qf[0][kk], st[0][nb]);
+        st[1][nb] = mfma16(ka[kk], qf[1][kk], st[1][nb]);
+        dpt[0][nb] = mfma16(va[kk], dof[0][kk], dpt[0][nb]);
+        dpt[1][nb] = mfma16(va[kk], dof[1][kk], dpt[1][nb]);
       }
     }
 #pragma unroll
@@ -295,10 +327,16 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v3_kernel(const bf16_t*
     const u32x4 sb0 = pack_c_pair(st[0][0], st[0][1]);
     const u32x4 sb1 = pack_c_pair(st[1][0], st[1][1]);
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const u32x4 ka = join8(lds8(&Kts[nb * 16 + lr][lq * 4]), lds8(&Kts[nb * 16 + lr][16 + lq * 4]));
-      dqt[0][nb] = mfma16(ka, sb0, dqt[0][nb]);
-      dqt[1][nb] = mfma16(ka, sb1, dqt[1][nb]);
+    for (int h4 = 0; h4 < 2; ++h4) {
+      u32x4 ka[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ka[i] = lds16(&Kts[(h4 * 4 + i) * 16 + lr][lq * 8]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dqt[0][h4 * 4 + i] = mfma16(ka[i], sb0, dqt[0][h4 * 4 + i]);
+        dqt[1][h4 * 4 + i] = mfma16(ka[i], sb1, dqt[1][h4 * 4 + i]);
+      }
     }
   }
   if (!active) return;
@@ -313,34 +351,54 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v3_kernel(const bf16_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dK/dV v3: 4 waves x 32 kv rows (B operand, two 16-wide column blocks), loops (q tile 32) x (q heads of the group).
+// dK/dV v3: NW waves x CB 16-wide kv column blocks (B operand), loops (q tile 32) x (q heads of the group).
 //   S[q][kv] = Q . K^T, dP[q][kv] = dO . V^T  (A = Q / dO fragments from LDS);  dV^T += dO^T . P,  dK^T += Q^T . dS.
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_v3_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                              int64_t v_stride, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qt,
-                                                              const bf16_t* __restrict__ dot_, const float* __restrict__ lse,
-                                                              const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64,
-                                                              int64_t n_pad, int hq, int hkv, float scale, bf16_t* __restrict__ dk,
-                                                              bf16_t* __restrict__ dv, int64_t dv_stride) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[32][kLd128];
-  __shared__ __attribute__((aligned(16))) bf16_t dOs[32][kLd128];
-  __shared__ __attribute__((aligned(16))) bf16_t Qts[kD][kLd32];
-  __shared__ __attribute__((aligned(16))) bf16_t dOts[kD][kLd32];
-  __shared__ float Ls[32], Ds[32];
-  __shared__ int Los[32];
+// Default NW=8, CB=1 (128 kv rows per workgroup, 16 per wave): with CB=2 the two 64-register accumulator sets push the kernel
+// past 256 architectural VGPRs and hipcc serialises every LDS fragment read behind a single register quad (measured 2.5 ms per
+// 16k-token layer); CB=1 keeps ~150 registers, 2 workgroups (16 waves) per CU and lets the other waves hide LDS latency.
+constexpr int kDkdvOffDO = 2 * 32 * kLd128 * 2;
+constexpr int kDkdvOffQt = 2 * kDkdvOffDO;
+constexpr int kDkdvOffDOt = kDkdvOffQt + 2 * kD * kLd32 * 2;
+constexpr int kDkdvOffL = kDkdvOffDOt + 2 * kD * kLd32 * 2;
+constexpr int kDkdvSmemBytes = kDkdvOffL + 768;
+
+template <int NW, int CB, int ABL = 0>  // ABL: ablation switch for profiling (0 = real kernel, 1 = no compute, 2 = no staging)
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_v3_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                  int64_t v_stride, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qt,
+                                                                  const bf16_t* __restrict__ dot_, const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64,
+                                                                  int64_t n_pad, int hq, int hkv, float scale, bf16_t* __restrict__ dk,
+                                                                  bf16_t* __restrict__ dv, int64_t dv_stride) {
+  constexpr int NT = NW * 64;
+  constexpr int ROWS = NW * CB * 16;  // kv rows per workgroup
+  constexpr int NCH = 512 / NT;       // 16-byte chunks per thread per staged tile
+  static_assert(512 % NT == 0, "tile chunks must divide evenly");
+  // double-buffered tiles in dynamic LDS (2 x 38.3 KB > the 64 KB static limit); one barrier per iteration
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  typedef bf16_t (*tile128_t)[32][kLd128];
+  typedef bf16_t (*tile32_t)[kD][kLd32];
+  tile128_t Qs = reinterpret_cast<tile128_t>(dyn_smem);
+  tile128_t dOs = reinterpret_cast<tile128_t>(dyn_smem + kDkdvOffDO);
+  tile32_t Qts = reinterpret_cast<tile32_t>(dyn_smem + kDkdvOffQt);
+  tile32_t dOts = reinterpret_cast<tile32_t>(dyn_smem + kDkdvOffDOt);
+  float(*Ls)[32] = reinterpret_cast<float(*)[32]>(dyn_smem + kDkdvOffL);
+  float(*Ds)[32] = reinterpret_cast<float(*)[32]>(dyn_smem + kDkdvOffL + 256);
+  int(*Los)[32] = reinterpret_cast<int(*)[32]>(dyn_smem + kDkdvOffL + 512);
+  __shared__ int s_ntiles;
   const int n = (int)n64;
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int group = hq / hkv;
   const int kvh = blockIdx.x % hkv;
-  const int kv0 = (blockIdx.x / hkv) * 128;
-  const int kvb = kv0 + w * 32;
+  const int kv0 = (blockIdx.x / hkv) * ROWS;
+  const int kvb = kv0 + w * CB * 16;
   const bool active = kvb < n;
-  u32x4 kf[2][4], vf[2][4];
-  int kvi[2];
-  f32x4 dkt[2][8], dvt[2][8];
+  u32x4 kf[CB][4], vf[CB][4];
+  int kvi[CB];
+  f32x4 dkt[CB][8], dvt[CB][8];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     kvi[cb] = kvb + cb * 16 + lr;
     const int row = kvi[cb] < n ? kvi[cb] : n - 1;
 #pragma unroll
@@ -351,75 +409,117 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_v3_kernel(const bf16_t* __r
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) dkt[cb][nb] = dvt[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int wg_last = (kv0 + 127 < n - 1) ? kv0 + 127 : n - 1;
+  const int wg_last = (kv0 + ROWS - 1 < n - 1) ? kv0 + ROWS - 1 : n - 1;
   const float sc2 = scale * 1.44269504088896340736f;
-  const int rr = t >> 4, rc = (t & 15) * 8;
-  const int tr = t >> 2, tc = (t & 3) * 8;
-  u32x4 rq[2], rdo[2], rqt[2], rdot[2];
-  float rL = 0.f, rD = 0.f;
-  int rLo = 0;
-  auto issue = [&](int qi0, int qh) {
+  // number of 32-row q tiles, starting at kv0, that can see this workgroup's kv rows: seq_start is non-decreasing, so count the
+  // tile starts whose document begins at or before the workgroup's last kv row (all candidates tested in parallel, no chain)
+  if (t == 0) s_ntiles = 0;
+  __syncthreads();
+  {
+    int mine = 0;
+    for (int c = t; kv0 + 32 * c < n; c += NT)
+      if (seq_start[kv0 + 32 * c] <= wg_last) mine = c + 1;
+    if (mine) atomicMax(&s_ntiles, mine);
+  }
+  __syncthreads();
+  const int total_iters = s_ntiles * group;
+
+  // Two register stages of prefetch (2 tiles = 64 KB per workgroup in flight) and DESCENDING q order: every workgroup of a
+  // (document, kv head) starts at the document's last q tile, so the workgroups that run together on one XCD read the same Q / dO
+  // tiles at about the same time and the XCD's L2 serves them once (ascending order had each workgroup at a different q tile:
+  // measured 2.0 ms per 16k-token layer, memory-latency bound).
+  struct Stage {
+    u32x4 rq[NCH], rdo[NCH], rqt[NCH], rdot[NCH];
+    float rL, rD;
+    int rLo;
+  };
+  Stage sa, sb_;
+  sa.rL = sa.rD = sb_.rL = sb_.rD = 0.f;
+  sa.rLo = sb_.rLo = 0;
+  auto issue = [&](Stage& st_, int j) {  // j-th iteration in execution order = iteration (total_iters-1-j) in (q tile, head) order
+    const int it = total_iters - 1 - j;
+    const int qi0 = kv0 + 32 * (it / group);
+    const int qh = kvh * group + (it % group);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int qrow = qi0 + rr + 16 * i;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = t + i * NT;
+      int qrow = qi0 + (c >> 4);
       if (qrow > n - 1) qrow = n - 1;
-      rq[i] = ldg16(q + ((int64_t)qrow * hq + qh) * kD + rc);
-      rdo[i] = ldg16(dout + ((int64_t)qrow * hq + qh) * kD + rc);
-      const int64_t off = ((int64_t)qh * kD + tr + 64 * i) * n_pad + qi0 + tc;
-      rqt[i] = ldg16(qt + off);
-      rdot[i] = ldg16(dot_ + off);
+      st_.rq[i] = ldg16(q + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+      st_.rdo[i] = ldg16(dout + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+      const int64_t off = ((int64_t)qh * kD + (c >> 2)) * n_pad + qi0 + (c & 3) * 8;
+      st_.rqt[i] = ldg16(qt + off);
+      st_.rdot[i] = ldg16(dot_ + off);
     }
     if (t < 32) {
       const int qrow = (qi0 + t < n) ? qi0 + t : n - 1;
-      rL = lse[(int64_t)qh * n + qrow] * 1.44269504088896340736f;
-      rD = delta[(int64_t)qh * n + qrow];
-      rLo = (qi0 + t < n) ? seq_start[qrow] : 0x7fffffff;  // out-of-range q rows can see nothing
+      // RAW loads only: any arithmetic on a just-loaded value makes hipcc wait for it here, and vmcnt retires in order, so the
+      // wait would drain the whole prefetch (measured: this alone cost 4x on the kernel)
+      st_.rL = lse[(int64_t)qh * n + qrow];
+      st_.rD = delta[(int64_t)qh * n + qrow];
+      st_.rLo = seq_start[qrow];
     }
   };
-  int qi0 = kv0;
-  int gi = 0;
-  bool more = (qi0 < n) && (seq_start[qi0] <= wg_last);
-  if (more) issue(qi0, kvh * group);
-  while (more) {
-    __syncthreads();
+  auto stage = [&](const Stage& st_, int jj, int buf) {  // write the prefetched tile of execution-order iteration jj into LDS buffer buf
+    const int qi0s = kv0 + 32 * ((total_iters - 1 - jj) / group);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      sts16(&Qs[rr + 16 * i][rc], rq[i]);
-      sts16(&dOs[rr + 16 * i][rc], rdo[i]);
-      sts16(&Qts[tr + 64 * i][tc], rqt[i]);
-      sts16(&dOts[tr + 64 * i][tc], rdot[i]);
+    for (int i = 0; i < NCH; ++i) {
+      const int c = t + i * NT;
+      sts16(&Qs[buf][c >> 4][(c & 15) * 8], st_.rq[i]);
+      sts16(&dOs[buf][c >> 4][(c & 15) * 8], st_.rdo[i]);
+      sts_perm(&Qts[buf][c >> 2][0], c & 3, st_.rqt[i]);
+      sts_perm(&dOts[buf][c >> 2][0], c & 3, st_.rdot[i]);
     }
     if (t < 32) {
-      Ls[t] = rL;
-      Ds[t] = rD;
-      Los[t] = rLo;
+      Ls[buf][t] = st_.rL * 1.44269504088896340736f;
+      Ds[buf][t] = st_.rD;
+      Los[buf][t] = (qi0s + t < n) ? st_.rLo : 0x7fffffff;  // out-of-range q rows can see nothing
     }
-    __syncthreads();
-    int nqi0 = qi0, ngi = gi + 1;
-    if (ngi == group) {
-      ngi = 0;
-      nqi0 = qi0 + 32;
+  };
+  // prologue: tile 0 -> LDS[0]; tiles 1 and 2 in flight in registers
+  if (total_iters > 0) issue(sa, 0);
+  if (total_iters > 1) issue(sb_, 1);
+  if (total_iters > 0) stage(sa, 0, 0);
+  if (total_iters > 2) issue(sa, 2);
+  for (int j = 0; j < total_iters; ++j) {
+    const int qi0 = kv0 + 32 * ((total_iters - 1 - j) / group);
+    const int buf = j & 1;
+    __syncthreads();  // compute(j-1) is finished everywhere (its buffer may be overwritten) and tile j is visible
+    if (ABL != 2 || j < 2) {
+      if (j + 1 < total_iters) {
+        if ((j & 1) == 0) {
+          stage(sb_, j + 1, buf ^ 1);
+          if (j + 3 < total_iters) issue(sb_, j + 3);
+        } else {
+          stage(sa, j + 1, buf ^ 1);
+          if (j + 3 < total_iters) issue(sa, j + 3);
+        }
+      }
     }
-    const bool nmore = (nqi0 < n) && (seq_start[nqi0] <= wg_last);
-    if (nmore) issue(nqi0, kvh * group + ngi);
 
-    if (active && qi0 + 31 >= kvb) {
+    if ((ABL != 1 || j < 2) && active && qi0 + 31 >= kvb) {
       // S[q][kv], dP[q][kv]: rows q = nb*16 + lq*4 + r, column kv = lr of block cb
-      f32x4 s[2][2], dp[2][2];
+      f32x4 s[CB][2], dp[CB][2];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) s[cb][nb] = dp[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
+        u32x4 qa[4], da[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const u32x4 qa = lds16(&Qs[nb * 16 + lr][kk * 32 + lq * 8]);
-          const u32x4 da = lds16(&dOs[nb * 16 + lr][kk * 32 + lq * 8]);
-          s[0][nb] = mfma16(qa, kf[0][kk], s[0][nb]);
-          s[1][nb] = mfma16(qa, kf[1][kk], s[1][nb]);
-          dp[0][nb] = mfma16(da, vf[0][kk], dp[0][nb]);
-          dp[1][nb] = mfma16(da, vf[1][kk], dp[1][nb]);
+          qa[kk] = lds16(&Qs[buf][nb * 16 + lr][kk * 32 + lq * 8]);
+          da[kk] = lds16(&dOs[buf][nb * 16 + lr][kk * 32 + lq * 8]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            s[cb][nb] = mfma16(qa[kk], kf[cb][kk], s[cb][nb]);
+            dp[cb][nb] = mfma16(da[kk], vf[cb][kk], dp[cb][nb]);
+          }
         }
       }
 #pragma unroll
@@ -428,10 +528,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_v3_kernel(const bf16_t* __r
         for (int r = 0; r < 4; ++r) {
           const int ql = nb * 16 + lq * 4 + r;
           const int qg = qi0 + ql;
-          const float L2 = Ls[ql], Dl = Ds[ql];
-          const int lo = Los[ql];
+          const float L2 = Ls[buf][ql], Dl = Ds[buf][ql];
+          const int lo = Los[buf][ql];
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
+          for (int cb = 0; cb < CB; ++cb) {
             const bool ok = (kvi[cb] <= qg) && (kvi[cb] >= lo);
             const float p = ok ? fast_exp2(s[cb][nb][r] * sc2 - L2) : 0.f;
             s[cb][nb][r] = p;
@@ -439,25 +539,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_v3_kernel(const bf16_t* __r
           }
         }
       }
-      const u32x4 pb0 = pack_c_pair(s[0][0], s[0][1]), pb1 = pack_c_pair(s[1][0], s[1][1]);
-      const u32x4 sb0 = pack_c_pair(dp[0][0], dp[0][1]), sb1 = pack_c_pair(dp[1][0], dp[1][1]);
+      u32x4 pb[CB], sb[CB];
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const u32x4 doa = join8(lds8(&dOts[nb * 16 + lr][lq * 4]), lds8(&dOts[nb * 16 + lr][16 + lq * 4]));
-        const u32x4 qa = join8(lds8(&Qts[nb * 16 + lr][lq * 4]), lds8(&Qts[nb * 16 + lr][16 + lq * 4]));
-        dvt[0][nb] = mfma16(doa, pb0, dvt[0][nb]);
-        dvt[1][nb] = mfma16(doa, pb1, dvt[1][nb]);
-        dkt[0][nb] = mfma16(qa, sb0, dkt[0][nb]);
-        dkt[1][nb] = mfma16(qa, sb1, dkt[1][nb]);
+      for (int cb = 0; cb < CB; ++cb) {
+        pb[cb] = pack_c_pair(s[cb][0], s[cb][1]);
+        sb[cb] = pack_c_pair(dp[cb][0], dp[cb][1]);
+      }
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        u32x4 doa[4], qa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nb = h4 * 4 + i;
+          doa[i] = lds16(&dOts[buf][nb * 16 + lr][lq * 8]);
+          qa[i] = lds16(&Qts[buf][nb * 16 + lr][lq * 8]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nb = h4 * 4 + i;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            dvt[cb][nb] = mfma16(doa[i], pb[cb], dvt[cb][nb]);
+            dkt[cb][nb] = mfma16(qa[i], sb[cb], dkt[cb][nb]);
+          }
+        }
       }
     }
-    qi0 = nqi0;
-    gi = ngi;
-    more = nmore;
   }
   if (!active) return;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     if (kvi[cb] < n) {
       bf16_t* pk_ = dk + ((int64_t)kvi[cb] * hkv + kvh) * kD + lq * 4;
       bf16_t* pv_ = dv + (int64_t)kvi[cb] * dv_stride + (int64_t)kvh * kD + lq * 4;
