@@ -54,6 +54,17 @@ def bench_k1(out):
         del logits, buf
 
 
+def bench_k1_step_shape(out):
+    """The launch the trainer step makes: 16384 rows of bf16 logits (used for the PMC HBM-traffic passes)."""
+    n, v = 16384, 151936
+    logits = torch.empty(n, v, device=DEV, dtype=torch.bfloat16).normal_(0, 4)
+    labels = torch.randint(0, v, (n,), device=DEV)
+    inv_t = torch.ones(n, device=DEV)
+    med, best = timeit(lambda: ops.logprob_entropy_fwd(logits, labels, inv_t), iters=5, warmup=1)
+    nbytes = n * (2 * v + 20)
+    out.append(dict(kernel="logprob_entropy_fwd[bf16 16384 rows]", ms=med * 1e3, best_ms=best * 1e3, GBps=nbytes / med / 1e9, frac_hbm=nbytes / med / HBM_PEAK))
+
+
 def bench_attn(out):
     hq, hkv, d = 32, 8, 128
     for n, seqs in ((2048, [2048]), (16384, [2048] * 8)):
@@ -98,6 +109,8 @@ def main():
     out = []
     if which in ("k1", "all"):
         bench_k1(out)
+    if which == "k1step":
+        bench_k1_step_shape(out)
     if which in ("attn", "all"):
         bench_attn(out)
     if which in ("norm", "all"):
