@@ -1,0 +1,78 @@
+"""Algorithm hook surface — mirrors `prime_rl.orchestrator.algo.base` (src/prime_rl/orchestrator/algo/base.py:35-81).
+Objects are duck-typed (`episode.traces`, `trace.{has_error, agent.trainable, nodes, reward, num_output_tokens,
+num_total_tokens, num_turns}`), so verifiers.v1 episodes plug in unchanged; `SimpleTrace` & co. are the minimal shapes used
+by the tests (verifiers is an un-vendored submodule of the reference)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import ClassVar
+
+
+@dataclass
+class SimpleNode:
+    token_ids: list[int]
+    mask: list[bool]
+    sampled: bool = True
+    advantages: list[float] | None = None
+    reference_logprobs: list[float] | None = None
+    loss_weights: dict | None = None
+
+
+@dataclass
+class SimpleAgent:
+    trainable: bool = True
+
+
+@dataclass
+class SimpleTrace:
+    id: str
+    reward: float
+    nodes: list[SimpleNode]
+    has_error: bool = False
+    agent: SimpleAgent = field(default_factory=SimpleAgent)
+    num_output_tokens: int = 0
+    num_total_tokens: int = 0
+    num_turns: int = 1
+
+
+@dataclass
+class SimpleEpisode:
+    traces: list[SimpleTrace]
+
+
+def iter_trainable_traces(episodes):
+    """Yield clean trainable traces that contain sampled tokens (base.py:35-42)."""
+    for episode in episodes:
+        for trace in episode.traces:
+            if trace.has_error or not trace.agent.trainable:
+                continue
+            if any(any(node.mask) for node in trace.nodes):
+                yield episode, trace
+
+
+class Algorithm:
+    """Override `score_episode` for rollout-local work and `score_group` for cohort-relative work (base.py:45-81)."""
+
+    action_loss_type: ClassVar[str] = "rl"
+
+    def __init__(self, config=None, policy_pool=None):
+        self.config = config
+        self.policy_pool = policy_pool
+        self.connected_pools: list = []
+
+    async def setup(self) -> None:
+        pass
+
+    async def score_episode(self, episode) -> None:
+        pass
+
+    async def score_group(self, episodes) -> None:
+        pass
+
+    async def finalize_episode(self, episode) -> None:
+        if any(True for _ in iter_trainable_traces([episode])):
+            await self.score_episode(episode)
+
+    async def finalize_group(self, episodes) -> None:
+        await self.score_group(episodes)

@@ -1,0 +1,108 @@
+"""Attention seam — mirrors `prime_rl.trainer.models.layers.attn` (src/prime_rl/trainer/models/layers/attn.py:29-189).
+
+`HipVarlenAttention(AttentionConfig)` has the reference's parameter names (`q_proj, k_proj, v_proj, o_proj, q_norm, k_norm`) and
+forward contract `forward(hidden_states [1,N,H], position_embeddings=(cos,sin), cu_seqlens i32 [S+1], max_seqlen) ->
+(out [1,N,H], None)`; it registers itself as `ATTN_IMPL2CLASS["hip_varlen"]` so `config._attn_implementation = "hip_varlen"`
+selects it (attn.py:185-189).  Inside: fused per-head q/k RMSNorm + RoPE (no transposes, attn.py:147-158 does two) and the
+MFMA varlen causal attention kernels; `max_seqlen` is accepted and ignored (the kernels need no host-side schedule)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Literal
+
+import torch
+from torch import nn
+
+from .... import ops
+from .norms import RMSNorm, RMSNormConfig
+
+
+@dataclass
+class AttentionConfig:
+    hidden_size: int
+    head_dim: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    is_causal: bool = True
+    attention_bias: bool = False
+    use_qk_norm: bool = True
+    rms_norm_eps: float = 1e-6
+    qk_norm_type: Literal["per_head", "per_layer"] = "per_head"
+    output_bias: bool = False
+
+
+class _QKNormRopeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qw, kw, cos, sin, hq, hkv, d, eps):
+        q, k, rstd = ops.qknorm_rope_fwd(qkv, qw.contiguous(), kw.contiguous(), cos, sin, hq, hkv, d, eps)
+        ctx.save_for_backward(qkv, qw, kw, cos, sin, rstd)
+        ctx.dims = (hq, hkv, d)
+        return q, k
+
+    @staticmethod
+    def backward(ctx, gq, gk):
+        qkv, qw, kw, cos, sin, rstd = ctx.saved_tensors
+        hq, hkv, d = ctx.dims
+        gqkv = torch.zeros_like(qkv)  # v columns carry no gradient through this op
+        gqw = torch.zeros(d, dtype=torch.float32, device=qkv.device)
+        gkw = torch.zeros(d, dtype=torch.float32, device=qkv.device)
+        ops.qknorm_rope_bwd(gq.contiguous(), gk.contiguous(), qkv, qw.contiguous(), kw.contiguous(), cos, sin, rstd, gqkv, gqw, gkw, hq, hkv, d)
+        return gqkv, gqw.to(qw.dtype), gkw.to(kw.dtype), None, None, None, None, None, None
+
+
+class _VarlenAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, seq_start, scale):
+        out, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+        ctx.save_for_backward(q, k, v, out, lse, seq_start)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, out, lse, seq_start = ctx.saved_tensors
+        gq, gk, gv = ops.attn_varlen_bwd(go.contiguous(), q, k, v, out, lse, seq_start, ctx.scale)
+        return gq, gk, gv, None, None
+
+
+def varlen_causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, scale: float) -> torch.Tensor:
+    """flash_attn_varlen_func(q, k, v, cu, cu, max, max, causal=True) equivalent on packed [N, heads, 128] bf16 tensors."""
+    seq_start = ops.seq_start_from_cu(cu_seqlens.to(torch.int32).contiguous(), q.shape[0])
+    return _VarlenAttnFn.apply(q.contiguous(), k.contiguous(), v, seq_start, scale)
+
+
+class HipVarlenAttention(nn.Module):
+    def __init__(self, config: AttentionConfig):
+        super().__init__()
+        if config.head_dim != 128 or not config.is_causal or not config.use_qk_norm or config.qk_norm_type != "per_head":
+            raise NotImplementedError("hip_varlen implements the Qwen3 attention block: head_dim 128, causal, per-head q/k RMSNorm")
+        if config.attention_bias or config.output_bias:
+            raise NotImplementedError("attention biases are not on the Qwen3 path")
+        self.head_dim = config.head_dim
+        self.hq, self.hkv = config.num_attention_heads, config.num_key_value_heads
+        self.num_key_value_groups = self.hq // self.hkv
+        self.scaling = self.head_dim**-0.5
+        self.eps = config.rms_norm_eps
+        self.q_proj = nn.Linear(config.hidden_size, self.hq * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(self.hq * self.head_dim, config.hidden_size, bias=False)
+        self.q_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
+        self.k_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
+
+    def forward(self, hidden_states, position_embeddings=None, cu_seqlens=None, max_seqlen=None):
+        b, n, _ = hidden_states.shape
+        assert b == 1, "packed batches are [1, N, H] (trainer/batch.py)"
+        x = hidden_states[0]
+        qkv = torch.cat([self.q_proj(x), self.k_proj(x), self.v_proj(x)], dim=-1)
+        cos, sin = position_embeddings
+        half = self.head_dim // 2
+        cos, sin = cos.reshape(n, -1)[:, :half].contiguous(), sin.reshape(n, -1)[:, :half].contiguous()  # accept the reference's cat(f,f) tables too
+        q, k = _QKNormRopeFn.apply(qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, self.hq, self.hkv, self.head_dim, self.eps)
+        v = qkv[:, (self.hq + self.hkv) * self.head_dim:].view(n, self.hkv, self.head_dim)
+        out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling)
+        return self.o_proj(out.view(n, self.hq * self.head_dim)).unsqueeze(0), None
+
+
+ATTN_IMPL2CLASS = {"hip_varlen": HipVarlenAttention}

@@ -91,3 +91,36 @@ class FakeDataLoader:
             ids.append(torch.randint(0, 120000, (ln,), generator=gen).long())
             pos.append(torch.arange(ln))
         return self._finish(torch.cat(ids), torch.cat(pos), lens, gen)
+
+
+class DataLoader:
+    """Receives packed micro batches from the orchestrator, one stream per DP rank (data.py:162-238): list fields -> `[1, seq]`
+    CPU tensors with the reference's dtypes."""
+
+    def __init__(self, output_dir, start_step: int, dp_world_size: int, config=None, dp_rank: int = 0):
+        from ...transports.rollouts import setup_micro_batch_receiver
+
+        self.receiver = setup_micro_batch_receiver(output_dir, dp_rank, start_step, config)
+
+    def wait_for_batch(self) -> None:
+        self.receiver.wait()
+
+    def get_batch(self) -> list[TensorMicroBatch]:
+        return [self._micro_batch_to_tensor(mb) for mb in self.receiver.receive()]
+
+    @staticmethod
+    def _micro_batch_to_tensor(mb) -> TensorMicroBatch:
+        def opt(v, dtype):
+            return torch.tensor(v, dtype=dtype).unsqueeze(0) if v is not None else None
+
+        if mb.mm_kwargs or mb.routed_experts is not None:
+            raise NotImplementedError("multimodal / router-replay payloads are outside the dense GRPO path (SURVEY.md section 2 rows 12, 21)")
+        return TensorMicroBatch(
+            input_ids=torch.tensor(mb.input_ids, dtype=torch.long).unsqueeze(0), position_ids=torch.tensor(mb.position_ids, dtype=torch.long).unsqueeze(0),
+            advantages=torch.tensor(mb.advantages, dtype=torch.float).unsqueeze(0),
+            inference_logprobs=torch.tensor(mb.inference_logprobs, dtype=torch.float).unsqueeze(0), ref_logprobs=opt(mb.ref_logprobs, torch.float),
+            loss_mask=torch.tensor(mb.loss_mask, dtype=torch.bool).unsqueeze(0), temperatures=torch.tensor(mb.temperatures, dtype=torch.float).unsqueeze(0),
+            env_names=mb.env_names, sequence_lengths=mb.sequence_lengths, lora_num_tokens=torch.tensor([len(mb.input_ids)], dtype=torch.int32),
+            seq_lens=torch.tensor(mb.seq_lens, dtype=torch.long), mm_kwargs=None, mm_token_type_ids=None, routed_experts=None,
+            rl_weights=opt(mb.rl_weights, torch.float), ce_weights=opt(mb.ce_weights, torch.float), ref_kl_weights=opt(mb.ref_kl_weights, torch.float),
+        )

@@ -211,3 +211,44 @@ def test_compute_loss_autograd_matches_golden(golden_dir):
     for k in [k for k in g if k.startswith("metric__")]:
         key = k[len("metric__"):].replace("__", "/")
         np.testing.assert_allclose(metrics[key].cpu().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=key)
+
+
+# ---- orchestrator algorithm plugin: reference tests/unit/orchestrator/test_advantage.py:173-240 ------------------------------
+def _episode(rewards, n_out=None):
+    from prime_rl_amd.orchestrator.algo.base import SimpleEpisode, SimpleNode, SimpleTrace
+
+    traces = []
+    for i, r in enumerate(rewards):
+        k = (n_out[i] if n_out else 4)
+        traces.append(SimpleTrace(f"t{i}", r, [SimpleNode(list(range(k + 2)), [False, False] + [True] * k)], num_output_tokens=k, num_total_tokens=k + 2))
+    return [SimpleEpisode([t]) for t in traces]
+
+
+def test_grpo_algorithm_plugin():
+    import asyncio
+
+    from prime_rl_amd.orchestrator.algo import ALGORITHM_CLASSES, GRPOAlgoConfig, LengthPenaltyConfig, build_algorithm
+
+    algo = build_algorithm(GRPOAlgoConfig())
+    eps = _episode([1.0, 0.0, 0.0, 1.0, 1.0])
+    asyncio.run(algo.finalize_group(eps))
+    advs = [e.traces[0].nodes[0].advantages[0] for e in eps]
+    assert abs(sum(advs)) < 1e-6 and advs[0] == pytest.approx(0.4) and len(eps[0].traces[0].nodes[0].advantages) == 4
+    single = _episode([0.7])
+    asyncio.run(algo.finalize_group(single))
+    assert single[0].traces[0].nodes[0].advantages == [0.0] * 4  # singleton group -> zero
+    mx = ALGORITHM_CLASSES["max_rl"]()
+    eps = _episode([1.0, 0.0, 0.0, 0.0])
+    asyncio.run(mx.finalize_group(eps))
+    assert [e.traces[0].nodes[0].advantages[0] for e in eps] == pytest.approx([3.0, -1.0, -1.0, -1.0])
+    eps = _episode([0.0, 0.0, 0.0])
+    asyncio.run(mx.finalize_group(eps))
+    assert [e.traces[0].nodes[0].advantages[0] for e in eps] == [0.0, 0.0, 0.0]
+    # length penalty monotonicity (:198-240): equal rewards, longer outputs get lower advantages; many groups in one launch
+    lp = build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig()))
+    g1, g2 = _episode([1.0, 1.0, 1.0], n_out=[10, 100, 1000]), _episode([1.0, 0.0], n_out=[5, 5])
+    lp.score_groups([g1, g2])
+    a = [e.traces[0].nodes[0].advantages[0] for e in g1]
+    assert a[0] > a[1] > a[2] and abs(sum(a)) < 1e-5
+    b = [e.traces[0].nodes[0].advantages[0] for e in g2]
+    assert abs(sum(b)) < 1e-6 and b[0] > 0 > b[1]
