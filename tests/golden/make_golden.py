@@ -205,6 +205,57 @@ def main() -> None:
                     arrs[tag + k] = mb[k].numpy()
                 arrs[tag + "sequence_lengths"] = np.asarray(mb["sequence_lengths"])
     np.savez_compressed(OUT / "fake_data.npz", **arrs)
+
+    # ---- 6. packing: the reference's prepare_batch (trainer/batch.py:796-835) on random text samples -> packing.json
+    import json
+    import random
+
+    ms = types.ModuleType("msgspec")
+
+    class Struct:  # minimal msgspec.Struct: keyword/positional init from annotations, class kwargs swallowed
+        def __init_subclass__(cls, **kwargs):
+            super().__init_subclass__()
+
+        def __init__(self, *args, **kwargs):
+            names = list(self.__class__.__annotations__)
+            for n_, v_ in zip(names, args):
+                setattr(self, n_, v_)
+            for n_ in names[len(args):]:
+                if n_ in kwargs:
+                    setattr(self, n_, kwargs.pop(n_))
+                elif hasattr(self.__class__, n_):
+                    setattr(self, n_, getattr(self.__class__, n_))
+                else:
+                    raise TypeError(f"missing field {n_}")
+            assert not kwargs, kwargs
+
+    ms.Struct = Struct
+    sys.modules["msgspec"] = ms
+    del sys.modules["prime_rl.transports.rollouts"]
+    rt = types.ModuleType("prime_rl.transports.rollouts")
+    rt.__path__ = []
+    sys.modules["prime_rl.transports.rollouts"] = rt
+    rtypes = _load("prime_rl.transports.rollouts.types", "prime_rl/transports/rollouts/types.py")
+    rt.TrainingSample, rt.MicroBatch = rtypes.TrainingSample, rtypes.MicroBatch
+    batch = _load("ref_batch", "prime_rl/trainer/batch.py")
+    qcfg = types.SimpleNamespace(hidden_size=4096, num_attention_heads=32, num_key_value_heads=8, head_dim=128, intermediate_size=12288,
+                                 num_hidden_layers=36, vocab_size=151936)
+    sys.path.insert(0, str(OUT))
+    import packing_cases as PC
+
+    cases = []
+    for case_id, (n_samples, seq_len, workers, pad, max_len, use_cfg, streams) in enumerate(PC.CASES):
+        samples = PC.make_samples(case_id)
+        grid = batch.prepare_batch([rtypes.TrainingSample(**s) for s in samples], seq_len, workers, batch.build_bin_cost(qcfg if use_cfg else None), pad)
+        cases.append(dict(case_id=case_id, grid=PC.digest_grid(grid)))
+    weights_cases = []
+    for seed in range(6):
+        rng = random.Random(100 + seed)
+        k = rng.choice([2, 3, 4, 8])
+        w = [rng.randint(1, 10**6) for _ in range(k * rng.randint(1, 6))]
+        weights_cases.append(dict(weights=w, k=k, parts=batch.balanced_partition(w, k)))
+    bc = batch.build_bin_cost(qcfg)
+    (OUT / "packing.json").write_text(json.dumps(dict(cases=cases, partitions=weights_cases, bin_cost_probe=[bc([2048]), bc([100, 200, 300])])))
     print("golden fixtures written to", OUT)
 
 
