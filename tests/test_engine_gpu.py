@@ -162,3 +162,27 @@ def test_engine_two_passes_equal_one_pass():
     assert abs(l1 - l2) < 1e-5
     rel = ((g1 - g2).norm() / g1.norm()).item()
     assert rel < 2e-2, rel
+
+
+def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
+    """train(config) end to end on the tiny model: reference step/version indexing (startup v0 + one broadcast per step), the
+    console line and metric keys dashboards regex, metrics.jsonl."""
+    import json
+    import re
+
+    from prime_rl_amd.trainer.rl.data import FakeDataLoaderConfig
+    from prime_rl_amd.trainer.rl.train import TrainerConfig, train
+
+    cfg = TrainerConfig(model="tiny", seq_len=128, max_steps=2, output_dir=str(tmp_path), fake_data=FakeDataLoaderConfig(batch_size=3, generate_samples=True),
+                        tokens_per_pass=256)
+    hist = train(cfg)
+    assert len(hist) == 2
+    for key in ("perf/throughput", "perf/mfu", "perf/peak_memory", "optim/lr", "optim/grad_norm", "time/step", "time/forward_backward", "time/broadcast_weights",
+                "loss/mean", "entropy/all/mean", "entropy/all/median", "mismatch_kl/all/max", "is_masked/mean", "masked_mismatch_kl/std", "kl_ent_ratio/mean"):
+        assert key in hist[0], key
+    assert all(math.isfinite(v) for v in hist[1].values())
+    out = capsys.readouterr().out
+    assert re.search(r"Step 2 \| Time: .* \| Loss: .* \| Entropy: .* \| Mismatch KL: .* \| Grad\. Norm: .* \| LR: .* \| Throughput: .* tokens/s \| MFU: .*% \| Peak Mem\.: .* GiB", out)
+    for step in (1, 2):  # keep=2: step_0 (startup policy) is already rotated out
+        assert (tmp_path / "broadcasts" / f"step_{step}" / "STABLE").exists()
+    assert len((tmp_path / "metrics.jsonl").read_text().strip().splitlines()) == 2
