@@ -198,7 +198,7 @@ int pm_embedding_fwd(const void* table_bf16, const int64_t* ids, int64_t n_token
                      void* out_bf16, void* stream);
 /* grad_table_f32[id] += sum of grad_out rows with that id.  `order` = argsort(ids) (stable), ids_sorted = ids[order]. */
 int pm_embedding_bwd(const void* grad_out_bf16, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens,
-                     int64_t hidden, float* grad_table_f32, void* stream);
+                     int64_t hidden, int64_t vocab, float* grad_table_f32, void* stream);  /* ids outside [0, vocab) are skipped */
 
 /* RMSNorm — RMSNorm.forward (models/layers/norms.py:36-44): y = w * bf16(x*rsqrt(mean(x^2)+eps)); fp32 math.
  * Optional fused residual: if residual != null, x_in = x + residual is written to sum_out (bf16) and normalised. */

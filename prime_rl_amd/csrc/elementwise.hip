@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const bf16_t* __rest
 
 // one workgroup per sorted position; only the first position of each run of equal ids does work, summing the run in order.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ ids_sorted,
-                                                           const int64_t* __restrict__ order, int64_t n_tokens, int64_t hidden,
+                                                           const int64_t* __restrict__ order, int64_t n_tokens, int64_t hidden, int64_t vocab,
                                                            float* __restrict__ gtable) {
   const int64_t p = blockIdx.x;
   const int64_t id = ids_sorted[p];
+  if (id < 0 || id >= vocab) return;  // never write outside the table
   if (p > 0 && ids_sorted[p - 1] == id) return;
   int64_t e = p + 1;
   while (e < n_tokens && ids_sorted[e] == id) ++e;
@@ -246,12 +247,12 @@ extern "C" int pm_embedding_fwd(const void* table, const int64_t* ids, int64_t n
 }
 
 extern "C" int pm_embedding_bwd(const void* grad_out, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens, int64_t hidden,
-                                float* grad_table, void* stream) {
+                                int64_t vocab, float* grad_table, void* stream) {
   PM_REQUIRE(grad_out && ids_sorted && order && grad_table, PM_ERR_INVALID_ARG, "pm_embedding_bwd: null pointer");
   PM_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden % 8 == 0, PM_ERR_UNSUPPORTED, "pm_embedding_bwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_out, ids_sorted, order,
-                     n_tokens, hidden, grad_table);
+                     n_tokens, hidden, vocab, grad_table);
   PM_CHECK_LAUNCH("pm_embedding_bwd");
   return PM_OK;
 }

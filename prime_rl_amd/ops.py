@@ -215,7 +215,7 @@ def embedding_bwd(grad_out: Tensor, ids: Tensor, grad_table_f32: Tensor) -> None
     _req(grad_out, torch.bfloat16, "grad_out"); _req(ids, torch.int64, "ids"); _req(grad_table_f32, torch.float32, "grad_table")
     ids_sorted, order = torch.sort(ids.reshape(-1), stable=True)  # plumbing: index sort only
     n, h = grad_out.shape
-    check(lib.pm_embedding_bwd(_p(grad_out), _p(ids_sorted), _p(order), n, h, _p(grad_table_f32), _stream()), "pm_embedding_bwd")
+    check(lib.pm_embedding_bwd(_p(grad_out), _p(ids_sorted), _p(order), n, h, grad_table_f32.shape[0], _p(grad_table_f32), _stream()), "pm_embedding_bwd")
 
 
 def rmsnorm_fwd(x: Tensor, weight: Tensor, eps: float, residual: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor | None]:

@@ -94,6 +94,9 @@ def train(config: TrainerConfig) -> list[dict]:
         t_wait = time.perf_counter() - t0
         t0 = time.perf_counter()
         mbs = loader.get_batch()
+        if config.fake_data is not None and dims.vocab_size < 120000:  # FakeDataLoader draws ids up to 120000 (data.py:101)
+            for mb in mbs:
+                mb["input_ids"] = mb["input_ids"] % dims.vocab_size
         passes = [pack_micro_batches(mbs[i:i + per_pass], device) for i in range(0, len(mbs), per_pass)]
         t_load = time.perf_counter() - t0
         t0 = time.perf_counter()
