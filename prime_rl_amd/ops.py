@@ -69,6 +69,8 @@ def logprob_entropy_fwd(logits: Tensor, labels: Tensor, inv_temp: Tensor) -> tup
     if labels.numel() != n or inv_temp.numel() != n:
         raise PrimeMI355XError("labels / inv_temp length must equal the number of logits rows")
     out = torch.empty((3, n), dtype=torch.float32, device=logits.device)
+    if n == 0:  # empty micro-batch: nothing to launch
+        return out[0], out[1], out[2]
     wsb = lib.pm_logprob_workspace_bytes(n, v)
     ws = workspace(wsb, logits.device, "logprob")
     check(
@@ -139,6 +141,8 @@ def grpo_advantage(rewards: Tensor, group_offsets: Tensor, mode: int = _lib.PM_A
         if t is not None:
             _req(t, torch.float32, nm)
     adv = torch.empty_like(rewards)
+    if rewards.numel() == 0 or group_offsets.numel() < 2:
+        return adv
     check(
         lib.pm_grpo_advantage(_p(rewards), _p(group_offsets), group_offsets.numel() - 1, mode, _p(num_output_tokens), _p(num_total_tokens),
                               _p(num_turns), weights[0], weights[1], weights[2], _p(adv), _stream()),

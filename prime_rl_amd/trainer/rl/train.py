@@ -104,9 +104,20 @@ def train(config: TrainerConfig) -> list[dict]:
         # --- step statistics, reduced on the device --------------------------------------------------------------------
         st: dict[str, torch.Tensor] = {}
         S = _lib.STAT
-        ent, mkl, losses = [], [], []
-        for p, lp, en, loss in zip(passes, out["logprobs"], out["entropy"], out["loss"]):
+        ent, mkl, losses, env_tok = [], [], [], []
+        env_ids: dict[str, int] = {}
+        for pi, (p, lp, en, loss) in enumerate(zip(passes, out["logprobs"], out["entropy"], out["loss"])):
             m = p.loss_mask
+            # per-env split (train.py:483-520) with integer env ids: one id per SAMPLE on the host (env_names is constant within a
+            # sample), expanded to tokens on the device — no per-token Python
+            sample_env, sample_len = [], []
+            for mb in mbs[pi * per_pass:(pi + 1) * per_pass]:
+                off = 0
+                for sl in mb["sequence_lengths"]:
+                    sample_env.append(env_ids.setdefault(mb["env_names"][off], len(env_ids)))
+                    sample_len.append(sl)
+                    off += sl
+            env_tok.append(torch.repeat_interleave(torch.tensor(sample_env, device=device), torch.tensor(sample_len, device=device))[m])
             starts = torch.zeros_like(m)
             # shift_tensor_right alignment: entropy/log-prob of token i come from head position i-1 (train.py:450-457)
             ent_s = torch.roll(en, 1)
@@ -122,6 +133,12 @@ def train(config: TrainerConfig) -> list[dict]:
         _stats("loss", torch.cat(losses), st)
         _stats("entropy/all", torch.cat(ent), st)
         _stats("mismatch_kl/all", torch.cat(mkl), st)
+        if len(env_ids) > 1 or (env_ids and next(iter(env_ids)) not in ("", "fake")):
+            et, ea, ka = torch.cat(env_tok), torch.cat(ent), torch.cat(mkl)
+            for name, eid in env_ids.items():
+                if name:
+                    _stats(f"entropy/{name}", ea[et == eid], st)
+                    _stats(f"mismatch_kl/{name}", ka[et == eid], st)
         met = torch.cat(out["sample_metrics"])
         stats = torch.cat(out["sample_stats"])
         for i, key in enumerate(_lib.METRIC_KEYS[:7]):

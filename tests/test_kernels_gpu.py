@@ -454,3 +454,51 @@ def test_adamw_sumsq_clip(ops):
     ops.grad_accumulate(mg, gb)
     ops.grad_accumulate(mg, gb)
     assert torch.equal(mg, 2 * gb.float())
+
+
+# ================================================================================================ edge cases
+def test_edge_cases(ops):
+    """Empty and degenerate inputs (the reference's tests cover empty components, singleton groups, length-1 documents)."""
+    from prime_rl_amd import _lib
+
+    # empty micro-batch
+    lp, ent, logz = ops.logprob_entropy_fwd(torch.empty(0, 128, device=DEV), torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, device=DEV))
+    assert lp.numel() == ent.numel() == logz.numel() == 0
+    assert ops.grpo_advantage(torch.empty(0, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)).numel() == 0
+    # vocab of one: log-prob 0, entropy 0; every alignment of a tiny odd-width row
+    for v in (1, 2, 3, 5, 7, 9, 17, 33):
+        logits = torch.randn(5, v, device=DEV)
+        labels = torch.randint(0, v, (5,), device=DEV)
+        lp, ent, _ = ops.logprob_entropy_fwd(logits, labels, torch.ones(5, device=DEV))
+        ref = torch.log_softmax(logits, -1)
+        _close(lp, ref[torch.arange(5), labels], 0, 1e-6, f"tiny vocab {v}")
+        _close(ent, -(ref.exp() * ref).sum(-1), 0, 2e-6, f"tiny vocab entropy {v}")
+    # rows that are views with a stride (a [N, V] slice of a wider buffer)
+    wide = torch.randn(9, 4099, device=DEV)
+    view = wide[:, 3:3 + 4001]
+    labels = torch.randint(0, 4001, (9,), device=DEV)
+    lp, _, _ = ops.logprob_entropy_fwd(view, labels, torch.ones(9, device=DEV))
+    _close(lp, torch.log_softmax(view, -1)[torch.arange(9), labels], 0, 1e-5, "strided unaligned rows")
+    # extreme logits: no overflow / NaN
+    big = torch.tensor([[1e4, -1e4, 0.0, 9999.0]], device=DEV)
+    lp, ent, logz = ops.logprob_entropy_fwd(big, torch.tensor([0], device=DEV), torch.ones(1, device=DEV))
+    # logprob = target - logz like the reference's fused head (lm_head.py:147): at |logit| = 1e4 one f32 ulp of logz is 1e-3
+    assert torch.isfinite(lp).all() and torch.isfinite(ent).all() and abs(lp.item() + math.log1p(math.exp(-1.0))) < 1e-3
+    # loss: a zero-length sample between two real ones, and a fully masked micro-batch
+    lpv = torch.randn(10, device=DEV)
+    z = torch.zeros(10, device=DEV)
+    cu = _t(np.array([0, 4, 4, 10], dtype=np.int32))
+    loss, grad, stats, _ = ops.grpo_loss_fwd_bwd(lpv, lpv.clone(), z + 1.0, torch.ones(10, dtype=torch.bool, device=DEV), cu, _loss_params(O.LossConfig(), (10, 1, 1)))
+    assert stats[1].abs().sum() == 0 and stats[:, _lib.STAT["RL_N_MASK"]].tolist() == [4.0, 0.0, 6.0]
+    _close(loss[0], -1.0, 1e-6, 1e-6, "ratio 1, adv 1 -> loss -1")
+    loss, grad, _, _ = ops.grpo_loss_fwd_bwd(lpv, z, z, torch.zeros(10, dtype=torch.bool, device=DEV), cu, _loss_params(O.LossConfig(), (1, 1, 1)))
+    assert loss.item() == 0.0 and not grad.any()
+    # attention on a single token and on documents of length 1
+    for lens in ([1], [1, 1, 1, 2]):
+        n = sum(lens)
+        q, k, v = _attn_case(n, lens, 4, 2, 1)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+        ss = ops.seq_start_from_cu(cu, n)
+        out, lse = ops.attn_varlen_fwd(q.to(DEV), k.to(DEV), v.to(DEV), ss, 128**-0.5)
+        want = O.varlen_causal_attention(q, k, v, lens, 128**-0.5)
+        _close(out, want, 1e-2, 1e-2, f"attention lens={lens}")
