@@ -43,6 +43,8 @@ def main() -> None:
     ap.add_argument("--model", default="qwen3-8b", choices=["qwen3-8b", "qwen3-0.6b", "tiny"])
     ap.add_argument("--tokens-per-pass", type=int, default=16384, help="micro-batches are concatenated into passes of at most this many tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="diagnostic: at N=1 run the RCCL reduce-scatter/all-gather + comm-stream path on a world_size-1 group (not the headline run)")
     args = ap.parse_args()
 
     from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
@@ -57,9 +59,13 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+    elif args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
 
     dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "tiny": ModelDims.tiny}[args.model]()
-    engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0)
+    engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 
     per_pass = max(args.tokens_per_pass // args.seq_len, 1)
@@ -167,10 +173,18 @@ def main() -> None:
                           f"{cpu['opt_params'] >> 20}Mi params {cpu['t_opt']:.2f}s (x params/{cpu['opt_params'] >> 20}Mi); scaled linearly to {args.seq_len} tokens "
                           f"(ignores quadratic attention: favours the CPU)",
             }
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        if args.force_collectives and world == 1:
+            result["config"]["diagnostic"] = "force_collectives: world_size-1 RCCL reduce-scatter/all-gather on the comm stream (not the headline run)"
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio (flushed at exit when stdout is a pipe/file): flush it first so that the
+        # JSON line is the LAST line of stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

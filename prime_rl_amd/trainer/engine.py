@@ -209,7 +209,7 @@ class ParamStore:
     `state_dict()` exposes HF-named views (q_proj.weight, k_proj.weight, ...) so checkpoints and the weight push keep the
     reference's names (trainer/models/qwen3/modeling_qwen3.py parameter names)."""
 
-    def __init__(self, dims: ModelDims, device, dp_rank: int = 0, dp_size: int = 1):
+    def __init__(self, dims: ModelDims, device, dp_rank: int = 0, dp_size: int = 1, force_collectives: bool = False):
         self.dims, self.device, self.dp_rank, self.dp_size = dims, torch.device(device), dp_rank, dp_size
         d = dims
         buckets: list[_Bucket] = []
@@ -254,7 +254,10 @@ class ParamStore:
         self.master = torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
         self.exp_avg = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
-        self.grad_shard = self.main_grad if dp_size == 1 else torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
+        # use_collectives: True whenever the reduce-scatter / all-gather path runs (dp > 1, or forced on one rank so the RCCL +
+        # side-stream plumbing can be exercised on a single GPU: the collectives then degenerate to device copies)
+        self.use_collectives = dp_size > 1 or force_collectives
+        self.grad_shard = self.main_grad if not self.use_collectives else torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
         self.w: dict[str, Tensor] = {}
         self.g: dict[str, Tensor] = {}
         for b in buckets:
@@ -342,7 +345,8 @@ class GRPOEngine:
     """forward -> log-probs -> GRPO loss -> backward -> (reduce-scatter) -> clip -> AdamW -> (all-gather) for one rank."""
 
     def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
-                 dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False):
+                 dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
+                 force_collectives: bool = False):
         self.dims, self.device = dims, torch.device(device)
         self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
         self.dp_group = dp_group
@@ -350,13 +354,16 @@ class GRPOEngine:
         self.dp_rank = dist.get_rank(dp_group) if self.dp_size > 1 else 0
         if dims.head_dim != 128:
             raise PrimeMI355XError("attention kernels are built for head_dim 128")
-        self.store = ParamStore(dims, self.device, self.dp_rank, self.dp_size)
+        if force_collectives and not dist.is_initialized():
+            raise PrimeMI355XError("force_collectives needs an initialised process group (a world_size-1 nccl group is enough)")
+        self.store = ParamStore(dims, self.device, self.dp_rank, self.dp_size, force_collectives=force_collectives)
+        self.use_collectives = self.store.use_collectives
         self.store.random_init(seed)
         self.inv_freq = ops.rope_inv_freq(dims.head_dim, dims.rope_theta, self.device)
         self.lm_head_token_chunk = lm_head_token_chunk
         self.recompute_act = recompute_act
         self.step_count = 0
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.dp_size > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_collectives else None
         self._gather_events: dict[str, torch.cuda.Event] = {}
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._wgrad_direct = self._probe_wgrad_direct()
@@ -525,7 +532,7 @@ class GRPOEngine:
 
     # -- data-parallel plumbing (RCCL on a side stream; trainer/zero.py) -------------------------------------------------
     def _bucket_done(self, name: str, last_pass: bool) -> None:
-        if self.dp_size == 1 or not last_pass:
+        if not self.use_collectives or not last_pass:
             return
         b = next(bk for bk in self.store.buckets if bk.name == name)
         zero.reduce_scatter_bucket(self.store, b, self.dp_group, self.comm_stream)

@@ -44,13 +44,14 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
     sumsq = scratch if scratch is not None else torch.zeros(1, dtype=torch.float32, device=store.main_grad.device)
     sumsq.zero_()
     gpu = _on_gpu(store.main_grad)
-    if dp > 1 and gpu and comm_stream is not None:
+    collectives = getattr(store, "use_collectives", dp > 1)  # True at dp == 1 only when forced (single-GPU check of this path)
+    if collectives and gpu and comm_stream is not None:
         torch.cuda.current_stream().wait_stream(comm_stream)  # every reduce-scatter has landed
     kernels.sumsq_accumulate(store.grad_shard, sumsq)
-    if dp > 1:
+    if collectives:
         dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=group)
     coef, norm = kernels.clip_coef(sumsq, 1.0, optim.max_norm if optim.max_norm else 0.0)
-    if dp == 1:
+    if not collectives:
         kernels.adamw_step(store.master, store.exp_avg, store.exp_avg_sq, store.grad_shard, store.params, optim.lr, optim.betas1, optim.betas2, optim.eps,
                            optim.weight_decay, step, 1.0, coef, zero_grad=False)
         return norm
