@@ -22,6 +22,7 @@ class SimpleNode:
 @dataclass
 class SimpleAgent:
     trainable: bool = True
+    name: str = "agent"
 
 
 @dataclass
@@ -39,6 +40,7 @@ class SimpleTrace:
 @dataclass
 class SimpleEpisode:
     traces: list[SimpleTrace]
+    id: str = ""
 
 
 def iter_trainable_traces(episodes):

@@ -7,22 +7,22 @@ from __future__ import annotations
 
 def assign_advantages(trace, values: float | list[float]) -> None:
     """Assign credit in compact sampled-token order across the trace graph (routing.py:11-34)."""
-    nodes = [node for node in trace.nodes if any(node.mask)]
-    for node in nodes:
+    sampled: list[tuple[object, int]] = []  # (node, number of mask-True tokens) for nodes that carry sampled tokens
+    for node in trace.nodes:
+        count = sum(1 for m in node.mask if m)
+        if count == 0:
+            continue
         if len(node.mask) != len(node.token_ids):
             raise ValueError(f"node masks must align with token ids in trace {trace.id!r}: got {len(node.mask)}, expected {len(node.token_ids)}")
-    total = sum(sum(node.mask) for node in nodes)
-    if isinstance(values, (int, float)):
-        advantages = [float(values)] * total
-    else:
-        if len(values) != total:
-            raise ValueError(f"advantages must align with trace {trace.id!r}'s sampled tokens: got {len(values)}, expected {total}")
-        advantages = [float(v) for v in values]
-    offset = 0
-    for node in nodes:
-        end = offset + sum(node.mask)
-        node.advantages = advantages[offset:end]
-        offset = end
+        sampled.append((node, count))
+    total = sum(count for _, count in sampled)
+    scalar = isinstance(values, (int, float))
+    if not scalar and len(values) != total:
+        raise ValueError(f"advantages must align with trace {trace.id!r}'s sampled tokens: got {len(values)}, expected {total}")
+    cursor = 0
+    for node, count in sampled:
+        node.advantages = [float(values)] * count if scalar else [float(v) for v in values[cursor:cursor + count]]
+        cursor += count
 
 
 def scalar_advantage(trace) -> float | None:

@@ -252,3 +252,24 @@ def test_grpo_algorithm_plugin():
     assert a[0] > a[1] > a[2] and abs(sum(a)) < 1e-5
     b = [e.traces[0].nodes[0].advantages[0] for e in g2]
     assert abs(sum(b)) < 1e-6 and b[0] > 0 > b[1]
+
+
+def test_hierarchical_grpo_peer_sets():
+    """hierarchical_grpo.py:33-42: solver traces are centered per episode, proposer traces across the cohort, singletons get zero —
+    all peer sets in one pm_grpo_advantage launch; checked against the plain restatement."""
+    import asyncio
+
+    from prime_rl_amd.orchestrator.algo import HierarchicalGRPOAlgoConfig, build_algorithm
+    from prime_rl_amd.orchestrator.algo.base import SimpleAgent, SimpleEpisode, SimpleNode, SimpleTrace
+
+    def tr(name, role, reward):
+        return SimpleTrace(name, reward, [SimpleNode([1, 2, 3], [False, True, True])], agent=SimpleAgent(name=role))
+
+    eps = [SimpleEpisode([tr("p0", "proposer", 0.2), tr("s00", "solver", 1.0), tr("s01", "solver", 0.0), tr("s02", "solver", 0.0)], id="e0"),
+           SimpleEpisode([tr("p1", "proposer", 0.8), tr("s10", "solver", 1.0), tr("s11", "solver", 1.0)], id="e1"),
+           SimpleEpisode([tr("p2", "proposer", 0.5), tr("s20", "solver", 0.3)], id="e2")]
+    asyncio.run(build_algorithm(HierarchicalGRPOAlgoConfig(episode_agents=["solver"])).finalize_group(eps))
+    got = {t.id: t.nodes[0].advantages for e in eps for t in e.traces}
+    want = {"p0": 0.2 - 0.5, "p1": 0.8 - 0.5, "p2": 0.0, "s00": 1 - 1 / 3, "s01": -1 / 3, "s02": -1 / 3, "s10": 0.0, "s11": 0.0, "s20": 0.0}
+    for k, v in want.items():
+        assert got[k] == pytest.approx([v, v], abs=1e-6), k
