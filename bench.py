@@ -92,6 +92,7 @@ def main() -> None:
     for s in range(args.warmup, total_steps):
         out = engine.step(batches[s])
         losses.append(out["loss"])
+    host_enqueue = time.perf_counter() - t0  # how long the host needed to enqueue the timed steps (GPU-bound when << elapsed)
     barrier()
     elapsed = time.perf_counter() - t0
     k1_events, engine.k1_events = engine.k1_events, None
@@ -144,6 +145,7 @@ def main() -> None:
                 "mfu_vs_2.5PF_bf16": round(value * flops_per_sample / (world * MFMA_BF16_PEAK), 4),
                 "tflop_per_sample": round(flops_per_sample / 1e12, 2),
                 "loss_last": float(sum(l.item() for l in losses[-1])),
+                "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 1),
             },
             "roofline": {
                 "kernel": f"logprob_fwd_row_kernel<{'bf16' if esz == 2 else 'f32'}> (selective log-softmax + entropy)",

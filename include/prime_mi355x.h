@@ -200,6 +200,12 @@ int pm_embedding_fwd(const void* table_bf16, const int64_t* ids, int64_t n_token
 int pm_embedding_bwd(const void* grad_out_bf16, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens,
                      int64_t hidden, int64_t vocab, float* grad_table_f32, void* stream);  /* ids outside [0, vocab) are skipped */
 
+/* 2-D transpose of 16-bit elements: dst[c*dst_ld + r] = src[r*src_ld + c].  Replaces the `.transpose(1, 2)` / `.t().contiguous()`
+ * copies around the attention and linear layers (models/layers/attn.py:147-158) and feeds the library GEMMs the operand
+ * orientation they run fastest in (K-contiguous weights for dgrad, K-contiguous activations for wgrad).  rows, cols and both
+ * leading dimensions must be multiples of 8. */
+int pm_transpose_2d(const void* src_16bit, int64_t rows, int64_t cols, int64_t src_ld, void* dst_16bit, int64_t dst_ld, void* stream);
+
 /* RMSNorm — RMSNorm.forward (models/layers/norms.py:36-44): y = w * bf16(x*rsqrt(mean(x^2)+eps)); fp32 math.
  * Optional fused residual: if residual != null, x_in = x + residual is written to sum_out (bf16) and normalised. */
 int pm_rmsnorm_fwd(const void* x_bf16, const void* residual_bf16 /* nullable */, const void* weight_bf16,

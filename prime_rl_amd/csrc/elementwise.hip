@@ -212,9 +212,58 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
+// ================================= 2-D transpose (16-bit elements) ============================
+// dst[c][r] = src[r][c].  One 64x64 tile per workgroup through LDS: 16-byte global loads along src rows, tile rows padded to 33
+// dwords so that the column gathers (8 x ds_read_u16 per 16-byte output vector) are bank-conflict free, 16-byte global stores
+// along dst rows.  HBM-bound: 2 bytes read + 2 written per element.  rows, cols and both leading dimensions are multiples of 8.
+constexpr int kTrTile = 64, kTrLd = 66;
+
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ src, int64_t rows, int64_t cols, int64_t src_ld,
+                                                         uint16_t* __restrict__ dst, int64_t dst_ld) {
+  __shared__ uint32_t tile32[kTrTile * kTrLd / 2];
+  const uint16_t* tile = reinterpret_cast<const uint16_t*>(tile32);
+  const int64_t r0 = (int64_t)blockIdx.y * kTrTile, c0 = (int64_t)blockIdx.x * kTrTile;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int vi = threadIdx.x + 256 * k;
+    const int r = vi >> 3, cv = vi & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < rows && c0 + cv * 8 < cols) v = *reinterpret_cast<const u32x4*>(src + (r0 + r) * src_ld + c0 + cv * 8);
+    uint32_t* t = tile32 + r * (kTrLd / 2) + cv * 4;
+    t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ch = threadIdx.x + 256 * k;
+    const int j = ch & 7, c = ch >> 3;
+    if (c0 + c < cols && r0 + j * 8 < rows) {
+      uint32_t e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = tile[(j * 8 + i) * kTrLd + c];
+      u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+      *reinterpret_cast<u32x4*>(dst + (c0 + c) * dst_ld + r0 + j * 8) = o;
+    }
+  }
+}
+
 }  // namespace pm
 
 using namespace pm;
+
+extern "C" int pm_transpose_2d(const void* src, int64_t rows, int64_t cols, int64_t src_ld, void* dst, int64_t dst_ld, void* stream) {
+  PM_REQUIRE(src && dst, PM_ERR_INVALID_ARG, "pm_transpose_2d: null pointer");
+  PM_REQUIRE(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && src_ld >= cols && dst_ld >= rows,
+             PM_ERR_UNSUPPORTED, "pm_transpose_2d: rows=%lld cols=%lld src_ld=%lld dst_ld=%lld (multiples of 8, ld >= extent)", (long long)rows,
+             (long long)cols, (long long)src_ld, (long long)dst_ld);
+  if (rows == 0 || cols == 0) return PM_OK;
+  const int64_t gx = cdiv(cols, (int64_t)kTrTile), gy = cdiv(rows, (int64_t)kTrTile);
+  PM_REQUIRE(gy <= 65535, PM_ERR_UNSUPPORTED, "pm_transpose_2d: rows=%lld too large", (long long)rows);
+  hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, as_stream(stream), (const uint16_t*)src, rows, cols, src_ld,
+                     (uint16_t*)dst, dst_ld);
+  PM_CHECK_LAUNCH("pm_transpose_2d");
+  return PM_OK;
+}
 
 extern "C" int pm_swiglu_fwd(const void* gate_up, int64_t n_rows, int64_t inter, void* act, void* stream) {
   PM_REQUIRE(gate_up && act, PM_ERR_INVALID_ARG, "pm_swiglu_fwd: null pointer");

@@ -69,100 +69,166 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// backward: each wave walks rows {first + 4*k + wave}, keeps dweight partials in registers, writes one partial row per wave.
+// backward.  A row is owned by a TEAM of two waves (128 lanes, lane l owns 8-element vectors {v*128 + l}), a workgroup holds two
+// teams: at H = 4096 that is 4 vectors per lane, ~100 VGPRs, 4 workgroups (16 waves) resident per CU, and every wave has its whole
+// x / dy / dresidual row slice in flight before the first use — memory-level parallelism comes from occupancy, nothing spills.
+// The row's dot product crosses the team through two LDS floats (double-buffered: one barrier per row).  dweight partials stay in
+// registers over the team's rows; at the end team 1 hands its partials to team 0 through LDS: ONE partial row per workgroup.
 template <int MAXV, bool HAS_DRES>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ w, const float* __restrict__ rstd,
-                                                         const bf16_t* __restrict__ dres, int64_t n_rows, int H, int64_t rows_per_wg,
-                                                         bf16_t* __restrict__ gx, float* __restrict__ dw_partials) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256, (MAXV <= 4 ? 4 : 2)) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+                                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                                              const bf16_t* __restrict__ dres, int64_t n_rows, int H,
+                                                                              int64_t rows_per_wg, bf16_t* __restrict__ gx,
+                                                                              float* __restrict__ dw_partials) {
+  extern __shared__ float dw_lds[];  // [H] fold buffer, [2 buffers][2 teams][2 waves] dot partials, [H] bf16 weights
+  float* red = dw_lds + H;
+  const int team = threadIdx.x >> 7, tl = threadIdx.x & 127, wave_in_team = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
   const int nvec = H >> 3;
   const int64_t first = (int64_t)blockIdx.x * rows_per_wg;
   int64_t last = first + rows_per_wg;
   if (last > n_rows) last = n_rows;
   float dw[MAXV][8];
-  float wf[MAXV][8];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
-    const int idx = v * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 8; ++k) dw[v][k] = 0.f;
-    if (idx < nvec) unpack8(reinterpret_cast<const u32x4*>(w)[idx], wf[v]);
   }
-  for (int64_t row = first + wave; row < last; row += 4) {
-    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * H);
-    const u32x4* gr = reinterpret_cast<const u32x4*>(gy + row * H);
-    const float r = rstd[row];
-    float xh[MAXV][8], gw[MAXV][8];
+  u32x4* wl = reinterpret_cast<u32x4*>(red + 8);  // the weight row lives in LDS (read twice per row by every team), not in VGPRs
+  for (int idx = threadIdx.x; idx < nvec; idx += 256) wl[idx] = reinterpret_cast<const u32x4*>(w)[idx];
+  __syncthreads();
+  const float inv_h = 1.0f / (float)H;
+  int it = 0;
+  for (int64_t base = first; base < last; base += 2, ++it) {  // uniform trip count over the workgroup (barrier inside)
+    const int64_t row = base + team;
+    const bool active = row < last;
+    u32x4 xp[MAXV], gp[MAXV], dp[MAXV];
+    float r = 0.f;
+    if (active) {
+      const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * H);
+      const u32x4* gr = reinterpret_cast<const u32x4*>(gy + row * H);
+      const u32x4* dr = HAS_DRES ? reinterpret_cast<const u32x4*>(dres + row * H) : nullptr;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * 128 + tl;
+        if (idx < nvec) {
+          xp[v] = xr[idx];
+          gp[v] = gr[idx];
+          if (HAS_DRES) dp[v] = dr[idx];
+        }
+      }
+      r = rstd[row];
+    }
     float dot = 0.f;
+    if (active) {
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int idx = v * 64 + lane;
-      if (idx < nvec) {
-        float gf[8];
-        unpack8(xr[idx], xh[v]);
-        unpack8(gr[idx], gf);
+      for (int v = 0; v < MAXV; ++v) {
+        if (v * 128 + tl < nvec) {
+          float xf[8], gf[8], wf[8];
+          unpack8(xp[v], xf);
+          unpack8(gp[v], gf);
+          unpack8(wl[v * 128 + tl], wf);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          xh[v][k] *= r;
-          dw[v][k] = fmaf(gf[k], xh[v][k], dw[v][k]);
-          gw[v][k] = gf[k] * wf[v][k];
-          dot = fmaf(gw[v][k], xh[v][k], dot);
+          for (int k = 0; k < 8; ++k) {
+            const float xh = xf[k] * r;
+            dw[v][k] = fmaf(gf[k], xh, dw[v][k]);
+            dot = fmaf(gf[k] * wf[k], xh, dot);
+          }
         }
       }
     }
-    dot = wave_sum(dot) / (float)H;
-    u32x4* ox = reinterpret_cast<u32x4*>(gx + row * H);
-    const u32x4* dr = HAS_DRES ? reinterpret_cast<const u32x4*>(dres + row * H) : nullptr;
+    dot = wave_sum(dot);
+    float* slot = red + (it & 1) * 4 + team * 2;
+    if (lane == 0) slot[wave_in_team] = dot;
+    __syncthreads();
+    if (active) {
+      dot = (slot[0] + slot[1]) * inv_h;
+      u32x4* ox = reinterpret_cast<u32x4*>(gx + row * H);
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int idx = v * 64 + lane;
-      if (idx < nvec) {
-        float o[8];
+      for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * 128 + tl;
+        if (idx < nvec) {
+          float xf[8], gf[8], wf[8], o[8];
+          unpack8(xp[v], xf);
+          unpack8(gp[v], gf);
+          unpack8(wl[v * 128 + tl], wf);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = r * (gw[v][k] - xh[v][k] * dot);
-        if (HAS_DRES) {
-          float df[8];
-          unpack8(dr[idx], df);
+          for (int k = 0; k < 8; ++k) o[k] = r * (gf[k] * wf[k] - (xf[k] * r) * dot);
+          if (HAS_DRES) {
+            float df[8];
+            unpack8(dp[v], df);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] += df[k];
+            for (int k = 0; k < 8; ++k) o[k] += df[k];
+          }
+          ox[idx] = pack8(o);
         }
-        ox[idx] = pack8(o);
       }
     }
   }
-  float* pw = dw_partials + ((int64_t)blockIdx.x * 4 + wave) * H;
+  // fold: team 1 -> LDS, team 0 adds (fixed order) and writes the workgroup's partial row
+  if (team == 1) {
 #pragma unroll
-  for (int v = 0; v < MAXV; ++v) {
-    const int idx = v * 64 + lane;
-    if (idx < nvec) {
-      float4* p4 = reinterpret_cast<float4*>(pw + (int64_t)idx * 8);
-      p4[0] = make_float4(dw[v][0], dw[v][1], dw[v][2], dw[v][3]);
-      p4[1] = make_float4(dw[v][4], dw[v][5], dw[v][6], dw[v][7]);
+    for (int v = 0; v < MAXV; ++v) {
+      const int idx = v * 128 + tl;
+      if (idx < nvec) {
+        float4* l4 = reinterpret_cast<float4*>(dw_lds + idx * 8);
+        l4[0] = make_float4(dw[v][0], dw[v][1], dw[v][2], dw[v][3]);
+        l4[1] = make_float4(dw[v][4], dw[v][5], dw[v][6], dw[v][7]);
+      }
+    }
+  }
+  __syncthreads();
+  if (team == 0) {
+    float* pw = dw_partials + (int64_t)blockIdx.x * H;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int idx = v * 128 + tl;
+      if (idx < nvec) {
+        const float4* l4 = reinterpret_cast<const float4*>(dw_lds + idx * 8);
+        const float4 a = l4[0], b = l4[1];
+        float4* p4 = reinterpret_cast<float4*>(pw + (int64_t)idx * 8);
+        p4[0] = make_float4(dw[v][0] + a.x, dw[v][1] + a.y, dw[v][2] + a.z, dw[v][3] + a.w);
+        p4[1] = make_float4(dw[v][4] + b.x, dw[v][5] + b.y, dw[v][6] + b.z, dw[v][7] + b.w);
+      }
     }
   }
 }
 
-// out[c] += sum_p partials[p][c]  (deterministic: fixed order over p)
-__global__ void column_reduce_accum_kernel(const float* __restrict__ partials, int64_t n_partials, int64_t ncols, float* __restrict__ out) {
+// Deterministic column sums of the per-workgroup partial rows, in two small launches so the reduction is spread over the chip:
+// stage 1: slice s of kReduceSlices sums partial rows {s, s + kReduceSlices, ...} into stage[s][c]; stage 2: out[c] += sum_s stage[s][c].
+constexpr int kReduceSlices = 32;
+
+__global__ void column_reduce_stage1_kernel(const float* __restrict__ partials, int64_t n_partials, int64_t ncols, float* __restrict__ stage) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t p = blockIdx.y;
+  for (; p + kReduceSlices < n_partials; p += 2 * kReduceSlices) {
+    s0 += partials[p * ncols + c];
+    s1 += partials[(p + kReduceSlices) * ncols + c];
+  }
+  if (p < n_partials) s0 += partials[p * ncols + c];
+  stage[(int64_t)blockIdx.y * ncols + c] = s0 + s1;
+}
+
+__global__ void column_reduce_stage2_kernel(const float* __restrict__ stage, int64_t ncols, float* __restrict__ out) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t p = 0;
-  for (; p + 3 < n_partials; p += 4) {
-    s0 += partials[(p + 0) * ncols + c];
-    s1 += partials[(p + 1) * ncols + c];
-    s2 += partials[(p + 2) * ncols + c];
-    s3 += partials[(p + 3) * ncols + c];
+#pragma unroll
+  for (int s = 0; s < kReduceSlices; s += 4) {
+    s0 += stage[(int64_t)(s + 0) * ncols + c];
+    s1 += stage[(int64_t)(s + 1) * ncols + c];
+    s2 += stage[(int64_t)(s + 2) * ncols + c];
+    s3 += stage[(int64_t)(s + 3) * ncols + c];
   }
-  for (; p < n_partials; ++p) s0 += partials[p * ncols + c];
   out[c] += (s0 + s1) + (s2 + s3);
 }
 
+// 4 workgroups (16 waves) per CU keep enough row loads in flight for HBM; 1024 = 4 x 256 CUs, so the grid is one full residency
 static int64_t rms_bwd_num_wg(int64_t n_rows) {
-  int64_t g = cdiv(n_rows, 32);
+  int64_t g = cdiv(n_rows, 8);
   if (g < 1) g = 1;
-  if (g > 512) g = 512;
+  if (g > 1024) g = 1024;
   return g;
 }
 
@@ -368,7 +434,7 @@ extern "C" int pm_rmsnorm_fwd(const void* x, const void* residual, const void* w
 
 extern "C" int64_t pm_rmsnorm_bwd_workspace_bytes(int64_t n_rows, int64_t hidden) {
   if (n_rows <= 0 || hidden <= 0) return 0;
-  return rms_bwd_num_wg(n_rows) * 4 * hidden * (int64_t)sizeof(float);
+  return (rms_bwd_num_wg(n_rows) + kReduceSlices) * hidden * (int64_t)sizeof(float);  // per-workgroup partial rows + the stage-1 rows
 }
 
 template <bool HAS_DRES>
@@ -376,11 +442,12 @@ static int rms_bwd_launch(const bf16_t* gy, const bf16_t* x, const bf16_t* w, co
                           bf16_t* gx, float* partials, int64_t num_wg, hipStream_t st) {
   const int64_t rows_per_wg = cdiv(n_rows, num_wg);
   const dim3 grid((unsigned)num_wg), block(256);
-  const int nv = (int)cdiv(H, 512);
-  if (nv <= 2) hipLaunchKernelGGL((rmsnorm_bwd_kernel<2, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
-  else if (nv <= 4) hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
-  else if (nv <= 8) hipLaunchKernelGGL((rmsnorm_bwd_kernel<8, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
-  else hipLaunchKernelGGL((rmsnorm_bwd_kernel<16, HAS_DRES>), grid, block, 0, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  const int nv = (int)cdiv(H, 1024);  // 8-element vectors per lane of a 128-lane team
+  const size_t lds = (size_t)(H + 8) * sizeof(float) + (size_t)H * sizeof(bf16_t);
+  if (nv <= 1) hipLaunchKernelGGL((rmsnorm_bwd_kernel<1, HAS_DRES>), grid, block, lds, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else if (nv <= 2) hipLaunchKernelGGL((rmsnorm_bwd_kernel<2, HAS_DRES>), grid, block, lds, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else if (nv <= 4) hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, HAS_DRES>), grid, block, lds, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
+  else hipLaunchKernelGGL((rmsnorm_bwd_kernel<8, HAS_DRES>), grid, block, lds, st, gy, x, w, rstd, dres, n_rows, H, rows_per_wg, gx, partials);
   PM_CHECK_LAUNCH("pm_rmsnorm_bwd");
   return PM_OK;
 }
@@ -404,8 +471,10 @@ extern "C" int pm_rmsnorm_bwd(const void* grad_y, const void* x, const void* wei
     rc = rms_bwd_launch<false>((const bf16_t*)grad_y, (const bf16_t*)x, (const bf16_t*)weight, rstd, nullptr, n_rows, (int)hidden,
                                (bf16_t*)grad_x, (float*)workspace, num_wg, st);
   if (rc != PM_OK) return rc;
-  hipLaunchKernelGGL(column_reduce_accum_kernel, dim3((unsigned)cdiv(hidden, 256)), dim3(256), 0, st, (const float*)workspace, num_wg * 4, hidden,
-                     grad_weight);
+  float* stage = (float*)workspace + num_wg * hidden;
+  hipLaunchKernelGGL(column_reduce_stage1_kernel, dim3((unsigned)cdiv(hidden, 256), kReduceSlices), dim3(256), 0, st, (const float*)workspace, num_wg,
+                     hidden, stage);
+  hipLaunchKernelGGL(column_reduce_stage2_kernel, dim3((unsigned)cdiv(hidden, 256)), dim3(256), 0, st, (const float*)stage, hidden, grad_weight);
   PM_CHECK_LAUNCH("pm_rmsnorm_bwd(reduce)");
   return PM_OK;
 }

@@ -354,6 +354,20 @@ def attn_varlen_bwd(grad_out: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tens
     return gq, gk, gv
 
 
+def transpose_2d(src: Tensor, out: Tensor | None = None) -> Tensor:
+    """out[c, r] = src[r, c] for a row-major bf16/f16 matrix (rows may be strided: `src.stride(1) == 1`)."""
+    lib = _lib.load()
+    if src.dtype not in (torch.bfloat16, torch.float16) or src.dim() != 2 or src.stride(1) != 1 or not src.is_cuda:
+        raise ValueError(f"transpose_2d: need a 2-D 16-bit GPU tensor with unit inner stride, got {src.dtype} {tuple(src.shape)} strides {src.stride()}")
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=src.dtype, device=src.device)
+    elif out.shape != (cols, rows) or out.dtype != src.dtype or out.stride(1) != 1:
+        raise ValueError("transpose_2d: out must be [cols, rows] of the same dtype with unit inner stride")
+    check(lib.pm_transpose_2d(_p(src), rows, cols, src.stride(0), _p(out), out.stride(0), _stream()), "pm_transpose_2d")
+    return out
+
+
 def swiglu_fwd(gate_up: Tensor) -> Tensor:
     lib = _lib.load()
     _req(gate_up, torch.bfloat16, "gate_up")

@@ -164,6 +164,29 @@ def test_engine_two_passes_equal_one_pass():
     assert rel < 2e-2, rel
 
 
+def test_gemm_layout_copies_track_parameter_updates():
+    """The K-contiguous weight copies used by dgrad (and the transposed MLP inputs used by wgrad) change only the operand layout:
+    gradients equal the plain-layout engine's up to GEMM summation order, also AFTER optimizer steps moved the weights (a stale
+    copy would show up as an O(lr) gradient error, made large here with lr = 3e-2), and after load_state_dict."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=512)
+    optim = OptimConfig(lr=3e-2, max_norm=1.0)
+    a = GRPOEngine(dims, device=DEV, optim=optim, seed=11, gemm_layouts=True)
+    b = GRPOEngine(dims, device=DEV, optim=optim, seed=11, gemm_layouts=False)
+    for step in range(3):
+        batch = pack_micro_batches(_mbs(dims.vocab_size, 128, 3, True, seed_shift=step), DEV)
+        if step == 2:  # externally loaded weights must invalidate the copies as well
+            sd = {k: v.float() * 1.5 for k, v in a.store.state_dict().items()}
+            a.store.load_state_dict(sd); b.store.load_state_dict(sd)
+        ra, rb = a.step(batch), b.step(batch)
+        ga, gb = a.store.main_grad, b.store.main_grad
+        rel = ((ga - gb).norm() / gb.norm()).item()
+        assert rel < 1e-2, (step, rel)
+        assert abs(ra["grad_norm"].item() - rb["grad_norm"].item()) <= 5e-3 * rb["grad_norm"].item()
+    assert len(a._wt) == 4 * dims.num_hidden_layers and not b._wt
+
+
 def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
     """train(config) end to end on the tiny model: reference step/version indexing (startup v0 + one broadcast per step), the
     console line and metric keys dashboards regex, metrics.jsonl."""

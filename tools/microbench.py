@@ -92,6 +92,15 @@ def bench_norm(out):
     gw = torch.zeros(h, device=DEV)
     med, _ = timeit(lambda: ops.rmsnorm_bwd(y, x, w, rstd, gw), flush_mb=512)
     out.append(dict(kernel="rmsnorm_bwd[16384x4096]", ms=med * 1e3, GBps=n * h * 6 / med / 1e9))
+    dres = torch.randn(n, h, device=DEV).to(torch.bfloat16)
+    med, _ = timeit(lambda: ops.rmsnorm_bwd(y, x, w, rstd, gw, dresidual=dres), flush_mb=512)
+    out.append(dict(kernel="rmsnorm_bwd+dres[16384x4096]", ms=med * 1e3, GBps=n * h * 8 / med / 1e9))
+    for r, c in ((16384, 4096), (16384, 12288), (24576, 4096), (151936, 4096)):
+        s = torch.randn(r, c, device=DEV).to(torch.bfloat16)
+        d = torch.empty(c, r, dtype=torch.bfloat16, device=DEV)
+        med, _ = timeit(lambda: ops.transpose_2d(s, out=d), flush_mb=512)
+        out.append(dict(kernel=f"transpose_2d[{r}x{c}]", ms=med * 1e3, GBps=r * c * 4 / med / 1e9))
+        del s, d
     gu = torch.randn(n, 2 * 12288, device=DEV).to(torch.bfloat16)
     med, _ = timeit(lambda: ops.swiglu_fwd(gu), flush_mb=512)
     out.append(dict(kernel="swiglu_fwd[16384x12288]", ms=med * 1e3, GBps=n * 12288 * 6 / med / 1e9))
@@ -104,9 +113,56 @@ def bench_norm(out):
     out.append(dict(kernel="hipBLASLt gemm 2048x4096x24576 bf16", ms=med * 1e3, TFLOPs=2 * 2048 * 4096 * 24576 / med / 1e12))
 
 
+def bench_gemm(out):
+    """Operand-orientation study for the library GEMMs of one Qwen3-8B layer at T = 16384 tokens (what the step runs): which layout
+    of W / dY / X does hipBLASLt run fastest for forward, dgrad and the f32-accumulating wgrad."""
+    t = 16384
+    shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
+    for name, (o, i) in shapes.items():
+        x = torch.randn(t, i, device=DEV).to(torch.bfloat16)
+        dy = torch.randn(t, o, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
+        wt = w.t().contiguous()
+        g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
+        gt = torch.zeros(i, o, dtype=torch.float32, device=DEV)
+        gb = torch.zeros(o, i, dtype=torch.bfloat16, device=DEV)
+        dyt, xt = dy.t().contiguous(), x.t().contiguous()
+        y, dx = torch.empty(t, o, dtype=torch.bfloat16, device=DEV), torch.empty(t, i, dtype=torch.bfloat16, device=DEV)
+        fl = 2 * t * o * i
+        variants = {
+            "fwd  x @ W.T        (W [out,in])": lambda: torch.mm(x, w.t(), out=y),
+            "fwd  x @ Wt         (Wt [in,out])": lambda: torch.mm(x, wt, out=y),
+            "dgrad dy @ W        (W [out,in])": lambda: torch.mm(dy, w, out=dx),
+            "dgrad dy @ Wt.T     (Wt [in,out])": lambda: torch.mm(dy, wt.t(), out=dx),
+            "wgrad dy.T @ x -> f32 [out,in]   (current)": lambda: torch.mm(dy.t(), x, out_dtype=torch.float32, out=g),
+            "wgrad addmm dy.T @ x -> f32      (accumulate)": lambda: torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g),
+            "wgrad dyt @ x -> f32             (dy pre-transposed)": lambda: torch.mm(dyt, x, out_dtype=torch.float32, out=g),
+            "wgrad dyt @ xt.T -> f32          (both K-contiguous)": lambda: torch.mm(dyt, xt.t(), out_dtype=torch.float32, out=g),
+            "wgrad dy.T @ xt.T -> f32         (x pre-transposed)": lambda: torch.mm(dy.t(), xt.t(), out_dtype=torch.float32, out=g),
+            "wgrad x.T @ dy -> f32 [in,out]   (transposed grad)": lambda: torch.mm(x.t(), dy, out_dtype=torch.float32, out=gt),
+            "wgrad dy.T @ x -> bf16": lambda: torch.mm(dy.t(), x, out=gb),
+            "transpose dy -> dyt": lambda: dyt.copy_(dy.t()),
+            "transpose x -> xt": lambda: xt.copy_(x.t()),
+        }
+        for label, fn in variants.items():
+            try:
+                med, best = timeit(fn, iters=8, warmup=2)
+            except Exception as ex:  # a layout the library refuses
+                out.append(dict(kernel=f"gemm {name} {label}", error=str(ex)[:80]))
+                continue
+            rec = dict(kernel=f"gemm {name} {label}", ms=med * 1e3)
+            if not label.startswith("transpose"):
+                rec["TFLOPs"] = fl / med / 1e12
+            out.append(rec)
+        del x, dy, w, wt, g, gt, gb, dyt, xt, y, dx
+        torch.cuda.empty_cache()
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
+    if which == "gemm":
+        bench_gemm(out)
     if which in ("k1", "all"):
         bench_k1(out)
     if which == "k1step":
