@@ -202,8 +202,8 @@ int pm_embedding_bwd(const void* grad_out_bf16, const int64_t* ids_sorted, const
 
 /* 2-D transpose of 16-bit elements: dst[c*dst_ld + r] = src[r*src_ld + c].  Replaces the `.transpose(1, 2)` / `.t().contiguous()`
  * copies around the attention and linear layers (models/layers/attn.py:147-158) and feeds the library GEMMs the operand
- * orientation they run fastest in (K-contiguous weights for dgrad, K-contiguous activations for wgrad).  rows, cols and both
- * leading dimensions must be multiples of 8. */
+ * orientation they run fastest in (K-contiguous weights for dgrad, K-contiguous activations for wgrad).  cols and both leading
+ * dimensions must be multiples of 8 (16-byte vectors); rows is arbitrary (dst_ld >= rows, e.g. rows rounded up to 8). */
 int pm_transpose_2d(const void* src_16bit, int64_t rows, int64_t cols, int64_t src_ld, void* dst_16bit, int64_t dst_ld, void* stream);
 
 /* RMSNorm — RMSNorm.forward (models/layers/norms.py:36-44): y = w * bf16(x*rsqrt(mean(x^2)+eps)); fp32 math.

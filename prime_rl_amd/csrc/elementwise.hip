@@ -237,12 +237,18 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
   for (int k = 0; k < 2; ++k) {
     const int ch = threadIdx.x + 256 * k;
     const int j = ch & 7, c = ch >> 3;
-    if (c0 + c < cols && r0 + j * 8 < rows) {
+    const int64_t rr = r0 + j * 8;
+    if (c0 + c < cols && rr < rows) {
       uint32_t e[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) e[i] = tile[(j * 8 + i) * kTrLd + c];
-      u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-      *reinterpret_cast<u32x4*>(dst + (c0 + c) * dst_ld + r0 + j * 8) = o;
+      uint16_t* d = dst + (c0 + c) * dst_ld + rr;
+      if (rr + 8 <= rows) {
+        u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        *reinterpret_cast<u32x4*>(d) = o;
+      } else {  // ragged last vector of a dst row (rows is not a multiple of 8: e.g. an unpadded token count)
+        for (int i = 0; i < 8 && rr + i < rows; ++i) d[i] = (uint16_t)e[i];
+      }
     }
   }
 }
@@ -253,9 +259,9 @@ using namespace pm;
 
 extern "C" int pm_transpose_2d(const void* src, int64_t rows, int64_t cols, int64_t src_ld, void* dst, int64_t dst_ld, void* stream) {
   PM_REQUIRE(src && dst, PM_ERR_INVALID_ARG, "pm_transpose_2d: null pointer");
-  PM_REQUIRE(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && src_ld >= cols && dst_ld >= rows,
-             PM_ERR_UNSUPPORTED, "pm_transpose_2d: rows=%lld cols=%lld src_ld=%lld dst_ld=%lld (multiples of 8, ld >= extent)", (long long)rows,
-             (long long)cols, (long long)src_ld, (long long)dst_ld);
+  PM_REQUIRE(rows >= 0 && cols >= 0 && cols % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && src_ld >= cols && dst_ld >= rows, PM_ERR_UNSUPPORTED,
+             "pm_transpose_2d: rows=%lld cols=%lld src_ld=%lld dst_ld=%lld (cols and both leading dimensions multiples of 8, ld >= extent)",
+             (long long)rows, (long long)cols, (long long)src_ld, (long long)dst_ld);
   if (rows == 0 || cols == 0) return PM_OK;
   const int64_t gx = cdiv(cols, (int64_t)kTrTile), gy = cdiv(rows, (int64_t)kTrTile);
   PM_REQUIRE(gy <= 65535, PM_ERR_UNSUPPORTED, "pm_transpose_2d: rows=%lld too large", (long long)rows);

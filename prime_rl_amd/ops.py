@@ -360,10 +360,12 @@ def transpose_2d(src: Tensor, out: Tensor | None = None) -> Tensor:
     if src.dtype not in (torch.bfloat16, torch.float16) or src.dim() != 2 or src.stride(1) != 1 or not src.is_cuda:
         raise ValueError(f"transpose_2d: need a 2-D 16-bit GPU tensor with unit inner stride, got {src.dtype} {tuple(src.shape)} strides {src.stride()}")
     rows, cols = src.shape
-    if out is None:
-        out = torch.empty((cols, rows), dtype=src.dtype, device=src.device)
+    if out is None:  # leading dimension rounded up to 8 elements so every output row starts 16-byte aligned for any `rows`
+        out = torch.empty((cols, (rows + 7) // 8 * 8), dtype=src.dtype, device=src.device)[:, :rows]
     elif out.shape != (cols, rows) or out.dtype != src.dtype or out.stride(1) != 1:
         raise ValueError("transpose_2d: out must be [cols, rows] of the same dtype with unit inner stride")
+    if rows == 0 or cols == 0:
+        return out
     check(lib.pm_transpose_2d(_p(src), rows, cols, src.stride(0), _p(out), out.stride(0), _stream()), "pm_transpose_2d")
     return out
 

@@ -99,14 +99,33 @@ class DataLoader:
 
     def __init__(self, output_dir, start_step: int, dp_world_size: int, config=None, dp_rank: int = 0):
         from ...transports.rollouts import setup_micro_batch_receiver
+        from ...transports.rollouts.binary import BinaryStepReceiver
 
-        self.receiver = setup_micro_batch_receiver(output_dir, dp_rank, start_step, config)
+        # `format = "binary"` selects the raw-array step blobs + pinned read-ahead (transports/rollouts/binary.py);
+        # the default is the reference's msgpack-of-lists wire
+        self.binary = getattr(config, "format", "msgpack") == "binary"
+        self.receiver = BinaryStepReceiver(output_dir, dp_rank, start_step) if self.binary else setup_micro_batch_receiver(output_dir, dp_rank, start_step, config)
+        self.last_blob = None
 
     def wait_for_batch(self) -> None:
         self.receiver.wait()
 
     def get_batch(self) -> list[TensorMicroBatch]:
+        if self.binary:
+            from ...transports.rollouts.binary import blob_to_tensor_micro_batches
+
+            self.last_blob = self.receiver.receive()
+            return blob_to_tensor_micro_batches(self.last_blob)
         return [self._micro_batch_to_tensor(mb) for mb in self.receiver.receive()]
+
+    def get_packed_batch(self, device):
+        """Binary wire only: the whole step as one device-resident `PackedBatch` (one H2D copy), plus the host-side micro-batch view."""
+        from ...transports.rollouts.binary import blob_to_packed_batch
+
+        if not self.binary:
+            raise RuntimeError("get_packed_batch needs the binary rollout wire (config.format = 'binary')")
+        mbs = self.get_batch()
+        return blob_to_packed_batch(self.last_blob, device), mbs
 
     @staticmethod
     def _micro_batch_to_tensor(mb) -> TensorMicroBatch:

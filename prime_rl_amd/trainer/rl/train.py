@@ -19,6 +19,7 @@ import os
 import time
 from dataclasses import asdict, dataclass, field
 from pathlib import Path
+from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
@@ -48,6 +49,7 @@ class TrainerConfig:
     weight_broadcast: WeightBroadcastConfig | None = field(default_factory=WeightBroadcastConfig)
     tokens_per_pass: int = 16384
     seed: int = 0
+    rollout_format: str = "msgpack"  # "msgpack" = the reference wire; "binary" = raw-array step blobs + pinned read-ahead (transports/rollouts/binary.py)
 
 
 def _stats(name: str, x: torch.Tensor, out: dict) -> None:
@@ -73,7 +75,7 @@ def train(config: TrainerConfig) -> list[dict]:
     if config.fake_data is not None:
         loader = FakeDataLoader(config.fake_data, config.seq_len, dp_world_size=world, dp_rank=rank)
     else:
-        loader = DataLoader(out_dir, start_step=1, dp_world_size=world, dp_rank=rank)
+        loader = DataLoader(out_dir, start_step=1, dp_world_size=world, dp_rank=rank, config=SimpleNamespace(type="filesystem", format=config.rollout_format))
     wb = setup_weight_broadcast(out_dir, config.weight_broadcast, is_master=is_master) if config.weight_broadcast is not None else None
     per_pass = max(config.tokens_per_pass // config.seq_len, 1)
     history: list[dict] = []
@@ -93,11 +95,18 @@ def train(config: TrainerConfig) -> list[dict]:
         loader.wait_for_batch()
         t_wait = time.perf_counter() - t0
         t0 = time.perf_counter()
-        mbs = loader.get_batch()
+        packed = None
+        if getattr(loader, "binary", False):
+            packed, mbs = loader.get_packed_batch(device)  # one H2D copy of the step blob; `mbs` is the host view used for the env split
+        else:
+            mbs = loader.get_batch()
         if config.fake_data is not None and dims.vocab_size < 120000:  # FakeDataLoader draws ids up to 120000 (data.py:101)
             for mb in mbs:
                 mb["input_ids"] = mb["input_ids"] % dims.vocab_size
-        passes = [pack_micro_batches(mbs[i:i + per_pass], device) for i in range(0, len(mbs), per_pass)]
+        if packed is not None and len(mbs) <= per_pass:
+            passes = [packed]
+        else:
+            passes = [pack_micro_batches(mbs[i:i + per_pass], device) for i in range(0, len(mbs), per_pass)]
         t_load = time.perf_counter() - t0
         t0 = time.perf_counter()
         out = engine.step(passes)

@@ -51,10 +51,11 @@ class MicroBatchReceiver(ABC):
 
 
 class FileSystemMicroBatchSender(MicroBatchSender):
-    def __init__(self, output_dir: Path, data_world_size: int, current_step: int = 0):
+    def __init__(self, output_dir: Path, data_world_size: int, current_step: int = 0, wire_format: str = "msgpack"):
         super().__init__(output_dir, data_world_size)
         self.rollout_dir = get_rollout_dir(output_dir)
         self.current_step = current_step
+        self.wire_format = wire_format  # "binary": raw-array step blobs (binary.py) instead of msgpack-of-lists
 
     async def send(self, micro_batch_grid: list[list[MicroBatch]]) -> None:
         assert len(micro_batch_grid) == self.data_world_size, "Number of micro batch lists must match data world size"
@@ -66,6 +67,11 @@ class FileSystemMicroBatchSender(MicroBatchSender):
         self.current_step += 1
 
     def _encode_and_write(self, grid, step_path: Path) -> None:
+        if self.wire_format == "binary":
+            from .binary import write_step
+
+            write_step(self.output_dir, self.current_step, grid)
+            return
         for rank in range(self.data_world_size):
             tmp = step_path / f"rank_{rank}.bin.tmp"
             tmp.write_bytes(encode_micro_batches(grid[rank]))

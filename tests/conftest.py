@@ -6,8 +6,9 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-if str(ROOT) not in sys.path:
-    sys.path.insert(0, str(ROOT))
+for p in (str(ROOT), str(ROOT / "tests")):  # repo root (package, oracle) and tests/ (helpers shared between test modules)
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
 GOLDEN = ROOT / "tests" / "golden"
 
