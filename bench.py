@@ -23,8 +23,10 @@ import sys
 import time
 from pathlib import Path
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC: RCCL needs this before HIP initialises
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -99,6 +99,7 @@ SIGNATURES: dict[str, tuple] = {
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
     "pm_mfma_probe_16x16x32": (I, [P, P, P, P]),
+    "pm_ds_read_tr16_probe": (I, [P, P, P]),
 }
 
 

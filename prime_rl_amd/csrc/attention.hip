@@ -53,6 +53,19 @@ __global__ void mfma_probe_kernel(const bf16_t* a, const bf16_t* b, float* c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ds_read_b64_tr_b16 probe (gfx950 LDS transpose-read): LDS holds lds[i] = i (u16, 4096 entries); lane l reads at element index
+// elem_index[l] (multiple of 4 = 8-byte aligned) and returns its 4 result elements.  One wave.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+__global__ void ds_read_tr16_probe_kernel(const int32_t* elem_index, uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t img[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) img[i] = (uint16_t)i;
+  __syncthreads();
+  const v4i16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)(img + elem_index[threadIdx.x]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)r[j];
+}
+
+// ---------------------------------------------------------------------------------------------
 // [n][row_stride] (head h at column h*128) -> [heads][128][n_pad], zero padding for tokens >= n.
 __global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* __restrict__ src, int64_t row_stride, int64_t n, int64_t n_pad,
                                                              bf16_t* __restrict__ dst) {
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 #include "attention_v2.cuh"
 #include "attention_v3.cuh"
+#include "attention_v4.cuh"
 
 static inline int64_t pad64(int64_t n) { return cdiv(n, 64) * 64; }
 static bool use_v2() {
@@ -470,6 +484,13 @@ extern "C" int pm_mfma_probe_16x16x32(const void* a, const void* b, float* c, vo
   PM_REQUIRE(a && b && c, PM_ERR_INVALID_ARG, "pm_mfma_probe_16x16x32: null pointer");
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), (const bf16_t*)a, (const bf16_t*)b, c);
   PM_CHECK_LAUNCH("pm_mfma_probe_16x16x32");
+  return PM_OK;
+}
+
+extern "C" int pm_ds_read_tr16_probe(const int32_t* elem_index, void* out_u16, void* stream) {
+  PM_REQUIRE(elem_index && out_u16, PM_ERR_INVALID_ARG, "pm_ds_read_tr16_probe: null pointer");
+  hipLaunchKernelGGL(ds_read_tr16_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), elem_index, (uint16_t*)out_u16);
+  PM_CHECK_LAUNCH("pm_ds_read_tr16_probe");
   return PM_OK;
 }
 
@@ -546,8 +567,12 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
   bf16_t* kt = (bf16_t*)(ws + 2 * qt_b);
   float* delta = (float*)(ws + 2 * qt_b + kt_b);
   int rc;
-  if ((rc = launch_transpose((const bf16_t*)q, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, qt, st)) != PM_OK) return rc;
-  if ((rc = launch_transpose((const bf16_t*)grad_out, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, dot_, st)) != PM_OK) return rc;
+  // dK/dV v4 reads its transposed fragments out of the row-major tiles (ds_read_b64_tr_b16): no transposed copies of Q / dO
+  const bool dkdv_v4 = !use_v1() && !use_v2() && getenv("PM_ATTN_DKDV_V3") == nullptr;
+  if (!dkdv_v4) {
+    if ((rc = launch_transpose((const bf16_t*)q, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, qt, st)) != PM_OK) return rc;
+    if ((rc = launch_transpose((const bf16_t*)grad_out, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, dot_, st)) != PM_OK) return rc;
+  }
   if ((rc = launch_transpose((const bf16_t*)k, (int64_t)n_kv_heads * kD, n, n_pad, n_kv_heads, kt, st)) != PM_OK) return rc;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, n,
                      n_q_heads, delta);
@@ -569,7 +594,20 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
       return ok;
     }();
     PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    if (getenv("PM_ATTN_DKDV_CB2") != nullptr)  // A/B: 4 waves x 32 kv rows (register-starved) vs 8 waves x 16
+    if (dkdv_v4) {
+      // PM_ATTN_DKDV_V4_VAR (A/B): 0 = 4 waves, 2 workgroups/CU, 4-fragment batches; 1 = 3 workgroups/CU, 2-fragment batches;
+      // 2 = 3 workgroups/CU, 4-fragment batches; 3 = one 8-wave workgroup (128 kv rows)
+      static const int var = getenv("PM_ATTN_DKDV_V4_VAR") ? atoi(getenv("PM_ATTN_DKDV_V4_VAR")) : 0;
+#define PM_LAUNCH_DKDV_V4(NW_, MINB_, FB_)                                                                                                       \
+  hipLaunchKernelGGL((attn_bwd_dkdv_v4_kernel<NW_, MINB_, FB_>), dim3((unsigned)(cdiv(n, NW_ * 16) * n_kv_heads)), dim3(NW_ * 64), kV4SmemBytes, st, \
+                     (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,        \
+                     n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride)
+      if (var == 1) PM_LAUNCH_DKDV_V4(4, 3, 2);
+      else if (var == 2) PM_LAUNCH_DKDV_V4(4, 3, 4);
+      else if (var == 3) PM_LAUNCH_DKDV_V4(8, 1, 4);
+      else PM_LAUNCH_DKDV_V4(4, 2, 4);
+#undef PM_LAUNCH_DKDV_V4
+    } else if (getenv("PM_ATTN_DKDV_CB2") != nullptr)  // A/B: 4 waves x 32 kv rows (register-starved) vs 8 waves x 16
       hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<4, 2>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), kDkdvSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
                          (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                          softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);

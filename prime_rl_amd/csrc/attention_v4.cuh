@@ -1,0 +1,238 @@
+// attention_v4.cuh — dK/dV with gfx950 LDS transpose-reads: ONE swizzled row-major image of each Q / dO tile serves both operand
+// orientations.
+//
+// v3's dK/dV kernel staged every Q and dO tile twice — row-major (A fragments of S = Q.K^T, dP = dO.V^T) and as a transposed copy
+// (A fragments of dV^T += dO^T.P, dK^T += Q^T.dS) that a pre-pass had to write to global memory first.  PMC counters on that kernel
+// (rocprofv3, MI355X): 58 % of wave cycles parked (one 8-wave workgroup per CU: 218 VGPRs, 76 KB LDS; every wave waits at the same
+// barrier), 41 % of LDS cycles are bank conflicts (ds_read_b128 is serviced in NON-contiguous 16-lane groups, which the padded
+// layouts did not account for), MFMA busy 14 %.  v4:
+//   * the transposed fragments come from the row-major tile through `ds_read_b64_tr_b16` (semantics pinned by
+//     tests/test_kernels_gpu.py::test_ds_read_tr16_semantics): no transposed global copies, no pre-pass, half the staging traffic
+//     and LDS footprint (32 KB double-buffered instead of 76 KB);
+//   * tiles are stored unpadded ([32][128] bf16, 256-byte rows) with a 16-byte-chunk XOR swizzle chunk' = chunk ^ f(row & 15),
+//     f(r) = ((r3^r2)<<3 | r1<<2 | r0<<1 | r2), chosen so that BOTH access patterns are conflict-free: the ds_read_b128 row reads
+//     (lane groups {0-3,12-15,20-27}, ...: two lanes collide iff f(a)^f(b) = 1 iff a^b = 12, which never pairs lanes of one group)
+//     and the transpose-reads (a 32-lane half touches 8 rows x 32 bytes; (f>>1) is injective over those rows, so the halves tile
+//     all 64 banks exactly), and the 16-byte staging stores (8-lane groups: 8 chunks of one row, distinct mod 8);
+//   * NW = 4 waves x 16 kv rows per workgroup, one register stage of prefetch (global loads of tile j+2 are in flight while tile j
+//     is consumed and tile j+1 sits in the other LDS buffer): ~130 VGPRs less pressure, two or more workgroups per CU, i.e.
+//     independent barrier domains that overlap each other's staging / LDS / MFMA phases.
+// Math, masking, accumulation order within a wave and the output path are those of v3 (S, dP in C layout -> P, dS packed in
+// registers as the B operand with the permuted contraction index q = (i>>2)*16 + lq*4 + (i&3), i = 0..7).
+#pragma once
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
+
+__device__ __forceinline__ int swz_f(int r) {  // r in [0, 16)
+  return (((r >> 3) ^ (r >> 2)) & 1) << 3 | (r & 2) << 1 | (r & 1) << 1 | ((r >> 2) & 1);
+}
+// element offset of (row, 16-byte chunk) in a swizzled [rows][128] bf16 tile
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * kD + ((chunk ^ swz_f(row & 15)) << 3); }
+
+// A fragment (16 x 32, M = 16 consecutive tile COLUMNS starting at col0, K = the 32 tile rows in the permuted order
+// q = (i>>2)*16 + lq*4 + (i&3)) of the TRANSPOSED tile, read from the row-major swizzled image with two transpose-reads.
+// Lane (lr, lq) addresses 4 contiguous elements of tile row r0 = lq*4 + (lr>>2) at column col0 + 4*(lr&3) (`p`, already swizzled);
+// the second read takes the same columns of row 16 + r0 (same row & 15, hence the same swizzle: a constant 16-row offset).
+__device__ __forceinline__ u32x4 lds_tr_pair(const bf16_t* p) {
+  const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)p);
+  const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(p + 16 * kD));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  return u32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
+constexpr int kV4TileElems = 32 * kD;                      // one [32][128] tile
+constexpr int kV4OffDO = 2 * kV4TileElems * 2;             // bytes: Q[2] then dO[2]
+constexpr int kV4OffL = 2 * kV4OffDO;                      // then lse / delta / lo rows [2][32] each
+constexpr int kV4SmemBytes = kV4OffL + 3 * 2 * 32 * 4 + 16;  // + the q-tile count (no static LDS in front of the dynamic region)
+
+template <int NW, int MINB, int FB>  // waves per workgroup, workgroups per CU the register budget is sized for, fragment batch
+__global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
+    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride) {
+  constexpr int NT = NW * 64;
+  constexpr int ROWS = NW * 16;      // kv rows per workgroup
+  constexpr int NCH = 512 / NT;      // 16-byte chunks per thread per staged tile
+  static_assert(512 % NT == 0, "tile chunks must divide evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(dyn_smem);
+  bf16_t* dOs = reinterpret_cast<bf16_t*>(dyn_smem + kV4OffDO);
+  float(*Ls)[32] = reinterpret_cast<float(*)[32]>(dyn_smem + kV4OffL);
+  float(*Ds)[32] = reinterpret_cast<float(*)[32]>(dyn_smem + kV4OffL + 256);
+  int(*Los)[32] = reinterpret_cast<int(*)[32]>(dyn_smem + kV4OffL + 512);
+  int& s_ntiles = *reinterpret_cast<int*>(dyn_smem + kV4OffL + 768);
+  const int n = (int)n64;
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int group = hq / hkv;
+  const int kvh = blockIdx.x % hkv;
+  const int kv0 = (blockIdx.x / hkv) * ROWS;
+  const int kvb = kv0 + w * 16;
+  const bool active = kvb < n;
+  const int kvi = kvb + lr;
+  u32x4 kf[4], vf[4];
+  f32x4 dkt[8], dvt[8];
+  {
+    const int row = kvi < n ? kvi : n - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = ldg16(k + ((int64_t)row * hkv + kvh) * kD + kk * 32 + lq * 8);
+      vf[kk] = ldg16(v + (int64_t)row * v_stride + (int64_t)kvh * kD + kk * 32 + lq * 8);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) dkt[nb] = dvt[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int wg_last = (kv0 + ROWS - 1 < n - 1) ? kv0 + ROWS - 1 : n - 1;
+  const float sc2 = scale * 1.44269504088896340736f;
+  // number of 32-row q tiles, starting at kv0, that can see this workgroup's kv rows (seq_start is non-decreasing)
+  if (t == 0) s_ntiles = 0;
+  __syncthreads();
+  {
+    int mine = 0;
+    for (int c = t; kv0 + 32 * c < n; c += NT)
+      if (seq_start[kv0 + 32 * c] <= wg_last) mine = c + 1;
+    if (mine) atomicMax(&s_ntiles, mine);
+  }
+  __syncthreads();
+  const int total_iters = s_ntiles * group;
+
+  // execution order j = 0.. walks (q tile, head) pairs from the LAST q tile down (workgroups of one document stay in step on L2).
+  // Three cursors (issue runs two tiles ahead, stage one) step through that order with a decrement instead of a divide per use.
+  struct Cursor {
+    int tile, head;
+  };
+  auto advance = [&](Cursor& c) {
+    if (--c.head < 0) {
+      c.head = group - 1;
+      --c.tile;
+    }
+  };
+  Cursor c_issue{s_ntiles - 1, group - 1}, c_stage = c_issue, c_cur = c_issue;
+  u32x4 rq[NCH], rdo[NCH];
+  float rL = 0.f, rD = 0.f;
+  int rLo = 0;
+  auto issue = [&]() {
+    const int qi0 = kv0 + 32 * c_issue.tile;
+    const int qh = kvh * group + c_issue.head;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = t + i * NT;
+      int qrow = qi0 + (c >> 4);
+      if (qrow > n - 1) qrow = n - 1;
+      rq[i] = ldg16(q + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+      rdo[i] = ldg16(dout + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+    }
+    if (t < 32) {  // RAW loads only (arithmetic on a just-loaded value would drain the prefetch queue: vmcnt retires in order)
+      const int qrow = (qi0 + t < n) ? qi0 + t : n - 1;
+      rL = lse[(int64_t)qh * n + qrow];
+      rD = delta[(int64_t)qh * n + qrow];
+      rLo = seq_start[qrow];
+    }
+    advance(c_issue);
+  };
+  int st_off[NCH];  // loop-invariant swizzled store offsets of this thread's chunks
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) st_off[i] = swz_off((t + i * NT) >> 4, (t + i * NT) & 15);
+  auto stage = [&](int buf) {
+    const int qi0s = kv0 + 32 * c_stage.tile;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      sts16(Qs + buf * kV4TileElems + st_off[i], rq[i]);
+      sts16(dOs + buf * kV4TileElems + st_off[i], rdo[i]);
+    }
+    if (t < 32) {
+      Ls[buf][t] = rL * 1.44269504088896340736f;
+      Ds[buf][t] = rD;
+      Los[buf][t] = (qi0s + t < n) ? rLo : 0x7fffffff;  // out-of-range q rows can see nothing
+    }
+    advance(c_stage);
+  };
+  // Lane-invariant parts of the fragment addresses (elements).  The swizzle XORs only bits 3..6 of the element offset, so the
+  // per-fragment part is ONE v_xor with a literal and everything else (row block, Q vs dO tile, second transpose-read) is an
+  // immediate offset of the LDS instruction.
+  const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);                                      // row read: ^ (kk << 5), + nb * 16 * kD
+  const int r0 = lq * 4 + (lr >> 2);
+  const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));     // transpose-read: ^ (col block << 4), + 16 * kD
+  if (total_iters > 0) {
+    issue();
+    stage(0);
+  }
+  if (total_iters > 1) issue();
+  for (int j = 0; j < total_iters; ++j) {
+    const int qi0 = kv0 + 32 * c_cur.tile;
+    advance(c_cur);
+    const int buf = j & 1;
+    __syncthreads();  // compute(j-1) is finished everywhere (buffer buf^1 may be overwritten) and tile j is visible
+    if (j + 1 < total_iters) {
+      stage(buf ^ 1);
+      if (j + 2 < total_iters) issue();
+    }
+    if (!active || qi0 + 31 < kvb) continue;
+    const bf16_t* Qt = Qs + buf * kV4TileElems;  // the dO tile of the same buffer sits kV4OffDO bytes further
+    constexpr int kDO = kV4OffDO / 2;
+    // S[q][kv], dP[q][kv]: rows q = nb*16 + lq*4 + r, column kv = lr
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      s[nb] = dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k0 = 0; k0 < 4; k0 += FB) {  // FB fragments of each operand in flight per batch (register pressure vs LDS latency hiding)
+        u32x4 qa[FB], da[FB];
+#pragma unroll
+        for (int kk = 0; kk < FB; ++kk) {
+          const bf16_t* pa = Qt + (bq ^ ((k0 + kk) << 5)) + nb * 16 * kD;
+          qa[kk] = lds16(pa);
+          da[kk] = lds16(pa + kDO);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < FB; ++kk) {
+          s[nb] = mfma16(qa[kk], kf[k0 + kk], s[nb]);
+          dp[nb] = mfma16(da[kk], vf[k0 + kk], dp[nb]);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[buf][nb * 16 + lq * 4]);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[buf][nb * 16 + lq * 4]);
+      const u32x4 lo4 = *reinterpret_cast<const u32x4*>(&Los[buf][nb * 16 + lq * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qg = qi0 + nb * 16 + lq * 4 + r;
+        const bool ok = (kvi <= qg) && (kvi >= (int)lo4[r]);
+        const float p = ok ? fast_exp2(s[nb][r] * sc2 - L4[r]) : 0.f;
+        s[nb][r] = p;
+        dp[nb][r] = p * (dp[nb][r] - D4[r]) * scale;  // dS
+      }
+    }
+    const u32x4 pb = pack_c_pair(s[0], s[1]);
+    const u32x4 sb = pack_c_pair(dp[0], dp[1]);
+#pragma unroll
+    for (int n0 = 0; n0 < 8; n0 += FB) {
+      u32x4 doa[FB], qa[FB];
+#pragma unroll
+      for (int i = 0; i < FB; ++i) {
+        const bf16_t* pt = Qt + (bt ^ ((n0 + i) << 4));
+        qa[i] = lds_tr_pair(pt);
+        doa[i] = lds_tr_pair(pt + kDO);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FB; ++i) {
+        dvt[n0 + i] = mfma16(doa[i], pb, dvt[n0 + i]);
+        dkt[n0 + i] = mfma16(qa[i], sb, dkt[n0 + i]);
+      }
+    }
+  }
+  if (!active || kvi >= n) return;
+  bf16_t* pk_ = dk + ((int64_t)kvi * hkv + kvh) * kD + lq * 4;
+  bf16_t* pv_ = dv + (int64_t)kvi * dv_stride + (int64_t)kvh * kD + lq * 4;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    st8_bf16(pk_ + nb * 16, dkt[nb], 1.0f);
+    st8_bf16(pv_ + nb * 16, dvt[nb], 1.0f);
+  }
+}

@@ -424,6 +424,15 @@ def adamw_step(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor
     )
 
 
+def ds_read_tr16_probe(elem_index: Tensor) -> Tensor:
+    """int32[64] element indices (multiples of 4) -> int32[64, 4] values returned by `ds_read_b64_tr_b16` over the image lds[i] = i."""
+    lib = _lib.load()
+    _req(elem_index, torch.int32, "elem_index")
+    out = torch.empty((64, 4), dtype=torch.int16, device=elem_index.device)
+    check(lib.pm_ds_read_tr16_probe(_p(elem_index), _p(out), _stream()), "pm_ds_read_tr16_probe")
+    return out.to(torch.int32) & 0xFFFF
+
+
 def mfma_probe(a: Tensor, b: Tensor) -> Tensor:
     lib = _lib.load()
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")

@@ -55,6 +55,28 @@ def test_mfma_fragment_layout(ops):
 
 
 # ================================================================================================ K1
+def test_ds_read_tr16_semantics(ops):
+    """Pins what the attention kernels assume about gfx950's `ds_read_b64_tr_b16`: every lane supplies the address of 4 contiguous
+    16-bit elements; within each 16-lane group the 16 x 4 elements form a 4 x 16 block (lane p holds row p>>2, columns 4*(p&3)..+3)
+    and lane i receives column i: result(i, j) = element (i & 3) of what lane 4*j + (i >> 2) of the same group addressed."""
+    g = torch.Generator().manual_seed(5)
+    linear = torch.arange(64, dtype=torch.int32) * 4
+    scattered = (torch.randperm(1000, generator=g)[:64].to(torch.int32)) * 4  # arbitrary distinct 8-byte aligned addresses
+    rows = torch.tensor([((l >> 4) * 8 + ((l & 15) >> 2)) * 128 + 4 * (l & 3) for l in range(64)], dtype=torch.int32)  # a [32][128] tile
+    for idx in (linear, scattered, rows):
+        got = ops.ds_read_tr16_probe(idx.to(DEV)).cpu()
+        want = torch.empty(64, 4, dtype=torch.int32)
+        for l in range(64):
+            grp, i = l >> 4, l & 15
+            for j in range(4):
+                want[l, j] = idx[grp * 16 + 4 * j + (i >> 2)] + (i & 3)
+        assert torch.equal(got, want), f"ds_read_b64_tr_b16 mapping differs:\nidx={idx.tolist()}\ngot={got.tolist()}"
+    # the documented closed form for the linear image: lane l, element j <- lds[(l & 15) + 16 j + 64 (l >> 4)]
+    got = ops.ds_read_tr16_probe(linear.to(DEV)).cpu()
+    for l in (0, 5, 17, 63):
+        assert got[l].tolist() == [(l & 15) + 16 * j + 64 * (l >> 4) for j in range(4)]
+
+
 def test_logprob_vanilla_golden_unaligned(ops, golden_dir):
     g = dict(np.load(golden_dir / "logprob_vanilla.npz"))
     inv_t = _t(1.0 / g["temperature"], torch.float32)

@@ -65,9 +65,9 @@ def bench_k1_step_shape(out):
     out.append(dict(kernel="logprob_entropy_fwd[bf16 16384 rows]", ms=med * 1e3, best_ms=best * 1e3, GBps=nbytes / med / 1e9, frac_hbm=nbytes / med / HBM_PEAK))
 
 
-def bench_attn(out):
+def bench_attn(out, cases=((2048, [2048]), (16384, [2048] * 8))):
     hq, hkv, d = 32, 8, 128
-    for n, seqs in ((2048, [2048]), (16384, [2048] * 8)):
+    for n, seqs in cases:
         q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
         k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
         v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
@@ -169,6 +169,8 @@ def main():
         bench_k1_step_shape(out)
     if which in ("attn", "all"):
         bench_attn(out)
+    if which == "attn16k":
+        bench_attn(out, cases=((16384, [2048] * 8),))
     if which in ("norm", "all"):
         bench_norm(out)
     for r in out:
