@@ -514,9 +514,18 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   hipStream_t st = as_stream(stream);
   const int64_t n_pad = pad64(n_tokens);
   bf16_t* vt = (bf16_t*)workspace;
+  const int64_t tiles = cdiv(n_tokens, 128);
+  if (!use_v1() && !use_v2() && getenv("PM_ATTN_FWD_V3") == nullptr) {  // v4: V^T fragments are LDS transpose-reads, no transposed copy of V
+    static const bool smem_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kV4FwdSmemBytes) == hipSuccess;
+    PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL((attn_fwd_v4_kernel<2>), dim3((unsigned)(tiles * n_q_heads)), dim3(256), kV4FwdSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+    PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
+    return PM_OK;
+  }
   int rc = launch_transpose((const bf16_t*)v, v_row_stride, n_tokens, n_pad, n_kv_heads, vt, st);
   if (rc != PM_OK) return rc;
-  const int64_t tiles = cdiv(n_tokens, 128);
   if (use_v1())
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(tiles * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start,
                        n_tokens, n_pad, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
@@ -573,7 +582,8 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
     if ((rc = launch_transpose((const bf16_t*)q, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, qt, st)) != PM_OK) return rc;
     if ((rc = launch_transpose((const bf16_t*)grad_out, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, dot_, st)) != PM_OK) return rc;
   }
-  if ((rc = launch_transpose((const bf16_t*)k, (int64_t)n_kv_heads * kD, n, n_pad, n_kv_heads, kt, st)) != PM_OK) return rc;
+  const bool dq_v4 = dkdv_v4 && getenv("PM_ATTN_DQ_V3") == nullptr;  // same scheme for dQ: no transposed copy of K either
+  if (!dq_v4 && (rc = launch_transpose((const bf16_t*)k, (int64_t)n_kv_heads * kD, n, n_pad, n_kv_heads, kt, st)) != PM_OK) return rc;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, n,
                      n_q_heads, delta);
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(delta)");
@@ -624,7 +634,11 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
                        (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                        softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
     PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
-    if (occ1())
+    if (dq_v4)
+      hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes, st, (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_q);
+    else if (occ1())
       hipLaunchKernelGGL((attn_bwd_dq_v3_kernel<1>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                          (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
                          softmax_scale, (bf16_t*)grad_q);

@@ -236,3 +236,343 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4_kerne
     st8_bf16(pv_ + nb * 16, dvt[nb], 1.0f);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ v4: 4 waves x 32 q rows (two 16-wide column blocks per wave), KV tile 32 — the v3 kernel on the v4 LDS scheme: K and V tiles are
+// stored once, row-major and swizzled (A fragments of S^T = K.Q^T and dP^T = V.dO^T by ds_read_b128), and the A fragments of
+// dQ^T[d][q] += K^T[d][kv] . dS^T[kv][q] come from the SAME K tile through ds_read_b64_tr_b16 — no [head][128][N] transposed copy of K,
+// no pre-pass, no bank conflicts (v3: 43 % of its LDS cycles), LDS double-buffered with one barrier per KV tile.
+constexpr int kV4DqOffV = 2 * kV4TileElems * 2;  // bytes: K[2] then V[2]
+constexpr int kV4DqSmemBytes = 2 * kV4DqOffV;
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                  int64_t v_stride, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64,
+                                                                  int hq, int hkv, float scale, bf16_t* __restrict__ dq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(dyn_smem);
+  const int n = (int)n64;
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int group = hq / hkv;
+  int b = blockIdx.x;
+  const int kvh = b % hkv;
+  b /= hkv;
+  const int gi = b % group;
+  b /= group;
+  const int num_tiles = gridDim.x / hq;
+  const int tile = num_tiles - 1 - b;
+  const int qh = kvh * group + gi;
+  const int qt0 = tile * 128;
+  const int q0 = qt0 + w * 32;
+  const bool active = q0 < n;
+  u32x4 qf[2][4], dof[2][4];
+  int qi[2], lo[2];
+  float L2[2], Dl[2];
+  f32x4 dqt[2][8];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    qi[cb] = q0 + cb * 16 + lr;
+    const int row = qi[cb] < n ? qi[cb] : n - 1;
+    lo[cb] = seq_start[row];
+    L2[cb] = lse[(int64_t)qh * n + row] * 1.44269504088896340736f;
+    Dl[cb] = delta[(int64_t)qh * n + row];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[cb][kk] = ldg16(q + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
+      dof[cb][kk] = ldg16(dout + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) dqt[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int tile_last = (qt0 + 127 < n - 1) ? qt0 + 127 : n - 1;
+  const int wave_last = (q0 + 31 < n - 1) ? q0 + 31 : n - 1;
+  const int kv_begin = (seq_start[qt0] / 32) * 32;
+  const int n_iters = (tile_last - kv_begin) / 32 + 1;
+  const float sc2 = scale * 1.44269504088896340736f;
+  const int rr = t >> 4, rc = (t & 15) * 8;
+  u32x4 rk[2], rv[2];
+  auto issue = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int krow = kv0 + rr + 16 * i;
+      if (krow > n - 1) krow = n - 1;
+      rk[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + rc);
+      rv[i] = ldg16(v + (int64_t)krow * v_stride + (int64_t)kvh * kD + rc);
+    }
+  };
+  const int st_off = swz_off(rr, t & 15);  // rows rr and rr + 16 share row & 15, hence the swizzle
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      sts16(Ks + buf * kV4TileElems + st_off + i * 16 * kD, rk[i]);
+      sts16(Ks + kV4DqOffV / 2 + buf * kV4TileElems + st_off + i * 16 * kD, rv[i]);
+    }
+  };
+  const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);
+  const int r0 = lq * 4 + (lr >> 2);
+  const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));
+  issue(kv_begin);
+  stage(0);
+  if (n_iters > 1) issue(kv_begin + 32);
+  for (int j = 0; j < n_iters; ++j) {
+    const int kv0 = kv_begin + 32 * j;
+    const int buf = j & 1;
+    __syncthreads();
+    if (j + 1 < n_iters) {
+      stage(buf ^ 1);
+      if (j + 2 < n_iters) issue(kv0 + 64);
+    }
+    if (!active || kv0 > wave_last) continue;
+    const bf16_t* Kt = Ks + buf * kV4TileElems;
+    constexpr int kV = kV4DqOffV / 2;
+    f32x4 st[2][2], dpt[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) st[cb][nb] = dpt[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      u32x4 ka[4], va[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16_t* pa = Kt + (bq ^ (kk << 5)) + nb * 16 * kD;
+        ka[kk] = lds16(pa);
+        va[kk] = lds16(pa + kV);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        st[0][nb] = mfma16(ka[kk], qf[0][kk], st[0][nb]);
+        st[1][nb] = mfma16(ka[kk], qf[1][kk], st[1][nb]);
+        dpt[0][nb] = mfma16(va[kk], dof[0][kk], dpt[0][nb]);
+        dpt[1][nb] = mfma16(va[kk], dof[1][kk], dpt[1][nb]);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kv = kv0 + nb * 16 + lq * 4 + r;
+          const bool ok = (kv <= qi[cb]) && (kv >= lo[cb]) && (qi[cb] < n);
+          const float p = ok ? fast_exp2(st[cb][nb][r] * sc2 - L2[cb]) : 0.f;
+          st[cb][nb][r] = p * (dpt[cb][nb][r] - Dl[cb]) * scale;  // dS^T
+        }
+      }
+    }
+    const u32x4 sb0 = pack_c_pair(st[0][0], st[0][1]);
+    const u32x4 sb1 = pack_c_pair(st[1][0], st[1][1]);
+#pragma unroll
+    for (int h4 = 0; h4 < 2; ++h4) {
+      u32x4 ka[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ka[i] = lds_tr_pair(Kt + (bt ^ ((h4 * 4 + i) << 4)));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dqt[0][h4 * 4 + i] = mfma16(ka[i], sb0, dqt[0][h4 * 4 + i]);
+        dqt[1][h4 * 4 + i] = mfma16(ka[i], sb1, dqt[1][h4 * 4 + i]);
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    if (qi[cb] < n) {
+      bf16_t* op = dq + ((int64_t)qi[cb] * hq + qh) * kD + lq * 4;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, dqt[cb][nb], 1.0f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward v4: 4 waves x 32 q rows, KV tile 64 — v3's online-softmax kernel on the v4 LDS scheme.  K and V tiles ([64][128], swizzled)
+// are staged straight from the row-major k / v tensors (v may be a strided view of the fused qkv buffer); the A fragments of
+// O^T[d][q] += V^T[d][kv] . P^T[kv][q] are transpose-reads of the row-major V tile, so the [head][128][N] copy of V and its pre-pass
+// are gone; double-buffered LDS, one barrier per KV tile.
+constexpr int kV4FwdTile = 64 * kD;              // elements of one [64][128] tile
+constexpr int kV4FwdOffV = 2 * kV4FwdTile * 2;   // bytes: K[2] then V[2]
+constexpr int kV4FwdSmemBytes = 2 * kV4FwdOffV;  // 64 KB
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                               int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
+                                                               float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(dyn_smem);
+  const int n = (int)n64;
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int group = hq / hkv;
+  int b = blockIdx.x;
+  const int kvh = b % hkv;
+  b /= hkv;
+  const int gi = b % group;
+  b /= group;
+  const int num_tiles = gridDim.x / hq;
+  const int tile = num_tiles - 1 - b;
+  const int qh = kvh * group + gi;
+  const int qt0 = tile * 128;
+  const int q0 = qt0 + w * 32;
+  const bool active = q0 < n;
+
+  u32x4 qf[2][4];
+  int qi[2], lo[2];
+  float m[2], l[2];
+  f32x4 ot[2][8];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    qi[cb] = q0 + cb * 16 + lr;
+    const int row = qi[cb] < n ? qi[cb] : n - 1;
+    lo[cb] = seq_start[row];
+    m[cb] = -INFINITY;
+    l[cb] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[cb][kk] = ldg16(q + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) ot[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int tile_last = (qt0 + 127 < n - 1) ? qt0 + 127 : n - 1;
+  const int wave_last = (q0 + 31 < n - 1) ? q0 + 31 : n - 1;
+  const int kv_begin = (seq_start[qt0] / 64) * 64;
+  const int n_iters = (tile_last - kv_begin) / 64 + 1;
+  const float sc2 = scale * 1.44269504088896340736f;
+
+  const int kr = t >> 4, kc = (t & 15) * 8;
+  u32x4 kreg[4], vreg[4];
+  auto issue = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int krow = kv0 + kr + 16 * i;
+      if (krow > n - 1) krow = n - 1;
+      kreg[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + kc);
+      vreg[i] = ldg16(v + (int64_t)krow * v_stride + (int64_t)kvh * kD + kc);
+    }
+  };
+  const int st_off = swz_off(kr, t & 15);  // rows kr + 16 i share row & 15, hence the swizzle
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sts16(Ks + buf * kV4FwdTile + st_off + i * 16 * kD, kreg[i]);
+      sts16(Ks + kV4FwdOffV / 2 + buf * kV4FwdTile + st_off + i * 16 * kD, vreg[i]);
+    }
+  };
+  const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);
+  const int r0 = lq * 4 + (lr >> 2);
+  const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));
+  issue(kv_begin);
+  stage(0);
+  if (n_iters > 1) issue(kv_begin + 64);
+  for (int j = 0; j < n_iters; ++j) {
+    const int kv0 = kv_begin + 64 * j;
+    const int buf = j & 1;
+    __syncthreads();
+    if (j + 1 < n_iters) {
+      stage(buf ^ 1);
+      if (j + 2 < n_iters) issue(kv0 + 128);
+    }
+    if (!active || kv0 > wave_last) continue;
+    const bf16_t* Kt = Ks + buf * kV4FwdTile;
+    const bf16_t* Vt = Kt + kV4FwdOffV / 2;
+
+    // S^T[kv][q]: rows kv = nb*16 + lq*4 + r, column q = lr of block cb
+    f32x4 st[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) st[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      u32x4 ka[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ka[0][kk] = lds16(Kt + (bq ^ (kk << 5)));
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        if (nb < 3) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ka[(nb + 1) & 1][kk] = lds16(Kt + (bq ^ (kk << 5)) + (nb + 1) * 16 * kD);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          st[0][nb] = mfma16(ka[nb & 1][kk], qf[0][kk], st[0][nb]);
+          st[1][nb] = mfma16(ka[nb & 1][kk], qf[1][kk], st[1][nb]);
+        }
+      }
+    }
+    const bool need_mask = (kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]);  // per lane; cheap and exact either way
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kv = kv0 + nb * 16 + lq * 4 + r;
+          float sv = st[cb][nb][r] * sc2;
+          if (need_mask) sv = ((kv <= qi[cb]) && (kv >= lo[cb])) ? sv : -INFINITY;
+          st[cb][nb][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = xrow_max(mx);
+      const float m_new = fmaxf(m[cb], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m[cb] - m_use);
+      float sum = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(st[cb][nb][r] - m_use);
+          st[cb][nb][r] = p;
+          sum += p;
+        }
+      }
+      l[cb] = l[cb] * alpha + sum;  // per-lane partial row sum (own kv subset); reduced across lq once at the end
+      m[cb] = m_new;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        ot[cb][nb][0] *= alpha;
+        ot[cb][nb][1] *= alpha;
+        ot[cb][nb][2] *= alpha;
+        ot[cb][nb][3] *= alpha;
+      }
+    }
+    // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
+#pragma unroll
+    for (int kk2 = 0; kk2 < 2; ++kk2) {
+      const u32x4 pb0 = pack_c_pair(st[0][2 * kk2], st[0][2 * kk2 + 1]);
+      const u32x4 pb1 = pack_c_pair(st[1][2 * kk2], st[1][2 * kk2 + 1]);
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        u32x4 va[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = lds_tr_pair(Vt + kk2 * 32 * kD + (bt ^ ((h4 * 4 + i) << 4)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int nb = h4 * 4 + i;
+          ot[0][nb] = mfma16(va[i], pb0, ot[0][nb]);
+          ot[1][nb] = mfma16(va[i], pb1, ot[1][nb]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const float lsum = xrow_sum(l[cb]);
+    if (qi[cb] < n) {
+      const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+      bf16_t* op = out + ((int64_t)qi[cb] * hq + qh) * kD + lq * 4;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, ot[cb][nb], inv);
+      if (lq == 0) lse[(int64_t)qh * n + qi[cb]] = m[cb] * 0.69314718055994530942f + logf(lsum);
+    }
+  }
+}

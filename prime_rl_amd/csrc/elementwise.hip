@@ -29,45 +29,77 @@ static inline unsigned capped_grid(int64_t work_items, int block) {
 
 // ---------------------------------- SwiGLU -------------------------------------------------------
 // act = bf16( bf16(silu(gate)) * up ): torch computes silu on bf16 in f32 and rounds, then a bf16 multiply.
+// Thread layout (both kernels): blockIdx.x * 256 + threadIdx.x = 16-byte column vector, blockIdx.y = block of kSwigluRows rows walked
+// kSwigluUnroll at a time with every load of the batch issued before the first use (no 64-bit divide per vector, 2-3 x kSwigluUnroll
+// independent 16-byte loads in flight per lane; each wave touches 1 KB contiguous per array per row).
+constexpr int kSwigluRows = 16, kSwigluUnroll = 4;
+
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, int64_t n_rows, int64_t inter, bf16_t* __restrict__ act) {
   const int64_t vec_per_row = inter >> 3;
-  const int64_t total = n_rows * vec_per_row;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / vec_per_row, c = i - r * vec_per_row;
-    const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
-    float g[8], u[8], o[8];
-    unpack8e(gp[c], g);
-    unpack8e(gp[vec_per_row + c], u);
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= vec_per_row) return;
+  const int64_t r0 = (int64_t)blockIdx.y * kSwigluRows;
+#pragma unroll 1
+  for (int64_t rb = r0; rb < r0 + kSwigluRows && rb < n_rows; rb += kSwigluUnroll) {
+    u32x4 gv[kSwigluUnroll], uv[kSwigluUnroll];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float s = g[k] / (1.0f + __expf(-g[k]));
-      o[k] = round_bf16(s) * u[k];
+    for (int j = 0; j < kSwigluUnroll; ++j) {
+      const int64_t r = rb + j < n_rows ? rb + j : n_rows - 1;
+      const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
+      gv[j] = gp[c];
+      uv[j] = gp[vec_per_row + c];
     }
-    reinterpret_cast<u32x4*>(act + r * inter)[c] = pack8e(o);
+#pragma unroll
+    for (int j = 0; j < kSwigluUnroll; ++j) {
+      if (rb + j >= n_rows) break;
+      float g[8], u[8], o[8];
+      unpack8e(gv[j], g);
+      unpack8e(uv[j], u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = g[k] / (1.0f + __expf(-g[k]));
+        o[k] = round_bf16(s) * u[k];
+      }
+      reinterpret_cast<u32x4*>(act + (rb + j) * inter)[c] = pack8e(o);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ ga, const bf16_t* __restrict__ gu, int64_t n_rows,
                                                         int64_t inter, bf16_t* __restrict__ ggu) {
   const int64_t vec_per_row = inter >> 3;
-  const int64_t total = n_rows * vec_per_row;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / vec_per_row, c = i - r * vec_per_row;
-    const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
-    float g[8], u[8], d[8], dg[8], du[8];
-    unpack8e(gp[c], g);
-    unpack8e(gp[vec_per_row + c], u);
-    unpack8e(reinterpret_cast<const u32x4*>(ga + r * inter)[c], d);
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= vec_per_row) return;
+  const int64_t r0 = (int64_t)blockIdx.y * kSwigluRows;
+#pragma unroll 1
+  for (int64_t rb = r0; rb < r0 + kSwigluRows && rb < n_rows; rb += kSwigluUnroll) {
+    u32x4 gv[kSwigluUnroll], uv[kSwigluUnroll], dv[kSwigluUnroll];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float sig = 1.0f / (1.0f + __expf(-g[k]));
-      const float s = g[k] * sig;
-      du[k] = d[k] * s;
-      dg[k] = d[k] * u[k] * (sig * (1.0f + g[k] * (1.0f - sig)));
+    for (int j = 0; j < kSwigluUnroll; ++j) {
+      const int64_t r = rb + j < n_rows ? rb + j : n_rows - 1;
+      const u32x4* gp = reinterpret_cast<const u32x4*>(gu + r * 2 * inter);
+      gv[j] = gp[c];
+      uv[j] = gp[vec_per_row + c];
+      dv[j] = reinterpret_cast<const u32x4*>(ga + r * inter)[c];
     }
-    u32x4* op = reinterpret_cast<u32x4*>(ggu + r * 2 * inter);
-    op[c] = pack8e(dg);
-    op[vec_per_row + c] = pack8e(du);
+#pragma unroll
+    for (int j = 0; j < kSwigluUnroll; ++j) {
+      if (rb + j >= n_rows) break;
+      float g[8], u[8], d[8], dg[8], du[8];
+      unpack8e(gv[j], g);
+      unpack8e(uv[j], u);
+      unpack8e(dv[j], d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float sig = 1.0f / (1.0f + __expf(-g[k]));
+        const float s = g[k] * sig;
+        du[k] = d[k] * s;
+        dg[k] = d[k] * u[k] * (sig * (1.0f + g[k] * (1.0f - sig)));
+      }
+      u32x4* op = reinterpret_cast<u32x4*>(ggu + (rb + j) * 2 * inter);
+      op[c] = pack8e(dg);
+      op[vec_per_row + c] = pack8e(du);
+    }
   }
 }
 
@@ -275,8 +307,8 @@ extern "C" int pm_swiglu_fwd(const void* gate_up, int64_t n_rows, int64_t inter,
   PM_REQUIRE(gate_up && act, PM_ERR_INVALID_ARG, "pm_swiglu_fwd: null pointer");
   PM_REQUIRE(n_rows >= 0 && inter > 0 && inter % 8 == 0, PM_ERR_UNSUPPORTED, "pm_swiglu_fwd: inter=%lld must be a multiple of 8", (long long)inter);
   if (n_rows == 0) return PM_OK;
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(capped_grid(n_rows * (inter >> 3), 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)gate_up,
-                     n_rows, inter, (bf16_t*)act);
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((unsigned)cdiv(inter >> 3, (int64_t)256), (unsigned)cdiv(n_rows, (int64_t)kSwigluRows)), dim3(256), 0,
+                     as_stream(stream), (const bf16_t*)gate_up, n_rows, inter, (bf16_t*)act);
   PM_CHECK_LAUNCH("pm_swiglu_fwd");
   return PM_OK;
 }
@@ -285,8 +317,8 @@ extern "C" int pm_swiglu_bwd(const void* grad_act, const void* gate_up, int64_t 
   PM_REQUIRE(grad_act && gate_up && grad_gate_up, PM_ERR_INVALID_ARG, "pm_swiglu_bwd: null pointer");
   PM_REQUIRE(n_rows >= 0 && inter > 0 && inter % 8 == 0, PM_ERR_UNSUPPORTED, "pm_swiglu_bwd: inter=%lld must be a multiple of 8", (long long)inter);
   if (n_rows == 0) return PM_OK;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(capped_grid(n_rows * (inter >> 3), 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_act,
-                     (const bf16_t*)gate_up, n_rows, inter, (bf16_t*)grad_gate_up);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)cdiv(inter >> 3, (int64_t)256), (unsigned)cdiv(n_rows, (int64_t)kSwigluRows)), dim3(256), 0,
+                     as_stream(stream), (const bf16_t*)grad_act, (const bf16_t*)gate_up, n_rows, inter, (bf16_t*)grad_gate_up);
   PM_CHECK_LAUNCH("pm_swiglu_bwd");
   return PM_OK;
 }

@@ -376,6 +376,8 @@ class GRPOEngine:
         self._wt_version: dict[int, int] = {}
         if self.gemm_layouts:  # allocated up front (one slab) so the caching allocator sees the same request stream from the first step on
             mats = [(f"model.layers.{i}.{s}", self.store.w[f"model.layers.{i}.{s}"].shape) for i in range(dims.num_hidden_layers) for s in self._DGRAD_MATRICES]
+            if dims.vocab_size % 8 == 0:  # rows of the [H, V] copy must start 16-byte aligned
+                mats.append(("head", self.store.head_weight().shape))
             slab = torch.empty(sum(o * k for _, (o, k) in mats), dtype=torch.bfloat16, device=self.device)
             cursor = 0
             for nm, (o, k) in mats:
@@ -512,10 +514,17 @@ class GRPOEngine:
         hf = ctx["hf"]
         dhf = torch.empty_like(hf)
         acc_head = accumulate
+        head_t = "head" in self._wt  # K-contiguous [H, V] copy of the head weight for the dgrad GEMM (same reasoning as _dgrad)
+        if head_t and self._wt_version.get("head") != self.store.version:
+            ops.transpose_2d(wh, out=self._wt["head"])
+            self._wt_version["head"] = self.store.version
         for s, e, logits in ctx["logits_chunks"]:
             dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
-            torch.mm(dl, wh, out=dhf[s:e])
-            self._wgrad(dl, hf[s:e], gh, acc_head)
+            if head_t:
+                torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
+            else:
+                torch.mm(dl, wh, out=dhf[s:e])
+            self._wgrad(dl, hf[s:e], gh, acc_head, k_contiguous_x=True)
             acc_head = True
         ctx["logits_chunks"] = None
         # tied embeddings: the embedding backward below must accumulate on top of the head gradient
@@ -571,6 +580,13 @@ class GRPOEngine:
             return
         b = next(bk for bk in self.store.buckets if bk.name == name)
         zero.reduce_scatter_bucket(self.store, b, self.dp_group, self.comm_stream)
+
+    def wait_params_ready(self) -> None:
+        """Make the current stream wait for every in-flight parameter all-gather (issued on the comm stream by the last optimizer
+        step): anything that reads `store.params` outside forward() — the weight push, a checkpoint — must call this first."""
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._gather_events.clear()
 
     def _wait_gather(self, name: str) -> None:
         ev = self._gather_events.pop(name, None)

@@ -48,6 +48,8 @@ class WeightBroadcast(ABC):
 def _named_tensors(model) -> dict[str, torch.Tensor]:
     """HF-named bf16 tensors of either a GRPOEngine / ParamStore (zero-copy views) or an nn.Module."""
     store = getattr(model, "store", model)
+    if hasattr(model, "wait_params_ready"):
+        model.wait_params_ready()  # the last optimizer step's parameter all-gathers run on the engine's comm stream
     if hasattr(store, "state_dict") and hasattr(store, "buckets"):
         return store.state_dict()
     return {k: v.detach() for k, v in model.state_dict().items()}
@@ -118,6 +120,8 @@ class RCCLWeightBroadcast(WeightBroadcast):
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
         store = getattr(model, "store", model)
+        if hasattr(model, "wait_params_ready"):
+            model.wait_params_ready()
         save_dir = get_step_path(get_broadcast_dir(self.output_dir), step)
         if self.rank == 0:
             save_dir.mkdir(parents=True, exist_ok=True)

@@ -184,7 +184,7 @@ def test_gemm_layout_copies_track_parameter_updates():
         rel = ((ga - gb).norm() / gb.norm()).item()
         assert rel < 1e-2, (step, rel)
         assert abs(ra["grad_norm"].item() - rb["grad_norm"].item()) <= 5e-3 * rb["grad_norm"].item()
-    assert len(a._wt) == 4 * dims.num_hidden_layers and not b._wt
+    assert len(a._wt) == 4 * dims.num_hidden_layers + 1 and not b._wt  # four projections per layer + the LM head
 
 
 def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):

@@ -104,6 +104,10 @@ def bench_norm(out):
     gu = torch.randn(n, 2 * 12288, device=DEV).to(torch.bfloat16)
     med, _ = timeit(lambda: ops.swiglu_fwd(gu), flush_mb=512)
     out.append(dict(kernel="swiglu_fwd[16384x12288]", ms=med * 1e3, GBps=n * 12288 * 6 / med / 1e9))
+    dact = torch.randn(n, 12288, device=DEV).to(torch.bfloat16)
+    med, _ = timeit(lambda: ops.swiglu_bwd(dact, gu), flush_mb=512)
+    out.append(dict(kernel="swiglu_bwd[16384x12288]", ms=med * 1e3, GBps=n * 12288 * 10 / med / 1e9))
+    del dact
     a = torch.randn(n, 4096, device=DEV).to(torch.bfloat16)
     wt = torch.randn(24576, 4096, device=DEV).to(torch.bfloat16)
     med, _ = timeit(lambda: a @ wt.T, iters=10)
