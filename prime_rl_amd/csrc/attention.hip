@@ -605,14 +605,23 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
     }();
     PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     if (dkdv_v4) {
-      // PM_ATTN_DKDV_V4_VAR (A/B): 0 = 4 waves, 2 workgroups/CU, 4-fragment batches; 1 = 3 workgroups/CU, 2-fragment batches;
-      // 2 = 3 workgroups/CU, 4-fragment batches; 3 = one 8-wave workgroup (128 kv rows)
-      static const int var = getenv("PM_ATTN_DKDV_V4_VAR") ? atoi(getenv("PM_ATTN_DKDV_V4_VAR")) : 0;
+      // PM_ATTN_DKDV_V4_VAR (A/B; whole backward per 16k-token layer): 4 (default) = 64-row q tiles, 4 waves, 2 workgroups/CU (1.37 ms);
+      // 0 = 32-row q tiles (1.47 ms); 1 / 2 = 3 workgroups/CU with 2- / 4-fragment batches (register spills: +9 % / +34 % over 0);
+      // 3 = one 8-wave workgroup with 128 kv rows (+5 % over 0)
+      static const int var = getenv("PM_ATTN_DKDV_V4_VAR") ? atoi(getenv("PM_ATTN_DKDV_V4_VAR")) : 4;
 #define PM_LAUNCH_DKDV_V4(NW_, MINB_, FB_)                                                                                                       \
   hipLaunchKernelGGL((attn_bwd_dkdv_v4_kernel<NW_, MINB_, FB_>), dim3((unsigned)(cdiv(n, NW_ * 16) * n_kv_heads)), dim3(NW_ * 64), kV4SmemBytes, st, \
                      (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,        \
                      n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride)
-      if (var == 1) PM_LAUNCH_DKDV_V4(4, 3, 2);
+      if (var == 4) {  // 64-row q tiles
+        constexpr int kSmemQ64 = 4 * 64 * kD * 2 + 6 * 64 * 4 + 16;
+        static const bool q64_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v4q_kernel<4, 2, 4, 64>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSmemQ64) == hipSuccess;
+        PM_REQUIRE(q64_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        hipLaunchKernelGGL((attn_bwd_dkdv_v4q_kernel<4, 2, 4, 64>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), kSmemQ64, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
+                           softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+      } else if (var == 1) PM_LAUNCH_DKDV_V4(4, 3, 2);
       else if (var == 2) PM_LAUNCH_DKDV_V4(4, 3, 4);
       else if (var == 3) PM_LAUNCH_DKDV_V4(8, 1, 4);
       else PM_LAUNCH_DKDV_V4(4, 2, 4);

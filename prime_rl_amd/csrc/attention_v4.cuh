@@ -237,6 +237,206 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4_kerne
   }
 }
 
+// The same kernel with a QT-row q tile per iteration (QT = 64: half the barriers, cursor steps and softmax-statistics loads per flop;
+// LDS 2 x 2 x QT x 256 B).  Kept next to the 32-row version for A/B (PM_ATTN_DKDV_V4_VAR=4).
+template <int NW, int MINB, int FB, int QT>
+__global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4q_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
+    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride) {
+  constexpr int NT = NW * 64;
+  constexpr int ROWS = NW * 16;      // kv rows per workgroup
+  constexpr int NCH = QT * 16 / NT;  // 16-byte chunks per thread per staged tile
+  static_assert((QT * 16) % NT == 0 && QT % 32 == 0, "tile chunks must divide evenly");
+  constexpr int TILE = QT * kD;                 // elements of one [QT][128] tile
+  constexpr int OFF_DO = 2 * TILE * 2;          // bytes: Q[2] then dO[2]
+  constexpr int OFF_L = 2 * OFF_DO;             // then lse / delta / lo rows [2][QT] each, then the q-tile count
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(dyn_smem);
+  bf16_t* dOs = reinterpret_cast<bf16_t*>(dyn_smem + OFF_DO);
+  float(*Ls)[QT] = reinterpret_cast<float(*)[QT]>(dyn_smem + OFF_L);
+  float(*Ds)[QT] = reinterpret_cast<float(*)[QT]>(dyn_smem + OFF_L + 2 * QT * 4);
+  int(*Los)[QT] = reinterpret_cast<int(*)[QT]>(dyn_smem + OFF_L + 4 * QT * 4);
+  int& s_ntiles = *reinterpret_cast<int*>(dyn_smem + OFF_L + 6 * QT * 4);
+  const int n = (int)n64;
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int group = hq / hkv;
+  const int kvh = blockIdx.x % hkv;
+  const int kv0 = (blockIdx.x / hkv) * ROWS;
+  const int kvb = kv0 + w * 16;
+  const bool active = kvb < n;
+  const int kvi = kvb + lr;
+  u32x4 kf[4], vf[4];
+  f32x4 dkt[8], dvt[8];
+  {
+    const int row = kvi < n ? kvi : n - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = ldg16(k + ((int64_t)row * hkv + kvh) * kD + kk * 32 + lq * 8);
+      vf[kk] = ldg16(v + (int64_t)row * v_stride + (int64_t)kvh * kD + kk * 32 + lq * 8);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) dkt[nb] = dvt[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int wg_last = (kv0 + ROWS - 1 < n - 1) ? kv0 + ROWS - 1 : n - 1;
+  const float sc2 = scale * 1.44269504088896340736f;
+  // number of QT-row q tiles, starting at kv0, that can see this workgroup's kv rows (seq_start is non-decreasing)
+  if (t == 0) s_ntiles = 0;
+  __syncthreads();
+  {
+    int mine = 0;
+    for (int c = t; kv0 + QT * c < n; c += NT)
+      if (seq_start[kv0 + QT * c] <= wg_last) mine = c + 1;
+    if (mine) atomicMax(&s_ntiles, mine);
+  }
+  __syncthreads();
+  const int total_iters = s_ntiles * group;
+
+  // execution order j = 0.. walks (q tile, head) pairs from the LAST q tile down (workgroups of one document stay in step on L2).
+  // Three cursors (issue runs two tiles ahead, stage one) step through that order with a decrement instead of a divide per use.
+  struct Cursor {
+    int tile, head;
+  };
+  auto advance = [&](Cursor& c) {
+    if (--c.head < 0) {
+      c.head = group - 1;
+      --c.tile;
+    }
+  };
+  Cursor c_issue{s_ntiles - 1, group - 1}, c_stage = c_issue, c_cur = c_issue;
+  u32x4 rq[NCH], rdo[NCH];
+  float rL = 0.f, rD = 0.f;
+  int rLo = 0;
+  auto issue = [&]() {
+    const int qi0 = kv0 + QT * c_issue.tile;
+    const int qh = kvh * group + c_issue.head;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = t + i * NT;
+      int qrow = qi0 + (c >> 4);
+      if (qrow > n - 1) qrow = n - 1;
+      rq[i] = ldg16(q + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+      rdo[i] = ldg16(dout + ((int64_t)qrow * hq + qh) * kD + (c & 15) * 8);
+    }
+    if (t < QT) {  // RAW loads only (arithmetic on a just-loaded value would drain the prefetch queue: vmcnt retires in order)
+      const int qrow = (qi0 + t < n) ? qi0 + t : n - 1;
+      rL = lse[(int64_t)qh * n + qrow];
+      rD = delta[(int64_t)qh * n + qrow];
+      rLo = seq_start[qrow];
+    }
+    advance(c_issue);
+  };
+  int st_off[NCH];  // loop-invariant swizzled store offsets of this thread's chunks
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) st_off[i] = swz_off((t + i * NT) >> 4, (t + i * NT) & 15);
+  auto stage = [&](int buf) {
+    const int qi0s = kv0 + QT * c_stage.tile;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      sts16(Qs + buf * TILE + st_off[i], rq[i]);
+      sts16(dOs + buf * TILE + st_off[i], rdo[i]);
+    }
+    if (t < QT) {
+      Ls[buf][t] = rL * 1.44269504088896340736f;
+      Ds[buf][t] = rD;
+      Los[buf][t] = (qi0s + t < n) ? rLo : 0x7fffffff;  // out-of-range q rows can see nothing
+    }
+    advance(c_stage);
+  };
+  // Lane-invariant parts of the fragment addresses (elements).  The swizzle XORs only bits 3..6 of the element offset, so the
+  // per-fragment part is ONE v_xor with a literal and everything else (row block, Q vs dO tile, second transpose-read) is an
+  // immediate offset of the LDS instruction.
+  const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);                                      // row read: ^ (kk << 5), + nb * 16 * kD
+  const int r0 = lq * 4 + (lr >> 2);
+  const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));     // transpose-read: ^ (col block << 4), + 16 * kD
+  if (total_iters > 0) {
+    issue();
+    stage(0);
+  }
+  if (total_iters > 1) issue();
+  for (int j = 0; j < total_iters; ++j) {
+    const int qi0 = kv0 + QT * c_cur.tile;
+    advance(c_cur);
+    const int buf = j & 1;
+    __syncthreads();  // compute(j-1) is finished everywhere (buffer buf^1 may be overwritten) and tile j is visible
+    if (j + 1 < total_iters) {
+      stage(buf ^ 1);
+      if (j + 2 < total_iters) issue();
+    }
+    if (!active || qi0 + QT - 1 < kvb) continue;
+    const bf16_t* Qt = Qs + buf * TILE;  // the dO tile of the same buffer sits OFF_DO bytes further
+    constexpr int kDO = OFF_DO / 2;
+    // S[q][kv], dP[q][kv]: rows q = nb*16 + lq*4 + r, column kv = lr
+    f32x4 s[QT / 16], dp[QT / 16];
+#pragma unroll
+    for (int nb = 0; nb < QT / 16; ++nb) {
+      s[nb] = dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k0 = 0; k0 < 4; k0 += FB) {  // FB fragments of each operand in flight per batch (register pressure vs LDS latency hiding)
+        u32x4 qa[FB], da[FB];
+#pragma unroll
+        for (int kk = 0; kk < FB; ++kk) {
+          const bf16_t* pa = Qt + (bq ^ ((k0 + kk) << 5)) + nb * 16 * kD;
+          qa[kk] = lds16(pa);
+          da[kk] = lds16(pa + kDO);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < FB; ++kk) {
+          s[nb] = mfma16(qa[kk], kf[k0 + kk], s[nb]);
+          dp[nb] = mfma16(da[kk], vf[k0 + kk], dp[nb]);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < QT / 16; ++nb) {
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[buf][nb * 16 + lq * 4]);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[buf][nb * 16 + lq * 4]);
+      const u32x4 lo4 = *reinterpret_cast<const u32x4*>(&Los[buf][nb * 16 + lq * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qg = qi0 + nb * 16 + lq * 4 + r;
+        const bool ok = (kvi <= qg) && (kvi >= (int)lo4[r]);
+        const float p = ok ? fast_exp2(s[nb][r] * sc2 - L4[r]) : 0.f;
+        s[nb][r] = p;
+        dp[nb][r] = p * (dp[nb][r] - D4[r]) * scale;  // dS
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < QT / 32; ++h) {  // 32-row halves of the q tile: one packed P / dS operand each
+      const u32x4 pb = pack_c_pair(s[2 * h], s[2 * h + 1]);
+      const u32x4 sb = pack_c_pair(dp[2 * h], dp[2 * h + 1]);
+#pragma unroll
+      for (int n0 = 0; n0 < 8; n0 += FB) {
+        u32x4 doa[FB], qa[FB];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          const bf16_t* pt = Qt + (bt ^ ((n0 + i) << 4)) + h * 32 * kD;
+          qa[i] = lds_tr_pair(pt);
+          doa[i] = lds_tr_pair(pt + kDO);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          dvt[n0 + i] = mfma16(doa[i], pb, dvt[n0 + i]);
+          dkt[n0 + i] = mfma16(qa[i], sb, dkt[n0 + i]);
+        }
+      }
+    }
+  }
+  if (!active || kvi >= n) return;
+  bf16_t* pk_ = dk + ((int64_t)kvi * hkv + kvh) * kD + lq * 4;
+  bf16_t* pv_ = dv + (int64_t)kvi * dv_stride + (int64_t)kvh * kD + lq * 4;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    st8_bf16(pk_ + nb * 16, dkt[nb], 1.0f);
+    st8_bf16(pv_ + nb * 16, dvt[nb], 1.0f);
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // dQ v4: 4 waves x 32 q rows (two 16-wide column blocks per wave), KV tile 32 — the v3 kernel on the v4 LDS scheme: K and V tiles are
 // stored once, row-major and swizzled (A fragments of S^T = K.Q^T and dP^T = V.dO^T by ds_read_b128), and the A fragments of
