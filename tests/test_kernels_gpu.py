@@ -512,6 +512,47 @@ def test_attention_full_size_properties(ops):
     assert torch.equal(gq, gq4) and torch.equal(gk, gk4) and torch.equal(gv, gv4)
 
 
+def test_attention_long_document_and_ragged_tail(ops):
+    """One 8 192-token document followed by ragged short ones (total not a multiple of any tile size): every q tile of the long
+    document walks 128 KV tiles, the tail exercises partial tiles; two heads are checked against f32 torch on the device."""
+    torch.manual_seed(12)
+    docs, hq, hkv, d = [8192, 77, 1, 300, 5], 8, 2, 128
+    n, scale = sum(docs), 128**-0.5
+    q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+    k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    go = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(docs)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    out, lse = ops.attn_varlen_fwd(q, k, v, ss, scale)
+    gq, gk, gv = ops.attn_varlen_bwd(go, q, k, v, out, lse, ss, scale)
+    bounds = np.cumsum([0] + docs)
+    for head in (0, 5):
+        kvh = head // (hq // hkv)
+        qf, kf, vf = (t.float().requires_grad_(True) for t in (q[:, head], k[:, kvh], v[:, kvh]))
+        want = torch.zeros(n, d, device=DEV)
+        parts = []
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            sc = (qf[s:e] @ kf[s:e].T) * scale
+            sc = sc.masked_fill(torch.ones(e - s, e - s, dtype=torch.bool, device=DEV).triu(1), float("-inf"))
+            parts.append(torch.softmax(sc, -1) @ vf[s:e])
+        want = torch.cat(parts)
+        _close(out[:, head], want, 1e-2, 1e-2, f"long-doc forward head {head}")
+        (want * go[:, head].float()).sum().backward()
+        _close(gq[:, head], qf.grad, 2e-2, 3e-2, f"long-doc dq head {head}")
+    # dk / dv of kv head 0 = sum over its 4 query heads
+    kf, vf = k[:, 0].float().requires_grad_(True), v[:, 0].float().requires_grad_(True)
+    total = 0.0
+    for head in range(4):
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            sc = (q[s:e, head].float() @ kf[s:e].T) * scale
+            sc = sc.masked_fill(torch.ones(e - s, e - s, dtype=torch.bool, device=DEV).triu(1), float("-inf"))
+            total = total + ((torch.softmax(sc, -1) @ vf[s:e]) * go[s:e, head].float()).sum()
+    total.backward()
+    _close(gk[:, 0], kf.grad, 2e-2, 4e-2, "long-doc dk")
+    _close(gv[:, 0], vf.grad, 2e-2, 4e-2, "long-doc dv")
+
+
 # ================================================================================================ optimizer
 def test_adamw_sumsq_clip(ops):
     torch.manual_seed(0)
