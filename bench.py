@@ -81,7 +81,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():  # N > 1, or the world_size-1 group of --force-collectives (same code path on one GPU)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -98,7 +98,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     k1_events, engine.k1_events = engine.k1_events, None
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
