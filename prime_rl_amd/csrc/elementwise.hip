@@ -164,19 +164,31 @@ __global__ __launch_bounds__(256) void grad_accumulate_kernel(float* __restrict_
   }
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));  // clang ext vector: usable with the non-temporal builtins
+
+// The gradient shard is read exactly once here and once by AdamW (tens of GB: nothing survives in L2 / Infinity Cache), so both
+// kernels stream with non-temporal accesses and keep several independent 16-byte loads in flight per lane.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
   __shared__ float smem[4];
   const int64_t nvec = n >> 2;
+  const f32x4v* xv = reinterpret_cast<const f32x4v*>(x);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    s0 = fmaf(v.x, v.x, s0);
-    s1 = fmaf(v.y, v.y, s1);
-    s2 = fmaf(v.z, v.z, s2);
-    s3 = fmaf(v.w, v.w, s3);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    const f32x4v a = __builtin_nontemporal_load(xv + i), b = __builtin_nontemporal_load(xv + i + stride),
+                 c = __builtin_nontemporal_load(xv + i + 2 * stride), d = __builtin_nontemporal_load(xv + i + 3 * stride);
+    s0 = fmaf(a.x, a.x, s0); s1 = fmaf(a.y, a.y, s1); s2 = fmaf(a.z, a.z, s2); s3 = fmaf(a.w, a.w, s3);
+    s0 = fmaf(b.x, b.x, s0); s1 = fmaf(b.y, b.y, s1); s2 = fmaf(b.z, b.z, s2); s3 = fmaf(b.w, b.w, s3);
+    s0 = fmaf(c.x, c.x, s0); s1 = fmaf(c.y, c.y, s1); s2 = fmaf(c.z, c.z, s2); s3 = fmaf(c.w, c.w, s3);
+    s0 = fmaf(d.x, d.x, s0); s1 = fmaf(d.y, d.y, s1); s2 = fmaf(d.z, d.z, s2); s3 = fmaf(d.w, d.w, s3);
+  }
+  for (; i < nvec; i += stride) {
+    const f32x4v v = __builtin_nontemporal_load(xv + i);
+    s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
   }
   if (blockIdx.x == 0) {
-    for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) s0 = fmaf(x[i], x[i], s0);
+    for (int64_t t = nvec * 4 + threadIdx.x; t < n; t += 256) s0 = fmaf(x[t], x[t], s0);
   }
   const float tot = block_sum<4>((s0 + s1) + (s2 + s3), smem);
   if (threadIdx.x == 0) partials[blockIdx.x] = tot;
@@ -206,30 +218,44 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
   const float step_size = lr / bc1;
   const int64_t nvec = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i],
-           G = reinterpret_cast<float4*>(g)[i];
-    float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w}, gg[4] = {G.x, G.y, G.z, G.w};
+  f32x4v* pv = reinterpret_cast<f32x4v*>(p);
+  f32x4v* mv = reinterpret_cast<f32x4v*>(m);
+  f32x4v* vv4 = reinterpret_cast<f32x4v*>(v);
+  f32x4v* gv = reinterpret_cast<f32x4v*>(g);
+  const float decay = 1.0f - lr * wd, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  auto update = [&](int64_t i, f32x4v P, f32x4v M, f32x4v V, const f32x4v G) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gr = gg[k] * gs;
-      pp[k] = pp[k] * (1.0f - lr * wd);                 // param.mul_(1 - lr*wd)
-      mm[k] = mm[k] + (gr - mm[k]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1-beta1)
-      vv[k] = vv[k] * b2 + (1.0f - b2) * gr * gr;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
-      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
-      pp[k] = pp[k] - step_size * (mm[k] / denom);      // param.addcdiv_(exp_avg, denom, -step_size)
+      const float gr = G[k] * gs;
+      P[k] = P[k] * decay;                              // param.mul_(1 - lr*wd)
+      M[k] = M[k] + (gr - M[k]) * omb1;                 // exp_avg.lerp_(grad, 1-beta1)
+      V[k] = V[k] * b2 + omb2 * gr * gr;                // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+      const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
+      P[k] = P[k] - step_size * (M[k] / denom);         // param.addcdiv_(exp_avg, denom, -step_size)
     }
-    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_nontemporal_store(P, pv + i);
+    __builtin_nontemporal_store(M, mv + i);
+    __builtin_nontemporal_store(V, vv4 + i);
+    if (zero_grad) __builtin_nontemporal_store(f32x4v{0.f, 0.f, 0.f, 0.f}, gv + i);
     if (pb) {
       u32x2 o;
-      o.x = pack_bf16(pp[0], pp[1]);
-      o.y = pack_bf16(pp[2], pp[3]);
-      reinterpret_cast<u32x2*>(pb)[i] = o;
+      o.x = pack_bf16(P[0], P[1]);
+      o.y = pack_bf16(P[2], P[3]);
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(pb) + i);
     }
+  };
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < nvec; i += 2 * stride) {  // two independent vectors of every stream in flight
+    const f32x4v P0 = __builtin_nontemporal_load(pv + i), M0 = __builtin_nontemporal_load(mv + i), V0 = __builtin_nontemporal_load(vv4 + i),
+                 G0 = __builtin_nontemporal_load(gv + i);
+    const f32x4v P1 = __builtin_nontemporal_load(pv + i + stride), M1 = __builtin_nontemporal_load(mv + i + stride),
+                 V1 = __builtin_nontemporal_load(vv4 + i + stride), G1 = __builtin_nontemporal_load(gv + i + stride);
+    update(i, P0, M0, V0, G0);
+    update(i + stride, P1, M1, V1, G1);
   }
+  for (; i < nvec; i += stride)
+    update(i, __builtin_nontemporal_load(pv + i), __builtin_nontemporal_load(mv + i), __builtin_nontemporal_load(vv4 + i), __builtin_nontemporal_load(gv + i));
   if (blockIdx.x == 0) {
     for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) {
       const float gr = g[i] * gs;
