@@ -40,21 +40,23 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// f32 -> bf16 is the hardware conversion v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN) everywhere: the integer emulation
+// (NaN test + biased add + shift) costs ~6 VALU ops per value, which made several "HBM-bound" kernels VALU-bound on their stores
+// (q/k-norm + RoPE forward: 124 -> 67 us per 16k-token layer after the switch).
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf16_hw(float lo, float hi) {
+  hw_f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hw_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16_hw(f, 0.f) & 0xffffu); }
 // round an f32 to the nearest bf16 and return it as f32 (emulates a bf16 torch op's output rounding)
-__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ float round_bf16(float f) { return __uint_as_float(pack_bf16_hw(f, 0.f) << 16); }
 
 // low / high halves of a packed pair
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return pack_bf16_hw(lo, hi); }
 
 // ---- wave / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -99,14 +101,8 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f32<0x128>(v);
   return v;
 }
-// hardware conversions: v_cvt_pk_bf16_f32 (RNE) and raw v_exp_f32
-typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float hw_f32x2_t;
-__device__ __forceinline__ uint32_t pack_bf16_hw(float lo, float hi) {
-  hw_f32x2_t f = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hw_bf16x2_t));
-}
-__device__ __forceinline__ bf16_t f32_to_bf16_hw(float f) { return (bf16_t)(pack_bf16_hw(f, 0.f) & 0xffffu); }
+// raw v_exp_f32
+__device__ __forceinline__ bf16_t f32_to_bf16_hw(float f) { return f32_to_bf16(f); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // block-wide sum for blockDim.x = NWAVES*64; `smem` needs NWAVES floats. Result valid in every thread.

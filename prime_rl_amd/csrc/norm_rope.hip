@@ -16,8 +16,18 @@ __device__ __forceinline__ void unpack8(const u32x4& v, float* o) {
 }
 __device__ __forceinline__ u32x4 pack8(const float* o) {
   u32x4 v;
-  v.x = pack_bf16(o[0], o[1]); v.y = pack_bf16(o[2], o[3]); v.z = pack_bf16(o[4], o[5]); v.w = pack_bf16(o[6], o[7]);
+  v.x = pack_bf16_hw(o[0], o[1]); v.y = pack_bf16_hw(o[2], o[3]); v.z = pack_bf16_hw(o[4], o[5]); v.w = pack_bf16_hw(o[6], o[7]);  // v_cvt_pk_bf16_f32 (RNE)
   return v;
+}
+// round 8 f32 values to the nearest bf16 in place (a bf16 torch op's output rounding): 4 x v_cvt_pk_bf16_f32 + 8 bit ops, where the
+// integer emulation costs ~6 VALU ops per value — the q/k-norm + RoPE forward has four such rounding points per element and was VALU-bound
+__device__ __forceinline__ void round8_bf16(float* a) {
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const uint32_t w = pack_bf16_hw(a[k], a[k + 1]);
+    a[k] = bf16lo(w);
+    a[k + 1] = bf16hi(w);
+  }
 }
 
 // ================================= RMSNorm =====================================================
@@ -44,7 +54,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
         float rf[8];
         unpack8(rr[idx], rf);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xf[v][k] = round_bf16(xf[v][k] + rf[k]);  // bf16 residual add (modeling_qwen3.py:80,84)
+        for (int k = 0; k < 8; ++k) xf[v][k] = xf[v][k] + rf[k];
+        round8_bf16(xf[v]);  // bf16 residual add (modeling_qwen3.py:80,84)
         sr[idx] = pack8(xf[v]);
       }
 #pragma unroll
@@ -63,7 +74,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
       float wf[8], o[8];
       unpack8(wr[idx], wf);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = wf[k] * round_bf16(xf[v][k] * r);  // weight * hidden.to(bf16); pack8 rounds the product
+      for (int k = 0; k < 8; ++k) o[k] = xf[v][k] * r;
+      round8_bf16(o);  // hidden.to(bf16)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = wf[k] * o[k];  // weight * hidden; pack8 rounds the product
       yr[idx] = pack8(o);
     }
   }
@@ -246,44 +260,65 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, int64_t n_tok
 }
 
 // ================================= q/k norm + RoPE =============================================
-// 16 lanes per (token, head) item, 8 contiguous elements per lane (head_dim = 128).
-// lanes 0-7 of a group hold elements [0,64), lanes 8-15 hold [64,128): the rotate_half partner is lane ^ 8.
+// 16 lanes per TOKEN, 8 contiguous elements per lane (head_dim = 128): the group walks the token's q and k heads in batches of
+// kQkBatch with every load of a batch issued before its first use; cos / sin (64 values per token) and the two norm weights are
+// loaded once per token instead of once per head, and nothing divides by the head count.  lanes 0-7 of a group hold elements
+// [0,64), lanes 8-15 hold [64,128): the rotate_half partner is lane ^ 8 = DPP row_ror:8; row sums are DPP too (VALU, no LDS).
+constexpr int kQkBatch = 4;
+
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
                                                              const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
                                                              const bf16_t* __restrict__ sinb, int64_t n_tokens, int hq, int hkv, float eps,
                                                              bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, float* __restrict__ rstd) {
   const int nh = hq + hkv;
-  const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int64_t tok = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int sub = threadIdx.x & 15;
-  const bool valid = item < n_tokens * nh;
-  const int64_t it = valid ? item : 0;
-  const int64_t tok = it / nh;
-  const int h = (int)(it - tok * nh);
+  if (tok >= n_tokens) return;  // a whole 16-lane row leaves together; the DPP row ops never cross rows
   const int64_t row_stride = (int64_t)(hq + 2 * hkv) * 128;
-  float xf[8];
-  unpack8(*reinterpret_cast<const u32x4*>(qkv + tok * row_stride + (int64_t)h * 128 + sub * 8), xf);
-  float ss = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) ss = fmaf(xf[k], xf[k], ss);
-  ss = group16_sum(ss);
-  const float r = rsqrtf(ss / 128.0f + eps);
-  float wf[8], cf[8], sf[8], yv[8], yp[8];
-  unpack8(*reinterpret_cast<const u32x4*>((h < hq ? qw : kw) + sub * 8), wf);
+  float wq[8], wk[8], cf[8], sf[8];
+  unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
+  unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
   const int cs = (sub & 7) * 8;
   unpack8(*reinterpret_cast<const u32x4*>(cosb + tok * 64 + cs), cf);
   unpack8(*reinterpret_cast<const u32x4*>(sinb + tok * 64 + cs), sf);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) yv[k] = round_bf16(wf[k] * round_bf16(xf[k] * r));
-#pragma unroll
-  for (int k = 0; k < 8; ++k) yp[k] = __shfl_xor(yv[k], 8, 64);
   const float sgn = (sub < 8) ? -1.0f : 1.0f;  // rotate_half: first half gets -x2, second half gets +x1
-  float o[8];
+  const bf16_t* row = qkv + tok * row_stride + sub * 8;
+  for (int h0 = 0; h0 < nh; h0 += kQkBatch) {
+    u32x4 xv[kQkBatch];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = round_bf16(yv[k] * cf[k]) + round_bf16((sgn * yp[k]) * sf[k]);
-  if (valid) {
-    bf16_t* dst = (h < hq) ? (qo + (tok * hq + h) * 128 + sub * 8) : (ko + (tok * hkv + (h - hq)) * 128 + sub * 8);
-    *reinterpret_cast<u32x4*>(dst) = pack8(o);
-    if (sub == 0) rstd[item] = r;
+    for (int j = 0; j < kQkBatch; ++j) xv[j] = *reinterpret_cast<const u32x4*>(row + (int64_t)(h0 + j < nh ? h0 + j : nh - 1) * 128);
+#pragma unroll
+    for (int j = 0; j < kQkBatch; ++j) {
+      const int h = h0 + j;
+      if (h >= nh) break;
+      float xf[8];
+      unpack8(xv[j], xf);
+      float ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss = fmaf(xf[k], xf[k], ss);
+      ss = row16_sum(ss);
+      const float r = rsqrtf(ss / 128.0f + eps);
+      const float* wf = h < hq ? wq : wk;
+      float yv[8], o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) yv[k] = xf[k] * r;
+      round8_bf16(yv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) yv[k] = wf[k] * yv[k];
+      round8_bf16(yv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o[k] = yv[k] * cf[k];
+        xf[k] = (sgn * dpp_f32<0x128>(yv[k])) * sf[k];
+      }
+      round8_bf16(o);
+      round8_bf16(xf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += xf[k];
+      bf16_t* dst = (h < hq) ? (qo + (tok * hq + h) * 128 + sub * 8) : (ko + (tok * hkv + (h - hq)) * 128 + sub * 8);
+      *reinterpret_cast<u32x4*>(dst) = pack8(o);
+      if (sub == 0) rstd[tok * nh + h] = r;
+    }
   }
 }
 
@@ -292,9 +327,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
                                                              const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
                                                              const bf16_t* __restrict__ sinb, const float* __restrict__ rstd,
                                                              int64_t n_tokens, int hq, int hkv, bf16_t* __restrict__ gqkv,
-                                                             float* __restrict__ dw_partials /* [grid*4][2][128] */) {
+                                                             float* __restrict__ dw_partials /* [grid][2][128] */) {
   const int nh = hq + hkv;
-  const int64_t n_items = n_tokens * nh;
   const int sub = threadIdx.x & 15;
   const int64_t row_stride = (int64_t)(hq + 2 * hkv) * 128;
   float dwq[8], dwk[8], wq[8], wk[8];
@@ -302,67 +336,69 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
   for (int k = 0; k < 8; ++k) dwq[k] = dwk[k] = 0.f;
   unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
   unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
-  const int64_t stride_items = (int64_t)gridDim.x * 16;
-  // all 16 lanes of a group iterate together; loop bound is uniform per group, shuffles stay inside the group
-  for (int64_t base = (int64_t)blockIdx.x * 16; base < n_items; base += stride_items) {
-    const int64_t item = base + (threadIdx.x >> 4);
-    const bool valid = item < n_items;
-    const int64_t it = valid ? item : 0;
-    const int64_t tok = it / nh;
-    const int h = (int)(it - tok * nh);
-    const bool is_q = h < hq;
-    float g[8], gp[8], cf[8], sf[8], xf[8];
-    const bf16_t* gsrc = is_q ? (gq + (tok * hq + h) * 128 + sub * 8) : (gk + (tok * hkv + (h - hq)) * 128 + sub * 8);
-    unpack8(*reinterpret_cast<const u32x4*>(gsrc), g);
-    const int cs = (sub & 7) * 8;
+  const int cs = (sub & 7) * 8;
+  const float sgn = (sub < 8) ? 1.0f : -1.0f;
+  for (int64_t tok = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); tok < n_tokens; tok += (int64_t)gridDim.x * 16) {
+    float cf[8], sf[8];
     unpack8(*reinterpret_cast<const u32x4*>(cosb + tok * 64 + cs), cf);
     unpack8(*reinterpret_cast<const u32x4*>(sinb + tok * 64 + cs), sf);
-    unpack8(*reinterpret_cast<const u32x4*>(qkv + tok * row_stride + (int64_t)h * 128 + sub * 8), xf);
+    const bf16_t* xrow = qkv + tok * row_stride + sub * 8;
+    bf16_t* orow = gqkv + tok * row_stride + sub * 8;
+    for (int h0 = 0; h0 < nh; h0 += kQkBatch) {
+      u32x4 xv[kQkBatch], gv[kQkBatch];
+      float rv[kQkBatch];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gp[k] = __shfl_xor(g[k], 8, 64);
-    // transpose of out = y*cos + rotate_half(y)*sin :  dy[j] = g[j]*cos[j] + (j<64 ? g[j+64] : -g[j-64]) * sin[j mod 64]
-    const float sgn = (sub < 8) ? 1.0f : -1.0f;
-    const float r = rstd[it];
-    const float* wv = is_q ? wq : wk;
-    float dn[8], nh_[8];
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float dy = g[k] * cf[k] + (sgn * gp[k]) * sf[k];
-      nh_[k] = xf[k] * r;
-      if (valid) {
-        if (is_q) dwq[k] = fmaf(dy, nh_[k], dwq[k]);
-        else dwk[k] = fmaf(dy, nh_[k], dwk[k]);
+      for (int j = 0; j < kQkBatch; ++j) {
+        const int h = h0 + j < nh ? h0 + j : nh - 1;
+        xv[j] = *reinterpret_cast<const u32x4*>(xrow + (int64_t)h * 128);
+        gv[j] = *reinterpret_cast<const u32x4*>(h < hq ? (gq + (tok * hq + h) * 128 + sub * 8) : (gk + (tok * hkv + (h - hq)) * 128 + sub * 8));
+        rv[j] = rstd[tok * nh + h];
       }
-      dn[k] = dy * wv[k];
-      dot = fmaf(dn[k], nh_[k], dot);
-    }
-    dot = group16_sum(dot) / 128.0f;
-    float o[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = r * (dn[k] - nh_[k] * dot);
-    if (valid) *reinterpret_cast<u32x4*>(gqkv + tok * row_stride + (int64_t)h * 128 + sub * 8) = pack8(o);
+      for (int j = 0; j < kQkBatch; ++j) {
+        const int h = h0 + j;
+        if (h >= nh) break;
+        const bool is_q = h < hq;
+        float g[8], xf[8], dn[8], nh_[8];
+        unpack8(gv[j], g);
+        unpack8(xv[j], xf);
+        const float r = rv[j];
+        const float* wv = is_q ? wq : wk;
+        // transpose of out = y*cos + rotate_half(y)*sin :  dy[j] = g[j]*cos[j] + (j<64 ? g[j+64] : -g[j-64]) * sin[j mod 64]
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dy = g[k] * cf[k] + (sgn * dpp_f32<0x128>(g[k])) * sf[k];
+          nh_[k] = xf[k] * r;
+          if (is_q) dwq[k] = fmaf(dy, nh_[k], dwq[k]);
+          else dwk[k] = fmaf(dy, nh_[k], dwk[k]);
+          dn[k] = dy * wv[k];
+          dot = fmaf(dn[k], nh_[k], dot);
+        }
+        dot = row16_sum(dot) / 128.0f;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = r * (dn[k] - nh_[k] * dot);
+        *reinterpret_cast<u32x4*>(orow + (int64_t)h * 128) = pack8(o);
+      }
+    }
   }
-  // reduce the 4 groups of a wave, then one partial row per wave
+  // the 16 groups of the block through LDS (fixed order): one partial row [q 128 | k 128] per block
+  __shared__ float red[16][256];
+  const int grp = threadIdx.x >> 4;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    dwq[k] += __shfl_xor(dwq[k], 16, 64);
-    dwq[k] += __shfl_xor(dwq[k], 32, 64);
-    dwk[k] += __shfl_xor(dwk[k], 16, 64);
-    dwk[k] += __shfl_xor(dwk[k], 32, 64);
-  }
-  // ... then the 4 waves of the block through LDS: one partial row [q 128 | k 128] per block
-  __shared__ float red[4][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < 16) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      red[wave][lane * 8 + k] = dwq[k];
-      red[wave][128 + lane * 8 + k] = dwk[k];
-    }
+    red[grp][sub * 8 + k] = dwq[k];
+    red[grp][128 + sub * 8 + k] = dwk[k];
   }
   __syncthreads();
-  dw_partials[(int64_t)blockIdx.x * 256 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int gI = 0; gI < 16; gI += 2) {
+    s0 += red[gI][threadIdx.x];
+    s1 += red[gI + 1][threadIdx.x];
+  }
+  dw_partials[(int64_t)blockIdx.x * 256 + threadIdx.x] = s0 + s1;
 }
 
 __global__ void qk_dw_reduce_kernel(const float* __restrict__ partials, int64_t n_partials, float* __restrict__ gqw, float* __restrict__ gkw) {
@@ -381,8 +417,8 @@ __global__ void qk_dw_reduce_kernel(const float* __restrict__ partials, int64_t 
   else gkw[c - 128] += s;
 }
 
-static int64_t qk_bwd_grid(int64_t n_tokens, int nh) {
-  int64_t g = cdiv(n_tokens * nh, 16);
+static int64_t qk_bwd_grid(int64_t n_tokens, int /*nh*/) {
+  int64_t g = cdiv(n_tokens, 16);  // one 16-lane group per token, 16 tokens per workgroup per sweep
   if (g > 512) g = 512;
   if (g < 1) g = 1;
   return g;
@@ -498,8 +534,7 @@ extern "C" int pm_qknorm_rope_fwd(const void* qkv, const void* q_norm_w, const v
   PM_REQUIRE(head_dim == 128, PM_ERR_UNSUPPORTED, "pm_qknorm_rope_fwd: head_dim=%d (only 128 is built)", head_dim);
   PM_REQUIRE(n_tokens >= 0 && n_q_heads > 0 && n_kv_heads > 0, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
-  const int64_t items = n_tokens * (n_q_heads + n_kv_heads);
-  hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)cdiv(items, 16)), dim3(256), 0, as_stream(stream), (const bf16_t*)qkv,
+  hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)cdiv(n_tokens, (int64_t)16)), dim3(256), 0, as_stream(stream), (const bf16_t*)qkv,
                      (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, n_tokens, n_q_heads, n_kv_heads,
                      eps, (bf16_t*)q_out, (bf16_t*)k_out, rstd);
   PM_CHECK_LAUNCH("pm_qknorm_rope_fwd");
