@@ -132,6 +132,7 @@ def test_engine_step_matches_oracle(packed):
     norm_o = math.sqrt(sum(float(p.grad.float().pow(2).sum()) for p in params.values()))
     before = eng.store.master.clone()
     norm_e = eng.optimizer_step().item()
+    eng.wait_params_ready()  # the AdamW pipeline runs on the engine's side stream
     assert abs(norm_e - norm_o) / norm_o < 2e-2, (norm_e, norm_o)
     assert not torch.equal(before, eng.store.master)
     # AdamW step 1: |delta| == lr for every element with a non-zero gradient (m/sqrt(v) = sign(g)), plus decay
@@ -177,6 +178,7 @@ def test_gemm_layout_copies_track_parameter_updates():
     for step in range(3):
         batch = pack_micro_batches(_mbs(dims.vocab_size, 128, 3, True, seed_shift=step), DEV)
         if step == 2:  # externally loaded weights must invalidate the copies as well
+            a.wait_params_ready(); b.wait_params_ready()  # the previous step's AdamW pipeline may still be running on the side streams
             sd = {k: v.float() * 1.5 for k, v in a.store.state_dict().items()}
             a.store.load_state_dict(sd); b.store.load_state_dict(sd)
         ra, rb = a.step(batch), b.step(batch)
