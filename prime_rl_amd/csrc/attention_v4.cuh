@@ -41,6 +41,19 @@ __device__ __forceinline__ u32x4 lds_tr_pair(const bf16_t* p) {
   return u32x4{l2.x, l2.y, h2.x, h2.y};
 }
 
+// max over the four 16-lane rows of a wave (lanes lr, lr+16, lr+32, lr+48) on the VALU: v_permlane32_swap exchanges the wave halves,
+// v_permlane16_swap the odd/even rows (gfx950); with both operands holding the same value the two results are "mine" and "the other
+// half's / row's".  Replaces two __shfl_xor = ds_bpermute round trips through the LDS pipe per call.
+typedef unsigned int pl_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float xrow_max_swap(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const pl_u32x2 a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float h = fmaxf(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y));
+  const unsigned uh = __builtin_bit_cast(unsigned, h);
+  const pl_u32x2 b = __builtin_amdgcn_permlane16_swap(uh, uh, false, false);
+  return fmaxf(__builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y));
+}
+
 constexpr int kV4TileElems = 32 * kD;                      // one [32][128] tile
 constexpr int kV4OffDO = 2 * kV4TileElems * 2;             // bytes: Q[2] then dO[2]
 constexpr int kV4OffL = 2 * kV4OffDO;                      // then lse / delta / lo rows [2][32] each
@@ -704,6 +717,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
         }
       }
     }
+    // Online softmax, written for the VALU (the unit that bounds this kernel: 32 scores per lane per tile against 64 MFMAs): the row
+    // max is taken on the RAW scores (scale > 0 commutes with max), scale and subtraction are one fma feeding v_exp_f32, the f32x4
+    // accumulators are rescaled with vector multiplies (v_pk_mul_f32), and the max crosses the four 16-lane rows of the wave through
+    // v_permlane32_swap / v_permlane16_swap (VALU) instead of two ds_bpermute round trips through the LDS pipe.
     const bool need_mask = (kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]);  // per lane; cheap and exact either way
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -712,36 +729,31 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
       for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int kv = kv0 + nb * 16 + lq * 4 + r;
-          float sv = st[cb][nb][r] * sc2;
-          if (need_mask) sv = ((kv <= qi[cb]) && (kv >= lo[cb])) ? sv : -INFINITY;
-          st[cb][nb][r] = sv;
-          mx = fmaxf(mx, sv);
+          if (need_mask) {
+            const int kv = kv0 + nb * 16 + lq * 4 + r;
+            st[cb][nb][r] = ((kv <= qi[cb]) && (kv >= lo[cb])) ? st[cb][nb][r] : -INFINITY;
+          }
+          mx = fmaxf(mx, st[cb][nb][r]);
         }
       }
-      mx = xrow_max(mx);
+      mx = xrow_max_swap(mx) * sc2;
       const float m_new = fmaxf(m[cb], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = fast_exp2(m[cb] - m_use);
-      float sum = 0.f;
+      f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
+        const f32x4 e = st[cb][nb] * sc2 - m_use;  // contracted to (packed) fma
+        f32x4 p;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(st[cb][nb][r] - m_use);
-          st[cb][nb][r] = p;
-          sum += p;
-        }
+        for (int r = 0; r < 4; ++r) p[r] = fast_exp2(e[r]);
+        st[cb][nb] = p;
+        sum4 += p;
       }
-      l[cb] = l[cb] * alpha + sum;  // per-lane partial row sum (own kv subset); reduced across lq once at the end
+      l[cb] = l[cb] * alpha + ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));  // per-lane partial row sum; reduced across lq at the end
       m[cb] = m_new;
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        ot[cb][nb][0] *= alpha;
-        ot[cb][nb][1] *= alpha;
-        ot[cb][nb][2] *= alpha;
-        ot[cb][nb][3] *= alpha;
-      }
+      for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
     }
     // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
 #pragma unroll
