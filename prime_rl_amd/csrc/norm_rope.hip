@@ -543,7 +543,7 @@ extern "C" int pm_qknorm_rope_fwd(const void* qkv, const void* q_norm_w, const v
 
 extern "C" int64_t pm_qknorm_rope_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads) {
   if (n_tokens <= 0) return 0;
-  return qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads) * 4 * 256 * (int64_t)sizeof(float);
+  return (qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads) + kReduceSlices) * 256 * (int64_t)sizeof(float);  // partial rows + stage-1 rows
 }
 
 extern "C" int pm_qknorm_rope_bwd(const void* grad_q, const void* grad_k, const void* qkv, const void* q_norm_w, const void* k_norm_w,
@@ -563,7 +563,10 @@ extern "C" int pm_qknorm_rope_bwd(const void* grad_q, const void* grad_k, const 
                      (const bf16_t*)qkv, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, rstd, n_tokens,
                      n_q_heads, n_kv_heads, (bf16_t*)grad_qkv, (float*)workspace);
   PM_CHECK_LAUNCH("pm_qknorm_rope_bwd");
-  hipLaunchKernelGGL(qk_dw_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, grad_q_norm_w, grad_k_norm_w);
+  // [grid][256] partial rows -> 32 slice sums spread over the chip -> one 256-thread block adds them into the two weight gradients
+  float* stage = (float*)workspace + grid * 256;
+  hipLaunchKernelGGL(column_reduce_stage1_kernel, dim3(1, kReduceSlices), dim3(256), 0, st, (const float*)workspace, grid, (int64_t)256, stage);
+  hipLaunchKernelGGL(qk_dw_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)stage, (int64_t)kReduceSlices, grad_q_norm_w, grad_k_norm_w);
   PM_CHECK_LAUNCH("pm_qknorm_rope_bwd(reduce)");
   return PM_OK;
 }
