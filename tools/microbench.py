@@ -120,6 +120,10 @@ def bench_norm(out):
 def bench_gemm(out):
     """Operand-orientation study for the library GEMMs of one Qwen3-8B layer at T = 16384 tokens (what the step runs): which layout
     of W / dY / X does hipBLASLt run fastest for forward, dgrad and the f32-accumulating wgrad."""
+    import os
+
+    if os.environ.get("PM_BLAS"):  # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (torch's names)
+        torch.backends.cuda.preferred_blas_library(os.environ["PM_BLAS"])
     t = 16384
     shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
     for name, (o, i) in shapes.items():
