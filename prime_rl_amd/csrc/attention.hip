@@ -264,7 +264,15 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
     else if (var == 2) PM_LAUNCH_DKDV_V4(4, 3, 4);
     else if (var == 3) PM_LAUNCH_DKDV_V4(8, 1, 4);
     else if (var == 0) PM_LAUNCH_DKDV_V4(4, 2, 4);
-    else {
+    else if (var == 5) {  // 64-row q tiles, one 8-wave workgroup per CU with 128 kv rows (half the staging traffic of the default)
+      constexpr int kSmemQ64 = 4 * 64 * kD * 2 + 6 * 64 * 4 + 16;
+      static const bool ok8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v4q_kernel<8, 1, 4, 64>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSmemQ64) == hipSuccess;
+      PM_REQUIRE(ok8, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      hipLaunchKernelGGL((attn_bwd_dkdv_v4q_kernel<8, 1, 4, 64>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kSmemQ64, st, (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
+                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
+    } else {
       constexpr int kSmemQ64 = 4 * 64 * kD * 2 + 6 * 64 * 4 + 16;
       static const bool q64_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v4q_kernel<4, 2, 4, 64>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kSmemQ64) == hipSuccess;

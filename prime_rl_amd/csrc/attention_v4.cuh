@@ -44,14 +44,24 @@ __device__ __forceinline__ u32x4 lds_tr_pair(const bf16_t* p) {
 // max over the four 16-lane rows of a wave (lanes lr, lr+16, lr+32, lr+48) on the VALU: v_permlane32_swap exchanges the wave halves,
 // v_permlane16_swap the odd/even rows (gfx950); with both operands holding the same value the two results are "mine" and "the other
 // half's / row's".  Replaces two __shfl_xor = ds_bpermute round trips through the LDS pipe per call.
-typedef unsigned int pl_u32x2 __attribute__((ext_vector_type(2)));
+// Written as inline asm on purpose: with this toolchain (ROCm 7.2 hipcc) the builtins `__builtin_amdgcn_permlane{16,32}_swap` return
+// their FIRST result twice (the v_max of the two results is folded away; tools/probes/swap_probe.hip shows it), which made every lane
+// adopt row 0's partial max — outputs stayed right, lse went to -inf for rows whose lq = 0 lane saw only masked scores.  Both
+// registers are read-write operands of the instruction; the s_nops keep the VALU-write -> permlane hazard distance explicit because
+// the hazard recognizer does not look inside inline asm.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float xrow_max_swap(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const pl_u32x2 a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  const float h = fmaxf(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y));
-  const unsigned uh = __builtin_bit_cast(unsigned, h);
-  const pl_u32x2 b = __builtin_amdgcn_permlane16_swap(uh, uh, false, false);
-  return fmaxf(__builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y));
+  float a = v, b = v;
+  permlane32_swap(a, b);  // a = [v.lo, v.lo], b = [v.hi, v.hi]
+  a = fmaxf(a, b);
+  b = a;
+  permlane16_swap(a, b);  // a = [r0, r0, r2, r2], b = [r1, r1, r3, r3]
+  return fmaxf(a, b);
 }
 
 constexpr int kV4TileElems = 32 * kD;                      // one [32][128] tile

@@ -452,6 +452,14 @@ def test_attention_forward_backward(ops, seq_lens, hq, hkv):
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
     want = O.varlen_causal_attention(qf, kf, vf, seq_lens, scale)
     _close(out, want, 1e-2, 1e-2, "attention forward")  # bf16 P and bf16 output
+    # the softmax statistic handed to backward: lse[h, i] = logsumexp_j(scale * q_i . k_j) over the visible keys (f32 math on bf16 q, k)
+    bounds = np.cumsum([0] + seq_lens)
+    want_lse = torch.empty(hq, n)
+    for h in range(hq):
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            sc = (q[s:e, h].float() @ k[s:e, h // (hq // hkv)].float().T) * scale
+            want_lse[h, s:e] = torch.logsumexp(sc.masked_fill(torch.ones(e - s, e - s, dtype=torch.bool).triu(1), float("-inf")), -1)
+    _close(lse, want_lse, 1e-4, 1e-4, "attention lse")
     go = torch.randn(n, hq, d).to(torch.bfloat16)
     (want * go.float()).sum().backward()
     gq, gk, gv = ops.attn_varlen_bwd(go.to(DEV), q.to(DEV), k.to(DEV), v_view, out, lse, ss, scale)
