@@ -296,9 +296,19 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
 
   // ---- dQ
   if (!dq_v3()) {
-    hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes, st, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
-                       softmax_scale, (bf16_t*)grad_q);
+    static const bool kt64 = getenv("PM_ATTN_DQ_KT32") == nullptr;  // default: 64 kv rows per barrier (backward 1.41 -> 1.37 ms per layer); PM_ATTN_DQ_KT32 = A/B
+    if (kt64) {
+      static const bool ok64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_v4_kernel<2, 64>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kV4DqSmemBytes<64>) == hipSuccess;
+      PM_REQUIRE(ok64, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2, 64>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes<64>, st,
+                         (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,
+                         n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_q);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2, 32>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes<32>, st,
+                         (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,
+                         n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_q);
+    }
   } else {
     if ((rc = launch_transpose((const bf16_t*)k, (int64_t)n_kv_heads * kD, n, n_pad, n_kv_heads, kt, st)) != PM_OK) return rc;
     hipLaunchKernelGGL((attn_bwd_dq_v3_kernel<2>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,

@@ -465,16 +465,21 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4q_kern
 // stored once, row-major and swizzled (A fragments of S^T = K.Q^T and dP^T = V.dO^T by ds_read_b128), and the A fragments of
 // dQ^T[d][q] += K^T[d][kv] . dS^T[kv][q] come from the SAME K tile through ds_read_b64_tr_b16 — no [head][128][N] transposed copy of K,
 // no pre-pass, no bank conflicts (v3: 43 % of its LDS cycles), LDS double-buffered with one barrier per KV tile.
-constexpr int kV4DqOffV = 2 * kV4TileElems * 2;  // bytes: K[2] then V[2]
-constexpr int kV4DqSmemBytes = 2 * kV4DqOffV;
+// KT = kv rows per barrier: the tile is consumed in 32-row halves (same registers), so KT = 64 halves the barriers per flop at the
+// price of 16 more staging registers and 64 KB of LDS.
+template <int KT>
+constexpr int kV4DqSmemBytes = 2 * 2 * KT * kD * 2;  // K[2] then V[2]
 
-template <int MINW>
+template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                   int64_t v_stride, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                   const float* __restrict__ delta, const int32_t* __restrict__ seq_start, int64_t n64,
                                                                   int hq, int hkv, float scale, bf16_t* __restrict__ dq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(dyn_smem);
+  constexpr int TILE = KT * kD;      // elements of one [KT][128] tile
+  constexpr int kV = 2 * TILE;       // element offset of the V tiles
+  constexpr int NCH = KT / 16;       // 16-byte chunks per thread per staged tile
   const int n = (int)n64;
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
@@ -512,14 +517,14 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t*
   }
   const int tile_last = (qt0 + 127 < n - 1) ? qt0 + 127 : n - 1;
   const int wave_last = (q0 + 31 < n - 1) ? q0 + 31 : n - 1;
-  const int kv_begin = (seq_start[qt0] / 32) * 32;
-  const int n_iters = (tile_last - kv_begin) / 32 + 1;
+  const int kv_begin = (seq_start[qt0] / KT) * KT;
+  const int n_iters = (tile_last - kv_begin) / KT + 1;
   const float sc2 = scale * 1.44269504088896340736f;
   const int rr = t >> 4, rc = (t & 15) * 8;
-  u32x4 rk[2], rv[2];
+  u32x4 rk[NCH], rv[NCH];
   auto issue = [&](int kv0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int krow = kv0 + rr + 16 * i;
       if (krow > n - 1) krow = n - 1;
       rk[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + rc);
@@ -529,9 +534,9 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t*
   const int st_off = swz_off(rr, t & 15);  // rows rr and rr + 16 share row & 15, hence the swizzle
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      sts16(Ks + buf * kV4TileElems + st_off + i * 16 * kD, rk[i]);
-      sts16(Ks + kV4DqOffV / 2 + buf * kV4TileElems + st_off + i * 16 * kD, rv[i]);
+    for (int i = 0; i < NCH; ++i) {
+      sts16(Ks + buf * TILE + st_off + i * 16 * kD, rk[i]);
+      sts16(Ks + kV + buf * TILE + st_off + i * 16 * kD, rv[i]);
     }
   };
   const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);
@@ -539,18 +544,21 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t*
   const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));
   issue(kv_begin);
   stage(0);
-  if (n_iters > 1) issue(kv_begin + 32);
+  if (n_iters > 1) issue(kv_begin + KT);
   for (int j = 0; j < n_iters; ++j) {
-    const int kv0 = kv_begin + 32 * j;
+    const int kvt = kv_begin + KT * j;
     const int buf = j & 1;
     __syncthreads();
     if (j + 1 < n_iters) {
       stage(buf ^ 1);
-      if (j + 2 < n_iters) issue(kv0 + 64);
+      if (j + 2 < n_iters) issue(kvt + 2 * KT);
     }
-    if (!active || kv0 > wave_last) continue;
-    const bf16_t* Kt = Ks + buf * kV4TileElems;
-    constexpr int kV = kV4DqOffV / 2;
+    if (!active) continue;
+#pragma unroll
+    for (int half = 0; half < KT / 32; ++half) {
+    const int kv0 = kvt + 32 * half;
+    if (kv0 > wave_last) break;
+    const bf16_t* Kt = Ks + buf * TILE + half * 32 * kD;
     f32x4 st[2][2], dpt[2][2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -600,6 +608,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t*
         dqt[0][h4 * 4 + i] = mfma16(ka[i], sb0, dqt[0][h4 * 4 + i]);
         dqt[1][h4 * 4 + i] = mfma16(ka[i], sb1, dqt[1][h4 * 4 + i]);
       }
+    }
     }
   }
   if (!active) return;
