@@ -394,23 +394,23 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4q_kern
     // S[q][kv], dP[q][kv]: rows q = nb*16 + lq*4 + r, column kv = lr
     f32x4 s[QT / 16], dp[QT / 16];
 #pragma unroll
-    for (int nb = 0; nb < QT / 16; ++nb) {
-      s[nb] = dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < QT / 16; ++nb) s[nb] = dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k-step outermost: the 2 * QT/16 accumulators of one batch are independent, so consecutive MFMAs never wait for each other
+    // (with the row block outermost every second MFMA depended on the one two slots earlier)
 #pragma unroll
-      for (int k0 = 0; k0 < 4; k0 += FB) {  // FB fragments of each operand in flight per batch (register pressure vs LDS latency hiding)
-        u32x4 qa[FB], da[FB];
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 qa[QT / 16], da[QT / 16];
 #pragma unroll
-        for (int kk = 0; kk < FB; ++kk) {
-          const bf16_t* pa = Qt + (bq ^ ((k0 + kk) << 5)) + nb * 16 * kD;
-          qa[kk] = lds16(pa);
-          da[kk] = lds16(pa + kDO);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int nb = 0; nb < QT / 16; ++nb) {
+        const bf16_t* pa = Qt + (bq ^ (kk << 5)) + nb * 16 * kD;
+        qa[nb] = lds16(pa);
+        da[nb] = lds16(pa + kDO);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < FB; ++kk) {
-          s[nb] = mfma16(qa[kk], kf[k0 + kk], s[nb]);
-          dp[nb] = mfma16(da[kk], vf[k0 + kk], dp[nb]);
-        }
+      for (int nb = 0; nb < QT / 16; ++nb) {
+        s[nb] = mfma16(qa[nb], kf[kk], s[nb]);
+        dp[nb] = mfma16(da[nb], vf[kk], dp[nb]);
       }
     }
 #pragma unroll
@@ -719,20 +719,20 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) st[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
+    {  // k-step outermost: 8 independent accumulators per batch (no back-to-back dependent MFMAs), next batch's fragments prefetched
       u32x4 ka[2][4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) ka[0][kk] = lds16(Kt + (bq ^ (kk << 5)));
+      for (int nb = 0; nb < 4; ++nb) ka[0][nb] = lds16(Kt + bq + nb * 16 * kD);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        if (nb < 3) {
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) ka[(nb + 1) & 1][kk] = lds16(Kt + (bq ^ (kk << 5)) + (nb + 1) * 16 * kD);
+          for (int nb = 0; nb < 4; ++nb) ka[(kk + 1) & 1][nb] = lds16(Kt + (bq ^ ((kk + 1) << 5)) + nb * 16 * kD);
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          st[0][nb] = mfma16(ka[nb & 1][kk], qf[0][kk], st[0][nb]);
-          st[1][nb] = mfma16(ka[nb & 1][kk], qf[1][kk], st[1][nb]);
+        for (int nb = 0; nb < 4; ++nb) {
+          st[0][nb] = mfma16(ka[kk & 1][nb], qf[0][kk], st[0][nb]);
+          st[1][nb] = mfma16(ka[kk & 1][nb], qf[1][kk], st[1][nb]);
         }
       }
     }
