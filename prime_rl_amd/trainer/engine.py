@@ -77,10 +77,15 @@ class ModelDims:
         return v * h * (1 if self.tie_word_embeddings else 2) + self.num_hidden_layers * per_layer + h
 
     def flops_per_token(self, seq_len: int) -> int:
-        """PerfCounter._get_num_flop_per_token (trainer/perf.py:177-213): 6 * matmul params + 12*L*H*Dh*T."""
+        """PerfCounter._get_num_flop_per_token (trainer/perf.py:177-213): 6 * active matmul params + 12 * L * H * q * T with
+        q = hidden_size // num_attention_heads — the reference's definition, which is NOT head_dim for models such as Qwen3-0.6B
+        (1024 // 16 = 64 vs head_dim 128); pinned by the reference's known answers (tests/unit/train/test_perf.py:8-35)."""
+        return 6 * self.active_mm_params() + 12 * self.num_hidden_layers * self.num_attention_heads * (self.hidden_size // self.num_attention_heads) * seq_len
+
+    def active_mm_params(self) -> int:
+        """PerfCounter.get_active_mm_params (trainer/perf.py:120-175), dense case: q/k/v/o + gate/up/down per layer + LM head."""
         h, i = self.hidden_size, self.intermediate_size
-        mm = self.num_hidden_layers * ((self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h) + self.vocab_size * h
-        return 6 * mm + 12 * self.num_hidden_layers * self.num_attention_heads * self.head_dim * seq_len
+        return self.num_hidden_layers * ((self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h) + self.vocab_size * h
 
 
 @dataclass

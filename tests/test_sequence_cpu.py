@@ -46,6 +46,20 @@ def test_cu_seqlens_matches_packer_boundaries():
     assert torch.equal(cu_a, cu_b) and mx_a == mx_b
 
 
+def test_mfu_formula_matches_reference_known_answers():
+    """trainer/perf.py:120-213 through the reference's own pins (tests/unit/train/test_perf.py:8-35): Qwen3-0.6B has 595 984 384
+    active matmul parameters and 3 928 227 840 FLOP/token at seq_len 1024 (attention term uses hidden // heads = 64, not head_dim);
+    Qwen3-8B gives the 49.03 GFLOP/token of SURVEY.md section 8d."""
+    from prime_rl_amd.trainer.engine import ModelDims
+
+    small = ModelDims.qwen3_0_6b()
+    assert small.active_mm_params() == 595_984_384
+    assert small.flops_per_token(1024) == 3_928_227_840
+    big = ModelDims.qwen3_8b()
+    assert big.flops_per_token(2048) == 6 * big.active_mm_params() + 12 * 36 * 32 * 128 * 2048
+    assert abs(big.flops_per_token(2048) / 1e9 - 49.03) < 0.01
+
+
 def test_rae_scores_before_updating_baseline():
     from prime_rl_amd.orchestrator.algo import RAEAlgoConfig, build_algorithm
     from prime_rl_amd.orchestrator.algo.base import SimpleAgent, SimpleEpisode, SimpleNode, SimpleTrace
