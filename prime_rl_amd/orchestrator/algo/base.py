@@ -26,6 +26,37 @@ class SimpleAgent:
 
 
 @dataclass
+class SimpleBranch:
+    """A linear path through the trace graph as one flat token sequence — the slice of `verifiers.v1.Branch` that
+    `trace_to_samples` reads (orchestrator/trajectories.py:111-160): `advantages` expands the nodes' compact sampled-token credit to
+    one value per token, 0.0 where the mask is False."""
+
+    nodes: list[SimpleNode]
+    logprobs: list[float] | None = None
+    reference_logprobs: list[float] | None = None
+    multi_modal_data: object | None = None
+    routed_experts: object | None = None
+
+    @property
+    def token_ids(self) -> list[int]:
+        return [t for n in self.nodes for t in n.token_ids]
+
+    @property
+    def sampled_mask(self) -> list[bool]:
+        return [m for n in self.nodes for m in n.mask]
+
+    @property
+    def advantages(self) -> list[float] | None:
+        if all(n.advantages is None for n in self.nodes):
+            return None
+        out: list[float] = []
+        for n in self.nodes:
+            compact = iter(n.advantages or [])
+            out += [next(compact, 0.0) if m else 0.0 for m in n.mask]
+        return out
+
+
+@dataclass
 class SimpleTrace:
     id: str
     reward: float
@@ -35,6 +66,11 @@ class SimpleTrace:
     num_output_tokens: int = 0
     num_total_tokens: int = 0
     num_turns: int = 1
+
+    @property
+    def branches(self) -> list[SimpleBranch]:
+        """A trace without forks is one branch over all of its nodes."""
+        return [SimpleBranch(self.nodes, logprobs=[0.0] * sum(len(n.token_ids) for n in self.nodes))]
 
 
 @dataclass

@@ -25,6 +25,27 @@ def test_shared_node_trains_once_and_streams_flatten():
     assert s[1].ce_weights is None and s[1].env_name == "env" and s[1].token_ids == [1, 2, 3, 4, 6, 7]
 
 
+def test_scalar_credit_reaches_the_training_sample_like_the_reference():
+    """The reference's known answers (tests/unit/orchestrator/test_advantage.py:248-270): a scalar broadcasts over the mask-True tokens,
+    mask-False positions stay 0.0 in the sample's per-token advantages, a list of the wrong length is rejected."""
+    import pytest
+
+    from prime_rl_amd.orchestrator.algo.base import SimpleNode, SimpleTrace
+    from prime_rl_amd.orchestrator.algo.routing import assign_advantages
+
+    # one masked prompt token + 2 sampled tokens
+    trace = SimpleTrace("t", 0.0, [SimpleNode([11], [False], sampled=False), SimpleNode([12, 13], [True, True])])
+    assign_advantages(trace, 0.7)
+    assert trace_to_samples(trace)[0].advantages == [0.0, 0.7, 0.7]
+    # prompt (masked) + 1 sampled + 1 observation token (masked) inside the sampled node's turn: mask [F, T, F]
+    trace = SimpleTrace("t", 0.0, [SimpleNode([11], [False], sampled=False), SimpleNode([12, 13], [True, False])])
+    assign_advantages(trace, 0.7)
+    s = trace_to_samples(trace)[0]
+    assert s.advantages == [0.0, 0.7, 0.0] and s.mask == [False, True, False] and s.token_ids == [11, 12, 13]
+    with pytest.raises(ValueError, match="align"):
+        assign_advantages(SimpleTrace("t", 0.0, [SimpleNode([11], [False], sampled=False), SimpleNode([12, 13], [True, True])]), [0.5])
+
+
 def test_prune_zero_advantages():
     s = TrainingSample(token_ids=[1, 2, 3], mask=[False, True, True], logprobs=[0.0] * 3, temperatures=[1.0] * 3, env_name="e", advantages=[0.0, 0.0, 0.5])
     assert prune_zero_advantages(s) and s.rl_weights == [0.0, 0.0, 1.0]
