@@ -254,6 +254,45 @@ def test_grpo_algorithm_plugin():
     assert abs(sum(b)) < 1e-6 and b[0] > 0 > b[1]
 
 
+def test_length_penalty_terms_like_the_reference():
+    """The remaining properties of tests/unit/orchestrator/test_advantage.py:184-240 on pm_grpo_advantage: MaxRL all-success groups
+    center to zero; equal lengths/turns reduce the linear penalty to plain GRPO; the context term penalises non-completion tokens
+    (total - output), the turns term higher turn counts; advantages stay zero-mean."""
+    import asyncio
+
+    from prime_rl_amd.orchestrator.algo import ALGORITHM_CLASSES, GRPOAlgoConfig, LengthPenaltyConfig, build_algorithm
+    from prime_rl_amd.orchestrator.algo.base import SimpleEpisode, SimpleNode, SimpleTrace
+
+    def group(rewards, out, total=None, turns=None):
+        eps = []
+        for i, r in enumerate(rewards):
+            t = SimpleTrace(f"t{i}", r, [SimpleNode([1, 2, 3], [False, True, True])], num_output_tokens=out[i],
+                            num_total_tokens=(total[i] if total else out[i] + 2), num_turns=(turns[i] if turns else 1))
+            eps.append(SimpleEpisode([t]))
+        return eps
+
+    def run(algo, eps):
+        asyncio.run(algo.finalize_group(eps))
+        return [e.traces[0].nodes[0].advantages[0] for e in eps]
+
+    assert run(ALGORITHM_CLASSES["max_rl"](), group([1.0, 1.0], [5, 5])) == pytest.approx([0.0, 0.0])
+    plain = run(build_algorithm(GRPOAlgoConfig()), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
+    shaped = run(build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig())), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
+    assert shaped == pytest.approx(plain, abs=1e-6)
+    ctx = LengthPenaltyConfig(num_output_tokens_weight=0.0, num_input_tokens_weight=0.25, num_turns_weight=0.0)
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=ctx)), group([1.0, 1.0], [10, 10], total=[12, 112]))
+    assert a[0] > a[1] and abs(sum(a)) < 1e-6
+    trn = LengthPenaltyConfig(num_output_tokens_weight=0.0, num_input_tokens_weight=0.0, num_turns_weight=0.25)
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=trn)), group([1.0, 1.0], [100, 100], turns=[1, 4]))
+    assert a[0] > a[1] and abs(sum(a)) < 1e-6
+    # exact value of the completion-only penalty: shaped_i = r_i - mean * w * out_i / max(out); advantages = shaped - mean(shaped)
+    cmp_ = LengthPenaltyConfig(num_output_tokens_weight=0.25, num_input_tokens_weight=0.0, num_turns_weight=0.0)
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=cmp_)), group([1.0, 1.0, 1.0], [10, 20, 30]))
+    shaped_ref = [1.0 - 0.25 * x / 30 for x in (10, 20, 30)]
+    mean_ref = sum(shaped_ref) / 3
+    assert a == pytest.approx([s - mean_ref for s in shaped_ref], abs=1e-6)
+
+
 def test_hierarchical_grpo_peer_sets():
     """hierarchical_grpo.py:33-42: solver traces are centered per episode, proposer traces across the cohort, singletons get zero —
     all peer sets in one pm_grpo_advantage launch; checked against the plain restatement."""
