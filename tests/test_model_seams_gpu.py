@@ -105,3 +105,48 @@ def test_autograd_model_equals_engine():
         a, b = p.grad.float().flatten(), g.float().flatten()
         rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
         assert rel < 3e-2, f"{name}: relative gradient difference {rel:.4f}"
+
+
+def test_inject_prime_lm_head_into_a_stock_hf_model():
+    """The LM-head seam exactly as the reference uses it (lm_head.py:205-291; tests/unit/train/rl/test_fused_lm_head.py:302-457): a
+    stock `transformers` Llama (built from a config, no download) gets `inject_prime_lm_head`; the vanilla flavour returns logits, the
+    fused flavour returns log-probs + entropy through the HIP kernels, the weight Parameter is shared with the old head, and the two
+    agree at the reference's bf16 bound (rtol 1e-3 / atol 1e-4 on the post-processed log-probs and entropy)."""
+    from transformers import AutoModelForCausalLM, LlamaConfig
+
+    from prime_rl_amd.trainer.models.layers.lm_head import FusedOutputLinear, VanillaOutputLinear, cast_float_and_contiguous, inject_prime_lm_head
+    from prime_rl_amd.trainer.rl.loss import compute_entropy, selective_log_softmax
+
+    torch.manual_seed(123)
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=256, max_position_embeddings=512, num_attention_heads=4, num_key_value_heads=2,
+                      num_hidden_layers=2, vocab_size=1000, rms_norm_eps=1e-5, rope_theta=10000.0, attention_bias=False, mlp_bias=False)
+    b, s = 2, 64
+    ids = torch.randint(0, cfg.vocab_size, (b, s), device=DEV)
+    pos = torch.arange(s, device=DEV).unsqueeze(0).expand(b, -1)
+    labels = torch.randint(0, cfg.vocab_size, (b, s), device=DEV)
+    temperature = torch.full((b, s), 1.5, dtype=torch.float32, device=DEV)
+
+    vanilla = AutoModelForCausalLM.from_config(cfg).to(DEV).to(torch.bfloat16)
+    fused = AutoModelForCausalLM.from_config(cfg).to(DEV).to(torch.bfloat16)
+    fused.load_state_dict(vanilla.state_dict())
+    old_weight = fused.lm_head.weight
+    inject_prime_lm_head(vanilla, chunk_size=None)
+    inject_prime_lm_head(fused, chunk_size=512)
+    assert isinstance(vanilla.lm_head, VanillaOutputLinear) and isinstance(fused.lm_head, FusedOutputLinear)
+    assert fused.lm_head.weight is old_weight  # shared Parameter, not a copy
+
+    out_v = vanilla(input_ids=ids, position_ids=pos, labels=labels, temperature=temperature)
+    assert isinstance(out_v, dict) and out_v.get("logits") is not None and out_v.get("logprobs") is None
+    assert out_v["logits"].shape == (b, s, cfg.vocab_size)
+    out_f = fused(input_ids=ids, position_ids=pos, labels=labels, temperature=temperature)
+    assert isinstance(out_f, dict) and out_f.get("logits") is None
+    assert out_f["logprobs"].shape == (b, s) and out_f["entropy"].shape == (b, s)
+
+    logits = cast_float_and_contiguous(out_v)["logits"] / temperature.unsqueeze(-1)
+    out_f = cast_float_and_contiguous(out_f)
+    torch.testing.assert_close(out_f["logprobs"], selective_log_softmax(logits, labels), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out_f["entropy"], compute_entropy(logits), rtol=1e-3, atol=1e-4)
+    # gradients reach the backbone through the fused head
+    out_f["logprobs"].sum().backward()
+    g = fused.model.layers[0].mlp.down_proj.weight.grad
+    assert g is not None and bool(torch.isfinite(g.float()).all()) and float(g.float().abs().sum()) > 0
