@@ -1,4 +1,5 @@
-"""CPU suite: the C-ABI library builds, loads, and exports exactly the symbols include/prime_mi355x.h declares."""
+"""CPU suite: the C-ABI library builds, loads, and exports exactly the symbols include/prime_mi355x.h declares; INTEGRATION.md
+names the reference interface behind every one of them."""
 
 import ctypes
 import re
@@ -32,6 +33,19 @@ def test_library_exports_every_declared_symbol(lib):
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in _declared_symbols():
         assert hasattr(raw, name), f"{name} is declared in the header but not exported"
+
+
+def test_integration_doc_covers_every_entry_point():
+    """INTEGRATION.md's table (symbol -> reference interface) may use `pm_x_{a,b}` and `pm_x_fwd`, `pm_x_bwd` shorthand; after
+    expanding the braces every declared symbol must be named, and the header must cite a reference file:line for each block."""
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    named = set(re.findall(r"pm_[a-z0-9_]+", doc))
+    for stem, alts in re.findall(r"(pm_[a-z0-9_]*)\{([a-z0-9_,]+)\}", doc):
+        named |= {stem + a for a in alts.split(",")}
+    missing = _declared_symbols() - named
+    assert not missing, f"INTEGRATION.md does not mention: {sorted(missing)}"
+    header = (ROOT / "include" / "prime_mi355x.h").read_text()
+    assert len(re.findall(r"\.py:\d+", header)) >= 20, "the header is expected to cite reference file:line for its entry points"
 
 
 def test_abi_version_and_error_plumbing(lib):
