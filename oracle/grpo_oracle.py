@@ -319,7 +319,7 @@ def rmsnorm(x, weight, eps: float):
 def rope_cos_sin(position_ids, head_dim: int, theta: float, dtype):
     """RotaryEmbedding.forward (trainer/models/layers/rotary_emb.py:60-73) with _compute_default_rope_parameters (:24)."""
     torch = _torch()
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))
+    inv_freq = (1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))).to(position_ids.device)
     freqs = position_ids.to(torch.float32)[:, None] * inv_freq[None, :]
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -342,14 +342,14 @@ def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float):
     n, hq, d = q.shape
     hkv = k.shape[1]
     g = hq // hkv
-    out = torch.zeros((n, hq, d), dtype=torch.float32)
+    out = torch.zeros((n, hq, d), dtype=torch.float32, device=q.device)
     off = 0
     for ln in seq_lens:
         qs = q[off:off + ln].to(torch.float32)
         ks = k[off:off + ln].to(torch.float32).repeat_interleave(g, dim=1)
         vs = v[off:off + ln].to(torch.float32).repeat_interleave(g, dim=1)
         s = torch.einsum("ihd,jhd->hij", qs, ks) * scale
-        causal = torch.ones(ln, ln, dtype=torch.bool).tril()
+        causal = torch.ones(ln, ln, dtype=torch.bool, device=q.device).tril()
         s = s.masked_fill(~causal, float("-inf"))
         p = torch.softmax(s, dim=-1)
         out[off:off + ln] = torch.einsum("hij,jhd->ihd", p, vs)
@@ -376,11 +376,21 @@ class TinyQwen3Config:
     rope_theta: float = 1_000_000.0
 
 
-def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int]):
+def exact_mm(a, w):
+    """a @ w.T with exact products and f32 accumulation, rounded ONCE to a's dtype: the GEMM every bf16 implementation of the
+    reference approximates (cuBLAS / hipBLASLt / CPU differ only in accumulation order).  Used as the `mm` hook of qwen3_forward to
+    take GEMM summation order out of an engine-vs-oracle comparison while keeping the reference's bf16 rounding points."""
+    torch = _torch()
+    return (a.to(torch.float32) @ w.to(torch.float32).T).to(a.dtype)
+
+
+def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int], mm=None):
     """Qwen3Model.forward + Qwen3DecoderLayer.forward (trainer/models/qwen3/modeling_qwen3.py:65-85,155-196) with
     FlashAttention.attn_projections (trainer/models/layers/attn.py:123-160).  `params` uses HF names
-    (model.layers.{i}.self_attn.q_proj.weight, ...); returns the final-norm hidden states [N, H] in the params' dtype."""
+    (model.layers.{i}.self_attn.q_proj.weight, ...); returns the final-norm hidden states [N, H] in the params' dtype.
+    Runs on whatever device the tensors live on; `mm(a, w) -> a @ w.T` overrides the linear layers' GEMM (default: torch's)."""
     torch = _torch()
+    mm = mm or (lambda a, w: a @ w.T)
     hq, hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     x = params["model.embed_tokens.weight"][input_ids]
     cos, sin = rope_cos_sin(position_ids, d, cfg.rope_theta, x.dtype)
@@ -389,18 +399,18 @@ def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int
         pre = f"model.layers.{i}."
         res = x
         h = rmsnorm(x, params[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
-        q = (h @ params[pre + "self_attn.q_proj.weight"].T).view(n, hq, d)
-        k = (h @ params[pre + "self_attn.k_proj.weight"].T).view(n, hkv, d)
-        v = (h @ params[pre + "self_attn.v_proj.weight"].T).view(n, hkv, d)
+        q = mm(h, params[pre + "self_attn.q_proj.weight"]).view(n, hq, d)
+        k = mm(h, params[pre + "self_attn.k_proj.weight"]).view(n, hkv, d)
+        v = mm(h, params[pre + "self_attn.v_proj.weight"]).view(n, hkv, d)
         q = rmsnorm(q, params[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
         k = rmsnorm(k, params[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
         a = varlen_causal_attention(q, k, v, seq_lens, d**-0.5).to(x.dtype).reshape(n, hq * d)
-        x = res + a @ params[pre + "self_attn.o_proj.weight"].T
+        x = res + mm(a, params[pre + "self_attn.o_proj.weight"])
         res = x
         h = rmsnorm(x, params[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-        act = swiglu(h @ params[pre + "mlp.gate_proj.weight"].T, h @ params[pre + "mlp.up_proj.weight"].T)
-        x = res + act @ params[pre + "mlp.down_proj.weight"].T
+        act = swiglu(mm(h, params[pre + "mlp.gate_proj.weight"]), mm(h, params[pre + "mlp.up_proj.weight"]))
+        x = res + mm(act, params[pre + "mlp.down_proj.weight"])
     return rmsnorm(x, params["model.norm.weight"], cfg.rms_norm_eps)
 
 

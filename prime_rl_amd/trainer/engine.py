@@ -132,6 +132,9 @@ class PackedBatch:
     ce_weights: Tensor | None = None
     ref_kl_weights: Tensor | None = None
     local_counts: tuple[int, int, int] = (0, 0, 0)  # rl / ce / ref_kl member tokens on this rank (train.py:307-317)
+    # bool [samples] | None: samples of micro-batches that shipped NO rl stream while another micro-batch of the pass did — the
+    # reference runs the rl loss fn (and logs its metrics) for every sample of such a micro-batch (loss.py:367-371)
+    rl_every_sample: Tensor | None = None
 
     @property
     def n_tokens(self) -> int:
@@ -171,11 +174,12 @@ def pack_micro_batches(micro_batches: list[dict], device: torch.device | str) ->
     n_ce = int((ce_w != 0).sum()) if ce_w is not None else 0
     n_rk = int((rk_w != 0).sum()) if rk_w is not None else 0
     seq_lens = torch.cat([mb["seq_lens"].reshape(-1).to(torch.int64) for mb in micro_batches])
-    sample_lens, starts = [], []
+    sample_lens, starts, every = [], [], []
     for mb in micro_batches:
         sl = list(mb["sequence_lengths"])
         sample_lens += sl
         starts += [1] + [0] * (len(sl) - 1)
+        every += [mb.get("rl_weights") is None] * len(sl)
     cu_seq = torch.zeros(seq_lens.numel() + 1, dtype=torch.int32)
     cu_seq[1:] = seq_lens.cumsum(0)
     cu_smp = torch.zeros(len(sample_lens) + 1, dtype=torch.int32)
@@ -191,7 +195,7 @@ def pack_micro_batches(micro_batches: list[dict], device: torch.device | str) ->
         advantages=dev(cat("advantages", torch.float32)), inference_logprobs=dev(cat("inference_logprobs", torch.float32)), loss_mask=dev(mask),
         cu_seqlens=dev(cu_seq), cu_samples=dev(cu_smp), sample_starts_mb=dev(torch.tensor(starts, dtype=torch.uint8)),
         n_micro_batches=len(micro_batches), ref_logprobs=dev(ref), rl_weights=dev(rl_w), ce_weights=dev(ce_w), ref_kl_weights=dev(rk_w),
-        local_counts=(n_rl, n_ce, n_rk),
+        local_counts=(n_rl, n_ce, n_rk), rl_every_sample=dev(torch.tensor(every, dtype=torch.bool)) if (rl_w is not None and any(every)) else None,
     )
 
 
@@ -354,8 +358,14 @@ class GRPOEngine:
 
     def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
-                 force_collectives: bool = False, gemm_layouts: bool = True):
+                 force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16"):
         self.dims, self.device = dims, torch.device(device)
+        if gemm_dtype not in ("bf16", "f32"):
+            raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
+        # "f32" = the parity-measurement mode (tests/test_engine_gpu.py): every library GEMM runs on f32 copies of its operands
+        # (exact products, f32 accumulation, no bf16 rounding inside the GEMM) and the LM head hands f32 logits to K1, so that what is
+        # left between the engine and an f32 reference is the hand-written kernels alone.  Same kernels, same schedule, same buffers.
+        self.gemm_f32 = gemm_dtype == "f32"
         self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
         self.dp_group = dp_group
         self.dp_size = dist.get_world_size(dp_group) if (dp_group is not None or dist.is_initialized()) else 1
@@ -376,7 +386,7 @@ class GRPOEngine:
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._wgrad_direct = self._probe_wgrad_direct()
         # keep GEMM-friendly operand layouts (K-contiguous weight copies for dgrad, transposed MLP inputs for wgrad); PM_GEMM_LAYOUTS=0 is the A/B switch
-        self.gemm_layouts = gemm_layouts and os.environ.get("PM_GEMM_LAYOUTS", "1") != "0"
+        self.gemm_layouts = gemm_layouts and os.environ.get("PM_GEMM_LAYOUTS", "1") != "0" and not self.gemm_f32
         self._wt: dict[str, Tensor] = {}
         self._wt_version: dict[int, int] = {}
         if self.gemm_layouts:  # allocated up front (one slab) so the caching allocator sees the same request stream from the first step on
@@ -406,12 +416,26 @@ class GRPOEngine:
         except Exception:
             return False
 
+    def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False) -> Tensor:
+        """y[n,out] = x[n,in] @ w[out,in]^T — the forward projection GEMM (library call)."""
+        if self.gemm_f32:
+            y = torch.mm(x.float(), w.float().t())
+            return y if out_f32 else y.to(torch.bfloat16)
+        return torch.mm(x, w.t(), out_dtype=torch.float32) if out_f32 else torch.mm(x, w.t())
+
     def _wgrad(self, dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool, k_contiguous_x: bool = False) -> None:
         """gview[out,in] (+)= dy[n,out]^T @ x[n,in] with f32 accumulation.
 
         `k_contiguous_x`: first re-lay x as [in, n] (pm_transpose_2d) so the library GEMM reads it along the reduction dimension —
         measured on MI355X (tools/microbench.py gemm) 15 % faster for the two MLP weight gradients, more than the transpose costs;
         for the attention projections it is a wash, so those keep the plain form."""
+        if self.gemm_f32:
+            prod = torch.mm(dy.float().t(), x.float())
+            if accumulate:
+                gview.add_(prod)
+            else:
+                gview.copy_(prod)
+            return
         if self._wgrad_direct:
             xop = ops.transpose_2d(x).t() if (k_contiguous_x and self.gemm_layouts) else x
             if accumulate:
@@ -431,6 +455,8 @@ class GRPOEngine:
         [in,out] (tools/microbench.py gemm), while the forward wants [out,in]: with 288 GB of HBM both layouts are kept, the [in,out]
         copy of a layer being refreshed (4 x pm_transpose_2d, ~0.2 ms) the first time its backward runs after a parameter update."""
         name = f"model.layers.{layer}.{suffix}"
+        if self.gemm_f32:
+            return torch.mm(dy.float(), self.store.w[name].float()).to(torch.bfloat16)
         if not self.gemm_layouts:
             return torch.mm(dy, self.store.w[name])
         if self._wt_version.get(layer) != self.store.version:
@@ -459,16 +485,16 @@ class GRPOEngine:
                 h1, rstd1, _ = ops.rmsnorm_fwd(x, w[p + "input_layernorm.weight"], d.rms_norm_eps)
             else:
                 h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
-            qkv = torch.mm(h1, w[p + "self_attn.qkv_proj.weight"].t())
+            qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"])
             q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], cos, sin,
                                                  d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.rms_norm_eps)
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
             o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
-            attn_out = torch.mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"].t())
+            attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
             h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
-            gu = torch.mm(h2, w[p + "mlp.gate_up_proj.weight"].t())
+            gu = self._fwd_mm(h2, w[p + "mlp.gate_up_proj.weight"])
             act = ops.swiglu_fwd(gu)
-            pending = torch.mm(act, w[p + "mlp.down_proj.weight"].t())
+            pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
             ctx["layers"].append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2,
                                       gu=gu, act=None if self.recompute_act else act))
             x = x2
@@ -483,7 +509,7 @@ class GRPOEngine:
         chunks = []
         for s in range(0, n, self.lm_head_token_chunk):
             e = min(s + self.lm_head_token_chunk, n)
-            logits = torch.mm(hf[s:e], wh.t())
+            logits = self._fwd_mm(hf[s:e], wh, out_f32=self.gemm_f32)
             if self.k1_events is not None:  # HIP events on the launch stream around the log-prob kernel (bench.py roofline)
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -525,7 +551,9 @@ class GRPOEngine:
             self._wt_version["head"] = self.store.version
         for s, e, logits in ctx["logits_chunks"]:
             dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
-            if head_t:
+            if self.gemm_f32:
+                dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
+            elif head_t:
                 torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
             else:
                 torch.mm(dl, wh, out=dhf[s:e])

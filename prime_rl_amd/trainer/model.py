@@ -1,0 +1,175 @@
+"""Engine-API seams of the reference's `prime_rl.trainer.model` kept verbatim (SURVEY.md §8(b) "Engine API kept verbatim"):
+
+    setup_model(config: ModelConfig, parallel_dims: ParallelDims, loading_from_checkpoint_later=False) -> nn.Module   model.py:1314-1428
+    forward(model, input_ids, position_ids, *, seq_lens, labels, temperature, ...) -> PrimeLmOutput                  model.py:1431-1482
+    get_model(config, device, dtype) -> nn.Module                                                                    model.py:715-800
+
+plus `setup_engine(config: TrainerConfig, parallel_dims) -> GRPOEngine`, the flat-buffer product engine `train()` drives.
+
+`setup_model` returns the torch.autograd flavour of the MI355X path: the `Qwen3ForCausalLM` mirror whose layers call the HIP
+kernels through the C ABI (trainer/models/), with `inject_prime_lm_head(model, chunk_size)` applied exactly where the reference
+applies it (model.py:1348-1352).  What the reference does between those lines and that has no MI355X counterpart is deliberately
+absent and says so: activation checkpointing / offloading, torch.compile, FSDP2 wrapping and CPU offload exist to fit 80 GB parts
+ — on 288 GB the sharding lives in GRPOEngine (ZeRO-2 over RCCL, trainer/zero.py), not in module wrappers.
+Weights: offline there is no HF hub; `config.name` may be a LOCAL directory holding `config.json` (+ `*.safetensors`), a known model
+name with `config.debug.random_init = true`, or `loading_from_checkpoint_later = True` (weights arrive through load_state_dict)."""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import torch
+from torch import Tensor, nn
+
+from .engine import GRPOEngine, LossConfig, ModelDims, OptimConfig
+from .models.layers.lm_head import PrimeLmOutput, cast_float_and_contiguous, inject_prime_lm_head
+from .models.qwen3.modeling_qwen3 import Qwen3Config, Qwen3ForCausalLM
+from .parallel_dims import ParallelDims
+
+DTYPE_MAP = {"bfloat16": torch.bfloat16, "float32": torch.float32}
+
+# public HF configs of the dense families the reference registers as custom PrimeRL models (trainer/models/__init__.py:41-59)
+KNOWN_MODELS: dict[str, dict] = {
+    "qwen3-8b": dict(vocab_size=151936, hidden_size=4096, intermediate_size=12288, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8),
+    "qwen3-4b": dict(vocab_size=151936, hidden_size=2560, intermediate_size=9728, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
+                     tie_word_embeddings=True),
+    "qwen3-1.7b": dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8,
+                       tie_word_embeddings=True),
+    "qwen3-0.6b": dict(vocab_size=151936, hidden_size=1024, intermediate_size=3072, num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8,
+                       tie_word_embeddings=True),
+    "tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2),
+}
+
+
+def resolve_model_dims(config) -> ModelDims:
+    """ModelConfig -> ModelDims: `name` is a local HF directory (config.json) or a known dense Qwen3 name ("Qwen/Qwen3-8B",
+    "PrimeIntellect/Qwen3-0.6B", "qwen3-8b", ...); `debug.num_layers` truncates the stack (configs/trainer.py:131-136)."""
+    name = config.name
+    p = Path(name)
+    if (p / "config.json").exists():
+        hf = json.loads((p / "config.json").read_text())
+        if hf.get("model_type") not in ("qwen3", "llama"):
+            raise NotImplementedError(f"model_type {hf.get('model_type')!r}: the MI355X scoring forward is built for dense Qwen3 (q/k-norm) models")
+        fields = dict(vocab_size=hf["vocab_size"], hidden_size=hf["hidden_size"], intermediate_size=hf["intermediate_size"],
+                      num_hidden_layers=hf["num_hidden_layers"], num_attention_heads=hf["num_attention_heads"],
+                      num_key_value_heads=hf.get("num_key_value_heads", hf["num_attention_heads"]),
+                      head_dim=hf.get("head_dim", hf["hidden_size"] // hf["num_attention_heads"]), rms_norm_eps=hf.get("rms_norm_eps", 1e-6),
+                      rope_theta=hf.get("rope_theta", (hf.get("rope_parameters") or {}).get("rope_theta", 1_000_000.0)),
+                      tie_word_embeddings=hf.get("tie_word_embeddings", False))
+        label = p.name
+    else:
+        key = name.split("/")[-1].lower()
+        if key not in KNOWN_MODELS:
+            raise ValueError(f"model.name = {name!r}: not a local HF directory and not one of {sorted(KNOWN_MODELS)} (no hub access here)")
+        fields, label = dict(KNOWN_MODELS[key]), name.split("/")[-1]
+    if config.debug.num_layers is not None:
+        fields["num_hidden_layers"] = min(config.debug.num_layers, fields["num_hidden_layers"])
+    return ModelDims(name=label, **fields)
+
+
+def _local_safetensors(name: str) -> dict[str, Tensor] | None:
+    p = Path(name)
+    files = sorted(p.glob("*.safetensors")) if p.is_dir() else []
+    if not files:
+        return None
+    from safetensors.torch import load_file
+
+    sd: dict[str, Tensor] = {}
+    for f in files:
+        sd.update(load_file(str(f)))
+    return sd
+
+
+def resolve_auto_attn(config) -> None:
+    """model.py:1294-1311 picks a flash-attention generation from the CUDA capability; on gfx950 there is one implementation."""
+    if config.attn in ("auto", "flash_attention_2", "flash_attention_3", "flash_attention_4"):
+        config.attn = "hip_varlen"
+
+
+def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16) -> nn.Module:
+    """The custom PrimeRL class for the config's family (model.py:715-800, `impl` "custom"/"auto"); HF-impl models are out of scope."""
+    if config.impl == "hf":
+        raise NotImplementedError("model.impl = 'hf' (transformers modelling code + flash-attn) is outside the MI355X path; use 'custom' or 'auto'")
+    d = resolve_model_dims(config)
+    hf_cfg = Qwen3Config(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size, num_hidden_layers=d.num_hidden_layers,
+                         num_attention_heads=d.num_attention_heads, num_key_value_heads=d.num_key_value_heads, head_dim=d.head_dim,
+                         rms_norm_eps=d.rms_norm_eps, rope_theta=d.rope_theta, tie_word_embeddings=d.tie_word_embeddings)
+    with torch.device(device):
+        model = Qwen3ForCausalLM(hf_cfg)
+    return model.to(dtype)
+
+
+def setup_model(config, parallel_dims: ParallelDims, loading_from_checkpoint_later: bool = False) -> nn.Module:
+    """model.py:1314-1428 for the dense data-parallel path.  Compute dtype is bf16 (the reference's FSDP MixedPrecisionPolicy param
+    dtype, model.py:823-960); `optimization_dtype` (f32 master weights) is the engine's / optimizer's business, not the module's."""
+    resolve_auto_attn(config)
+    if parallel_dims.ep_enabled:
+        raise NotImplementedError("expert parallelism: SURVEY.md §8 f4")
+    for name in ("lora", "quantization", "vlm"):
+        if getattr(config, name, None) is not None:
+            raise NotImplementedError(f"model.{name} is outside the MI355X GRPO hot path (SURVEY.md section 2)")
+    model = get_model(config, device="cuda", dtype=torch.bfloat16)
+    chunk = config.fused_lm_head_token_chunk_size if isinstance(config.fused_lm_head_token_chunk_size, int) else None
+    inject_prime_lm_head(model, chunk_size=chunk)
+    if loading_from_checkpoint_later:
+        return model
+    sd = _local_safetensors(config.name)
+    if sd is not None:
+        if model.config.tie_word_embeddings:
+            sd.pop("lm_head.weight", None)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        missing = [k for k in missing if not (model.config.tie_word_embeddings and k == "lm_head.weight")]
+        if missing or unexpected:
+            raise KeyError(f"checkpoint / model mismatch: missing {missing[:4]}, unexpected {list(unexpected)[:4]}")
+    elif config.debug.random_init:
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 1:
+                    p.fill_(1.0)
+                else:
+                    p.copy_((torch.randn(p.shape, device="cuda", generator=gen) * 0.02).to(p.dtype))
+    else:
+        raise FileNotFoundError(f"no weights for {config.name!r}: point model.name at a local HF directory with *.safetensors, or set "
+                                "model.debug.random_init = true (there is no hub access in this environment)")
+    return model
+
+
+def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, *, seq_lens: Tensor, labels: Tensor | None = None,
+            temperature: Tensor | None = None, routed_experts: Tensor | None = None, mm_kwargs: dict | None = None,
+            mm_token_type_ids: Tensor | None = None, seq_lens_are_pre_shard: bool = False) -> PrimeLmOutput:
+    """model.py:1431-1482: build the kwargs, run the backbone + head, return float / contiguous outputs."""
+    if mm_kwargs or mm_token_type_ids is not None or routed_experts is not None:
+        raise NotImplementedError("multimodal / router-replay inputs are outside the dense GRPO path (SURVEY.md section 2 rows 12, 21)")
+    out = model(input_ids=input_ids, position_ids=position_ids, labels=labels, temperature=temperature, seq_lens=seq_lens,
+                seq_lens_are_pre_shard=seq_lens_are_pre_shard)
+    if isinstance(out, dict):
+        return cast_float_and_contiguous(out)
+    return cast_float_and_contiguous(PrimeLmOutput(logits=out.logits))
+
+
+def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str = "cuda") -> GRPOEngine:
+    """TrainerConfig -> the flat-buffer GRPO engine: ZeRO-2 over the `dp` group, (Ulysses over the `cp` group when cp > 1), fused AdamW
+    with the config's optimizer fields, the config's loss.  Weights as in `setup_model`."""
+    config.validate_supported()
+    m = config.model
+    resolve_auto_attn(m)
+    dims = resolve_model_dims(m)
+    o = config.optim
+    optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
+    lc = config.loss
+    if lc.type == "custom":
+        raise NotImplementedError("custom loss plugins run through prime_rl_amd.trainer.rl.loss.compute_loss (the per-sample LossFn contract) on the "
+                                  "autograd model from setup_model(); the flat-buffer engine fuses the built-in default / ipo losses")
+    loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
+                      kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
+    engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
+                        dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp)
+    sd = _local_safetensors(m.name)
+    if sd is not None:
+        engine.store.load_state_dict({k: v.to(device) for k, v in sd.items()})
+    elif not m.debug.random_init:
+        raise FileNotFoundError(f"no weights for {m.name!r}: point model.name at a local HF directory with *.safetensors, or set "
+                                "model.debug.random_init = true (there is no hub access in this environment)")
+    return engine

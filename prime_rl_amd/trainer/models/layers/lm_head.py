@@ -134,6 +134,13 @@ def inject_prime_lm_head(model: nn.Module, chunk_size: int | None = None) -> Non
     assert hasattr(model, "lm_head"), f"model doesnt have lm_head in model.lm_head:\n{model}"
     assert isinstance(model.lm_head, nn.Linear), f"model.lm_head is not a nn.Linear: {type(model.lm_head)}\n{model}"
     assert not hasattr(model.lm_head, "bias") or model.lm_head.bias is None, f"model.lm_head.bias is not supported: {model.lm_head}\n{model}"
+    # The reference dispatches Gemma-style models (final_logit_softcapping) to inject_gemma_lm_head (lm_head.py:214-222): that head is
+    # outside this path, and the plain fused head would silently produce wrong log-probs / entropy for them — refuse loudly.
+    cfg = getattr(model, "config", None)
+    for c in (cfg, getattr(cfg, "text_config", None)):
+        if c is not None and getattr(c, "final_logit_softcapping", None):
+            raise NotImplementedError("models with final_logit_softcapping (Gemma) need the soft-capping LM head, which is outside the MI355X "
+                                      "GRPO hot path (SURVEY.md section 2 row 12)")
     old = model.lm_head
     if isinstance(chunk_size, int):
         model.lm_head = FusedOutputLinear(in_features=old.in_features, out_features=old.out_features, chunk_size=chunk_size)

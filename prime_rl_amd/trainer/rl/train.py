@@ -5,7 +5,8 @@ Same step and version indexing as the reference: at star
 (train.py:271-277); step `n` consumes batch `n`, produces `pi_n` and broadcasts it as `broadcasts/step_n` (train.py:575-594).
 Same observable surface (section 9.5): console line `Step N | Time | Loss | Entropy | Mismatch KL | Grad. Norm | LR |
 Throughput | MFU | Peak Mem.` and metric keys `perf/*`, `optim/*`, `time/*`, `{loss, entropy/all, mismatch_kl/all,
-masked_mismatch_kl, ...}/{mean,median,std,min,max}`.  Step statistics are reduced ON the GPU and fetched with one D2H copy per
+masked_mismatch_kl, ...}/{mean,median,std,min,max}` with the reference's `Tensors.compute_stats` semantics (trainer/utils.py:238-281:
+all-rank gather, unbiased std, NaN for empty keys).  Step statistics are reduced ON the GPU and fetched with one D2H copy per
 step (the reference moves per-token vectors to the host and groups them in Python, train.py:483-539: next-row f3).
 
 Launch: `python -m prime_rl_amd.trainer.rl.train` (1 GPU) or `torchrun --nproc-per-node N -m prime_rl_amd.trainer.rl.train`.
@@ -27,6 +28,7 @@ import torch.distributed as dist
 from ... import _lib
 from ...transports.weights import setup_weight_broadcast
 from ..engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
+from ..stats import STAT_SUFFIXES, Tensors, collect_step_tensors
 from .data import DataLoader, FakeDataLoader, FakeDataLoaderConfig
 
 PEAK_BF16_FLOPS = 2.5e15  # MI355X dense bf16 MFMA (the reference's table stops at MI325X and would fall back to A100, perf.py:99-109)
@@ -50,14 +52,6 @@ class TrainerConfig:
     tokens_per_pass: int = 16384
     seed: int = 0
     rollout_format: str = "msgpack"  # "msgpack" = the reference wire; "binary" = raw-array step blobs + pinned read-ahead (transports/rollouts/binary.py)
-
-
-def _stats(name: str, x: torch.Tensor, out: dict) -> None:
-    """{name}/{mean,median,std,min,max} (trainer/utils.py:289-321) on the device."""
-    if x.numel() == 0:
-        return
-    x = x.float()
-    out[name] = torch.stack([x.mean(), x.median(), x.std(unbiased=False) if x.numel() > 1 else x.new_zeros(()), x.min(), x.max()])
 
 
 def train(config: TrainerConfig) -> list[dict]:
@@ -110,55 +104,29 @@ def train(config: TrainerConfig) -> list[dict]:
         t_load = time.perf_counter() - t0
         t0 = time.perf_counter()
         out = engine.step(passes)
-        # --- step statistics, reduced on the device --------------------------------------------------------------------
-        st: dict[str, torch.Tensor] = {}
-        S = _lib.STAT
-        ent, mkl, losses, env_tok = [], [], [], []
+        # --- step statistics (trainer/stats.py): per-token vectors stay on the device, gathered over all ranks, ONE D2H copy ------
+        tensors = Tensors(group=engine.dp_group)
         env_ids: dict[str, int] = {}
-        for pi, (p, lp, en, loss) in enumerate(zip(passes, out["logprobs"], out["entropy"], out["loss"])):
-            m = p.loss_mask
-            # per-env split (train.py:483-520) with integer env ids: one id per SAMPLE on the host (env_names is constant within a
+        for pi, (p, lp, en) in enumerate(zip(passes, out["logprobs"], out["entropy"])):
+            # per-env split (train.py:486-494) with integer env ids: one id per SAMPLE on the host (env_names is constant within a
             # sample), expanded to tokens on the device — no per-token Python
-            sample_env, sample_len = [], []
+            sample_env = []
             for mb in mbs[pi * per_pass:(pi + 1) * per_pass]:
                 off = 0
                 for sl in mb["sequence_lengths"]:
                     sample_env.append(env_ids.setdefault(mb["env_names"][off], len(env_ids)))
-                    sample_len.append(sl)
                     off += sl
-            env_tok.append(torch.repeat_interleave(torch.tensor(sample_env, device=device), torch.tensor(sample_len, device=device))[m])
-            starts = torch.zeros_like(m)
-            # shift_tensor_right alignment: entropy/log-prob of token i come from head position i-1 (train.py:450-457)
-            ent_s = torch.roll(en, 1)
-            lp_s = torch.roll(lp, 1)
-            first = p.cu_samples[:-1][p.sample_starts_mb.bool()].long()
-            starts[first] = True
-            ent_s[first] = math.log(dims.vocab_size)
-            lp_s[first] = math.log(1.0 / dims.vocab_size)
-            ent.append(ent_s[m])
-            lr = lp_s - p.inference_logprobs
-            mkl.append((torch.exp(lr) - lr - 1)[m])
-            losses.append(loss)
-        _stats("loss", torch.cat(losses), st)
-        _stats("entropy/all", torch.cat(ent), st)
-        _stats("mismatch_kl/all", torch.cat(mkl), st)
-        if len(env_ids) > 1 or (env_ids and next(iter(env_ids)) not in ("", "fake")):
-            et, ea, ka = torch.cat(env_tok), torch.cat(ent), torch.cat(mkl)
-            for name, eid in env_ids.items():
-                if name:
-                    _stats(f"entropy/{name}", ea[et == eid], st)
-                    _stats(f"mismatch_kl/{name}", ka[et == eid], st)
-        met = torch.cat(out["sample_metrics"])
-        stats = torch.cat(out["sample_stats"])
-        for i, key in enumerate(_lib.METRIC_KEYS[:7]):
-            _stats(key, met[:, i], st)
-        flat = torch.cat([v for v in st.values()] + [out["grad_norm"].reshape(1)]).cpu()  # ONE device-to-host copy per step
+            names = list(env_ids)
+            collect_step_tensors(tensors, p, lp, en, out["sample_stats"][pi], out["sample_metrics"][pi], out["scales"], dims.vocab_size, config.loss.type,
+                                 torch.tensor(sample_env), names, _lib.METRIC_KEYS, _lib.STAT)
+        keys, stat_dev = tensors.compute_stats_device()
+        flat = torch.cat([stat_dev.reshape(-1), out["grad_norm"].reshape(1).float()]).cpu()  # ONE device-to-host copy per step
         torch.cuda.synchronize()
         t_fb = time.perf_counter() - t0
         vals = flat.tolist()
         rec: dict[str, float] = {"step": step}
-        for i, name in enumerate(st):
-            for j, suffix in enumerate(("mean", "median", "std", "min", "max")):
+        for i, name in enumerate(keys):
+            for j, suffix in enumerate(STAT_SUFFIXES):
                 rec[f"{name}/{suffix}"] = vals[i * 5 + j]
         grad_norm = vals[-1]
         if wb is not None and not (config.max_steps is not None and step == config.max_steps and getattr(config.weight_broadcast, "type", "") == "nccl"):
@@ -172,7 +140,9 @@ def train(config: TrainerConfig) -> list[dict]:
         rec.update({"perf/throughput": thr, "perf/throughput_per_gpu": thr / world, "perf/mfu": mfu, "perf/peak_memory": peak, "optim/lr": config.optim.lr,
                     "optim/grad_norm": grad_norm, "time/step": time.perf_counter() - t_step, "time/wait_for_batch": t_wait, "time/load_data": t_load,
                     "time/broadcast_weights": t_bcast, "time/forward_backward": t_fb,
-                    "kl_ent_ratio/mean": rec["mismatch_kl/all/mean"] / max(rec["entropy/all/mean"], 1e-12)})
+                    })
+        if rec.get("entropy/all/mean", 0.0) > 0 and "mismatch_kl/all/mean" in rec:  # train.py:669-672
+            rec["kl_ent_ratio/mean"] = rec["mismatch_kl/all/mean"] / rec["entropy/all/mean"]
         if is_master:
             print(f"Step {step} | Time: {rec['time/step']:.2f}s | Loss: {rec['loss/mean']:.4f} | Entropy: {rec['entropy/all/mean']:.4f} | "
                   f"Mismatch KL: {rec['mismatch_kl/all/mean']:.4f} | Grad. Norm: {grad_norm:.4f} | LR: {config.optim.lr:.2e} | "

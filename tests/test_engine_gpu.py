@@ -1,9 +1,11 @@
 """GPU suite: the engine's full step (forward -> log-probs -> loss -> backward -> clip -> AdamW) against the oracle's CPU
 port of the reference step (oracle/cpu_trainer.py) on identical rollout batches and identical bf16 weights.
 
-north_star tolerance: scalar loss |delta| <= 1e-4; per-token log-probs within the reference's own bf16 bound
-(rtol 1e-3 / atol 1e-4 is for identical logits; here the bf16 backbones differ by GEMM accumulation order, so the
-log-prob bound is 2e-3 absolute) with the DPPO-mask flip count reported separately (SURVEY.md §7 hard part (e))."""
+north_star tolerance: scalar loss |delta| <= 1e-4, asserted UNCONDITIONALLY (`_engine_vs_f32_oracle`): the engine is run
+with gemm_dtype="f32" (library GEMMs on f32 copies, every hand-written kernel as shipped) against the f32 oracle and against
+the oracle with the reference's bf16 rounding points + exact GEMMs; the shipped bf16 engine is measured against the same
+oracles; DPPO-mask flips are counted and printed separately (SURVEY.md §7 hard part (e)).  The gate also runs at Qwen3-8B
+width (H=4096, 32q/8kv, I=12288, V=151936) on BASELINE.md's parity variant."""
 
 import math
 
@@ -39,97 +41,176 @@ def _oracle_cfg(dims):
                              vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta)
 
 
+def _parity_variant_mbs(vocab, seq_len, n_rollouts, prompt_len, seed=0):
+    """BASELINE.md section 3 'parity variant': ids uniform over the full vocab, 8 groups x 16 rollouts with Bernoulli(0.5) rewards and
+    adv = r - mean(group) (orchestrator/algo/grpo.py:27-45) broadcast over the completion tokens (algo/routing.py:11-34), a masked
+    prompt, temperatures in {0.7, 1.0}; `n_rollouts` of the 128 rollouts (strided over the groups) form the step."""
+    g = torch.Generator().manual_seed(seed)
+    rewards = (torch.rand(8, 16, generator=g) < 0.5).float()
+    adv = (rewards - rewards.mean(1, keepdim=True)).reshape(-1)
+    pick = [(i * 128) // n_rollouts + (i % 16) for i in range(n_rollouts)]
+    mbs = []
+    for r in pick:
+        mask = torch.ones(1, seq_len, dtype=torch.bool)
+        mask[0, :prompt_len] = False
+        a = float(adv[r % 128]) if float(adv[r % 128]) != 0 else 0.5
+        mbs.append(dict(input_ids=torch.randint(0, vocab, (1, seq_len), generator=g), position_ids=torch.arange(seq_len)[None],
+                        advantages=a * mask.float(), inference_logprobs=torch.zeros(1, seq_len), loss_mask=mask,
+                        temperatures=torch.full((1, seq_len), 0.7 if r % 2 else 1.0), seq_lens=torch.tensor([seq_len]),
+                        sequence_lengths=[seq_len], env_names=["parity"] * seq_len))
+    return mbs
+
+
+def _to(mbs, device):
+    return [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in mb.items()} for mb in mbs]
+
+
+def _shifted(x, n_mb, n, pad):
+    return torch.cat([torch.cat([x.new_full((1,), pad), x[i * n:(i + 1) * n - 1]]) for i in range(n_mb)])
+
+
+def _flips(lp_a, lp_b, inf, adv, mask):
+    """DPPO trust-region mask decisions (default_loss_fn, loss.py:124-133) that differ between two log-prob vectors."""
+    def invalid(lp):
+        pd = torch.exp(lp) - torch.exp(inf)
+        return torch.where(adv > 0, pd > 0.2, pd < -0.2) & mask
+    return int((invalid(lp_a) != invalid(lp_b)).sum())
+
+
+def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=None, tag="", assert_f32=True):
+    """The parity MEASUREMENT (north_star: scalar loss |delta| <= 1e-4, flips reported separately).
+
+    Three computations of the same step on identical weights (bf16-valued) and identical rollouts:
+      A  the f32 oracle: the reference arithmetic in f32 end to end (oracle/cpu_trainer.py on `oracle_device`);
+      B  the oracle with the reference's bf16 rounding points and exact (f32) GEMMs: what a bf16 run of the reference computes
+         once GEMM summation order is taken out;
+      E32 the engine with gemm_dtype="f32": the hand-written kernels (RMSNorm, q/k-norm + RoPE, varlen attention, SwiGLU, K1,
+         K2) exactly as shipped, library GEMMs on f32 copies  -> isolates the kernels;
+      E16 the engine as shipped (hipBLASLt bf16 GEMMs, bf16 logits).
+    Asserted unconditionally, for E32 AND E16: |loss(E) - loss(B)| <= 1e-4 on every data set.  |loss(E) - loss(A)| <= 1e-4 is asserted
+    as well (`assert_f32`) where the reference's own dtype semantics are themselves within 1e-5 of f32 (the tiny parity-variant case,
+    |loss(B) - loss(A)| = 9.6e-6).  Elsewhere the reference's bf16 arithmetic sits 1.7e-4 (Qwen3-8B width) / 2.6e-4 (FakeDataLoader
+    batches: randn advantages of either sign on every token) from f32 — printed as |loss(B) - loss(A)| — so f32 is not the oracle of a
+    bf16 model there: B is asserted, A is reported.  DPPO flips are counted and printed for every pair, never used as an excuse."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, OptimConfig, pack_micro_batches
+
+    n_mb, n = len(mbs), seq_len
+    cfg = _oracle_cfg(dims)
+    dev_o = torch.device(oracle_device)
+    p32 = {k: v.float().to(dev_o) for k, v in sd.items()}
+    p16 = {k: v.to(torch.bfloat16).to(dev_o) for k, v in sd.items()}
+    mbs_o = _to(mbs, dev_o)
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        _, lps0, _ = C.step_logprobs_and_loss(p32, cfg, mbs_o, O.LossConfig(), 1, f32_logits=True)
+    for mb, mbo, lp in zip(mbs, mbs_o, lps0):  # sampling-policy log-probs = oracle log-probs + N(0, 0.02^2): ratios ~ 1, the mask fires rarely
+        mb["inference_logprobs"] = (lp.cpu() + 0.02 * torch.randn(lp.shape, generator=g))[None]
+        mbo["inference_logprobs"] = mb["inference_logprobs"].to(dev_o)
+    rl_scale = max(sum(int(mb["loss_mask"].sum()) for mb in mbs), 1)
+    params_a = {k: v.clone().requires_grad_(check_grads_on is not None) for k, v in p32.items()}
+    with torch.set_grad_enabled(check_grads_on is not None):
+        loss_a, lps_a, ents_a = C.step_logprobs_and_loss(params_a, cfg, mbs_o, O.LossConfig(), rl_scale, f32_logits=True)
+    with torch.no_grad():
+        loss_b, lps_b, _ = C.step_logprobs_and_loss(p16, cfg, mbs_o, O.LossConfig(), rl_scale, mm=O.exact_mm, f32_logits=True)
+        # C: the same reference-dtype arithmetic with the platform's own bf16 GEMMs (torch `@`): |B - C| is what GEMM summation order alone
+        # does to the reference's log-probs — the yardstick the per-token differences of the engine are held against
+        loss_c, lps_c, _ = C.step_logprobs_and_loss(p16, cfg, mbs_o, O.LossConfig(), rl_scale)
+    lp_a, lp_b, lp_c = torch.cat(lps_a).detach().cpu(), torch.cat(lps_b).cpu(), torch.cat(lps_c).cpu()
+    ent_a = torch.cat(ents_a).cpu()
+    mask = torch.cat([mb["loss_mask"][0] for mb in mbs])
+    inf = torch.cat([mb["inference_logprobs"][0] for mb in mbs])
+    adv = torch.cat([mb["advantages"][0] for mb in mbs])
+    pad = math.log(1.0 / dims.vocab_size)
+    res = {}
+    engines = {}
+    for mode in ("f32", "bf16"):
+        eng = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), loss=LossConfig(), seed=0, gemm_dtype=mode)
+        eng.store.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+        pb = pack_micro_batches(mbs, DEV)
+        assert pb.local_counts[0] == rl_scale
+        ctx = eng.forward(pb)
+        eng.loss(ctx, (rl_scale, 1, 1))
+        lp_e = _shifted(ctx["logprobs"].cpu(), n_mb, n, pad)
+        ent_e = _shifted(ctx["entropy"].cpu(), n_mb, n, math.log(dims.vocab_size))
+        res[mode] = dict(loss=ctx["loss"].item(), lp=lp_e, ent=ent_e)
+        engines[mode] = (eng, ctx)
+        da, db = (lp_e - lp_a).abs()[mask], (lp_e - lp_b).abs()[mask]
+        print(f"[{tag} engine gemm={mode}] loss {ctx['loss'].item():+.7f} | f32 oracle {float(loss_a.detach()):+.7f} (d={ctx['loss'].item() - float(loss_a.detach()):+.2e}) | "
+              f"bf16-points/exact-GEMM oracle {float(loss_b):+.7f} (d={ctx['loss'].item() - float(loss_b):+.2e}) | logprob |d| vs f32: mean {da.mean():.2e} "
+              f"max {da.max():.2e}; vs bf16-points: mean {db.mean():.2e} max {db.max():.2e} | entropy max|d| vs f32 {(ent_e - ent_a).abs()[mask].max():.2e} | "
+              f"DPPO flips vs f32 {_flips(lp_e, lp_a, inf, adv, mask)} / vs bf16-points {_flips(lp_e, lp_b, inf, adv, mask)} of {int(mask.sum())}")
+    la, lb = float(loss_a.detach()), float(loss_b)
+    # --- the gate: unconditional, no flip escape hatch --------------------------------------------------------------------------
+    # B is the reference in its OWN dtype (bf16 compute under FSDP MixedPrecisionPolicy(param_dtype=bf16), trainer/model.py:823-960;
+    # GEMM summation order removed): both engine modes must reproduce its scalar loss to <= 1e-4, on every data set.
+    print(f"[{tag}] reference-dtype oracle vs f32 oracle: |loss(B) - loss(A)| = {abs(lb - la):.2e} (bf16 activation rounding of the reference itself)")
+    assert abs(res["f32"]["loss"] - lb) <= 1e-4, ("scalar loss parity, kernels only (gemm=f32) vs the reference-dtype oracle", res["f32"]["loss"], lb)
+    assert abs(res["bf16"]["loss"] - lb) <= 1e-4, ("scalar loss parity, shipped engine vs the reference-dtype oracle", res["bf16"]["loss"], lb)
+    if assert_f32:
+        # On BASELINE.md's parity workload the f32 oracle is within reach of a bf16 model as well: asserted for both modes.
+        assert abs(res["f32"]["loss"] - la) <= 1e-4, ("scalar loss parity vs the f32 oracle (north_star: <= 1e-4)", res["f32"]["loss"], la)
+        assert abs(res["bf16"]["loss"] - la) <= 1e-4, ("shipped bf16 engine vs the f32 oracle", res["bf16"]["loss"], la)
+    # per-token log-probs: same rounding points on both sides, so what separates E from B is 1-ulp bf16 rounding flips of activations
+    # (seeded by bf16 P in the attention MFMA and by summation orders) propagating to the logits — the same mechanism that separates B
+    # from C.  The engine must not be further from B than GEMM-order noise alone puts the reference from itself (x1.5), nor may the
+    # worst token exceed twice the worst token of that pair.
+    yard = (lp_c - lp_b).abs()[mask]
+    d32, d16 = (res["f32"]["lp"] - lp_b).abs()[mask], (res["bf16"]["lp"] - lp_b).abs()[mask]
+    print(f"[{tag}] per-token log-prob |d| vs B: engine gemm=f32 mean {d32.mean():.2e} max {d32.max():.2e} | engine bf16 mean {d16.mean():.2e} max {d16.max():.2e} | "
+          f"yardstick (torch bf16 GEMMs vs exact GEMMs, same arithmetic) mean {yard.mean():.2e} max {yard.max():.2e}; loss(C) - loss(B) = {float(loss_c) - lb:+.2e}")
+    assert d32.mean() <= 1.5 * yard.mean() + 1e-4 and d32.max() <= 2.0 * yard.max() + 1e-3, (d32.mean(), d32.max(), yard.mean(), yard.max())
+    assert d16.mean() <= 1.5 * yard.mean() + 1e-4 and d16.max() <= 2.0 * yard.max() + 1e-3, (d16.mean(), d16.max(), yard.mean(), yard.max())
+    if check_grads_on is not None:
+        loss_a.backward()
+        eng, ctx = engines[check_grads_on]
+        eng.backward(ctx, accumulate=False)
+        d = dims
+        gsd = {}
+        for name, gv in eng.store.g.items():
+            if name.endswith("qkv_proj.weight"):
+                base = name[: -len("qkv_proj.weight")]
+                gsd[base + "q_proj.weight"], gsd[base + "k_proj.weight"], gsd[base + "v_proj.weight"] = gv[: d.q_dim], gv[d.q_dim: d.q_dim + d.kv_dim], gv[d.q_dim + d.kv_dim:]
+            elif name.endswith("gate_up_proj.weight"):
+                base = name[: -len("gate_up_proj.weight")]
+                gsd[base + "gate_proj.weight"], gsd[base + "up_proj.weight"] = gv[: d.intermediate_size], gv[d.intermediate_size:]
+            else:
+                gsd[name] = gv
+        worst = 1.0
+        for name, p in params_a.items():
+            ge, go = gsd[name].float().flatten(), p.grad.float().flatten().to(DEV)
+            cos = torch.nn.functional.cosine_similarity(ge, go, dim=0).item() if go.norm() > 0 else 1.0
+            rel = ((ge - go).norm() / (go.norm() + 1e-12)).item()
+            worst = min(worst, cos)
+            assert cos > 0.99 and rel < 0.12, f"{name}: cosine {cos:.5f}, relative error {rel:.4f}"
+        print(f"[{tag}] worst gradient cosine similarity (engine gemm={check_grads_on} vs f32 autograd): {worst:.6f}")
+        norm_o = math.sqrt(sum(float(p.grad.float().pow(2).sum()) for p in params_a.values()))
+        return engines, norm_o
+    return engines, None
+
+
 @pytest.mark.parametrize("packed", [False, True])
 def test_engine_step_matches_oracle(packed):
-    from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
+    """Tiny model (H=256, V=512, 2 layers), 8 x 256 tokens: the loss gate, then gradients and the optimizer of the SHIPPED bf16
+    engine against f32 autograd of the same model."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
 
     dims = ModelDims.tiny(layers=2, vocab=512)
-    eng = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), loss=LossConfig(), seed=0)
-    # give the model non-trivial logits (std ~1: bf16 logit ulp 2^-8..2^-7, so GEMM-order rounding flips stay ~4e-3)
-    sd = {k: v.detach().cpu().clone() for k, v in eng.store.state_dict().items()}
+    seed_eng = GRPOEngine(dims, device=DEV, seed=0)
+    # give the model non-trivial logits (std ~1)
+    sd = {k: v.detach().cpu().clone() for k, v in seed_eng.store.state_dict().items()}
+    del seed_eng
     g = torch.Generator().manual_seed(1)
     sd["lm_head.weight"] = (torch.randn(sd["lm_head.weight"].shape, generator=g) * 0.06).to(torch.bfloat16)
     sd["model.embed_tokens.weight"] = (torch.randn(sd["model.embed_tokens.weight"].shape, generator=g) * 1.0).to(torch.bfloat16)
     for k in sd:
         if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
             sd[k] = (1 + 0.1 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
-    eng.store.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
-    cfg = _oracle_cfg(dims)
-    mbs = _mbs(dims.vocab_size, 256, 2, packed)
-    # realistic sampling-policy log-probs: the oracle's own log-probs + N(0, 0.05^2) so ratios ~ 1 and the DPPO mask fires rarely
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    with torch.no_grad():
-        _, lps0, _ = C.step_logprobs_and_loss(params, cfg, mbs, O.LossConfig(), 1)
-    for mb, lp in zip(mbs, lps0):
-        mb["inference_logprobs"] = (lp + 0.05 * torch.randn(lp.shape, generator=g))[None]
-    rl_scale = max(sum(int(mb["loss_mask"].sum()) for mb in mbs), 1)
-    loss_o, lps_o, ents_o = C.step_logprobs_and_loss(params, cfg, mbs, O.LossConfig(), rl_scale)
-    loss_o.backward()
-
-    pb = pack_micro_batches(mbs, DEV)
-    assert pb.local_counts[0] == rl_scale
-    ctx = eng.forward(pb)
-    eng.loss(ctx, (rl_scale, 1, 1))
-    n = 256
-    pad = math.log(1.0 / dims.vocab_size)
-    lp_e = ctx["logprobs"].cpu()
-    lp_shift = torch.cat([torch.cat([torch.tensor([pad]), lp_e[i * n:(i + 1) * n - 1]]) for i in range(2)])
-    lp_ref = torch.cat(lps_o)
-    mask = torch.cat([mb["loss_mask"][0] for mb in mbs])
-    d_lp = (lp_shift - lp_ref).abs()[mask]
-    print(f"logprob max|d|={d_lp.max():.3e} mean|d|={d_lp.mean():.3e}; loss engine={ctx['loss'].item():.6f} oracle={loss_o.item():.6f}")
-    # Both bf16 backbones (engine on the GPU, oracle's bf16 CPU port) are compared with the SAME model in f32: the engine must
-    # be as close to the f32 truth as the reference-style bf16 computation is (GEMM accumulation order is the only difference).
-    params32 = {k: v.float() for k, v in sd.items()}
-    with torch.no_grad():
-        loss32, lps32, ents32 = C.step_logprobs_and_loss(params32, cfg, mbs, O.LossConfig(), rl_scale)
-    lp32 = torch.cat(lps32)
-    e_eng, e_ora = (lp_shift - lp32).abs()[mask], (lp_ref - lp32).abs()[mask]
-    print(f"vs f32 truth: engine mean {e_eng.mean():.3e} max {e_eng.max():.3e} | bf16 CPU port mean {e_ora.mean():.3e} max {e_ora.max():.3e}")
-    assert e_eng.mean() <= 1.5 * e_ora.mean() + 1e-4 and e_eng.max() <= 2.0 * e_ora.max() + 2e-3
-    assert d_lp.mean() < 2e-3
-    ent_shift = torch.cat([torch.cat([torch.tensor([math.log(dims.vocab_size)]), ctx["entropy"].cpu()[i * n:(i + 1) * n - 1]]) for i in range(2)])
-    ent32 = torch.cat(ents32)
-    assert (ent_shift - ent32).abs().max() <= 2.0 * (torch.cat(ents_o) - ent32).abs().max() + 2e-3
-    # DPPO trust-region mask flips between the two backbones, reported separately from the smooth error
-    inf = torch.cat([mb["inference_logprobs"][0] for mb in mbs])
-    adv = torch.cat([mb["advantages"][0] for mb in mbs])
-
-    def invalid(lp):
-        pd = torch.exp(lp) - torch.exp(inf)
-        return torch.where(adv > 0, pd > 0.2, pd < -0.2) & mask
-
-    flips = int((invalid(lp_shift) != invalid(lp_ref)).sum())
-    print(f"DPPO mask flips: {flips} of {int(mask.sum())} tokens")
-    assert flips <= 2
-    if flips == 0:
-        # scalar loss parity (north_star: <= 1e-4): either directly against the bf16 CPU port, or — when bf16 rounding noise of
-        # the two backbones alone exceeds 1e-4 — the engine must sit as close to the f32 loss as the bf16 CPU port does.
-        le, lo_, l32 = ctx["loss"].item(), loss_o.item(), float(loss32)
-        print(f"loss: engine {le:.6f}  bf16 CPU port {lo_:.6f}  f32 {l32:.6f}")
-        assert abs(le - lo_) <= 1e-4 or abs(le - l32) <= 1.5 * abs(lo_ - l32) + 5e-5, (le, lo_, l32)
-    # backward + optimizer: gradients against CPU autograd of the same bf16 model
-    eng.backward(ctx, accumulate=False)
-    gsd = {}
-    d = dims
-    for name, gv in eng.store.g.items():
-        if name.endswith("qkv_proj.weight"):
-            base = name[: -len("qkv_proj.weight")]
-            gsd[base + "q_proj.weight"], gsd[base + "k_proj.weight"], gsd[base + "v_proj.weight"] = gv[: d.q_dim], gv[d.q_dim: d.q_dim + d.kv_dim], gv[d.q_dim + d.kv_dim:]
-        elif name.endswith("gate_up_proj.weight"):
-            base = name[: -len("gate_up_proj.weight")]
-            gsd[base + "gate_proj.weight"], gsd[base + "up_proj.weight"] = gv[: d.intermediate_size], gv[d.intermediate_size:]
-        else:
-            gsd[name] = gv
-    worst = 1.0
-    for name, p in params.items():
-        ge, go = gsd[name].float().cpu().flatten(), p.grad.float().flatten()
-        cos = torch.nn.functional.cosine_similarity(ge, go, dim=0).item() if go.norm() > 0 else 1.0
-        rel = ((ge - go).norm() / (go.norm() + 1e-12)).item()
-        worst = min(worst, cos)
-        assert cos > 0.99 and rel < 0.12, f"{name}: cosine {cos:.5f}, relative error {rel:.4f}"
-    print(f"worst gradient cosine similarity vs CPU autograd: {worst:.6f}")
-    norm_o = math.sqrt(sum(float(p.grad.float().pow(2).sum()) for p in params.values()))
+    if packed:  # FakeDataLoader's packed-document micro-batches (data.py:87-130) with a masked prefix and mixed temperatures
+        mbs = _mbs(dims.vocab_size, 256, 8, True)
+    else:
+        mbs = _parity_variant_mbs(dims.vocab_size, 256, 8, prompt_len=32)
+    engines, norm_o = _engine_vs_f32_oracle(dims, sd, mbs, "cpu", 256, check_grads_on="bf16", tag=f"tiny packed={packed}", assert_f32=not packed)
+    eng, _ = engines["bf16"]
     before = eng.store.master.clone()
     norm_e = eng.optimizer_step().item()
     eng.wait_params_ready()  # the AdamW pipeline runs on the engine's side stream
@@ -140,6 +221,23 @@ def test_engine_step_matches_oracle(packed):
     nz = eng.store.main_grad.abs() > 1e-5
     assert torch.allclose(delta[nz], torch.full_like(delta[nz], 1e-3), rtol=2e-2)
     assert torch.equal(eng.store.params, eng.store.master.to(torch.bfloat16))
+
+
+def test_engine_qwen3_8b_width_parity():
+    """The same gate at the BASELINE shape: Qwen3-8B width (H=4096, 32 q / 8 kv heads, I=12288, V=151936), 2 layers, 4 x 2048-token
+    rollouts of the parity variant (256 masked prompt + 1792 trained tokens), against the oracles run with torch ON the device.  At this
+    width the reference's own bf16 arithmetic (B) sits 1.7e-4 from the f32 arithmetic (A): B is the oracle, A is printed."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
+
+    full = ModelDims.qwen3_8b()
+    dims = ModelDims(full.vocab_size, full.hidden_size, full.intermediate_size, 2, full.num_attention_heads, full.num_key_value_heads, full.head_dim,
+                     name="qwen3_8b_width")
+    seed_eng = GRPOEngine(dims, device=DEV, seed=0)  # random-init bf16 weights, std 0.02 (config.debug.random_init equivalent)
+    sd = {k: v.detach().clone() for k, v in seed_eng.store.state_dict().items()}
+    del seed_eng
+    torch.cuda.empty_cache()
+    mbs = _parity_variant_mbs(dims.vocab_size, 2048, 4, prompt_len=256)
+    _engine_vs_f32_oracle(dims, sd, mbs, DEV, 2048, check_grads_on="f32", tag="qwen3_8b_width", assert_f32=False)
 
 
 def test_engine_two_passes_equal_one_pass():
