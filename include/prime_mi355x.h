@@ -29,7 +29,7 @@ extern "C" {
 
 #define PM_ABI_VERSION 1
 
-enum { PM_DTYPE_F32 = 0, PM_DTYPE_BF16 = 1 };
+enum { PM_DTYPE_F32 = 0, PM_DTYPE_BF16 = 1, PM_DTYPE_I64 = 2, PM_DTYPE_U8 = 3 /* the last two: pm_comm_* payloads only */ };
 
 enum {
   PM_OK = 0,
@@ -289,6 +289,46 @@ int pm_adamw_step(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, 
                   void* param_bf16 /* nullable */, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */,
                   int32_t zero_grad, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * pm_comm_*: RCCL collectives over xGMI behind the C ABI (SURVEY.md section 8(b) minimum set).
+ *
+ * What they replace in the reference: the raw NCCL communicator of the trainer -> inference weight push
+ * (vllm PyNcclCommunicator on a StatelessProcessGroup: transports/weights/nccl.py:27-68,128-136 sender,
+ * inference/vllm/worker/nccl.py:28-89 receiver) — a communicator that lives NEXT to whatever process group the host framework
+ * already has — and, optionally, the c10d collectives FSDP2 issues for sharding (trainer/model.py:823-960: all-gather,
+ * reduce-scatter) and the i64[3] scale all-reduce (trainer/rl/train.py:318-323).
+ *
+ * A communicator is created from a 128-byte unique id: one rank calls pm_comm_unique_id() and ships the bytes to the others out
+ * of band (the Python side uses a torch TCPStore at weight_broadcast.host:port, configs/trainer.py:557-578); every rank then calls
+ * pm_comm_init(&comm, id, n_ranks, rank) with its HIP device current.  All data pointers are DEVICE pointers; every call only
+ * ENQUEUES on `stream` (a hipStream_t) and returns — order against compute with events, wait with the stream.  Sums only
+ * (ncclSum): that is all the path uses.  pm_comm_group_start/end bracket point-to-point batches (ncclGroupStart/End): the
+ * sharded weight push sends every trainer's slice to every inference GPU over its own xGMI link in one group.
+ * librccl is resolved with dlopen at first use (the copy already mapped into the process wins); pm_comm_available() == 0 and
+ * PM_ERR_UNSUPPORTED everywhere else if there is none.
+ * ------------------------------------------------------------------------------------------ */
+#define PM_COMM_UNIQUE_ID_BYTES 128
+int pm_comm_available(void);
+int pm_comm_rccl_version(void);                       /* ncclGetVersion code (e.g. 22107), negative on error */
+int pm_comm_unique_id(void* id_host_128);
+int pm_comm_init(void** comm_out, const void* id_host_128, int32_t n_ranks, int32_t rank);
+int pm_comm_destroy(void* comm);
+int pm_comm_rank_size(void* comm, int32_t* rank_out_host, int32_t* size_out_host);
+/* recv[i] = sum over ranks of send[i]; in place allowed (send == recv). */
+int pm_comm_all_reduce(void* comm, const void* send, void* recv, int64_t count, int dtype, void* stream);
+/* recv <- root's send (send is ignored on non-root ranks; send == recv allowed). */
+int pm_comm_broadcast(void* comm, const void* send, void* recv, int64_t count, int dtype, int32_t root, void* stream);
+/* send holds n_ranks * recv_count elements; rank r receives the sum of everybody's r-th block (FSDP gradient reduce-scatter). */
+int pm_comm_reduce_scatter(void* comm, const void* send, void* recv, int64_t recv_count, int dtype, void* stream);
+/* recv holds n_ranks * send_count elements, block r = rank r's send (in place allowed when send == recv + rank*send_count). */
+int pm_comm_all_gather(void* comm, const void* send, void* recv, int64_t send_count, int dtype, void* stream);
+/* block p of send goes to rank p, block r of recv comes from rank r (Ulysses sequence <-> head exchange). */
+int pm_comm_all_to_all(void* comm, const void* send, void* recv, int64_t count_per_peer, int dtype, void* stream);
+int pm_comm_send(void* comm, const void* send, int64_t count, int dtype, int32_t peer, void* stream);
+int pm_comm_recv(void* comm, void* recv, int64_t count, int dtype, int32_t peer, void* stream);
+int pm_comm_group_start(void);
+int pm_comm_group_end(void);
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

@@ -16,7 +16,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "lib" / "libprime_mi355x.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-PM_DTYPE_F32, PM_DTYPE_BF16 = 0, 1
+PM_DTYPE_F32, PM_DTYPE_BF16, PM_DTYPE_I64, PM_DTYPE_U8 = 0, 1, 2, 3
 PM_LOSS_DEFAULT, PM_LOSS_IPO = 0, 1
 PM_ADV_GRPO, PM_ADV_MAXRL = 0, 1
 PM_LOSS_NSTATS = 20
@@ -98,6 +98,21 @@ SIGNATURES: dict[str, tuple] = {
     "pm_sumsq": (I, [P, I64, P, P, I64, P]),
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
+    "pm_comm_available": (c_int, []),
+    "pm_comm_rccl_version": (c_int, []),
+    "pm_comm_unique_id": (I, [P]),
+    "pm_comm_init": (I, [POINTER(c_void_p), P, I32, I32]),
+    "pm_comm_destroy": (I, [P]),
+    "pm_comm_rank_size": (I, [P, POINTER(c_int32), POINTER(c_int32)]),
+    "pm_comm_all_reduce": (I, [P, P, P, I64, I, P]),
+    "pm_comm_broadcast": (I, [P, P, P, I64, I, I32, P]),
+    "pm_comm_reduce_scatter": (I, [P, P, P, I64, I, P]),
+    "pm_comm_all_gather": (I, [P, P, P, I64, I, P]),
+    "pm_comm_all_to_all": (I, [P, P, P, I64, I, P]),
+    "pm_comm_send": (I, [P, P, I64, I, I32, P]),
+    "pm_comm_recv": (I, [P, P, I64, I, I32, P]),
+    "pm_comm_group_start": (I, []),
+    "pm_comm_group_end": (I, []),
     "pm_mfma_probe_16x16x32": (I, [P, P, P, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
 }

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import sys
 from pathlib import Path
-from typing import Annotated, Any, Literal, Union
+from typing import Annotated, Any, ClassVar, Literal, Union
 
 from pydantic import BaseModel, ConfigDict, Field, model_validator
 
@@ -30,12 +30,20 @@ class BaseConfig(BaseModel):
     """Unknown keys are errors (as in the reference); the string "None" means null (the reference's TOMLs write `compile = "None"`)."""
 
     model_config = ConfigDict(extra="forbid", validate_assignment=True, arbitrary_types_allowed=True)
+    _FLAG_TABLES: ClassVar[frozenset] = frozenset({"compile", "ac", "ac_offloading", "gc"})
 
     @model_validator(mode="before")
     @classmethod
     def _none_strings(cls, data: Any) -> Any:
         if isinstance(data, dict):
-            return {k: (None if isinstance(v, str) and v == "None" else v) for k, v in data.items()}
+            out = {}
+            for k, v in data.items():
+                if isinstance(v, str) and v == "None":
+                    v = None
+                elif v is True and k in cls._FLAG_TABLES:  # `--model.compile` / `--model.ac` as bare flags = "enable with defaults"
+                    v = {}
+                out[k] = v
+            return out
         return data
 
 
@@ -291,6 +299,19 @@ class TrainerConfig(BaseConfig):
     # MI355X engine knob (not in the reference): micro-batches are concatenated into packed passes of at most this many tokens
     tokens_per_pass: int = Field(16384, ge=1)
     seed: int = 0
+
+    _DEFAULT_TAGS: ClassVar[dict] = {"optim": "adamw", "loss": "default", "scheduler": "constant", "weight_broadcast": "filesystem", "rollout_transport": "zmq"}
+
+    @model_validator(mode="before")
+    @classmethod
+    def _default_union_tags(cls, data: Any) -> Any:
+        """`--optim.lr 3e-6` alone keeps the default member of the tagged union (AdamW), as with the reference's config loader."""
+        if isinstance(data, dict):
+            data = dict(data)
+            for key, tag in cls._DEFAULT_TAGS.items():
+                if isinstance(data.get(key), dict) and "type" not in data[key]:
+                    data[key] = dict(data[key], type=tag)
+        return data
 
     @model_validator(mode="after")
     def _scheduler_fits_max_steps(self):  # validate_scheduler, configs/trainer.py:391-412

@@ -268,6 +268,19 @@ def rope_table(position_ids: Tensor, inv_freq: Tensor) -> tuple[Tensor, Tensor]:
     return cs[0], cs[1]
 
 
+def _check_qknorm_operands(q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, n: int, head_dim: int) -> None:
+    """The kernels read these through raw bf16 pointers: an f32 cos/sin table (a model that is not bf16) or a mis-shaped norm weight
+    would be read as garbage without any error."""
+    for t, nm in ((q_norm_w, "q_norm_w"), (k_norm_w, "k_norm_w")):
+        _req(t, torch.bfloat16, nm)
+        if t.numel() != head_dim:
+            raise PrimeMI355XError(f"{nm}: expected {head_dim} elements, got {t.numel()}")
+    for t, nm in ((cos, "cos"), (sin, "sin")):
+        _req(t, torch.bfloat16, nm)
+        if t.numel() != n * (head_dim // 2):
+            raise PrimeMI355XError(f"{nm}: expected a [{n}, {head_dim // 2}] bf16 half-table (pm_rope_table layout), got {tuple(t.shape)}")
+
+
 def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, n_q_heads: int, n_kv_heads: int,
                     head_dim: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
     lib = _lib.load()
@@ -275,6 +288,7 @@ def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor
     n = qkv.shape[0]
     if qkv.shape[1] != (n_q_heads + 2 * n_kv_heads) * head_dim:
         raise PrimeMI355XError("qkv: wrong width")
+    _check_qknorm_operands(q_norm_w, k_norm_w, cos, sin, n, head_dim)
     q = torch.empty((n, n_q_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
     k = torch.empty((n, n_kv_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
     rstd = torch.empty((n, n_q_heads + n_kv_heads), dtype=torch.float32, device=qkv.device)
@@ -293,6 +307,8 @@ def qknorm_rope_bwd(grad_q: Tensor, grad_k: Tensor, qkv: Tensor, q_norm_w: Tenso
     for t, nm in ((grad_q, "grad_q"), (grad_k, "grad_k"), (qkv, "qkv"), (grad_qkv, "grad_qkv")):
         _req(t, torch.bfloat16, nm)
     n = qkv.shape[0]
+    _check_qknorm_operands(q_norm_w, k_norm_w, cos, sin, n, head_dim)
+    _req(rstd, torch.float32, "rstd")
     wsb = lib.pm_qknorm_rope_bwd_workspace_bytes(n, n_q_heads, n_kv_heads)
     ws = workspace(wsb, qkv.device, "qknorm_bwd")
     check(

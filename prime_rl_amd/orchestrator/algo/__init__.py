@@ -12,10 +12,11 @@ ALGORITHM_CLASSES: dict[str, type[Algorithm]] = {"grpo": GRPOAlgorithm, "max_rl"
                                                  "rae": RAEAlgorithm}
 
 
-def build_algorithm(config, policy_pool=None) -> Algorithm:
+def build_algorithm(config, policy_pool=None, device: str | None = None) -> Algorithm:
+    """`device`: None keeps the class default (host arithmetic, like the reference's orchestrator); "cuda" scores on the MI355X."""
     cls = ALGORITHM_CLASSES[config.type]
     assert cls.action_loss_type == getattr(config, "action_loss_type", "rl")
-    return cls(config, policy_pool)
+    return cls(config, policy_pool) if device is None else cls(config, policy_pool, device=device)
 
 
 __all__ = ["Algorithm", "GRPOAlgorithm", "MaxRLAlgorithm", "HierarchicalGRPOAlgorithm", "RAEAlgorithm", "GRPOAlgoConfig", "LengthPenaltyConfig",

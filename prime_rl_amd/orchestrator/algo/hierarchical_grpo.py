@@ -27,7 +27,7 @@ class HierarchicalGRPOAlgoConfig:
 
 
 class HierarchicalGRPOAlgorithm(Algorithm):
-    def __init__(self, config: HierarchicalGRPOAlgoConfig | None = None, policy_pool=None, device: str = "cuda"):
+    def __init__(self, config: HierarchicalGRPOAlgoConfig | None = None, policy_pool=None, device: str = "cpu"):
         super().__init__(config, policy_pool)
         self.episode_agents = set(getattr(config, "episode_agents", ["solver"]))
         self.device = device
@@ -43,7 +43,14 @@ class HierarchicalGRPOAlgorithm(Algorithm):
         offs = [0]
         for members in peers.values():
             offs.append(offs[-1] + len(members))
-        rewards = torch.tensor([t.reward for t in flat], dtype=torch.float32, device=self.device)
-        offsets = torch.tensor(offs, dtype=torch.int32, device=self.device)
-        for trace, a in zip(flat, group_advantages(rewards, offsets, _lib.PM_ADV_GRPO).tolist(), strict=True):
+        if torch.device(self.device).type == "cpu":  # host arithmetic like the reference (hierarchical_grpo.py:33-42): r - mean per peer set
+            adv: list[float] = []
+            for a, b in zip(offs[:-1], offs[1:]):
+                r = torch.tensor([t.reward for t in flat[a:b]], dtype=torch.float32)
+                adv += (r - r.mean()).tolist()
+        else:  # every peer set in one pm_grpo_advantage launch
+            rewards = torch.tensor([t.reward for t in flat], dtype=torch.float32, device=self.device)
+            offsets = torch.tensor(offs, dtype=torch.int32, device=self.device)
+            adv = group_advantages(rewards, offsets, _lib.PM_ADV_GRPO).tolist()
+        for trace, a in zip(flat, adv, strict=True):
             assign_advantages(trace, a)

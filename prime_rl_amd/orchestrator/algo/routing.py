@@ -1,6 +1,8 @@
-"""Training annotations and loss routing — mirrors `prime_rl.orchestrator.algo.routing`
-(src/prime_rl/orchestrator/algo/routing.py:11-84).  Host-side list plumbing on duck-typed verifiers objects
-(`trace.nodes[*].{mask, token_ids, advantages}`); the arithmetic lives in `grpo.py` / the K3 kernels."""
+"""Training annotations and loss routing: the contract of `prime_rl.orchestrator.algo.routing`
+(src/prime_rl/orchestrator/algo/routing.py:11-84) on duck-typed verifiers objects (`trace.nodes[*].{mask, token_ids,
+advantages}`, `sample.{token_ids, mask, rl_weights, ce_weights, ref_kl_weights}`).  Written from the behaviour the reference's tests
+pin (tests/unit/orchestrator/test_advantage.py:248-270, test_algorithms.py:112-150), not from its source; the arithmetic lives in
+`grpo.py` / the K3 kernels."""
 
 from __future__ import annotations
 
@@ -25,31 +27,48 @@ def assign_advantages(trace, values: float | list[float]) -> None:
         cursor += count
 
 
+def _token_credit(trace) -> list[float]:
+    """Every per-token advantage the trace carries, node after node."""
+    credit: list[float] = []
+    for node in trace.nodes:
+        if node.advantages:
+            credit.extend(node.advantages)
+    return credit
+
+
 def scalar_advantage(trace) -> float | None:
-    """Mean nonzero token advantage, or zero for an assigned-zero trace (routing.py:53-59)."""
-    advantages = [v for node in trace.nodes for v in (node.advantages or [])]
-    if not advantages:
+    """The trace's advantage as ONE number for logging / filtering: the mean over its nonzero token advantages; 0.0 when credit was
+    assigned but is zero everywhere; None when nothing was assigned (routing.py:53-59 semantics, plain sequential float sum)."""
+    credit = _token_credit(trace)
+    if not credit:
         return None
-    nonzero = [v for v in advantages if v != 0.0]
-    return sum(nonzero) / len(nonzero) if nonzero else 0.0
+    live = [c for c in credit if c != 0.0]
+    if not live:
+        return 0.0
+    return sum(live) / len(live)
 
 
 def is_trainable(trace) -> bool:
-    return any(v != 0.0 for node in trace.nodes for v in (node.advantages or []))
+    """A trace trains iff some token of it carries nonzero credit (routing.py:62-64 semantics)."""
+    return any(c != 0.0 for c in _token_credit(trace))
 
 
 def stamp_loss_routing(sample, action_loss_type: str) -> None:
-    """Route action tokens into the algorithm's declared loss component (routing.py:67-84)."""
+    """Send the sample's ACTION tokens (mask True) to the loss component the algorithm declares (routing.py:67-84 semantics):
+      "rl"      nothing to do — an absent rl stream already means weight 1 on the mask;
+      "ce"      rl stream all-zero; ce weight 1.0 on every action token, on top of whatever graph-native ce weights the sample has;
+      "ref_kl"  rl stream all-zero; a fresh ref_kl stream with 1.0 on every action token."""
     if action_loss_type == "rl":
         return
-    seq_len = len(sample.token_ids)
-    sample.rl_weights = [0.0] * seq_len
-    action_weights = sample.ce_weights if action_loss_type == "ce" and sample.ce_weights is not None else [0.0] * seq_len
-    for i, trains in enumerate(sample.mask):
-        if trains:
-            action_weights[i] = 1.0
+    if action_loss_type not in ("ce", "ref_kl"):
+        raise ValueError(f"unknown action loss type {action_loss_type!r}")
+    n_tok = len(sample.token_ids)
+    acts = [i for i, is_action in enumerate(sample.mask) if is_action]
+    sample.rl_weights = [0.0] * n_tok
+    stream = list(sample.ce_weights) if (action_loss_type == "ce" and sample.ce_weights is not None) else [0.0] * n_tok
+    for i in acts:
+        stream[i] = 1.0
     if action_loss_type == "ce":
-        sample.ce_weights = action_weights
+        sample.ce_weights = stream
     else:
-        assert action_loss_type == "ref_kl"
-        sample.ref_kl_weights = action_weights
+        sample.ref_kl_weights = stream

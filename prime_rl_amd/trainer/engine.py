@@ -358,7 +358,8 @@ class GRPOEngine:
 
     def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
-                 force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16"):
+                 force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
+                 cp_group: dist.ProcessGroup | None = None, cp_size: int = 1):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -368,8 +369,19 @@ class GRPOEngine:
         self.gemm_f32 = gemm_dtype == "f32"
         self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
         self.dp_group = dp_group
-        self.dp_size = dist.get_world_size(dp_group) if (dp_group is not None or dist.is_initialized()) else 1
+        # `dp_size` given (trainer/model.py:setup_engine passes ParallelDims.dp_size): the gradient/optimizer shards span exactly the dp
+        # group.  Not given: the whole default group is the dp group — only right when every rank of it is a trainer rank, so a caller that
+        # shares its default group with inference ranks (the weight-push world) MUST pass dp_group / dp_size explicitly.
+        if dp_size is not None:
+            self.dp_size = dp_size
+            if dp_size > 1 and dist.get_world_size(dp_group) != dp_size:
+                raise PrimeMI355XError(f"dp_size {dp_size} != size of dp_group {dist.get_world_size(dp_group)}")
+        else:
+            self.dp_size = dist.get_world_size(dp_group) if (dp_group is not None or dist.is_initialized()) else 1
         self.dp_rank = dist.get_rank(dp_group) if self.dp_size > 1 else 0
+        self.cp_group, self.cp_size = cp_group, cp_size
+        if cp_size > 1:
+            raise PrimeMI355XError("context parallelism (cp > 1) is SURVEY.md section 8 row f4: not part of this engine yet")
         if dims.head_dim != 128:
             raise PrimeMI355XError("attention kernels are built for head_dim 128")
         if force_collectives and not dist.is_initialized():
@@ -399,6 +411,7 @@ class GRPOEngine:
                 self._wt[nm] = slab[cursor:cursor + o * k].view(k, o)
                 cursor += o * k
         self.k1_events: list | None = None
+        self._param_readers: list = []  # events of asynchronous readers of store.params (the weight push): waited for before AdamW rewrites them
 
     # -- GEMM helpers (library calls: hipBLASLt via torch) ------------------------------------------------------------
     def _probe_wgrad_direct(self) -> bool:
@@ -621,6 +634,10 @@ class GRPOEngine:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._gather_events.clear()
 
+    def add_param_reader(self, event) -> None:
+        """Register the completion event of an asynchronous reader of `store.params` (transports/weights: the push stream)."""
+        self._param_readers.append(event)
+
     def _wait_gather(self, name: str) -> None:
         ev = self._gather_events.pop(name, None)
         if ev is not None:
@@ -635,6 +652,11 @@ class GRPOEngine:
         same sum, here done in one reduce-scatter(SUM)."""
         self.step_count += 1
         self.store.version += 1  # parameters change: derived weight layouts are refreshed on next use
+        for ev in self._param_readers:  # an in-flight weight push still reads the parameters this step is about to overwrite
+            torch.cuda.current_stream().wait_event(ev)
+            if self.comm_stream is not None:
+                self.comm_stream.wait_event(ev)
+        self._param_readers.clear()
         return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.dp_group, ops, self.comm_stream, self._gather_events, self._sumsq)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------

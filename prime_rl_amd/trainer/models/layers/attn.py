@@ -98,7 +98,8 @@ class HipVarlenAttention(nn.Module):
         qkv = torch.cat([self.q_proj(x), self.k_proj(x), self.v_proj(x)], dim=-1)
         cos, sin = position_embeddings
         half = self.head_dim // 2
-        cos, sin = cos.reshape(n, -1)[:, :half].contiguous(), sin.reshape(n, -1)[:, :half].contiguous()  # accept the reference's cat(f,f) tables too
+        # accept the reference's cat(f,f) tables too; the kernels read bf16 (the reference casts cos/sin to x.dtype, rotary_emb.py:72-73)
+        cos, sin = cos.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous(), sin.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous()
         q, k = _QKNormRopeFn.apply(qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, self.hq, self.hkv, self.head_dim, self.eps)
         v = qkv[:, (self.hq + self.hkv) * self.head_dim:].view(n, self.hkv, self.head_dim)
         out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling)

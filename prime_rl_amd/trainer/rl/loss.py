@@ -164,18 +164,30 @@ def _one_sample(inputs: LossInputs, cfg, component: str) -> LossOutputs:
                                              cu, _params(cfg))
         keys = _lib.METRIC_KEYS[:3] if getattr(cfg, "type", "default") == "ipo" else _lib.METRIC_KEYS[:7]
     elif component == "ce":
+        # The kernel derives a component's membership from its weight stream (w != 0); the reference's ce / ref_kl loss fns take the
+        # given loss_mask as membership and the weights only as multipliers (loss.py:246-259, 199-243), so an in-mask token with weight
+        # 0.0 still counts in the metric denominators.  Loss and gradient come from the weighted launch; when weights are present the
+        # METRICS come from a second launch whose weight stream is 1.0 on the mask (membership == loss_mask exactly).
         zeros = torch.zeros(n, dtype=torch.float32, device=dev)
-        cw = torch.where(inputs.loss_mask, w if w is not None else torch.ones_like(zeros), zeros)
-        loss, stats, met = _GrpoLossFn.apply(inputs.trainer_logprobs, zeros, None, zeros, torch.zeros(n, dtype=torch.bool, device=dev), None, cw, None, cu,
-                                             _params(DefaultLossConfig()))
+        ones_on_mask = inputs.loss_mask.to(torch.float32)
+        no_rl = torch.zeros(n, dtype=torch.bool, device=dev)
+        cw = ones_on_mask if w is None else torch.where(inputs.loss_mask, w.float(), zeros)
+        loss, stats, met = _GrpoLossFn.apply(inputs.trainer_logprobs, zeros, None, zeros, no_rl, None, cw, None, cu, _params(DefaultLossConfig()))
+        if w is not None:
+            _, _, met = _GrpoLossFn.apply(inputs.trainer_logprobs.detach(), zeros, None, zeros, no_rl, None, ones_on_mask, None, cu, _params(DefaultLossConfig()))
         keys = ["nll"]
     else:
         if inputs.ref_logprobs is None:
             raise ValueError("ref_kl loss type requires ref_logprobs — use the 'opd' or 'opsd' algorithm.")
         zeros = torch.zeros(n, dtype=torch.float32, device=dev)
-        rw = torch.where(inputs.loss_mask, w if w is not None else torch.ones_like(zeros), zeros)
-        loss, stats, met = _GrpoLossFn.apply(inputs.trainer_logprobs, inputs.inference_logprobs, inputs.ref_logprobs.contiguous().float(), zeros,
-                                             torch.zeros(n, dtype=torch.bool, device=dev), None, None, rw, cu, _params(DefaultLossConfig()))
+        ones_on_mask = inputs.loss_mask.to(torch.float32)
+        no_rl = torch.zeros(n, dtype=torch.bool, device=dev)
+        ref = inputs.ref_logprobs.contiguous().float()
+        rw = ones_on_mask if w is None else torch.where(inputs.loss_mask, w.float(), zeros)
+        loss, stats, met = _GrpoLossFn.apply(inputs.trainer_logprobs, inputs.inference_logprobs, ref, zeros, no_rl, None, None, rw, cu, _params(DefaultLossConfig()))
+        if w is not None:
+            _, _, met = _GrpoLossFn.apply(inputs.trainer_logprobs.detach(), inputs.inference_logprobs, ref, zeros, no_rl, None, None, ones_on_mask, cu,
+                                          _params(DefaultLossConfig()))
         keys = _lib.METRIC_KEYS[8:12]
     return LossOutputs(loss=loss, metrics={k: met[0, _lib.METRIC_KEYS.index(k)] for k in keys})
 

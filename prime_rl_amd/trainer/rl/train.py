@@ -15,66 +15,106 @@ Launch: `python -m prime_rl_amd.trainer.rl.train` (1 GPU) or `torchrun --nproc-p
 from __future__ import annotations
 
 import json
-import math
 import os
 import time
-from dataclasses import asdict, dataclass, field
+from datetime import timedelta
 from pathlib import Path
-from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
 
 from ... import _lib
+from ...configs.trainer import TrainerConfig, parse_argv
 from ...transports.weights import setup_weight_broadcast
-from ..engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
+from ..engine import pack_micro_batches
+from ..model import setup_engine
+from ..parallel_dims import get_parallel_dims
 from ..stats import STAT_SUFFIXES, Tensors, collect_step_tensors
-from .data import DataLoader, FakeDataLoader, FakeDataLoaderConfig
+from .data import DataLoader, FakeDataLoader
 
 PEAK_BF16_FLOPS = 2.5e15  # MI355X dense bf16 MFMA (the reference's table stops at MI325X and would fall back to A100, perf.py:99-109)
 
 
-@dataclass
-class WeightBroadcastConfig:
-    type: str = "filesystem"  # "filesystem" | "nccl" (trainer/configs: standalone trainer defaults to filesystem, configs/trainer.py:617)
+def setup_scheduler(config: TrainerConfig):
+    """LR schedule exactly as trainer/scheduler.py builds it — the same torch.optim.lr_scheduler objects on a one-parameter stand-in
+    optimizer (the fused AdamW kernel takes `lr` as an argument per step); returns a callable step -> lr for 1-based steps."""
+    from torch.optim.lr_scheduler import ConstantLR, CosineAnnealingLR, LinearLR, SequentialLR
 
+    lr, sc, max_steps = config.optim.lr, config.scheduler, config.max_steps
+    opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=lr)
+    if sc.type == "constant":
+        sched = ConstantLR(opt, factor=1.0)
+    else:
+        floor = sc.min_lr / lr if sc.min_lr > 0 else 1e-8
+        parts, milestones = [], []
+        if sc.warmup_steps > 0:
+            parts.append(LinearLR(opt, start_factor=floor, end_factor=1.0, total_iters=sc.warmup_steps))
+            milestones.append(sc.warmup_steps)
+        if sc.type == "linear":
+            if sc.decay_steps > 0:
+                start = max_steps - sc.decay_steps
+                parts.append(LinearLR(opt, start_factor=1.0, end_factor=1.0, total_iters=start - sc.warmup_steps))
+                parts.append(LinearLR(opt, start_factor=1.0, end_factor=floor, total_iters=sc.decay_steps - 1))
+                milestones.append(start)
+        else:
+            parts.append(CosineAnnealingLR(opt, T_max=max_steps - sc.warmup_steps, eta_min=sc.min_lr))
+        sched = parts[0] if len(parts) == 1 else SequentialLR(opt, parts, milestones=milestones)
+    cache: list[float] = [sched.get_last_lr()[0]]
 
-@dataclass
-class TrainerConfig:
-    model: str = "qwen3-8b"  # qwen3-8b | qwen3-0.6b | tiny
-    seq_len: int = 2048
-    max_steps: int | None = 4
-    output_dir: str = "outputs"
-    fake_data: FakeDataLoaderConfig | None = field(default_factory=lambda: FakeDataLoaderConfig(batch_size=8))
-    loss: LossConfig = field(default_factory=LossConfig)
-    optim: OptimConfig = field(default_factory=OptimConfig)
-    weight_broadcast: WeightBroadcastConfig | None = field(default_factory=WeightBroadcastConfig)
-    tokens_per_pass: int = 16384
-    seed: int = 0
-    rollout_format: str = "msgpack"  # "msgpack" = the reference wire; "binary" = raw-array step blobs + pinned read-ahead (transports/rollouts/binary.py)
+    def lr_at(step: int) -> float:
+        while len(cache) < step:
+            opt.step()
+            sched.step()
+            cache.append(sched.get_last_lr()[0])
+        return cache[step - 1]
+
+    return lr_at
 
 
 def train(config: TrainerConfig) -> list[dict]:
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    """`prime_rl.trainer.rl.train.train(config)` (train.py:75) for the dense data-parallel path: one process per GPU under torchrun
+    (RANK / LOCAL_RANK / WORLD_SIZE), every rank a trainer rank."""
+    config.validate_supported()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=device)
+    torch.set_float32_matmul_precision(config.matmul_precision)  # train.py:117-120
+    wbc = config.weight_broadcast
+    trainer_world = launched
+    if launched > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", device_id=device, timeout=timedelta(seconds=config.dist_timeout_seconds))
     is_master = rank == 0
-    dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "tiny": ModelDims.tiny}[config.model]()
-    engine = GRPOEngine(dims, device=device, optim=config.optim, loss=config.loss, seed=config.seed)
+    # the torchrun world holds trainer ranks only; the inference GPUs are reached through a SEPARATE raw RCCL communicator bootstrapped at
+    # weight_broadcast.host:port (below), as in the reference (transports/weights/nccl.py:128-136) — ZeRO shards can never span them
+    parallel_dims = get_parallel_dims(config.model, config.model.seq_len, world_size=trainer_world)
+    engine = setup_engine(config, parallel_dims, device=device)
+    dims = engine.dims
+    dp_rank, dp_world = parallel_dims.dp_rank_of(rank), parallel_dims.dp_size
     out_dir = Path(config.output_dir)
-    if config.fake_data is not None:
-        loader = FakeDataLoader(config.fake_data, config.seq_len, dp_world_size=world, dp_rank=rank)
+    seq_len = config.model.seq_len
+    if config.data.fake is not None:
+        loader = FakeDataLoader(config.data.fake, seq_len, dp_world_size=dp_world, dp_rank=dp_rank)
     else:
-        loader = DataLoader(out_dir, start_step=1, dp_world_size=world, dp_rank=rank, config=SimpleNamespace(type="filesystem", format=config.rollout_format))
-    wb = setup_weight_broadcast(out_dir, config.weight_broadcast, is_master=is_master) if config.weight_broadcast is not None else None
-    per_pass = max(config.tokens_per_pass // config.seq_len, 1)
+        loader = DataLoader(out_dir, start_step=1, dp_world_size=dp_world, dp_rank=dp_rank, config=config.rollout_transport)
+    wb = None
+    if wbc is not None:
+        if wbc.type == "nccl":
+            from ...transports.weights import init_push_communicator
+
+            protocol = os.environ.get("PRIME_PUSH_PROTOCOL", "sharded")  # "reference" = the reference's single-source byte stream
+            comm = init_push_communicator(wbc.host, wbc.port, rank, trainer_world, wbc.inference_world_size, device, wbc.timeout, protocol)
+            wb = setup_weight_broadcast(out_dir, wbc, comm=comm, trainer_rank=rank, n_trainers=trainer_world, n_inference=wbc.inference_world_size,
+                                        protocol=protocol, ready_timeout=wbc.timeout, trainer_group=parallel_dims.get_group("dp_cp"))
+        else:
+            wb = setup_weight_broadcast(out_dir, wbc, is_master=is_master)
+    lr_at = setup_scheduler(config)
+    per_pass = max(config.tokens_per_pass // seq_len, 1)
     history: list[dict] = []
     step, start_step = 1, 1
-    metrics_path = out_dir / "metrics.jsonl"
+    mon = (config.monitors.get("file") or {}).get("path") if isinstance(config.monitors, dict) else None
+    metrics_path = out_dir / (mon or "metrics.jsonl")
     if is_master:
         out_dir.mkdir(parents=True, exist_ok=True)
     while config.max_steps is None or step <= config.max_steps:
@@ -94,7 +134,7 @@ def train(config: TrainerConfig) -> list[dict]:
             packed, mbs = loader.get_packed_batch(device)  # one H2D copy of the step blob; `mbs` is the host view used for the env split
         else:
             mbs = loader.get_batch()
-        if config.fake_data is not None and dims.vocab_size < 120000:  # FakeDataLoader draws ids up to 120000 (data.py:101)
+        if config.data.fake is not None and dims.vocab_size < 120000:  # FakeDataLoader draws ids up to 120000 (data.py:101)
             for mb in mbs:
                 mb["input_ids"] = mb["input_ids"] % dims.vocab_size
         if packed is not None and len(mbs) <= per_pass:
@@ -103,6 +143,7 @@ def train(config: TrainerConfig) -> list[dict]:
             passes = [pack_micro_batches(mbs[i:i + per_pass], device) for i in range(0, len(mbs), per_pass)]
         t_load = time.perf_counter() - t0
         t0 = time.perf_counter()
+        engine.optim.lr = lr_at(step)
         out = engine.step(passes)
         # --- step statistics (trainer/stats.py): per-token vectors stay on the device, gathered over all ranks, ONE D2H copy ------
         tensors = Tensors(group=engine.dp_group)
@@ -129,23 +170,29 @@ def train(config: TrainerConfig) -> list[dict]:
             for j, suffix in enumerate(STAT_SUFFIXES):
                 rec[f"{name}/{suffix}"] = vals[i * 5 + j]
         grad_norm = vals[-1]
+        t_transfer = None
         if wb is not None and not (config.max_steps is not None and step == config.max_steps and getattr(config.weight_broadcast, "type", "") == "nccl"):
+            if hasattr(wb, "last_transfer_seconds"):
+                t_transfer = wb.last_transfer_seconds()  # device time of the PREVIOUS (asynchronous) push, long finished by now
             t0 = time.perf_counter()
             wb.broadcast_weights(engine, step)  # pi_step -> broadcasts/step_{step}; the final nccl push is skipped (train.py:582-587)
             t_bcast += time.perf_counter() - t0
-        n_tokens = sum(p.n_tokens for p in passes) * world
+        n_tokens = sum(p.n_tokens for p in passes) * dp_world
         thr = n_tokens / t_fb
-        mfu = thr * dims.flops_per_token(config.seq_len) / (world * PEAK_BF16_FLOPS) * 100
+        world = trainer_world
+        mfu = thr * dims.flops_per_token(seq_len) / (world * PEAK_BF16_FLOPS) * 100
         peak = torch.cuda.max_memory_allocated() / 2**30
-        rec.update({"perf/throughput": thr, "perf/throughput_per_gpu": thr / world, "perf/mfu": mfu, "perf/peak_memory": peak, "optim/lr": config.optim.lr,
+        rec.update({"perf/throughput": thr, "perf/throughput_per_gpu": thr / world, "perf/mfu": mfu, "perf/peak_memory": peak, "optim/lr": engine.optim.lr,
                     "optim/grad_norm": grad_norm, "time/step": time.perf_counter() - t_step, "time/wait_for_batch": t_wait, "time/load_data": t_load,
                     "time/broadcast_weights": t_bcast, "time/forward_backward": t_fb,
                     })
+        if t_transfer is not None:
+            rec["time/broadcast_weights_transfer"] = t_transfer  # extension: wire time of the asynchronous push (overlapped with this step)
         if rec.get("entropy/all/mean", 0.0) > 0 and "mismatch_kl/all/mean" in rec:  # train.py:669-672
             rec["kl_ent_ratio/mean"] = rec["mismatch_kl/all/mean"] / rec["entropy/all/mean"]
         if is_master:
             print(f"Step {step} | Time: {rec['time/step']:.2f}s | Loss: {rec['loss/mean']:.4f} | Entropy: {rec['entropy/all/mean']:.4f} | "
-                  f"Mismatch KL: {rec['mismatch_kl/all/mean']:.4f} | Grad. Norm: {grad_norm:.4f} | LR: {config.optim.lr:.2e} | "
+                  f"Mismatch KL: {rec['mismatch_kl/all/mean']:.4f} | Grad. Norm: {grad_norm:.4f} | LR: {engine.optim.lr:.2e} | "
                   f"Throughput: {thr:.0f} tokens/s | MFU: {mfu:.1f}% | Peak Mem.: {peak:.1f} GiB", flush=True)
             with open(metrics_path, "a") as f:
                 f.write(json.dumps(rec) + "\n")
@@ -154,16 +201,11 @@ def train(config: TrainerConfig) -> list[dict]:
     return history
 
 
-if __name__ == "__main__":
-    import argparse
+def main(argv: list[str] | None = None) -> None:
+    """`torchrun -m prime_rl_amd.trainer.rl.train @ cfg.toml --model.seq-len 2048 ...` — the reference's launch grammar
+    (entrypoints/rl.py:320-335, benchmarks/scripts/run_single_benchmark.py:111-191)."""
+    train(parse_argv(argv))
 
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="qwen3-8b")
-    ap.add_argument("--max-steps", type=int, default=4)
-    ap.add_argument("--micro-batches", type=int, default=8, help="per GPU")
-    ap.add_argument("--seq-len", type=int, default=2048)
-    ap.add_argument("--output-dir", default="outputs")
-    a = ap.parse_args()
-    ws = int(os.environ.get("WORLD_SIZE", "1"))
-    train(TrainerConfig(model=a.model, seq_len=a.seq_len, max_steps=a.max_steps, output_dir=a.output_dir,
-                        fake_data=FakeDataLoaderConfig(batch_size=a.micro_batches * ws)))
+
+if __name__ == "__main__":
+    main()

@@ -6,13 +6,15 @@ dicts (non-layer + 36 layers), per dict a pickled metadata blob and one flat ten
 single-source funnel bound by one xGMI link (16.4 GB at ~150 GB/s ~ 107 ms for Qwen3-8B).
 
 Here: the flat bf16 parameter buffer is already bucketed per decoder layer and replicated on every trainer rank (ZeRO-2), so
-no gather is needed.  Each bucket is cut into `dp` equal chunks and trainer rank r broadcasts chunk r to the inference ranks
-over its own group {trainer r} + inference ranks: every inference GPU receives `dp` chunks over `dp` different links at once
-(4+4 split: ~27 ms of wire time).  Buckets go out in layer order so the receiver can load layer-wise
-(`load_weights_checkpoint_layerwise` contract, inference/vllm/worker/nccl.py:138-158).  The rendezvous is the reference's:
-`broadcasts/step_N/STABLE` written by the trainer master, `NCCL_READY` awaited before any collective is enqueued
-(nccl.py:195-224), names in HF checkpoint format.  The layout manifest (`LAYOUT.json`: bucket -> [(name, offset, shape)])
-replaces the per-dict pickled metadata broadcast.
+no gather is needed.  Each bucket is cut into `dp` equal chunks and trainer rank r SENDS chunk r to every inference rank
+(grouped point-to-point over a raw RCCL communicator, prime_rl_amd/comm.py): every inference GPU receives `dp` chunks over `dp`
+different direct xGMI links at once (4+4 split: ~27 ms of wire time), nothing is forwarded.  Buckets go out in layer order so
+the receiver can load layer-wise (`load_weights_checkpoint_layerwise` contract, inference/vllm/worker/nccl.py:138-158).  The
+rendezvous is the reference's: a TCP store at `weight_broadcast.host:port` bootstraps the communicator, `broadcasts/step_N/STABLE`
+is written by the trainer master and `NCCL_READY` awaited before anything is enqueued (nccl.py:195-224), names in HF checkpoint
+format.  The layout manifest (`LAYOUT.json`: bucket -> [(name, offset, shape)]) replaces the per-dict pickled metadata broadcast.
+The push is asynchronous (own stream; the next optimizer step waits for it on the device).  For a receiver that speaks the
+reference's byte protocol there is `protocol="reference"` (single source, pickled metadata, one flat tensor per dtype).
 """
 
 from __future__ import annotations
@@ -59,9 +61,9 @@ class FileSystemWeightBroadcast(WeightBroadcast):
     """HF-format safetensors checkpoint under `broadcasts/step_N/` + STABLE marker (the reference's fallback transport);
     broadcasts older than `keep` steps are deleted like trainer/utils.py:349-363."""
 
-    def __init__(self, output_dir: Path, is_master: bool = True, keep: int = 2):
+    def __init__(self, output_dir: Path, is_master: bool = True, keep: int = 2, group=None):
         super().__init__(output_dir)
-        self.is_master, self.keep = is_master, keep
+        self.is_master, self.keep, self.group = is_master, keep, group
 
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
@@ -84,8 +86,8 @@ class FileSystemWeightBroadcast(WeightBroadcast):
                     for f in old.iterdir():
                         f.unlink()
                     old.rmdir()
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.barrier()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.barrier(group=self.group)
 
 
 def build_layout(store) -> list[dict]:
@@ -109,13 +111,101 @@ def build_layout(store) -> list[dict]:
     return out
 
 
-class RCCLWeightBroadcast(WeightBroadcast):
-    """Sharded multi-source push.  World layout of the push communicator: trainer ranks [0, dp) then inference ranks
-    [dp, dp + n_inf) — created by `init_push_groups` on BOTH sides (collective call)."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# Protocol 1 — "sharded": the xGMI-native push.  Push world = trainer ranks [0, T) then inference ranks [T, T + I).  Every bucket of
+# the flat bf16 buffer is cut into T equal chunks; trainer r SENDS chunk r to every inference rank, every inference rank RECEIVES T
+# chunks from T different trainers — point-to-point, grouped (ncclGroupStart/End), so on the xGMI full mesh every (trainer,
+# inference) pair uses its own direct link and no GPU forwards anything.  No metadata travels: LAYOUT.json sits next to STABLE.
+def push_sharded(comm, store, trainer_rank: int, n_trainers: int, n_inference: int) -> None:
+    for b in store.buckets:
+        chunk = b.size // n_trainers
+        view = store.params[b.offset + trainer_rank * chunk: b.offset + (trainer_rank + 1) * chunk]
+        comm.group_start()
+        for i in range(n_inference):
+            comm.send(view, n_trainers + i)
+        comm.group_end()
 
-    def __init__(self, output_dir: Path, trainer_rank: int, n_trainers: int, groups: list, ready_timeout: float | None = None):
+
+def receive_sharded(comm, layout: list[dict], n_trainers: int, device):
+    """Yields (hf_name, tensor) bucket by bucket (layer order) for a layer-wise `load_weights`."""
+    for b in layout:
+        buf = torch.empty(b["size"], dtype=torch.bfloat16, device=device)
+        chunk = b["size"] // n_trainers
+        comm.group_start()
+        for r in range(n_trainers):
+            comm.recv(buf[r * chunk:(r + 1) * chunk], r)
+        comm.group_end()
+        for name, off, shape in b["params"]:
+            yield name, buf[off: off + math.prod(shape)].view(shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Protocol 2 — "reference": the byte stream of the reference's single-source broadcast, for a receiver that speaks it
+# (transports/weights/nccl.py:27-84 sender, inference/vllm/worker/nccl.py:28-89 receiver; SURVEY.md section 9.3).  World =
+# trainer master (rank 0) + inference ranks; per step: i64[1] number of state dicts, then per dict: i64[1] pickle length, u8[len]
+# pickled {dtype: [(key, shape, numel), ...]}, then one flat tensor per dtype.  Dict order: non-layer weights, then layer 0, 1, ...
+def _layer_state_dicts(state_dict: dict[str, torch.Tensor], layer_prefix: str = "model.layers."):
+    layer_ids = sorted({int(k[len(layer_prefix):].split(".")[0]) for k in state_dict if k.startswith(layer_prefix)})
+    yield {k: v for k, v in state_dict.items() if not k.startswith(layer_prefix)}
+    for i in layer_ids:
+        yield {k: v for k, v in state_dict.items() if k.startswith(f"{layer_prefix}{i}.")}
+
+
+def send_reference_protocol(comm, state_dict: dict[str, torch.Tensor], device) -> None:
+    import pickle
+
+    dicts = list(_layer_state_dicts(state_dict))
+    comm.broadcast(torch.tensor([len(dicts)], dtype=torch.int64, device=device), 0)
+    for sd in dicts:
+        by_dtype: dict[torch.dtype, list[tuple[str, torch.Tensor]]] = {}
+        for k, v in sd.items():
+            by_dtype.setdefault(v.dtype, []).append((k, v))
+        meta = pickle.dumps({dt: [(k, v.shape, v.numel()) for k, v in items] for dt, items in by_dtype.items()})
+        comm.broadcast(torch.tensor([len(meta)], dtype=torch.int64, device=device), 0)
+        comm.broadcast(torch.frombuffer(bytearray(meta), dtype=torch.uint8).to(device), 0)
+        for items in by_dtype.values():
+            comm.broadcast(torch.cat([v.reshape(-1) for _, v in items]).contiguous(), 0)
+
+
+def receive_reference_protocol(comm, device):
+    import pickle
+
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    comm.broadcast(count, 0)
+    for _ in range(int(count.item())):
+        size = torch.zeros(1, dtype=torch.int64, device=device)
+        comm.broadcast(size, 0)
+        blob = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+        comm.broadcast(blob, 0)
+        meta = pickle.loads(bytes(blob.cpu().numpy()))
+        for dtype, infos in meta.items():
+            flat = torch.empty(sum(n for _, _, n in infos), dtype=dtype, device=device)
+            comm.broadcast(flat, 0)
+            off = 0
+            for key, shape, numel in infos:
+                yield key, flat[off: off + numel].view(shape).clone()
+                off += numel
+
+
+class RCCLWeightBroadcast(WeightBroadcast):
+    """Trainer half of the push.  `comm` is a communicator of prime_rl_amd.comm (RCCLCommunicator on the GPU).
+
+    Asynchronous on the GPU: the sends are enqueued on a dedicated push stream behind an event that marks the parameters final, and
+    the call returns; the engine only waits for the push (`add_param_reader`) right before the NEXT optimizer step rewrites the
+    parameters, so the transfer overlaps with the next step's data wait, forward and backward.  `last_transfer_seconds()` reports the
+    device time of the previous push from stream events."""
+
+    def __init__(self, output_dir: Path, comm, trainer_rank: int, n_trainers: int, n_inference: int, protocol: str = "sharded",
+                 ready_timeout: float | None = None, trainer_group=None):
         super().__init__(output_dir)
-        self.rank, self.dp, self.groups, self.ready_timeout = trainer_rank, n_trainers, groups, ready_timeout
+        if protocol not in ("sharded", "reference"):
+            raise ValueError(f"unknown push protocol {protocol!r}")
+        if protocol == "reference" and n_trainers != 1 and comm is not None and comm.size != n_inference + 1:
+            raise ValueError("the reference protocol runs on a communicator of the trainer master + the inference ranks")
+        self.comm, self.rank, self.dp, self.n_inf, self.protocol = comm, trainer_rank, n_trainers, n_inference, protocol
+        self.ready_timeout, self.trainer_group = ready_timeout, trainer_group
+        self._stream = None
+        self._events: tuple | None = None
 
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
@@ -129,53 +219,86 @@ class RCCLWeightBroadcast(WeightBroadcast):
             self._notify_orchestrator(save_dir)
             sync_wait_for_path(save_dir / NCCL_READY_MARKER, interval=0.05, timeout=self.ready_timeout)
         # every trainer rank waits for the inference pool before enqueuing collectives (nccl.py:203-211)
-        dist.barrier(group=self.groups[-1])
-        works = []
-        for b in store.buckets:
-            chunk = b.size // self.dp
-            view = store.params[b.offset + self.rank * chunk: b.offset + (self.rank + 1) * chunk]
-            works.append(dist.broadcast(view, src=self.rank, group=self.groups[self.rank], async_op=True))
-        for w in works:
-            w.wait()
+        if self.dp > 1 and dist.is_initialized():
+            dist.barrier(group=self.trainer_group)
+        on_gpu = store.params.is_cuda
+        if on_gpu:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=store.params.device)
+            final = torch.cuda.Event()
+            final.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(final)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self._stream)
+                self._push(store, model)
+                t1.record(self._stream)
+            self._events = (t0, t1)
+            if hasattr(model, "add_param_reader"):
+                model.add_param_reader(t1)  # the next optimizer step waits for the push on the device, the host never blocks
+            else:
+                torch.cuda.current_stream().wait_event(t1)
+        else:
+            self._push(store, model)
+
+    def _push(self, store, model) -> None:
+        if self.protocol == "sharded":
+            push_sharded(self.comm, store, self.rank, self.dp, self.n_inf)
+        elif self.rank == 0:
+            send_reference_protocol(self.comm, store.state_dict(), store.params.device)
+
+    def last_transfer_seconds(self) -> float | None:
+        """Device time of the most recent push (synchronises with its completion)."""
+        if self._events is None:
+            return None
+        t0, t1 = self._events
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e-3
 
 
 class RCCLWeightReceiver:
-    """Inference-side half (replaces inference/vllm/worker/nccl.py:28-89): posts one receive per (bucket, trainer chunk) and yields
-    `(hf_name, tensor)` bucket by bucket for a layer-wise `load_weights`."""
+    """Inference-side half (replaces inference/vllm/worker/nccl.py:28-89): yields `(hf_name, tensor)` in layer order."""
 
-    def __init__(self, n_trainers: int, groups: list, device):
-        self.dp, self.groups, self.device = n_trainers, groups, torch.device(device)
+    def __init__(self, comm, n_trainers: int, device, protocol: str = "sharded"):
+        self.comm, self.dp, self.device, self.protocol = comm, n_trainers, torch.device(device), protocol
 
     @torch.no_grad()
-    def receive_state_dict(self, weight_dir: Path):
+    def receive_state_dict(self, weight_dir: Path | None = None):
+        if self.protocol == "reference":
+            yield from receive_reference_protocol(self.comm, self.device)
+            return
         layout = json.loads((Path(weight_dir) / "LAYOUT.json").read_text())
-        dist.barrier(group=self.groups[-1])
-        pending = []
-        for b in layout:
-            buf = torch.empty(b["size"], dtype=torch.bfloat16, device=self.device)
-            chunk = b["size"] // self.dp
-            works = [dist.broadcast(buf[r * chunk:(r + 1) * chunk], src=r, group=self.groups[r], async_op=True) for r in range(self.dp)]
-            pending.append((b, buf, works))
-        for b, buf, works in pending:  # all receives are in flight; hand layers over in order as they complete
-            for w in works:
-                w.wait()
-            for name, off, shape in b["params"]:
-                yield name, buf[off: off + math.prod(shape)].view(shape)
+        yield from receive_sharded(self.comm, layout, self.dp, self.device)
 
 
-def init_push_groups(n_trainers: int, n_inference: int) -> list:
-    """Collective on every rank of the push world (trainers first): groups[r] = {trainer r} + all inference ranks, groups[-1] = world."""
-    inf = list(range(n_trainers, n_trainers + n_inference))
-    groups = [dist.new_group([r] + inf) for r in range(n_trainers)]
-    groups.append(dist.new_group(list(range(n_trainers + n_inference))))
-    return groups
+def init_push_communicator(host: str, port: int, rank: int, n_trainers: int, n_inference: int, device, timeout: float = 1200.0,
+                           protocol: str = "sharded"):
+    """Both sides call this (trainers with rank in [0, T), inference GPU g with rank T + g): a raw RCCL communicator bootstrapped from a
+    TCP store at host:port, the reference's rendezvous (transports/weights/nccl.py:128-136, configs/trainer.py:557-578).  With the
+    reference protocol only the trainer master joins (world = 1 + I); other trainer ranks get None."""
+    from ...comm import RCCLCommunicator, StatelessRendezvous
+
+    if protocol == "reference":
+        if rank != 0 and rank < n_trainers:
+            return None
+        world = n_inference + 1
+        rank = 0 if rank == 0 else rank - n_trainers + 1
+    else:
+        world = n_trainers + n_inference
+    return RCCLCommunicator(StatelessRendezvous(host, port, rank, world, timeout), device)
 
 
 def setup_weight_broadcast(output_dir: Path, config, **kw) -> WeightBroadcast:
-    """`weight_broadcast.type` dispatch (transports/weights/__init__.py:13-26): "nccl" -> RCCL sharded push, "filesystem" -> checkpoint."""
+    """`weight_broadcast.type` dispatch (transports/weights/__init__.py:13-26): "nccl" -> RCCL push, "filesystem" -> checkpoint.
+    For "nccl" pass `comm` (a prime_rl_amd.comm communicator), `trainer_rank`, `n_trainers`, `n_inference`."""
     kind = getattr(config, "type", "filesystem")
     if kind == "filesystem":
-        return FileSystemWeightBroadcast(output_dir, is_master=kw.get("is_master", True))
+        return FileSystemWeightBroadcast(output_dir, is_master=kw.get("is_master", True), group=kw.get("group"))
     if kind in ("nccl", "rccl"):
-        return RCCLWeightBroadcast(output_dir, kw["trainer_rank"], kw["n_trainers"], kw["groups"], kw.get("ready_timeout"))
+        missing = [k for k in ("comm", "trainer_rank", "n_trainers", "n_inference") if k not in kw]
+        if missing:
+            raise TypeError(f"weight_broadcast.type = {kind!r} needs {missing}: build the push communicator with init_push_communicator() "
+                            "(trainer/rl/train.py does) and pass it here")
+        return RCCLWeightBroadcast(output_dir, kw["comm"], kw["trainer_rank"], kw["n_trainers"], kw["n_inference"], kw.get("protocol", "sharded"),
+                                   kw.get("ready_timeout"), kw.get("trainer_group"))
     raise ValueError(f"Invalid weight broadcast type: {kind} (nixl / ModelExpress RDMA is multi-node and stays with the reference)")

@@ -42,7 +42,8 @@ def test_packed_batch_on_device_is_bit_identical():
 
 
 def test_train_loop_same_metrics_with_either_wire(tmp_path):
-    from prime_rl_amd.trainer.rl.train import TrainerConfig, train
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.rl.train import train
     from prime_rl_amd.transports.rollouts import FileSystemMicroBatchSender
 
     hist = {}
@@ -51,7 +52,8 @@ def test_train_loop_same_metrics_with_either_wire(tmp_path):
         sender = FileSystemMicroBatchSender(out, data_world_size=1, current_step=1, wire_format=fmt)
         for step in range(2):
             asyncio.run(sender.send([_grid(100 + step, 3, 512)]))
-        cfg = TrainerConfig(model="tiny", seq_len=256, max_steps=2, output_dir=str(out), fake_data=None, tokens_per_pass=4096, rollout_format=fmt)
+        cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny", seq_len=256, debug=dict(random_init=True)), max_steps=2, output_dir=str(out),
+                                                tokens_per_pass=4096, rollout_transport=dict(type="filesystem", format=fmt)))
         hist[fmt] = train(cfg)
     for a, b in zip(hist["msgpack"], hist["binary"]):
         for key in ("loss/mean", "entropy/all/mean", "mismatch_kl/all/mean", "optim/grad_norm", "is_masked/mean"):

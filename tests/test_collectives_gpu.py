@@ -65,9 +65,10 @@ def test_forced_collectives_step_equals_plain_step(rccl_world1):
 
 
 def test_rccl_weight_push_trainer_side_on_device(rccl_world1, tmp_path):
-    """Trainer half of the sharded push (transports/weights RCCLWeightBroadcast) over RCCL with an empty inference pool: the
-    NCCL_READY handshake, the LAYOUT.json manifest and one async device broadcast per bucket run on the GPU and leave the
-    parameters untouched.  (Sender + receiver together: tests/test_weight_push_cpu.py, gloo world_size 3.)"""
+    """Trainer half of the sharded push (transports/weights RCCLWeightBroadcast) on a raw RCCL communicator (pm_comm_*, bootstrapped from
+    a TCP store like the reference's StatelessProcessGroup) with an empty inference pool: the NCCL_READY handshake, the LAYOUT.json
+    manifest, the asynchronous push stream + the engine's reader event run on the GPU and leave the parameters untouched.
+    (Sender + receivers together: tests/test_weight_push_cpu.py, gloo world_size 4.)"""
     import json
     import math
 
@@ -78,13 +79,23 @@ def test_rccl_weight_push_trainer_side_on_device(rccl_world1, tmp_path):
     dims = ModelDims.tiny(layers=1, vocab=512)
     eng = GRPOEngine(dims, device=DEV, seed=9)
     before = eng.store.params.clone()
-    groups = W.init_push_groups(1, 0)
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    comm = W.init_push_communicator("127.0.0.1", port, 0, 1, 0, DEV, timeout=60)
+    assert (comm.rank, comm.size) == (0, 1)
     step_dir = get_step_path(get_broadcast_dir(tmp_path), 1)
     step_dir.mkdir(parents=True)
     (step_dir / W.NCCL_READY_MARKER).touch()  # what the inference pool writes once its receives are posted
-    W.RCCLWeightBroadcast(tmp_path, 0, 1, groups, ready_timeout=10).broadcast_weights(eng, 1)
+    wb = W.RCCLWeightBroadcast(tmp_path, comm, 0, 1, 0, ready_timeout=10)
+    wb.broadcast_weights(eng, 1)
+    assert len(eng._param_readers) == 1  # the next optimizer step will wait for the push on the device
+    assert wb.last_transfer_seconds() is not None
     torch.cuda.synchronize()
     assert torch.equal(before, eng.store.params)
+    comm.close()
     layout = json.loads((step_dir / "LAYOUT.json").read_text())
     sd = eng.store.state_dict()
     names = {n for b in layout for n, _, _ in b["params"]}
@@ -93,3 +104,75 @@ def test_rccl_weight_push_trainer_side_on_device(rccl_world1, tmp_path):
         for name, off, shape in b["params"]:
             view = eng.store.params[bk.offset + off: bk.offset + off + math.prod(shape)].view(shape)
             assert torch.equal(view, sd[name])
+
+
+def test_train_loop_with_nccl_weight_broadcast_from_the_config_path(tmp_path):
+    """`[weight_broadcast] type = "nccl"` through train(config) (this path used to raise KeyError): train() bootstraps the raw
+    RCCL push communicator from host:port, pushes the startup policy v0 and one policy per step except the last (train.py:582-587), the
+    engine's optimizer waits for the asynchronous push, and the ZeRO shards stay on the trainer ranks.  The 'inference pool' here is a
+    thread that answers STABLE with NCCL_READY (inference_world_size = 0: no receiver GPU on a one-GPU box)."""
+    import socket
+    import threading
+    import time
+
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.rl.train import train
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    stop = threading.Event()
+
+    def pool():
+        while not stop.is_set():
+            for d in (tmp_path / "broadcasts").glob("step_*"):
+                if (d / "STABLE").exists() and not (d / "NCCL_READY").exists():
+                    (d / "NCCL_READY").touch()
+            time.sleep(0.02)
+
+    th = threading.Thread(target=pool, daemon=True)
+    th.start()
+    try:
+        cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny", seq_len=128, debug=dict(random_init=True)), max_steps=3, output_dir=str(tmp_path),
+                                                data=dict(fake=dict(batch_size=2, generate_samples=True)), tokens_per_pass=256,
+                                                weight_broadcast=dict(type="nccl", host="127.0.0.1", port=port, inference_world_size=0, timeout=60)))
+        hist = train(cfg)
+    finally:
+        stop.set()
+        th.join()
+    assert len(hist) == 3
+    pushed = sorted(int(d.name.split("_")[1]) for d in (tmp_path / "broadcasts").glob("step_*") if (d / "LAYOUT.json").exists())
+    assert pushed == [0, 1, 2]  # v0 at start-up, v1, v2; the final v3 is skipped for nccl
+    assert "time/broadcast_weights" in hist[1] and "time/broadcast_weights_transfer" in hist[1]
+
+
+def test_setup_model_and_forward_keep_the_reference_signatures():
+    """trainer/model.py:1314 setup_model(config, parallel_dims, loading_from_checkpoint_later) and :1431 forward(model, input_ids,
+    position_ids, *, seq_lens, labels, temperature) -> PrimeLmOutput{logprobs, entropy} f32 contiguous; the fused head is injected with
+    the config's chunk size; the autograd path reaches every parameter."""
+    import inspect
+
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer import model as M
+    from prime_rl_amd.trainer.models.layers.lm_head import FusedOutputLinear, VanillaOutputLinear
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims
+
+    assert list(inspect.signature(M.setup_model).parameters) == ["config", "parallel_dims", "loading_from_checkpoint_later"]
+    fp = inspect.signature(M.forward).parameters
+    assert list(fp)[:3] == ["model", "input_ids", "position_ids"] and all(fp[k].kind is inspect.Parameter.KEYWORD_ONLY for k in ("seq_lens", "labels", "temperature"))
+    cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny", seq_len=64, debug=dict(random_init=True, num_layers=1), fused_lm_head_token_chunk_size=32)))
+    pd = get_parallel_dims(cfg.model, cfg.model.seq_len, world_size=1)
+    model = M.setup_model(cfg.model, pd)
+    assert isinstance(model.lm_head, FusedOutputLinear) and cfg.model.attn == "hip_varlen" and len(model.model.layers) == 1
+    n = 64
+    ids = torch.randint(0, 512, (1, n), device=DEV)
+    labels = torch.cat([ids[:, 1:], ids.new_zeros(1, 1)], 1)
+    out = M.forward(model, ids, torch.arange(n, device=DEV)[None], seq_lens=torch.tensor([40, 24], device=DEV), labels=labels,
+                    temperature=torch.ones(1, n, device=DEV))
+    assert out["logprobs"].shape == (1, n) and out["logprobs"].dtype == torch.float32 and out["entropy"].is_contiguous() and out.get("logits") is None
+    out["logprobs"].sum().backward()
+    assert all(p.grad is not None for p in model.parameters())
+    cfg2 = TrainerConfig.model_validate(dict(model=dict(name="tiny", debug=dict(random_init=True, num_layers=1), fused_lm_head_token_chunk_size="disabled")))
+    assert isinstance(M.setup_model(cfg2.model, pd).lm_head, VanillaOutputLinear)
+    with pytest.raises(FileNotFoundError):
+        M.setup_model(TrainerConfig.model_validate(dict(model=dict(name="tiny"))).model, pd)  # no weights and no random_init: loud

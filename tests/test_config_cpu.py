@@ -1,0 +1,108 @@
+"""CPU suite: the reference's trainer config surface (packages/prime-rl-configs/src/prime_rl/configs/trainer.py:597-661) drives
+`prime_rl_amd` unchanged — its TOML tables, its `@ file.toml --dotted.key value` launch grammar (the exact argv of
+benchmarks/scripts/run_single_benchmark.py:111-191), its defaults, its scheduler arithmetic and its ParallelDims rules."""
+
+import math
+
+import pytest
+import torch
+
+from prime_rl_amd.configs.trainer import TrainerConfig, parse_argv
+from prime_rl_amd.trainer.parallel_dims import ParallelDims, get_parallel_dims
+
+
+def test_defaults_are_the_references():
+    c = TrainerConfig()
+    assert (c.model.name, c.model.seq_len, c.model.attn, c.model.impl) == ("Qwen/Qwen3-0.6B", 2048, "auto", "auto")
+    assert (c.optim.type, c.optim.lr, c.optim.weight_decay, c.optim.max_norm, c.optim.betas1, c.optim.betas2) == ("adamw", 1e-6, 0.01, 1.0, 0.9, 0.999)
+    assert (c.loss.type, c.loss.dppo_mask_low, c.loss.dppo_mask_high, c.loss.adv_tau, c.loss.kl_tau) == ("default", 0.2, 0.2, 1.0, 1e-3)
+    assert c.model.fused_lm_head_token_chunk_size == 8192 and c.model.optim_cpu_offload and c.model.reshard_after_forward
+    assert c.weight_broadcast.type == "filesystem" and c.rollout_transport.type == "zmq" and c.rollout_transport.port == 5555
+    assert c.scheduler.type == "constant" and c.max_steps is None and c.dist_timeout_seconds == 3600 and c.matmul_precision == "high"
+    assert c.data.fake is None and c.model.optimization_dtype == "float32" and c.model.reduce_dtype == "float32"
+
+
+def test_reference_benchmark_argv_parses():
+    """The argv `run_single_benchmark.py` builds for an RL run (its flags verbatim, dashes included)."""
+    argv = ["--model.name", "Qwen/Qwen3-8B", "--model.seq-len", "2048", "--model.attn", "flash_attention_2", "--max-steps", "4", "--output-dir", "/tmp/bench",
+            "--monitors.file.path", "metrics.jsonl", "--model.compile", "--dist-timeout-seconds", "3600", "--model.ac", "--model.fused-lm-head-token-chunk-size",
+            "4096", "--data.fake.batch-size", "16"]
+    c = parse_argv(argv)
+    assert c.model.name == "Qwen/Qwen3-8B" and c.model.seq_len == 2048 and c.max_steps == 4 and c.data.fake.batch_size == 16
+    assert c.model.compile is not None and c.model.ac is not None and c.model.fused_lm_head_token_chunk_size == 4096
+    assert c.monitors == {"file": {"path": "metrics.jsonl"}}
+    c.validate_supported()
+
+
+def test_toml_tables_and_overrides(tmp_path):
+    f = tmp_path / "rl.toml"
+    f.write_text('max_steps = 5\n\n[data.fake]\nbatch_size = 2\n\n[model]\nseq_len = 1024\ncompile = "None"\n\n[loss]\ntype = "ipo"\nipo_threshold = 0.05\n\n'
+                 '[weight_broadcast]\ntype = "nccl"\nport = 29777\ninference_world_size = 4\n\n[scheduler]\ntype = "cosine"\nwarmup_steps = 2\n')
+    c = parse_argv(["@", str(f), "--model.seq-len", "4096", "--optim.lr=3e-6"])
+    assert c.max_steps == 5 and c.model.seq_len == 4096 and c.model.compile is None and c.loss.type == "ipo" and c.loss.ipo_threshold == 0.05
+    assert c.weight_broadcast.type == "nccl" and c.weight_broadcast.port == 29777 and c.weight_broadcast.inference_world_size == 4
+    assert c.optim.lr == 3e-6 and c.scheduler.type == "cosine"
+    with pytest.raises(Exception):
+        parse_argv(["--model.not-a-key", "1"])  # unknown keys are errors, as in the reference
+    with pytest.raises(Exception):
+        parse_argv(["--scheduler.type", "cosine"])  # cosine needs max_steps (validate_scheduler, configs/trainer.py:408-412)
+
+
+def test_out_of_scope_keys_are_refused_loudly():
+    for argv in (["--model.lora.rank", "8"], ["--model.ep", "8"], ["--optim.type", "muon"], ["--enable-router-replay"]):
+        with pytest.raises(NotImplementedError):
+            parse_argv(argv).validate_supported()
+
+
+@pytest.mark.parametrize("kind", ["constant", "linear", "cosine"])
+def test_scheduler_equals_torch_schedulers_the_reference_builds(kind):
+    """trainer/scheduler.py builds ConstantLR / LinearLR / CosineAnnealingLR / SequentialLR objects; `setup_scheduler` must hand the
+    fused AdamW kernel the same lr at every step.  Spot values: warm-up starts at lr*1e-8-ish floor, peaks at lr, ends at min_lr."""
+    from prime_rl_amd.trainer.rl.train import setup_scheduler
+
+    lr, steps = 2e-5, 12
+    sched = {"constant": {"type": "constant"}, "linear": {"type": "linear", "warmup_steps": 3, "decay_steps": 4, "min_lr": 2e-6},
+             "cosine": {"type": "cosine", "warmup_steps": 3, "min_lr": 2e-6}}[kind]
+    c = TrainerConfig.model_validate(dict(max_steps=steps, optim=dict(lr=lr), scheduler=sched))
+    lr_at = setup_scheduler(c)
+    got = [lr_at(s) for s in range(1, steps + 1)]
+    if kind == "constant":
+        assert got == [lr] * steps
+    else:
+        assert got[0] == pytest.approx(2e-6) and got[3] == pytest.approx(lr) and max(got) == pytest.approx(lr)
+        assert got[-1] < got[3] and all(g >= 2e-6 - 1e-12 for g in got)
+        if kind == "linear":
+            assert got[3:8] == pytest.approx([lr] * 5)  # constant phase between warm-up and decay
+        else:
+            mid = 3 + (steps - 3) // 2
+            assert got[mid] == pytest.approx(2e-6 + (lr - 2e-6) * (1 + math.cos(math.pi * (mid - 3) / (steps - 3))) / 2, rel=1e-6)
+
+
+def test_parallel_dims_rules():
+    d = ParallelDims(dp_replicate=1, dp_shard=-1, cp=2, pp=1, ep=1, world_size=8)
+    assert (d.dp_shard, d.dp_size, d.fsdp_gradient_divide_factor, d.non_data_parallel_size, d.seq_len_divisor) == (4, 4, 8, 2, 4)
+    assert d.cp_enabled and d.dp_enabled and not d.ep_enabled and not d.pp_enabled
+    assert [d.dp_rank_of(r) for r in range(8)] == [0, 0, 1, 1, 2, 2, 3, 3]  # dp_rank = rank // non_dp_size (data.py:174-175)
+    with pytest.raises(ValueError):
+        ParallelDims(dp_replicate=3, dp_shard=-1, cp=1, pp=1, ep=1, world_size=8)
+    c = TrainerConfig.model_validate(dict(model=dict(cp=2, seq_len=2050)))
+    with pytest.raises(ValueError, match="seq_len_divisor"):
+        get_parallel_dims(c.model, c.model.seq_len, world_size=8)
+    assert get_parallel_dims(TrainerConfig().model, 2048, world_size=1).dp_size == 1
+
+
+def test_model_name_resolution(tmp_path):
+    import json
+
+    from prime_rl_amd.trainer.model import resolve_model_dims
+
+    c = TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen3-8B", debug=dict(num_layers=2))))
+    d = resolve_model_dims(c.model)
+    assert (d.hidden_size, d.num_hidden_layers, d.vocab_size, d.num_attention_heads, d.num_key_value_heads) == (4096, 2, 151936, 32, 8)
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="qwen3", vocab_size=1000, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
+                                                          num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-6, rope_theta=1e6,
+                                                          tie_word_embeddings=True)))
+    d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+    assert (d.vocab_size, d.num_hidden_layers, d.tie_word_embeddings) == (1000, 3, True)
+    with pytest.raises(ValueError):
+        resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="meta-llama/Nope"))).model)

@@ -293,17 +293,22 @@ def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
     import json
     import re
 
-    from prime_rl_amd.trainer.rl.data import FakeDataLoaderConfig
-    from prime_rl_amd.trainer.rl.train import TrainerConfig, train
+    from prime_rl_amd.configs.trainer import parse_argv
+    from prime_rl_amd.trainer.rl.train import train
 
-    cfg = TrainerConfig(model="tiny", seq_len=128, max_steps=2, output_dir=str(tmp_path), fake_data=FakeDataLoaderConfig(batch_size=3, generate_samples=True),
-                        tokens_per_pass=256)
+    # the reference's launch grammar: `@ file.toml` + dotted overrides (configs/debug/fake/rl.toml has exactly these tables)
+    toml = tmp_path / "rl.toml"
+    toml.write_text('max_steps = 2\n\n[data.fake]\nbatch_size = 3\ngenerate_samples = true\n\n[model]\nseq_len = 128\ncompile = "None"\n')
+    cfg = parse_argv(["@", str(toml), "--model.name", "tiny", "--model.debug.random-init", "--output-dir", str(tmp_path), "--tokens-per-pass", "256",
+                      "--monitors.file.path", "metrics.jsonl", "--model.ac", "--dist-timeout-seconds", "600"])
+    assert cfg.model.compile is None and cfg.model.ac is not None and cfg.data.fake.batch_size == 3
     hist = train(cfg)
     assert len(hist) == 2
     for key in ("perf/throughput", "perf/mfu", "perf/peak_memory", "optim/lr", "optim/grad_norm", "time/step", "time/forward_backward", "time/broadcast_weights",
                 "loss/mean", "entropy/all/mean", "entropy/all/median", "mismatch_kl/all/max", "is_masked/mean", "masked_mismatch_kl/std", "kl_ent_ratio/mean"):
         assert key in hist[0], key
-    assert all(math.isfinite(v) for v in hist[1].values())
+    assert all(math.isfinite(hist[1][k]) for k in ("loss/mean", "loss/std", "entropy/all/std", "mismatch_kl/all/median", "optim/grad_norm", "perf/mfu"))
+    assert any(k.startswith("entropy/") and not k.startswith("entropy/all/") for k in hist[1])  # per-env keys (train.py:486-494)
     out = capsys.readouterr().out
     assert re.search(r"Step 2 \| Time: .* \| Loss: .* \| Entropy: .* \| Mismatch KL: .* \| Grad\. Norm: .* \| LR: .* \| Throughput: .* tokens/s \| MFU: .*% \| Peak Mem\.: .* GiB", out)
     for step in (1, 2):  # keep=2: step_0 (startup policy) is already rotated out

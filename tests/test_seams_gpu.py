@@ -224,12 +224,12 @@ def _episode(rewards, n_out=None):
     return [SimpleEpisode([t]) for t in traces]
 
 
-def test_grpo_algorithm_plugin():
+def test_grpo_algorithm_plugin(device="cuda"):
     import asyncio
 
     from prime_rl_amd.orchestrator.algo import ALGORITHM_CLASSES, GRPOAlgoConfig, LengthPenaltyConfig, build_algorithm
 
-    algo = build_algorithm(GRPOAlgoConfig())
+    algo = build_algorithm(GRPOAlgoConfig(), device=device)
     eps = _episode([1.0, 0.0, 0.0, 1.0, 1.0])
     asyncio.run(algo.finalize_group(eps))
     advs = [e.traces[0].nodes[0].advantages[0] for e in eps]
@@ -237,7 +237,7 @@ def test_grpo_algorithm_plugin():
     single = _episode([0.7])
     asyncio.run(algo.finalize_group(single))
     assert single[0].traces[0].nodes[0].advantages == [0.0] * 4  # singleton group -> zero
-    mx = ALGORITHM_CLASSES["max_rl"]()
+    mx = ALGORITHM_CLASSES["max_rl"](device=device)
     eps = _episode([1.0, 0.0, 0.0, 0.0])
     asyncio.run(mx.finalize_group(eps))
     assert [e.traces[0].nodes[0].advantages[0] for e in eps] == pytest.approx([3.0, -1.0, -1.0, -1.0])
@@ -245,7 +245,7 @@ def test_grpo_algorithm_plugin():
     asyncio.run(mx.finalize_group(eps))
     assert [e.traces[0].nodes[0].advantages[0] for e in eps] == [0.0, 0.0, 0.0]
     # length penalty monotonicity (:198-240): equal rewards, longer outputs get lower advantages; many groups in one launch
-    lp = build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig()))
+    lp = build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig()), device=device)
     g1, g2 = _episode([1.0, 1.0, 1.0], n_out=[10, 100, 1000]), _episode([1.0, 0.0], n_out=[5, 5])
     lp.score_groups([g1, g2])
     a = [e.traces[0].nodes[0].advantages[0] for e in g1]
@@ -254,7 +254,7 @@ def test_grpo_algorithm_plugin():
     assert abs(sum(b)) < 1e-6 and b[0] > 0 > b[1]
 
 
-def test_length_penalty_terms_like_the_reference():
+def test_length_penalty_terms_like_the_reference(device="cuda"):
     """The remaining properties of tests/unit/orchestrator/test_advantage.py:184-240 on pm_grpo_advantage: MaxRL all-success groups
     center to zero; equal lengths/turns reduce the linear penalty to plain GRPO; the context term penalises non-completion tokens
     (total - output), the turns term higher turn counts; advantages stay zero-mean."""
@@ -275,25 +275,25 @@ def test_length_penalty_terms_like_the_reference():
         asyncio.run(algo.finalize_group(eps))
         return [e.traces[0].nodes[0].advantages[0] for e in eps]
 
-    assert run(ALGORITHM_CLASSES["max_rl"](), group([1.0, 1.0], [5, 5])) == pytest.approx([0.0, 0.0])
-    plain = run(build_algorithm(GRPOAlgoConfig()), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
-    shaped = run(build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig())), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
+    assert run(ALGORITHM_CLASSES["max_rl"](device=device), group([1.0, 1.0], [5, 5])) == pytest.approx([0.0, 0.0])
+    plain = run(build_algorithm(GRPOAlgoConfig(), device=device), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
+    shaped = run(build_algorithm(GRPOAlgoConfig(length_penalty=LengthPenaltyConfig()), device=device), group([1.0, 0.0, 1.0], [10, 10, 10], turns=[2, 2, 2]))
     assert shaped == pytest.approx(plain, abs=1e-6)
     ctx = LengthPenaltyConfig(num_output_tokens_weight=0.0, num_input_tokens_weight=0.25, num_turns_weight=0.0)
-    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=ctx)), group([1.0, 1.0], [10, 10], total=[12, 112]))
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=ctx), device=device), group([1.0, 1.0], [10, 10], total=[12, 112]))
     assert a[0] > a[1] and abs(sum(a)) < 1e-6
     trn = LengthPenaltyConfig(num_output_tokens_weight=0.0, num_input_tokens_weight=0.0, num_turns_weight=0.25)
-    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=trn)), group([1.0, 1.0], [100, 100], turns=[1, 4]))
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=trn), device=device), group([1.0, 1.0], [100, 100], turns=[1, 4]))
     assert a[0] > a[1] and abs(sum(a)) < 1e-6
     # exact value of the completion-only penalty: shaped_i = r_i - mean * w * out_i / max(out); advantages = shaped - mean(shaped)
     cmp_ = LengthPenaltyConfig(num_output_tokens_weight=0.25, num_input_tokens_weight=0.0, num_turns_weight=0.0)
-    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=cmp_)), group([1.0, 1.0, 1.0], [10, 20, 30]))
+    a = run(build_algorithm(GRPOAlgoConfig(length_penalty=cmp_), device=device), group([1.0, 1.0, 1.0], [10, 20, 30]))
     shaped_ref = [1.0 - 0.25 * x / 30 for x in (10, 20, 30)]
     mean_ref = sum(shaped_ref) / 3
     assert a == pytest.approx([s - mean_ref for s in shaped_ref], abs=1e-6)
 
 
-def test_hierarchical_grpo_peer_sets():
+def test_hierarchical_grpo_peer_sets(device="cuda"):
     """hierarchical_grpo.py:33-42: solver traces are centered per episode, proposer traces across the cohort, singletons get zero —
     all peer sets in one pm_grpo_advantage launch; checked against the plain restatement."""
     import asyncio
@@ -307,7 +307,7 @@ def test_hierarchical_grpo_peer_sets():
     eps = [SimpleEpisode([tr("p0", "proposer", 0.2), tr("s00", "solver", 1.0), tr("s01", "solver", 0.0), tr("s02", "solver", 0.0)], id="e0"),
            SimpleEpisode([tr("p1", "proposer", 0.8), tr("s10", "solver", 1.0), tr("s11", "solver", 1.0)], id="e1"),
            SimpleEpisode([tr("p2", "proposer", 0.5), tr("s20", "solver", 0.3)], id="e2")]
-    asyncio.run(build_algorithm(HierarchicalGRPOAlgoConfig(episode_agents=["solver"])).finalize_group(eps))
+    asyncio.run(build_algorithm(HierarchicalGRPOAlgoConfig(episode_agents=["solver"]), device=device).finalize_group(eps))
     got = {t.id: t.nodes[0].advantages for e in eps for t in e.traces}
     want = {"p0": 0.2 - 0.5, "p1": 0.8 - 0.5, "p2": 0.0, "s00": 1 - 1 / 3, "s01": -1 / 3, "s02": -1 / 3, "s10": 0.0, "s11": 0.0, "s20": 0.0}
     for k, v in want.items():

@@ -1,4 +1,4 @@
-"""CPU suite (gloo, 2 trainers + 1 inference rank): the sharded weight push delivers every HF-named parameter bit-exactly
+"""CPU suite (gloo, 2 trainers + 2 inference ranks): the weight push (sharded multi-source protocol and the reference's byte protocol) delivers every HF-named parameter bit-exactly
 ("bytes in == bytes out" is the only property the reference's skipped test_nccl_broadcast.py states), follows the
 STABLE -> NCCL_READY rendezvous, and the filesystem transport writes a loadable checkpoint + marker."""
 
@@ -18,45 +18,126 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+N_TR, N_INF = 2, 2
+
+
+class _FakeVllmModel:
+    """What the worker extension hands the stream to: vLLM models expose `load_weights(iterable of (name, tensor))`."""
+
+    def __init__(self):
+        self.loaded: dict = {}
+
+    def load_weights(self, it):
+        for name, t in it:
+            self.loaded[name] = t.clone()
+
+
+def _worker(rank, world, port, out_dir, protocol):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prime_rl_amd.comm import TorchGroupCommunicator
     from prime_rl_amd.trainer.engine import ModelDims, ParamStore
-    from prime_rl_amd.transports.weights import NCCL_READY_MARKER, RCCLWeightBroadcast, RCCLWeightReceiver, init_push_groups
+    from prime_rl_amd.transports.weights import NCCL_READY_MARKER, RCCLWeightBroadcast, RCCLWeightReceiver
 
-    n_tr, n_inf = 2, 1
-    groups = init_push_groups(n_tr, n_inf)
+    # push world: trainer ranks first, then the inference ranks.  The reference protocol runs on {trainer master} + inference ranks.
+    if protocol == "reference":
+        members = [0] + list(range(N_TR, N_TR + N_INF))
+        grp = dist.new_group(members)
+        comm = TorchGroupCommunicator(grp) if rank in members else None
+    else:
+        comm = TorchGroupCommunicator(None)
+    trainers = dist.new_group(list(range(N_TR)))
     out = Path(out_dir)
     step_dir = out / "broadcasts" / "step_7"
-    if rank < n_tr:
-        store = ParamStore(ModelDims.tiny(layers=2, vocab=320), "cpu", dp_rank=rank, dp_size=n_tr)
+    if rank < N_TR:
+        store = ParamStore(ModelDims.tiny(layers=2, vocab=320), "cpu", dp_rank=rank, dp_size=N_TR)
         store.random_init(seed=11)
         if rank == 0:
             torch.save({k: v.clone() for k, v in store.state_dict().items()}, out / "sent.pt")
-        RCCLWeightBroadcast(out, rank, n_tr, groups, ready_timeout=60).broadcast_weights(store, 7)
+        RCCLWeightBroadcast(out, comm, rank, N_TR, N_INF, protocol=protocol, ready_timeout=60, trainer_group=trainers).broadcast_weights(store, 7)
     else:
         t0 = time.time()
         while not (step_dir / "STABLE").exists():  # the orchestrator's WeightWatcher polls this marker (watcher.py:91-158)
             time.sleep(0.05)
             assert time.time() - t0 < 60
-        (step_dir / NCCL_READY_MARKER).touch()  # inference engines are paused and listening
-        got = {name: t.clone() for name, t in RCCLWeightReceiver(n_tr, groups, "cpu").receive_state_dict(step_dir)}
-        torch.save(got, out / "received.pt")
+        if rank == N_TR:
+            (step_dir / NCCL_READY_MARKER).touch()  # inference engines are paused and listening
+        if rank == N_TR:  # plain receiver
+            got = {name: t.clone() for name, t in RCCLWeightReceiver(comm, N_TR, "cpu", protocol).receive_state_dict(step_dir)}
+        else:  # the vLLM-worker-extension-shaped receiver, minus the communicator bootstrap (raw RCCL: GPU suite)
+            from types import SimpleNamespace
+
+            from prime_rl_amd.inference.vllm.worker.rccl import RCCLWeightUpdateWorker
+
+            w = RCCLWeightUpdateWorker()
+            w.device, w.model_runner = torch.device("cpu"), SimpleNamespace(model=_FakeVllmModel())
+            w.rccl_weight_receiver = RCCLWeightReceiver(comm, N_TR, "cpu", protocol)
+            assert w.liveness_probe() is None
+            w.update_weights_from_path(str(step_dir))
+            got = w.model_runner.model.loaded
+        torch.save(got, out / f"received_{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_push_round_trip(tmp_path):
-    mp.start_processes(_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True, start_method="spawn")
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("protocol", ["sharded", "reference"])
+def test_push_round_trip(tmp_path, protocol):
+    """2 trainer ranks + 2 inference ranks over gloo: both inference ranks (a plain receiver and the worker-extension-shaped one) end up
+    with every HF-named parameter bit-exactly, in checkpoint order."""
+    world = N_TR + N_INF
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), protocol), nprocs=world, join=True, start_method="spawn")
     sent = torch.load(tmp_path / "sent.pt")
-    got = torch.load(tmp_path / "received.pt")
-    assert set(sent) == set(got) and "model.layers.1.self_attn.k_proj.weight" in got and "lm_head.weight" in got
-    for k in sent:
-        assert got[k].shape == sent[k].shape and torch.equal(got[k], sent[k]), k
+    for r in range(N_TR, world):
+        got = torch.load(tmp_path / f"received_{r}.pt")
+        assert set(sent) == set(got) and "model.layers.1.self_attn.k_proj.weight" in got and "lm_head.weight" in got
+        for k in sent:
+            assert got[k].shape == sent[k].shape and torch.equal(got[k], sent[k]), k
+        names = list(got)
+        if protocol == "sharded":  # bucket order on the wire: embed, layers ascending, head
+            assert names[0] == "model.embed_tokens.weight" and names[-1] == "lm_head.weight"
+        else:  # the reference's order: the non-layer state dict first, then layer 0, 1, ... (nccl.py:70-84)
+            first_layer = next(i for i, n in enumerate(names) if n.startswith("model.layers."))
+            assert all(not n.startswith("model.layers.") for n in names[:first_layer]) and all(n.startswith("model.layers.") for n in names[first_layer:])
+            assert [n for n in names if n.startswith("model.layers.0.")] and names.index("model.layers.0.mlp.up_proj.weight") < names.index("model.layers.1.mlp.up_proj.weight")
     assert (tmp_path / "broadcasts" / "step_7" / "STABLE").exists() and (tmp_path / "broadcasts" / "step_7" / "LAYOUT.json").exists()
-    # layer order on the wire: non-layer (embed) first, then layers ascending, head last
-    names = list(got)
-    assert names[0] == "model.embed_tokens.weight" and names[-1] == "lm_head.weight"
+
+
+def test_reference_protocol_stream_is_the_reference_byte_layout():
+    """The 'reference' protocol's stream, field by field: i64 count, then per state dict i64 pickle length, the
+    pickled {dtype: [(key, shape, numel)]} and one flat tensor per dtype — recorded from the sender through a loop-back communicator."""
+    import pickle
+
+    from prime_rl_amd.transports.weights import receive_reference_protocol, send_reference_protocol
+
+    class Tape:
+        def __init__(self):
+            self.sent, self.i = [], 0
+
+        def broadcast(self, t, src):
+            assert src == 0
+            if self.i < len(self.sent):  # replay
+                t.copy_(self.sent[self.i].view(t.dtype).reshape(t.shape))
+            else:
+                self.sent.append(t.clone())
+            self.i += 1
+
+    sd = {"lm_head.weight": torch.arange(6, dtype=torch.bfloat16).view(2, 3), "model.norm.weight": torch.ones(3, dtype=torch.bfloat16),
+          "model.layers.0.a": torch.full((2, 2), 2.0, dtype=torch.bfloat16), "model.layers.0.b": torch.arange(3, dtype=torch.float32),
+          "model.layers.1.a": torch.full((2, 2), 3.0, dtype=torch.bfloat16)}
+    tape = Tape()
+    send_reference_protocol(tape, sd, "cpu")
+    assert tape.sent[0].dtype == torch.int64 and tape.sent[0].tolist() == [3]  # non-layer + 2 layers (nccl.py:147-150)
+    assert tape.sent[1].dtype == torch.int64 and tape.sent[2].dtype == torch.uint8 and tape.sent[2].numel() == int(tape.sent[1])
+    meta = pickle.loads(bytes(tape.sent[2].numpy()))
+    assert meta == {torch.bfloat16: [("lm_head.weight", torch.Size([2, 3]), 6), ("model.norm.weight", torch.Size([3]), 3)]}
+    assert tape.sent[3].dtype == torch.bfloat16 and tape.sent[3].numel() == 9  # one flat tensor per dtype (nccl.py:59-63)
+    n_sent = len(tape.sent)
+    tape.i = 0
+    got = dict(receive_reference_protocol(tape, "cpu"))
+    assert tape.i == n_sent and set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
 
 
 def test_filesystem_broadcast(tmp_path):
