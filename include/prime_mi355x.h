@@ -93,6 +93,32 @@ int pm_logprob_chunk_bwd(const void* logits_chunk, int dtype, int64_t n_rows, in
                          const float* grad_logprobs, void* dlogits, int dlogits_dtype, int64_t dlogits_stride, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * J1. Fused LM head: logits = hidden . W^T on the MFMA units with the K1 epilogue applied to the accumulator tile — the [N, V]
+ *     logits never reach HBM.  Replaces FusedOutputLinear.forward / _SequenceChunkedLogProbEntropyFn
+ *     (trainer/models/layers/lm_head.py:42-62, 89-156: 19 chunk GEMMs + ~10 elementwise passes over every chunk) and the
+ *     recompute + dlogits part of its backward (lm_head.py:158-191); the two gradient GEMMs (:193-199) stay library calls on the
+ *     dlogits this writes.
+ *
+ *     hidden [n_tokens, hidden] bf16, weight [vocab, hidden] bf16 (both row-major, K-contiguous: no transposed copy of the head);
+ *     hidden % 64 == 0.  round_logits_bf16 != 0 rounds the GEMM result to bf16 before the f32 epilogue (the reference's bf16
+ *     `hidden_chunk @ w_chunk.t()`, lm_head.py:133); 0 keeps the f32 accumulator.
+ *     fwd: logprobs / entropy / logz [n_tokens] f32 as K1.  logits_out (nullable): also store the raw (unscaled) bf16 logits,
+ *          row stride logits_ld — for callers that prefer keeping logits to recomputing them in backward.
+ *     bwd: dlogits[n, v] = grad_logprobs[n] * inv_temp[n] * ([v == label[n]] - exp(l[n, v] * inv_temp[n] - logz[n])) as bf16 with
+ *          row stride dlogits_ld (a multiple of 4); logits are recomputed on the fly.
+ *     workspace (fwd): pm_lmhead_workspace_bytes(n_tokens, vocab): per-token partial online-softmax states.
+ * ------------------------------------------------------------------------------------------ */
+int64_t pm_lmhead_workspace_bytes(int64_t n_tokens, int64_t vocab);
+int pm_lmhead_logprob_fwd(const void* hidden_bf16, const void* weight_bf16, int64_t n_tokens, int64_t hidden, int64_t vocab,
+                          const int64_t* labels, const float* inv_temp, int32_t round_logits_bf16,
+                          float* logprobs, float* entropy, float* logz,
+                          void* logits_out_bf16 /* nullable */, int64_t logits_ld,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+int pm_lmhead_logprob_bwd(const void* hidden_bf16, const void* weight_bf16, int64_t n_tokens, int64_t hidden, int64_t vocab,
+                          const int64_t* labels, const float* inv_temp, const float* logz, const float* grad_logprobs,
+                          int32_t round_logits_bf16, void* dlogits_bf16, int64_t dlogits_ld, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * K3. Group-relative advantage — GRPOAlgorithm.score_group (orchestrator/algo/grpo.py:25-45),
  *     MaxRLAlgorithm.score_group (algo/max_rl.py:22-28).
  *     rewards: flat [n_rollouts]; group g owns rollouts [group_offsets[g], group_offsets[g+1]).

@@ -73,6 +73,9 @@ SIGNATURES: dict[str, tuple] = {
     "pm_logprob_chunk_update": (I, [P, I, I64, I64, I64, I64, P, P, P, P, P, P, P]),
     "pm_logprob_chunk_finalize": (I, [P, P, P, P, I64, P, P, P, P]),
     "pm_logprob_chunk_bwd": (I, [P, I, I64, I64, I64, I64, P, P, P, P, P, I, I64, P]),
+    "pm_lmhead_workspace_bytes": (I64, [I64, I64]),
+    "pm_lmhead_logprob_fwd": (I, [P, P, I64, I64, I64, P, P, I32, P, P, P, P, I64, P, I64, P]),
+    "pm_lmhead_logprob_bwd": (I, [P, P, I64, I64, I64, P, P, P, P, I32, P, I64, P]),
     "pm_grpo_advantage": (I, [P, P, I32, I, P, P, P, F, F, F, P, P]),
     "pm_advantage_broadcast": (I, [P, P, I32, P, P, I64, P]),
     "pm_grpo_loss_fwd_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I32, I64, POINTER(LossParams), P, P, P, P, P]),

@@ -131,6 +131,57 @@ class ChunkedLogprobState:
         return out[0], out[1], out[2]
 
 
+# ------------------------------------------------------------------------------------------------ J1
+def lmhead_logprob_fwd(hidden: Tensor, weight: Tensor, labels: Tensor, inv_temp: Tensor, round_logits_bf16: bool = True,
+                       logits_out: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor]:
+    """Fused LM head forward (pm_lmhead_logprob_fwd): hidden [N, H] bf16, weight [V, H] bf16 -> (logprobs, entropy, logz) f32 [N];
+    the logits only ever exist as MFMA accumulator tiles.  `logits_out` ([N, >=V] bf16, unit inner stride) optionally receives them."""
+    lib = _lib.load()
+    _req(hidden, torch.bfloat16, "hidden"); _req(weight, torch.bfloat16, "weight")
+    _req(labels, torch.int64, "labels"); _req(inv_temp, torch.float32, "inv_temp")
+    if hidden.dim() != 2 or weight.dim() != 2 or hidden.shape[1] != weight.shape[1]:
+        raise PrimeMI355XError(f"lmhead: hidden {tuple(hidden.shape)} / weight {tuple(weight.shape)} mismatch")
+    n, h = hidden.shape
+    v = weight.shape[0]
+    if labels.numel() != n or inv_temp.numel() != n:
+        raise PrimeMI355XError("labels / inv_temp length must equal the number of hidden rows")
+    out = torch.empty((3, n), dtype=torch.float32, device=hidden.device)
+    if n == 0:
+        return out[0], out[1], out[2]
+    ld = 0
+    if logits_out is not None:
+        _req(logits_out, torch.bfloat16, "logits_out", contiguous=False)
+        if logits_out.dim() != 2 or logits_out.shape[0] != n or logits_out.shape[1] != v or logits_out.stride(1) != 1:
+            raise PrimeMI355XError("logits_out must be [N, V] bf16 with unit inner stride")
+        ld = logits_out.stride(0)
+    ws = workspace(lib.pm_lmhead_workspace_bytes(n, v), hidden.device, "lmhead")
+    check(lib.pm_lmhead_logprob_fwd(_p(hidden), _p(weight), n, h, v, _p(labels), _p(inv_temp), 1 if round_logits_bf16 else 0, _p(out[0]), _p(out[1]),
+                                    _p(out[2]), _p(logits_out), ld, _p(ws), ws.numel(), _stream()), "pm_lmhead_logprob_fwd")
+    return out[0], out[1], out[2]
+
+
+def lmhead_logprob_bwd(hidden: Tensor, weight: Tensor, labels: Tensor, inv_temp: Tensor, logz: Tensor, grad_logprobs: Tensor,
+                       round_logits_bf16: bool = True, out: Tensor | None = None) -> Tensor:
+    """dlogits [N, V] bf16 = g * inv_T * (onehot(label) - softmax), logits recomputed on the MFMA units (pm_lmhead_logprob_bwd)."""
+    lib = _lib.load()
+    _req(hidden, torch.bfloat16, "hidden"); _req(weight, torch.bfloat16, "weight")
+    for t, nm in ((labels, "labels"),):
+        _req(t, torch.int64, nm)
+    for t, nm in ((inv_temp, "inv_temp"), (logz, "logz"), (grad_logprobs, "grad_logprobs")):
+        _req(t, torch.float32, nm)
+    n, h = hidden.shape
+    v = weight.shape[0]
+    if out is None:
+        out = torch.empty((n, (v + 7) // 8 * 8), dtype=torch.bfloat16, device=hidden.device)[:, :v]
+    _req(out, torch.bfloat16, "dlogits", contiguous=False)
+    if out.shape != (n, v) or out.stride(1) != 1:
+        raise PrimeMI355XError("dlogits must be [N, V] bf16 with unit inner stride")
+    if n:
+        check(lib.pm_lmhead_logprob_bwd(_p(hidden), _p(weight), n, h, v, _p(labels), _p(inv_temp), _p(logz), _p(grad_logprobs),
+                                        1 if round_logits_bf16 else 0, _p(out), out.stride(0), _stream()), "pm_lmhead_logprob_bwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ K3
 def grpo_advantage(rewards: Tensor, group_offsets: Tensor, mode: int = _lib.PM_ADV_GRPO, num_output_tokens: Tensor | None = None,
                    num_total_tokens: Tensor | None = None, num_turns: Tensor | None = None,

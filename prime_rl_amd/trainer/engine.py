@@ -359,7 +359,7 @@ class GRPOEngine:
     def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
-                 cp_group: dist.ProcessGroup | None = None, cp_size: int = 1):
+                 cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -410,6 +410,15 @@ class GRPOEngine:
             for nm, (o, k) in mats:
                 self._wt[nm] = slab[cursor:cursor + o * k].view(k, o)
                 cursor += o * k
+        # LM head: "library" = hipBLASLt logits [N, V] bf16 in HBM -> K1 (kept for backward, overwritten in place by dlogits);
+        # "fused" = J1 (csrc/lmhead.hip): GEMM tile + log-prob epilogue in one kernel, no logits in HBM, backward recomputes them on the
+        # MFMA units per token chunk.  The default is whichever measured faster for the step (profiles/: the library GEMM runs at
+        # ~1.45 PFLOP/s, J1 at ~0.95, and the fused form pays a second GEMM in backward) — "fused" trades ~25 ms/step for 5 GB at 16k tokens.
+        self.lm_head_impl = lm_head_impl or os.environ.get("PM_LM_HEAD", "library")
+        if self.lm_head_impl not in ("library", "fused"):
+            raise PrimeMI355XError(f"lm_head_impl must be 'library' or 'fused', got {self.lm_head_impl!r}")
+        if self.lm_head_impl == "fused" and (self.gemm_f32 or dims.hidden_size % 64):
+            raise PrimeMI355XError("the fused LM head is a bf16 MFMA kernel (hidden size a multiple of 64)")
         self.k1_events: list | None = None
         self._param_readers: list = []  # events of asynchronous readers of store.params (the weight push): waited for before AdamW rewrites them
 
@@ -522,6 +531,10 @@ class GRPOEngine:
         chunks = []
         for s in range(0, n, self.lm_head_token_chunk):
             e = min(s + self.lm_head_token_chunk, n)
+            if self.lm_head_impl == "fused":
+                logprobs[s:e], entropy[s:e], logz[s:e] = ops.lmhead_logprob_fwd(hf[s:e], wh, b.labels[s:e], b.inv_temp[s:e])
+                chunks.append((s, e, None))
+                continue
             logits = self._fwd_mm(hf[s:e], wh, out_f32=self.gemm_f32)
             if self.k1_events is not None:  # HIP events on the launch stream around the log-prob kernel (bench.py roofline)
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -562,8 +575,18 @@ class GRPOEngine:
         if head_t and self._wt_version.get("head") != self.store.version:
             ops.transpose_2d(wh, out=self._wt["head"])
             self._wt_version["head"] = self.store.version
+        fused_chunk = 8192  # tokens per recompute + dlogits pass of the fused head (2.5 GB of bf16 dlogits at the Qwen3 vocab)
+        todo = []
         for s, e, logits in ctx["logits_chunks"]:
-            dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
+            if logits is None:
+                todo += [(s0, min(s0 + fused_chunk, e), None) for s0 in range(s, e, fused_chunk)]
+            else:
+                todo.append((s, e, logits))
+        for s, e, logits in todo:
+            if logits is None:
+                dl = ops.lmhead_logprob_bwd(hf[s:e], wh, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e])
+            else:
+                dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
             if self.gemm_f32:
                 dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
             elif head_t:

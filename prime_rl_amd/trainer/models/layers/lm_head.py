@@ -60,7 +60,18 @@ class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
         logz = torch.empty_like(logprobs)
         labels = labels.contiguous()
         inv_t = inv_temperature.contiguous().float()
-        for start in range(0, n, chunk_size):
+        # bf16 operands (the trainer's case): J1 — GEMM tile + log-prob epilogue in ONE kernel per token chunk, logits stay in the MFMA
+        # accumulators (csrc/lmhead.hip).  Other dtypes (the reference's fp32 unit-test case): library GEMM per vocab chunk + the
+        # online-state kernels below.
+        fused = hidden.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and hidden.shape[1] % 64 == 0
+        ctx.fused = fused
+        for start in range(0, n, chunk_size if not fused else n):
+            if fused:
+                for s0 in range(0, n, chunk_size):
+                    s1 = min(s0 + chunk_size, n)
+                    lp, en, lz = ops.lmhead_logprob_fwd(hidden[s0:s1].contiguous(), weight.contiguous(), labels[s0:s1], inv_t[s0:s1])
+                    logprobs[s0:s1], entropy[s0:s1], logz[s0:s1] = lp, en, lz
+                break
             end = min(start + chunk_size, n)
             state = ops.ChunkedLogprobState(end - start, dev)
             lab, it = labels[start:end], inv_t[start:end]
@@ -90,6 +101,13 @@ class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
         for start in range(0, n, chunk_size):
             end = min(start + chunk_size, n)
             h = hidden[start:end]
+            if ctx.fused:  # J1 backward: logits recomputed on the MFMA units, dlogits written once (bf16), then the two gradient GEMMs
+                dl = ops.lmhead_logprob_bwd(h.contiguous(), weight.contiguous(), labels[start:end], inv_t[start:end], logz[start:end], g[start:end])
+                if needs_hidden:
+                    torch.mm(dl, weight, out=grad_hidden[start:end])
+                if needs_weight:
+                    grad_weight.addmm_(dl.t(), h)
+                continue
             for v0 in range(0, vocab, vchunk):
                 v1 = min(v0 + vchunk, vocab)
                 w = weight[v0:v1]

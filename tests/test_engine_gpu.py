@@ -287,6 +287,25 @@ def test_gemm_layout_copies_track_parameter_updates():
     assert len(a._wt) == 4 * dims.num_hidden_layers + 1 and not b._wt  # four projections per layer + the LM head
 
 
+def test_fused_lm_head_engine_equals_library_engine():
+    """lm_head_impl="fused" (J1: no logits in HBM, backward recomputes them on the MFMA units) against the library path (hipBLASLt logits
+    + K1) on the same weights and batch: same log-probs / entropy / loss to bf16-GEMM rounding, same gradients, same update."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=3000)  # vocab no multiple of the 128-wide tile
+    optim = OptimConfig(lr=1e-3)
+    lib_e = GRPOEngine(dims, device=DEV, optim=optim, seed=21, lm_head_impl="library")
+    fus_e = GRPOEngine(dims, device=DEV, optim=optim, seed=21, lm_head_impl="fused")
+    batch = pack_micro_batches(_mbs(dims.vocab_size, 192, 3, True), DEV)
+    ra, rb = lib_e.step(batch), fus_e.step(batch)
+    torch.testing.assert_close(rb["logprobs"][0], ra["logprobs"][0], rtol=1e-3, atol=4e-2)
+    torch.testing.assert_close(rb["entropy"][0], ra["entropy"][0], rtol=1e-3, atol=5e-3)
+    assert abs(ra["loss"][0].item() - rb["loss"][0].item()) <= 1e-4
+    rel = ((lib_e.store.main_grad - fus_e.store.main_grad).norm() / lib_e.store.main_grad.norm()).item()
+    assert rel < 2e-2, rel
+    assert abs(ra["grad_norm"].item() - rb["grad_norm"].item()) <= 1e-2 * ra["grad_norm"].item()
+
+
 def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
     """train(config) end to end on the tiny model: reference step/version indexing (startup v0 + one broadcast per step), the
     console line and metric keys dashboards regex, metrics.jsonl."""

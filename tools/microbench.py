@@ -166,9 +166,42 @@ def bench_gemm(out):
         torch.cuda.empty_cache()
 
 
+def bench_lmhead(out, n=16384, h=4096, v=151936):
+    """J1 (fused MFMA LM head) against the library path it can replace: hipBLASLt GEMM -> bf16 logits in HBM -> K1."""
+    hidden = torch.randn(n, h, device=DEV).to(torch.bfloat16)
+    weight = (torch.randn(v, h, device=DEV) * 0.02).to(torch.bfloat16)
+    labels = torch.randint(0, v, (n,), device=DEV)
+    inv_t = torch.ones(n, device=DEV)
+    flop = 2.0 * n * v * h
+    med, best = timeit(lambda: ops.lmhead_logprob_fwd(hidden, weight, labels, inv_t), iters=8, warmup=2)
+    out.append(dict(kernel=f"J1 lmhead_logprob_fwd n={n}", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    store = torch.empty(n, v, dtype=torch.bfloat16, device=DEV)
+    med, best = timeit(lambda: ops.lmhead_logprob_fwd(hidden, weight, labels, inv_t, logits_out=store), iters=8, warmup=2)
+    out.append(dict(kernel="J1 fwd + logits store", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    _, _, logz = ops.lmhead_logprob_fwd(hidden, weight, labels, inv_t)
+    g = torch.randn(n, device=DEV)
+    med, best = timeit(lambda: ops.lmhead_logprob_bwd(hidden, weight, labels, inv_t, logz, g, out=store), iters=8, warmup=2)
+    out.append(dict(kernel="J1 lmhead_logprob_bwd (recompute + dlogits)", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+
+    def lib():
+        torch.mm(hidden, weight.t(), out=store)
+        return ops.logprob_entropy_fwd(store, labels, inv_t)
+
+    med, best = timeit(lib, iters=8, warmup=2)
+    out.append(dict(kernel="library: hipBLASLt logits + K1", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    med, best = timeit(lambda: torch.mm(hidden, weight.t(), out=store), iters=8, warmup=2)
+    out.append(dict(kernel="library: hipBLASLt logits only", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    med, best = timeit(lambda: ops.logprob_bwd(store, labels, inv_t, logz, g, out=store), iters=8, warmup=2)
+    out.append(dict(kernel="library path: K1 bwd in place", ms=med * 1e3, best_ms=best * 1e3))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
+    if which == "lmhead":
+        bench_lmhead(out)
+    if which == "lmhead4k":
+        bench_lmhead(out, n=4096)
     if which == "gemm":
         bench_gemm(out)
     if which in ("k1", "all"):
