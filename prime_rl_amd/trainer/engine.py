@@ -393,7 +393,9 @@ class GRPOEngine:
         self.lm_head_token_chunk = lm_head_token_chunk
         self.recompute_act = recompute_act
         self.step_count = 0
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_collectives else None
+        # a dedicated stream for the collectives — on the GPU; the CPU flavour (tests/test_engine_gloo_cpu.py: the SAME engine code over gloo with
+        # stand-in kernels) issues them synchronously
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_collectives and self.device.type == "cuda") else None
         self._gather_events: dict[str, torch.cuda.Event] = {}
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._wgrad_direct = self._probe_wgrad_direct()
@@ -663,7 +665,7 @@ class GRPOEngine:
 
     def _wait_gather(self, name: str) -> None:
         ev = self._gather_events.pop(name, None)
-        if ev is not None:
+        if ev is not None and self.device.type == "cuda":
             torch.cuda.current_stream().wait_event(ev)
 
     # -- optimizer ---------------------------------------------------------------------------------------------------
@@ -676,6 +678,8 @@ class GRPOEngine:
         self.step_count += 1
         self.store.version += 1  # parameters change: derived weight layouts are refreshed on next use
         for ev in self._param_readers:  # an in-flight weight push still reads the parameters this step is about to overwrite
+            if self.device.type != "cuda":
+                break
             torch.cuda.current_stream().wait_event(ev)
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(ev)

@@ -1,0 +1,212 @@
+"""CPU stand-ins for `prime_rl_amd.ops` — TEST INFRASTRUCTURE ONLY (tests/test_engine_gloo_cpu.py).
+
+They let the UNCHANGED GRPOEngine / zero.py code (bucket bookkeeping, scale all-reduce, per-bucket reduce-scatter, sharded clip +
+AdamW, in-place parameter all-gather, multi-pass accumulation) run end to end over gloo at world_size 2 in this GPU-less container,
+so that the first multi-GPU run of the engine is not a debugging session ('Next round' 9).  Every function has the
+signature of its `prime_rl_amd.ops` namesake and is written with plain torch on the oracle's restatements (autograd supplies the
+backward passes).  Nothing here is a fallback of the product: the engine module is pointed at this file by monkeypatching inside the
+test's worker processes only."""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from oracle import grpo_oracle as O
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rope_inv_freq(head_dim, theta, device):
+    return (1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(F32) / head_dim))).to(device)
+
+
+def embedding_fwd(table, ids):
+    return table[ids]
+
+
+def embedding_bwd(grad_out, ids, grad_table_f32):
+    grad_table_f32.index_add_(0, ids.reshape(-1), grad_out.float())
+
+
+def rope_table(position_ids, inv_freq):
+    ang = position_ids.to(F32)[:, None] * inv_freq[None, :]
+    return ang.cos().to(BF16), ang.sin().to(BF16)
+
+
+def seq_start_from_cu(cu_seqlens, n_tokens):
+    lens = (cu_seqlens[1:] - cu_seqlens[:-1]).long()
+    return torch.repeat_interleave(cu_seqlens[:-1], lens, output_size=n_tokens).to(torch.int32)
+
+
+def _rms(x, w, eps):
+    h = x.float()
+    rstd = torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return (w.float() * (h * rstd).to(x.dtype).float()).to(x.dtype), rstd[..., 0]
+
+
+def rmsnorm_fwd(x, weight, eps, residual=None):
+    s = (x.float() + residual.float()).to(BF16) if residual is not None else None
+    y, rstd = _rms(s if s is not None else x, weight, eps)
+    return y, rstd.reshape(-1), s
+
+
+def rmsnorm_bwd(grad_y, x, weight, rstd, grad_weight_f32, dresidual=None):
+    xf = x.float().requires_grad_(True)
+    wf = weight.float().requires_grad_(True)
+    y = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    gx, gw = torch.autograd.grad(y, (xf, wf), grad_y.float())
+    grad_weight_f32 += gw
+    if dresidual is not None:
+        gx = gx + dresidual.float()
+    return gx.to(BF16)
+
+
+def _qk(qkv, qw, kw, cos, sin, hq, hkv, d, eps):
+    n = qkv.shape[0]
+    q = qkv[:, : hq * d].reshape(n, hq, d)
+    k = qkv[:, hq * d: (hq + hkv) * d].reshape(n, hkv, d)
+    c = torch.cat([cos, cos], -1).float()[:, None, :]
+    s = torch.cat([sin, sin], -1).float()[:, None, :]
+
+    def one(x, w):
+        xn = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+        rot = torch.cat([-xn[..., d // 2:], xn[..., : d // 2]], -1)
+        return xn * c + rot * s
+
+    return one(q, qw), one(k, kw)
+
+
+def qknorm_rope_fwd(qkv, q_norm_w, k_norm_w, cos, sin, n_q_heads, n_kv_heads, head_dim, eps):
+    q, k = _qk(qkv.float(), q_norm_w.float(), k_norm_w.float(), cos, sin, n_q_heads, n_kv_heads, head_dim, eps)
+    rstd = torch.zeros(qkv.shape[0], n_q_heads + n_kv_heads)
+    return q.to(BF16), k.to(BF16), rstd
+
+
+def qknorm_rope_bwd(grad_q, grad_k, qkv, q_norm_w, k_norm_w, cos, sin, rstd, grad_qkv, gqw, gkw, n_q_heads, n_kv_heads, head_dim):
+    x = qkv.float().requires_grad_(True)
+    qw, kw = q_norm_w.float().requires_grad_(True), k_norm_w.float().requires_grad_(True)
+    q, k = _qk(x, qw, kw, cos, sin, n_q_heads, n_kv_heads, head_dim, 1e-6)
+    gx, gq, gk = torch.autograd.grad((q, k), (x, qw, kw), (grad_q.float(), grad_k.float()))
+    w = (n_q_heads + n_kv_heads) * head_dim
+    grad_qkv[:, :w] = gx[:, :w].to(BF16)
+    gqw += gq
+    gkw += gk
+
+
+def _seq_lens(seq_start):
+    starts = seq_start.long()
+    n = starts.numel()
+    bounds = torch.unique_consecutive(starts).tolist() + [n]
+    return [b - a for a, b in zip(bounds[:-1], bounds[1:])]
+
+
+def attn_varlen_fwd(q, k, v, seq_start, softmax_scale):
+    o = O.varlen_causal_attention(q.float(), k.float(), v.float(), _seq_lens(seq_start), softmax_scale)
+    return o.to(BF16), torch.zeros(q.shape[1], q.shape[0])
+
+
+def attn_varlen_bwd(grad_out, q, k, v, out, lse, seq_start, softmax_scale, grad_v_out=None):
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    o = O.varlen_causal_attention(qf, kf, vf, _seq_lens(seq_start), softmax_scale)
+    gq, gk, gv = torch.autograd.grad(o, (qf, kf, vf), grad_out.float())
+    if grad_v_out is not None:
+        grad_v_out.copy_(gv.to(BF16))
+    return gq.to(BF16), gk.to(BF16), gv.to(BF16)
+
+
+def swiglu_fwd(gate_up):
+    i = gate_up.shape[1] // 2
+    return (torch.nn.functional.silu(gate_up[:, :i].float()).to(BF16).float() * gate_up[:, i:].float()).to(BF16)
+
+
+def swiglu_bwd(grad_act, gate_up):
+    x = gate_up.float().requires_grad_(True)
+    i = x.shape[1] // 2
+    act = torch.nn.functional.silu(x[:, :i]) * x[:, i:]
+    (g,) = torch.autograd.grad(act, x, grad_act.float())
+    return g.to(BF16)
+
+
+def logprob_entropy_fwd(logits, labels, inv_temp):
+    l = logits.float() * inv_temp[:, None]
+    logz = torch.logsumexp(l, -1)
+    lp = l.gather(-1, labels[:, None])[:, 0] - logz
+    ent = logz - (torch.softmax(l, -1) * l).sum(-1)
+    return lp, ent, logz
+
+
+def logprob_bwd(logits, labels, inv_temp, logz, grad_logprobs, out=None, out_dtype=None, vocab_start=0):
+    l = logits.float() * inv_temp[:, None]
+    p = torch.exp(l - logz[:, None])
+    onehot = torch.zeros_like(p).scatter_(1, labels[:, None], 1.0)
+    d = (grad_logprobs * inv_temp)[:, None] * (onehot - p)
+    if out is None:
+        return d.to(out_dtype or logits.dtype)
+    out.copy_(d.to(out.dtype))
+    return out
+
+
+def lmhead_logprob_fwd(hidden, weight, labels, inv_temp, round_logits_bf16=True, logits_out=None):
+    return logprob_entropy_fwd((hidden.float() @ weight.float().T).to(BF16), labels, inv_temp)
+
+
+def lmhead_logprob_bwd(hidden, weight, labels, inv_temp, logz, grad_logprobs, round_logits_bf16=True, out=None):
+    return logprob_bwd((hidden.float() @ weight.float().T).to(BF16), labels, inv_temp, logz, grad_logprobs, out_dtype=BF16)
+
+
+def grpo_loss_fwd_bwd(trainer_logprobs, inference_logprobs, advantages, loss_mask, cu_samples, params, ref_logprobs=None, rl_weights=None,
+                      ce_weights=None, ref_kl_weights=None, sample_starts_mb=None):
+    """default_loss_fn over the packed pass with the in-kernel shift_tensor_right (K2 with shift=1); only the rl component, which is all
+    the FakeDataLoader batches of the gloo test exercise.  Per-sample stats / metrics are zeros (not under test here)."""
+    assert ref_logprobs is None and rl_weights is None and ce_weights is None and ref_kl_weights is None and params.shift == 1
+    lp = trainer_logprobs.clone().requires_grad_(True)
+    first = cu_samples[:-1][sample_starts_mb.bool()].long() if sample_starts_mb is not None else torch.zeros(1, dtype=torch.long)
+    shifted = torch.roll(lp, 1)
+    pad = torch.zeros_like(shifted)
+    pad[first] = 1.0
+    shifted = shifted * (1 - pad) + params.pad_logprob * pad
+    lr = shifted - inference_logprobs
+    ratio = torch.exp(lr)
+    pd = torch.exp(shifted) - torch.exp(inference_logprobs)
+    invalid = torch.where(advantages > 0, pd > params.dppo_mask_high, pd < -params.dppo_mask_low)
+    keep = loss_mask & ~invalid
+    loss = (-(keep * (params.adv_tau * advantages) * ratio) + params.kl_tau * loss_mask * lr**2).sum() / params.rl_scale
+    (g,) = torch.autograd.grad(loss, lp)
+    s = cu_samples.numel() - 1
+    return loss.detach().reshape(1), g, torch.zeros(s, 20), torch.zeros(s, 12)
+
+
+def transpose_2d(src, out=None):
+    if out is None:
+        return src.t().contiguous()
+    out.copy_(src.t())
+    return out
+
+
+def grad_accumulate(main_grad_f32, grad_bf16):
+    main_grad_f32 += grad_bf16.float()
+
+
+def sumsq_accumulate(x, out_scalar):
+    out_scalar += x.double().pow(2).sum().float()
+
+
+def clip_coef(total_sumsq, grad_scale, max_norm):
+    norm = total_sumsq.sqrt() * grad_scale
+    coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) if max_norm > 0 else torch.ones(1)
+    return coef, norm
+
+
+def adamw_step(master, exp_avg, exp_avg_sq, grad, param_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, clip=None, zero_grad=True):
+    g = grad * grad_scale * (clip if clip is not None else 1.0)
+    master.mul_(1 - lr * weight_decay)
+    exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = (exp_avg_sq / (1 - beta2**step)).sqrt_().add_(eps)
+    master.addcdiv_(exp_avg / (1 - beta1**step), denom, value=-lr)
+    if param_bf16 is not None:
+        param_bf16.copy_(master.to(BF16))
+    if zero_grad:
+        grad.zero_()
