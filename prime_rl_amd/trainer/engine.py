@@ -30,7 +30,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .. import _lib, ops
-from . import zero
+from . import ulysses, zero
 from .._lib import LossParams, PrimeMI355XError
 
 
@@ -359,7 +359,8 @@ class GRPOEngine:
     def __init__(self, dims: ModelDims, device="cuda:0", optim: OptimConfig | None = None, loss: LossConfig | None = None,
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
-                 cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None):
+                 cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
+                 shard_group: dist.ProcessGroup | None = None):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -369,9 +370,9 @@ class GRPOEngine:
         self.gemm_f32 = gemm_dtype == "f32"
         self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
         self.dp_group = dp_group
-        # `dp_size` given (trainer/model.py:setup_engine passes ParallelDims.dp_size): the gradient/optimizer shards span exactly the dp
-        # group.  Not given: the whole default group is the dp group — only right when every rank of it is a trainer rank, so a caller that
-        # shares its default group with inference ranks (the weight-push world) MUST pass dp_group / dp_size explicitly.
+        # `dp_size` given (trainer/model.py:setup_engine passes ParallelDims.dp_size): the data-parallel group is exactly dp_group.  Not given:
+        # the whole default group is the dp group — only right when every rank of it is a trainer rank, so a caller that shares its default
+        # group with other ranks MUST pass dp_group / dp_size explicitly.
         if dp_size is not None:
             self.dp_size = dp_size
             if dp_size > 1 and dist.get_world_size(dp_group) != dp_size:
@@ -379,14 +380,28 @@ class GRPOEngine:
         else:
             self.dp_size = dist.get_world_size(dp_group) if (dp_group is not None or dist.is_initialized()) else 1
         self.dp_rank = dist.get_rank(dp_group) if self.dp_size > 1 else 0
+        # Context parallelism (Ulysses, trainer/ulysses.py): the cp ranks of one dp position see the SAME packed pass, run the token-local
+        # layers on 1/cp of its tokens and exchange heads <-> sequence around attention.  Gradients are partial sums over token shards,
+        # so the ZeRO shard group (reduce-scatter / all-gather / norm all-reduce) is the dp x cp group; token counts and step statistics
+        # are per pass, so they reduce over the dp group only.
         self.cp_group, self.cp_size = cp_group, cp_size
+        self.cp_rank = dist.get_rank(cp_group) if cp_size > 1 else 0
         if cp_size > 1:
-            raise PrimeMI355XError("context parallelism (cp > 1) is SURVEY.md section 8 row f4: not part of this engine yet")
+            if dims.num_attention_heads % cp_size or (dims.num_key_value_heads % cp_size and cp_size % dims.num_key_value_heads):
+                raise PrimeMI355XError(f"cp_size {cp_size} must divide the {dims.num_attention_heads} query heads and divide or be divided by the "
+                                       f"{dims.num_key_value_heads} KV heads (ulysses_attn.py:27-31)")
+            self.shard_group = shard_group
+            self.shard_size = self.dp_size * cp_size
+            if dist.get_world_size(shard_group) != self.shard_size:
+                raise PrimeMI355XError(f"shard_group must hold the dp x cp = {self.shard_size} trainer ranks, got {dist.get_world_size(shard_group)}")
+            self.shard_rank = dist.get_rank(shard_group)
+        else:
+            self.shard_group, self.shard_size, self.shard_rank = self.dp_group, self.dp_size, self.dp_rank
         if dims.head_dim != 128:
             raise PrimeMI355XError("attention kernels are built for head_dim 128")
         if force_collectives and not dist.is_initialized():
             raise PrimeMI355XError("force_collectives needs an initialised process group (a world_size-1 nccl group is enough)")
-        self.store = ParamStore(dims, self.device, self.dp_rank, self.dp_size, force_collectives=force_collectives)
+        self.store = ParamStore(dims, self.device, self.shard_rank, self.shard_size, force_collectives=force_collectives)
         self.use_collectives = self.store.use_collectives
         self.store.random_init(seed)
         self.inv_freq = ops.rope_inv_freq(dims.head_dim, dims.rope_theta, self.device)
@@ -493,12 +508,18 @@ class GRPOEngine:
     # -- forward ----------------------------------------------------------------------------------------------------
     def forward(self, b: PackedBatch) -> dict:
         d, w = self.dims, self.store.w
-        n = b.n_tokens
-        ctx: dict = {"batch": b, "layers": []}
+        n_full = b.n_tokens
+        cp = self.cp_size
+        # context parallel: this rank runs the token-local layers on chunk cp_rank of the pass (utils/cp.py:97-120); attention and the
+        # loss see the full pass
+        tok = (lambda t: t) if cp == 1 else (lambda t: ulysses.shard_for_cp(t, self.cp_rank, cp))
+        ids, labels, inv_temp = tok(b.input_ids), tok(b.labels), tok(b.inv_temp)
+        n = ids.numel()
+        ctx: dict = {"batch": b, "layers": [], "labels": labels, "inv_temp": inv_temp, "ids": ids}
         self._wait_gather("embed")
-        x = ops.embedding_fwd(w["model.embed_tokens.weight"], b.input_ids)
-        cos, sin = ops.rope_table(b.position_ids, self.inv_freq)
-        seq_start = ops.seq_start_from_cu(b.cu_seqlens, n)
+        x = ops.embedding_fwd(w["model.embed_tokens.weight"], ids)
+        cos, sin = ops.rope_table(tok(b.position_ids), self.inv_freq)
+        seq_start = ops.seq_start_from_cu(b.cu_seqlens, n_full)
         ctx.update(cos=cos, sin=sin, seq_start=seq_start)
         scale = d.head_dim**-0.5
         pending = None  # mlp output whose residual add is fused into the next RMSNorm
@@ -513,14 +534,19 @@ class GRPOEngine:
             q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], cos, sin,
                                                  d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.rms_norm_eps)
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
-            o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+            if cp == 1:
+                o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+                attn_saved = None
+            else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads)
+                o, attn_saved = self._ulysses_attn_fwd(q, k, v, seq_start, scale)
+                lse = None
             attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
             h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
             gu = self._fwd_mm(h2, w[p + "mlp.gate_up_proj.weight"])
             act = ops.swiglu_fwd(gu)
             pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
             ctx["layers"].append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2,
-                                      gu=gu, act=None if self.recompute_act else act))
+                                      gu=gu, act=None if self.recompute_act else act, attn_saved=attn_saved))
             x = x2
         self._wait_gather("head")
         hf, rstd_f, x_last = ops.rmsnorm_fwd(pending, w["model.norm.weight"], d.rms_norm_eps, residual=x)
@@ -534,21 +560,45 @@ class GRPOEngine:
         for s in range(0, n, self.lm_head_token_chunk):
             e = min(s + self.lm_head_token_chunk, n)
             if self.lm_head_impl == "fused":
-                logprobs[s:e], entropy[s:e], logz[s:e] = ops.lmhead_logprob_fwd(hf[s:e], wh, b.labels[s:e], b.inv_temp[s:e])
+                logprobs[s:e], entropy[s:e], logz[s:e] = ops.lmhead_logprob_fwd(hf[s:e], wh, labels[s:e], inv_temp[s:e])
                 chunks.append((s, e, None))
                 continue
             logits = self._fwd_mm(hf[s:e], wh, out_f32=self.gemm_f32)
             if self.k1_events is not None:  # HIP events on the launch stream around the log-prob kernel (bench.py roofline)
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            lp, en, lz = ops.logprob_entropy_fwd(logits, b.labels[s:e], b.inv_temp[s:e])
+            lp, en, lz = ops.logprob_entropy_fwd(logits, labels[s:e], inv_temp[s:e])
             if self.k1_events is not None:
                 ev1.record()
                 self.k1_events.append((ev0, ev1, e - s, logits.element_size()))
             logprobs[s:e], entropy[s:e], logz[s:e] = lp, en, lz
             chunks.append((s, e, logits))
+        if cp > 1:  # the loss (and the shift_tensor_right inside it) runs over the FULL pass: gather_for_cp (utils/cp.py:129-139, train.py:446-448)
+            ctx["logprobs_local"] = logprobs
+            logprobs = ulysses.all_gather_tokens(logprobs, cp, self.cp_group)
+            entropy = ulysses.all_gather_tokens(entropy, cp, self.cp_group)
         ctx.update(logits_chunks=chunks, logprobs=logprobs, entropy=entropy, logz=logz)
         return ctx
+
+    def _ulysses_attn_fwd(self, q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, scale: float):
+        cp, grp, hkv = self.cp_size, self.cp_group, self.dims.num_key_value_heads
+        v = v.contiguous()
+        if hkv < cp:
+            k, v = ulysses.replicate_kv_heads(k, cp), ulysses.replicate_kv_heads(v, cp)
+        qh, kh, vh = ulysses.seq_to_head(q, cp, grp), ulysses.seq_to_head(k, cp, grp), ulysses.seq_to_head(v, cp, grp)
+        oh, lse = ops.attn_varlen_fwd(qh, kh, vh, seq_start, scale)
+        return ulysses.head_to_seq(oh, cp, grp), (qh, kh, vh, oh, lse)
+
+    def _ulysses_attn_bwd(self, do: Tensor, saved, seq_start: Tensor, scale: float, dv_view: Tensor):
+        cp, grp, hkv = self.cp_size, self.cp_group, self.dims.num_key_value_heads
+        qh, kh, vh, oh, lse = saved
+        doh = ulysses.seq_to_head(do.contiguous(), cp, grp)
+        dqh, dkh, dvh = ops.attn_varlen_bwd(doh, qh, kh, vh, oh, lse, seq_start, scale)
+        dq, dk, dv = ulysses.head_to_seq(dqh, cp, grp), ulysses.head_to_seq(dkh, cp, grp), ulysses.head_to_seq(dvh, cp, grp)
+        if hkv < cp:
+            dk, dv = ulysses.reduce_kv_replicas(dk, hkv), ulysses.reduce_kv_replicas(dv, hkv)
+        dv_view.copy_(dv)
+        return dq, dk
 
     # -- loss -------------------------------------------------------------------------------------------------------
     def loss(self, ctx: dict, scales: tuple[int, int, int]) -> dict:
@@ -568,7 +618,9 @@ class GRPOEngine:
     def backward(self, ctx: dict, accumulate: bool, last_pass: bool = True) -> None:
         d, w, g = self.dims, self.store.w, self.store.g
         b: PackedBatch = ctx["batch"]
-        n = b.n_tokens
+        labels, inv_temp, ids = ctx["labels"], ctx["inv_temp"], ctx["ids"]
+        n = ids.numel()
+        grad_lp = ctx["grad_logprobs"] if self.cp_size == 1 else ulysses.shard_for_cp(ctx["grad_logprobs"], self.cp_rank, self.cp_size)
         wh, gh = self.store.head_weight(), self.store.head_grad()
         hf = ctx["hf"]
         dhf = torch.empty_like(hf)
@@ -586,9 +638,9 @@ class GRPOEngine:
                 todo.append((s, e, logits))
         for s, e, logits in todo:
             if logits is None:
-                dl = ops.lmhead_logprob_bwd(hf[s:e], wh, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e])
+                dl = ops.lmhead_logprob_bwd(hf[s:e], wh, labels[s:e], inv_temp[s:e], ctx["logz"][s:e], grad_lp[s:e])
             else:
-                dl = ops.logprob_bwd(logits, b.labels[s:e], b.inv_temp[s:e], ctx["logz"][s:e], ctx["grad_logprobs"][s:e], out=logits)
+                dl = ops.logprob_bwd(logits, labels[s:e], inv_temp[s:e], ctx["logz"][s:e], grad_lp[s:e], out=logits)
             if self.gemm_f32:
                 dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
             elif head_t:
@@ -623,7 +675,10 @@ class GRPOEngine:
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
             dqkv = torch.empty_like(qkv)
             dv_view = dqkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
-            dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
+            if self.cp_size == 1:
+                dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
+            else:
+                dq, dk = self._ulysses_attn_bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
             ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
                                 L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),
                                 self._norm_grad(g[p + "self_attn.k_norm.weight"], accumulate), d.num_attention_heads, d.num_key_value_heads,
@@ -636,7 +691,7 @@ class GRPOEngine:
             self._bucket_done(f"layer{i}", last_pass)
         if not emb_accumulate:
             g["model.embed_tokens.weight"].zero_()
-        ops.embedding_bwd(dx, b.input_ids, g["model.embed_tokens.weight"])
+        ops.embedding_bwd(dx, ids, g["model.embed_tokens.weight"])
         self._bucket_done("embed", last_pass)
 
     @staticmethod
@@ -650,7 +705,7 @@ class GRPOEngine:
         if not self.use_collectives or not last_pass:
             return
         b = next(bk for bk in self.store.buckets if bk.name == name)
-        zero.reduce_scatter_bucket(self.store, b, self.dp_group, self.comm_stream)
+        zero.reduce_scatter_bucket(self.store, b, self.shard_group, self.comm_stream)
 
     def wait_params_ready(self) -> None:
         """Make the current stream wait for every in-flight parameter all-gather (issued on the comm stream by the last optimizer
@@ -684,11 +739,15 @@ class GRPOEngine:
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(ev)
         self._param_readers.clear()
-        return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.dp_group, ops, self.comm_stream, self._gather_events, self._sumsq)
+        return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:
-        """dist.all_reduce of the i64[3] token counts (train.py:318-323)."""
+        """dist.all_reduce of the i64[3] token counts (train.py:318-323) over the DATA-parallel group: the cp ranks of one dp position hold
+        the same pass, whose tokens count once (the reference reduces over dp x cp and lets the cp-fold count cancel against the cp-fold
+        gradient of its gathered log-probs, utils/cp.py:129-132 — same quotient)."""
+        if self.dp_size == 1:
+            return tuple(max(int(c), 1) for c in local_counts)
         return zero.all_reduce_counts(local_counts, self.dp_group, self.device)
 
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:

@@ -156,6 +156,9 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     m = config.model
     resolve_auto_attn(m)
     dims = resolve_model_dims(m)
+    if parallel_dims.cp_enabled and m.cp_style != "ulysses":
+        raise NotImplementedError("context parallelism on MI355X is Ulysses (all-to-all over the xGMI full mesh): set model.cp_style = 'ulysses'; "
+                                  "ring attention (models/layers/ring_attn.py) is not part of this engine")
     o = config.optim
     optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
     lc = config.loss
@@ -165,7 +168,8 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
                       kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
     engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
-                        dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp)
+                        dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp,
+                        shard_group=parallel_dims.get_group("dp_cp"))
     sd = _local_safetensors(m.name)
     if sd is not None:
         engine.store.load_state_dict({k: v.to(device) for k, v in sd.items()})

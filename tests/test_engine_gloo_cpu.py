@@ -1,4 +1,4 @@
-"""CPU suite, world_size 2 over gloo: the WHOLE `GRPOEngine.step` plumbing — packed passes, the i64[3] scale all-reduce, per-bucket
+"""CPU suite, world_size 2 and 4 over gloo: the WHOLE `GRPOEngine.step` plumbing — packed passes, the i64[3] scale all-reduce, per-bucket
 gradient reduce-scatter as each layer's backward finishes, global-norm clip from the all-reduced squared norm, sharded AdamW, in-place
 bf16 parameter all-gather with per-bucket gather events consumed by the next forward — runs unchanged with CPU stand-in kernels
 (tests/cpu_standin_ops.py) and must reproduce a single-process step over the same global batch:
@@ -50,23 +50,33 @@ def _batches(E, dims, world, rank, step):
     return mbs
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cp=1):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    E, eng = _engine()
-    assert eng.dp_size == world and eng.use_collectives and eng.comm_stream is None
+    dp = world // cp
+    if cp == 1:
+        E, eng = _engine()
+        assert eng.dp_size == world and eng.use_collectives and eng.comm_stream is None
+    else:  # the trainer's own construction path: ParallelDims -> dp / cp / dp_cp groups -> engine
+        from prime_rl_amd.trainer.parallel_dims import ParallelDims
+
+        pd = ParallelDims(dp_replicate=1, dp_shard=-1, cp=cp, pp=1, ep=1, world_size=world)
+        assert pd.dp_size == dp and pd.dp_rank_of(rank) == rank // cp
+        E, eng = _engine(dp_group=pd.get_group("dp"), dp_size=pd.dp_size, cp_group=pd.get_group("cp"), cp_size=cp, shard_group=pd.get_group("dp_cp"))
+        assert (eng.dp_size, eng.cp_size, eng.shard_size, eng.cp_rank, eng.dp_rank) == (dp, cp, world, rank % cp, rank // cp)
     rec = {"loss": [], "grad_norm": [], "shards": None}
     for step in range(STEPS):
-        mbs = _batches(E, eng.dims, world, rank, step)
+        mbs = _batches(E, eng.dims, dp, rank // cp, step)
         # two passes per step: gradient accumulation across passes, reduce-scatter only after the last one
         passes = [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
         out = eng.step(passes)
         rec["loss"].append(sum(l.item() for l in out["loss"]))
         rec["grad_norm"].append(out["grad_norm"].item())
-        assert out["scales"][0] > sum(p.local_counts[0] for p in passes)  # the GLOBAL count, not the rank's own
+        own = sum(p.local_counts[0] for p in passes)
+        assert out["scales"][0] > own if dp > 1 else out["scales"][0] == own  # the count over the dp group: every pass counts once
         if step == 0:
             rec["shards"] = eng.store.grad_shard.clone()
             rec["main_grad"] = eng.store.main_grad.clone()
@@ -78,9 +88,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_engine_step_world2_equals_single_process(tmp_path):
-    world = 2
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+@pytest.mark.parametrize("world,cp", [(2, 1), (2, 2), (4, 2)])
+def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp):
+    """(2, 1): ZeRO-2 data parallel.  (2, 2): one dp position, Ulysses context parallel over two ranks (heads <-> sequence all-to-all around
+    attention, log-probs gathered for the full-pass loss, gradients reduce-scattered over dp x cp).  (4, 2): both at once."""
+    dp = world // cp
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp), nprocs=world, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"r{k}.pt") for k in range(world)]
     # single process, same global batch (rank 0's micro-batches then rank 1's), one pass per rank-pass to keep the same accumulation units
     E, eng = _engine()
@@ -88,8 +101,8 @@ def test_engine_step_world2_equals_single_process(tmp_path):
     ref = {"loss": [], "grad_norm": [], "grad": None}
     for step in range(STEPS):
         passes = []
-        for k in range(world):
-            mbs = _batches(E, eng.dims, world, k, step)
+        for k in range(dp):
+            mbs = _batches(E, eng.dims, dp, k, step)
             passes += [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
         out = eng.step(passes)
         ref["loss"].append(sum(l.item() for l in out["loss"]))
@@ -99,8 +112,11 @@ def test_engine_step_world2_equals_single_process(tmp_path):
     for step in range(STEPS):
         # bf16 CPU GEMMs block differently under different thread counts (spawned workers vs this process): bf16-level tolerance
         # (step 1 starts from parameters that already differ by a few bf16 flips of an AdamW step-1 update, |delta| = lr per element)
-        assert r[0]["loss"][step] + r[1]["loss"][step] == pytest.approx(ref["loss"][step], rel=1e-3 if step == 0 else 1e-2, abs=1e-4)
-        assert r[0]["grad_norm"][step] == pytest.approx(r[1]["grad_norm"][step], rel=1e-6)  # every rank sees the GLOBAL norm
+        # one loss per dp position (cp ranks of a position evaluate the same full-pass loss)
+        assert sum(r[k * cp]["loss"][step] for k in range(dp)) == pytest.approx(ref["loss"][step], rel=1e-3 if step == 0 else 1e-2, abs=1e-4)
+        for k in range(world):
+            assert r[k]["loss"][step] == pytest.approx(r[(k // cp) * cp]["loss"][step], rel=1e-6)
+            assert r[0]["grad_norm"][step] == pytest.approx(r[k]["grad_norm"][step], rel=1e-6)  # every rank sees the GLOBAL norm
         assert r[0]["grad_norm"][step] == pytest.approx(ref["grad_norm"][step], rel=2e-3 if step == 0 else 3e-2)
     # The flat layout depends on dp (buckets are padded to 256 * dp elements): address every parameter through the layout of the store
     # that produced the vector — `lay2` for the world-2 ranks, `eng.store` for the single-process reference.
@@ -134,4 +150,4 @@ def test_engine_step_world2_equals_single_process(tmp_path):
             diff = (p2 - lay1.params[off1[name]: off1[name] + n].float()).abs()
             assert float(diff.max()) <= 25 * LR and float((diff > 0).float().mean()) < 0.05, (name, float(diff.max()))
     print(f"worst relative gradient difference world-2 vs single process: {worst:.2e}")
-    assert torch.equal(r[0]["params"], r[1]["params"])  # replicas in lock-step after the in-place all-gather
+    assert all(torch.equal(r[0]["params"], r[k]["params"]) for k in range(1, world))  # replicas in lock-step after the in-place all-gather
