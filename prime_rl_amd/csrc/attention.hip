@@ -7,18 +7,16 @@
 // P = softmax_row(S), O = P V; backward dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(dO o O)), dQ = scale dS K,
 // dK = scale dS^T Q.
 //
-// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_v4.cuh = default and
-// attention_v3.cuh = the previous generation kept behind PM_ATTN_{FWD,DKDV,DQ}_V3 for A/B; the correct-first v1 and the
-// LDS-round-trip v2 kernels are in the git history only):
+// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_v4.cuh; the earlier
+// generations — correct-first v1, LDS-round-trip v2, padded-LDS / transposed-global-copy v3 — are in the git history only):
 //   * tiles live on the GLOBAL token grid of the packed row: row i may attend to j in [seq_start[i], i].  No per-document
 //     tile scheduling on the host, no max_seqlen, no host sync: grid = ceil(N/BM) * heads.
 //   * v_mfma_f32_16x16x32_bf16; every A/B fragment is 16 bytes along the contraction dim (lane l: row l&15,
 //     k = (l>>4)*8..+8), C layout row = (l>>4)*4 + r, col = l&15 (guide §3, verified by pm_mfma_probe_16x16x32).
 //   * TRANSPOSED products (S^T = K.Q^T, ...): probabilities stay in registers, the C layout is the B-fragment layout up to a
-//     permutation of the contraction index (attention_v3.cuh header).
-//   * operands whose contraction dim is the token axis (V in PV; Q, dO in dK/dV; K in dQ): v4 reads them out of the row-major LDS
-//     tile with ds_read_b64_tr_b16 (pinned by pm_ds_read_tr16_probe); v3 reads [head][128][N_pad] transposed copies written by a
-//     pre-pass (transpose_heads_kernel) into the caller's workspace.
+//     permutation of the contraction index (attention_v4.cuh header).
+//   * operands whose contraction dim is the token axis (V in PV; Q, dO in dK/dV; K in dQ) are read out of the row-major LDS
+//     tile with ds_read_b64_tr_b16 (pinned by pm_ds_read_tr16_probe): no transposed copies in global memory, no pre-pass.
 //   * blockIdx -> (kv head fastest): the workgroups that share K/V land on the same XCD (block b runs on XCD b%8),
 //     q tiles are issued heaviest-first (causal imbalance).
 //   * backward is two kernels (dK/dV per kv tile, dQ per q tile): no atomics, bitwise reproducible.
@@ -40,13 +38,9 @@ __device__ __forceinline__ void lds_fence() {
 }
 
 constexpr int kD = 128;       // head_dim
-// padded LDS row lengths of the v3 kernels (elements) and the 16-byte LDS accessors shared by v3 / v4
-constexpr int kLd128 = 136;  // 128 + 8
-constexpr int kLd64 = 72;    // 64 + 8
-constexpr int kLd32 = 40;    // 32 + 8
+// 16-byte LDS accessors
 __device__ __forceinline__ u32x4 lds16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void sts16(bf16_t* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
-constexpr int kPadLd = 72;    // 64 + 8 bf16: 144-byte LDS rows
 
 // ---------------------------------------------------------------------------------------------
 // MFMA layout probe: c[i][j] = sum_k a[i][k] * b[j][k], a,b [16][32] bf16 row-major.  One wave.
@@ -74,41 +68,6 @@ __global__ void ds_read_tr16_probe_kernel(const int32_t* elem_index, uint16_t* o
 }
 
 // ---------------------------------------------------------------------------------------------
-// [n][row_stride] (head h at column h*128) -> [heads][128][n_pad], zero padding for tokens >= n.
-__global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* __restrict__ src, int64_t row_stride, int64_t n, int64_t n_pad,
-                                                             bf16_t* __restrict__ dst) {
-  __shared__ bf16_t tile[64][66];
-  const int64_t t0 = (int64_t)blockIdx.x * 64;
-  const int d0 = blockIdx.y * 64;
-  const int h = blockIdx.z;
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int tr = (t >> 3) + pass * 32;
-    const int c8 = (t & 7) * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (t0 + tr < n) v = ldg16(src + (t0 + tr) * row_stride + (int64_t)h * kD + d0 + c8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      tile[tr][c8 + 2 * k] = (bf16_t)(w[k] & 0xffffu);
-      tile[tr][c8 + 2 * k + 1] = (bf16_t)(w[k] >> 16);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int d = (t >> 3) + pass * 32;
-    const int tk = (t & 7) * 8;
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[tk + 2 * k][d] | ((uint32_t)tile[tk + 2 * k + 1][d] << 16);
-    u32x4 v = {w[0], w[1], w[2], w[3]};
-    *reinterpret_cast<u32x4*>(dst + ((int64_t)h * kD + d0 + d) * n_pad + t0 + tk) = v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // delta[h][i] = sum_d dO[i,h,d] * O[i,h,d]   (16 lanes per (token, head))
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, int64_t n, int hq,
                                                         float* __restrict__ delta) {
@@ -133,31 +92,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-#include "attention_v3.cuh"
 #include "attention_v4.cuh"
 
-static inline int64_t pad64(int64_t n) { return cdiv(n, 64) * 64; }
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
-// A/B switches: the v3 kernels (padded LDS tiles + transposed global copies written by a pre-pass) stay selectable per kernel.
-static bool fwd_v3() {
-  static const bool f = getenv("PM_ATTN_FWD_V3") != nullptr;
-  return f;
-}
-static bool dkdv_v3() {
-  static const bool f = getenv("PM_ATTN_DKDV_V3") != nullptr;
-  return f;
-}
-static bool dq_v3() {
-  static const bool f = getenv("PM_ATTN_DQ_V3") != nullptr || getenv("PM_ATTN_DKDV_V3") != nullptr;
-  return f;
-}
-
-static int launch_transpose(const bf16_t* src, int64_t row_stride, int64_t n, int64_t n_pad, int heads, bf16_t* dst, hipStream_t st) {
-  hipLaunchKernelGGL(transpose_heads_kernel, dim3((unsigned)(n_pad / 64), 2, (unsigned)heads), dim3(256), 0, st, src, row_stride, n, n_pad, dst);
-  PM_CHECK_LAUNCH("attention transpose");
-  return PM_OK;
-}
-
 }  // namespace pm
 
 using namespace pm;
@@ -176,11 +113,10 @@ extern "C" int pm_ds_read_tr16_probe(const int32_t* elem_index, void* out_u16, v
   return PM_OK;
 }
 
-// Workspace: the default (v4) kernels need none in forward and only delta[h][n] in backward; the sizes below also cover the
-// transposed copies of the v3 kernels so that the A/B switches work with the same caller-owned buffer.
+// Workspace: none in forward (the entry point keeps the argument for ABI stability), delta[h][n] f32 in backward.
 extern "C" int64_t pm_attn_fwd_workspace_bytes(int64_t n_tokens, int32_t n_kv_heads, int32_t head_dim) {
-  if (n_tokens <= 0) return 0;
-  return align256((int64_t)n_kv_heads * head_dim * pad64(n_tokens) * 2);
+  (void)n_kv_heads; (void)head_dim;
+  return n_tokens <= 0 ? 0 : 256;
 }
 
 extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t v_row_stride, const int32_t* seq_start, int64_t n_tokens,
@@ -192,24 +128,31 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   PM_REQUIRE(n_tokens >= 0 && n_tokens < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
              "pm_attn_varlen_fwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
-  const int64_t need = pm_attn_fwd_workspace_bytes(n_tokens, n_kv_heads, head_dim);
-  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_attn_varlen_fwd: workspace %lld < %lld", (long long)workspace_bytes,
-             (long long)need);
+  (void)workspace; (void)workspace_bytes;
   hipStream_t st = as_stream(stream);
-  const unsigned grid = (unsigned)(cdiv(n_tokens, 128) * n_q_heads);
-  if (!fwd_v3()) {  // v4: V^T fragments are LDS transpose-reads of the row-major V tile
-    static const bool smem_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_v4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    kV4FwdSmemBytes) == hipSuccess;
-    PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    hipLaunchKernelGGL((attn_fwd_v4_kernel<2>), dim3(grid), dim3(256), kV4FwdSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
-  } else {
-    const int64_t n_pad = pad64(n_tokens);
-    bf16_t* vt = (bf16_t*)workspace;
-    const int rc = launch_transpose((const bf16_t*)v, v_row_stride, n_tokens, n_pad, n_kv_heads, vt, st);
-    if (rc != PM_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd_v3_kernel<2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, vt, seq_start, n_tokens, n_pad,
-                       n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+  {  // V^T fragments are LDS transpose-reads of the row-major V tile
+    // PM_ATTN_FWD_VAR (A/B, tools/microbench.py attn16k): tens digit = waves per workgroup (4 | 8), units digit = OPT bits
+    // (1 = s_setprio around the MFMA clusters, 2 = skip the exact-no-op O rescale).  Default 40 = round 1's kernel.
+    static const int var = getenv("PM_ATTN_FWD_VAR") ? atoi(getenv("PM_ATTN_FWD_VAR")) : 40;
+#define PM_LAUNCH_FWD_V4(MINW_, NW_, OPT_)                                                                                                        \
+  do {                                                                                                                                            \
+    static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_v4_kernel<MINW_, NW_, OPT_>),                             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kV4FwdSmemBytes) == hipSuccess;                       \
+    PM_REQUIRE(ok_, PM_ERR_LAUNCH, "pm_attn_varlen_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                                 \
+    hipLaunchKernelGGL((attn_fwd_v4_kernel<MINW_, NW_, OPT_>), dim3((unsigned)(cdiv(n_tokens, NW_ * 32) * n_q_heads)), dim3(NW_ * 64),            \
+                       kV4FwdSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads,   \
+                       n_kv_heads, softmax_scale, (bf16_t*)out, lse);                                                                             \
+  } while (0)
+    switch (var) {
+      case 41: PM_LAUNCH_FWD_V4(2, 4, 1); break;
+      case 42: PM_LAUNCH_FWD_V4(2, 4, 2); break;
+      case 43: PM_LAUNCH_FWD_V4(2, 4, 3); break;
+      case 80: PM_LAUNCH_FWD_V4(2, 8, 0); break;  // one 8-wave workgroup per CU (the ~212 VGPRs of this kernel allow 2 waves per SIMD)
+      case 82: PM_LAUNCH_FWD_V4(2, 8, 2); break;
+      case 83: PM_LAUNCH_FWD_V4(2, 8, 3); break;
+      default: PM_LAUNCH_FWD_V4(2, 4, 0); break;
+    }
+#undef PM_LAUNCH_FWD_V4
   }
   PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
   return PM_OK;
@@ -217,11 +160,8 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
 
 extern "C" int64_t pm_attn_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim) {
   if (n_tokens <= 0) return 0;
-  const int64_t n_pad = pad64(n_tokens);
-  const int64_t qt = align256((int64_t)n_q_heads * head_dim * n_pad * 2);
-  const int64_t kt = align256((int64_t)n_kv_heads * head_dim * n_pad * 2);
-  const int64_t dl = align256((int64_t)n_q_heads * n_tokens * 4);
-  return qt * 2 + kt + dl;
+  (void)n_kv_heads; (void)head_dim;
+  return align256((int64_t)n_q_heads * n_tokens * 4);
 }
 
 extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
@@ -237,21 +177,14 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
   PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_attn_varlen_bwd: workspace %lld < %lld", (long long)workspace_bytes,
              (long long)need);
   hipStream_t st = as_stream(stream);
-  const int64_t n = n_tokens, n_pad = pad64(n);
-  const int64_t qt_b = align256((int64_t)n_q_heads * kD * n_pad * 2);
-  const int64_t kt_b = align256((int64_t)n_kv_heads * kD * n_pad * 2);
-  char* ws = (char*)workspace;
-  bf16_t* qt = (bf16_t*)ws;
-  bf16_t* dot_ = (bf16_t*)(ws + qt_b);
-  bf16_t* kt = (bf16_t*)(ws + 2 * qt_b);
-  float* delta = (float*)(ws + 2 * qt_b + kt_b);
-  int rc;
+  const int64_t n = n_tokens;
+  float* delta = (float*)workspace;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, n,
                      n_q_heads, delta);
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(delta)");
 
   // ---- dK / dV
-  if (!dkdv_v3()) {
+  {
     // PM_ATTN_DKDV_V4_VAR (A/B; whole backward per 16k-token layer): 4 (default) = 64-row q tiles, 4 waves, 2 workgroups/CU (1.37 ms);
     // 0 = 32-row q tiles (1.47 ms); 1 / 2 = 3 workgroups/CU with 2- / 4-fragment batches (register spills: +9 % / +34 % over 0);
     // 3 = one 8-wave workgroup with 128 kv rows (+5 % over 0)
@@ -282,20 +215,11 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
                          softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
     }
 #undef PM_LAUNCH_DKDV_V4
-  } else {
-    static const bool smem_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v3_kernel<8, 1, 0>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvSmemBytes) == hipSuccess;
-    PM_REQUIRE(smem_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    if ((rc = launch_transpose((const bf16_t*)q, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, qt, st)) != PM_OK) return rc;
-    if ((rc = launch_transpose((const bf16_t*)grad_out, (int64_t)n_q_heads * kD, n, n_pad, n_q_heads, dot_, st)) != PM_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<8, 1>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kDkdvSmemBytes, st, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, qt, dot_, lse, delta, seq_start, n, n_pad, n_q_heads,
-                       n_kv_heads, softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
   }
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
 
   // ---- dQ
-  if (!dq_v3()) {
+  {
     static const bool kt64 = getenv("PM_ATTN_DQ_KT32") == nullptr;  // default: 64 kv rows per barrier (backward 1.41 -> 1.37 ms per layer); PM_ATTN_DQ_KT32 = A/B
     if (kt64) {
       static const bool ok64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_v4_kernel<2, 64>),
@@ -309,11 +233,6 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
                          (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,
                          n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_q);
     }
-  } else {
-    if ((rc = launch_transpose((const bf16_t*)k, (int64_t)n_kv_heads * kD, n, n_pad, n_kv_heads, kt, st)) != PM_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dq_v3_kernel<2>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, kt, lse, delta, seq_start, n, n_pad, n_q_heads, n_kv_heads,
-                       softmax_scale, (bf16_t*)grad_q);
   }
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dq)");
   return PM_OK;

@@ -21,6 +21,30 @@
 // registers as the B operand with the permuted contraction index q = (i>>2)*16 + lq*4 + (i&3), i = 0..7).
 #pragma once
 
+// ---- the transposed-product formulation shared by all three kernels (introduced with the v3 generation, now in the git history) -----
+// Every product is computed TRANSPOSED:
+//     S^T[kv][q]  = K[kv][:]   . Q[q][:]^T          A = K fragment (LDS),  B = Q fragment (registers)
+//     O^T[d][q]  += V^T[d][kv] . P^T[kv][q]         A = V^T fragment (LDS), B = P^T (registers)
+// With v_mfma_f32_16x16x32_bf16 the C layout of S^T puts, in lane (lr = q, lq), the 4 consecutive kv rows lq*4..lq*4+3 of each
+// 16-row block — and a B fragment wants, in the same lane (n = lr = q), 8 values along the contraction (kv) axis.  The
+// contraction index may be permuted freely as long as A and B agree, so the B fragment of k-step kk2 is built IN REGISTERS from
+// the C registers of blocks 2*kk2 and 2*kk2+1 (j<4 -> block 2kk2 row lq*4+j, j>=4 -> block 2kk2+1 row lq*4+j-4) and the
+// matching A fragment of V^T is read with the same permutation.  Consequences: no P / dS LDS round trip, no 2-byte LDS stores;
+// softmax statistics are per LANE (q = lr): the row max is 15 in-lane v_max + 2 cross-row exchanges, the row sum is kept as a
+// per-lane partial and reduced once at the end; the O^T rescale is a per-lane scalar multiply; outputs leave as 8-byte stores.
+// The same trick gives dQ^T = K^T . dS^T (dq kernel) and dV^T = dO^T . P, dK^T = Q^T . dS (dk/dv kernel).
+__device__ __forceinline__ u32x4 pack_c_pair(const f32x4& c0, const f32x4& c1) {
+  return u32x4{pack_bf16_hw(c0[0], c0[1]), pack_bf16_hw(c0[2], c0[3]), pack_bf16_hw(c1[0], c1[1]), pack_bf16_hw(c1[2], c1[3])};
+}
+__device__ __forceinline__ float xrow_sum(float v) {  // across the 4 sixteen-lane rows of a wave (lanes lr, lr+16, lr+32, lr+48)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* p, const f32x4& c, float mul) {
+  *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16_hw(c[0] * mul, c[1] * mul), pack_bf16_hw(c[2] * mul, c[3] * mul)};
+}
+
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
 
@@ -631,10 +655,14 @@ constexpr int kV4FwdTile = 64 * kD;              // elements of one [64][128] ti
 constexpr int kV4FwdOffV = 2 * kV4FwdTile * 2;   // bytes: K[2] then V[2]
 constexpr int kV4FwdSmemBytes = 2 * kV4FwdOffV;  // 64 KB
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                               int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
-                                                               float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+// NW waves x 32 q rows per workgroup (4 -> 128-row q tiles, two workgroups per CU; 8 -> 256-row q tiles: every staged K/V tile feeds twice the
+// MFMA work and the same 64 KB of LDS hosts 16 waves per CU).  OPT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O-accumulator
+// rescale when no lane's running max moved (alpha == 1 exactly for the whole wave: bit-identical results, 64 fewer VALU multiplies per tile).
+template <int MINW, int NW = 4, int OPT = 0>
+__global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                  int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
+                                                                  float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+  constexpr int NT = NW * 64, QR = NW * 32, SROWS = NT / 16, SPASS = 64 / SROWS;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(dyn_smem);
   const int n = (int)n64;
@@ -650,7 +678,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
   const int num_tiles = gridDim.x / hq;
   const int tile = num_tiles - 1 - b;
   const int qh = kvh * group + gi;
-  const int qt0 = tile * 128;
+  const int qt0 = tile * QR;
   const int q0 = qt0 + w * 32;
   const bool active = q0 < n;
 
@@ -670,29 +698,29 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) ot[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int tile_last = (qt0 + 127 < n - 1) ? qt0 + 127 : n - 1;
+  const int tile_last = (qt0 + QR - 1 < n - 1) ? qt0 + QR - 1 : n - 1;
   const int wave_last = (q0 + 31 < n - 1) ? q0 + 31 : n - 1;
   const int kv_begin = (seq_start[qt0] / 64) * 64;
   const int n_iters = (tile_last - kv_begin) / 64 + 1;
   const float sc2 = scale * 1.44269504088896340736f;
 
   const int kr = t >> 4, kc = (t & 15) * 8;
-  u32x4 kreg[4], vreg[4];
+  u32x4 kreg[SPASS], vreg[SPASS];
   auto issue = [&](int kv0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int krow = kv0 + kr + 16 * i;
+    for (int i = 0; i < SPASS; ++i) {
+      int krow = kv0 + kr + SROWS * i;
       if (krow > n - 1) krow = n - 1;
       kreg[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + kc);
       vreg[i] = ldg16(v + (int64_t)krow * v_stride + (int64_t)kvh * kD + kc);
     }
   };
-  const int st_off = swz_off(kr, t & 15);  // rows kr + 16 i share row & 15, hence the swizzle
+  const int st_off = swz_off(kr, t & 15);  // rows kr + SROWS i share row & 15 (SROWS is a multiple of 16), hence the swizzle
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      sts16(Ks + buf * kV4FwdTile + st_off + i * 16 * kD, kreg[i]);
-      sts16(Ks + kV4FwdOffV / 2 + buf * kV4FwdTile + st_off + i * 16 * kD, vreg[i]);
+    for (int i = 0; i < SPASS; ++i) {
+      sts16(Ks + buf * kV4FwdTile + st_off + i * SROWS * kD, kreg[i]);
+      sts16(Ks + kV4FwdOffV / 2 + buf * kV4FwdTile + st_off + i * SROWS * kD, vreg[i]);
     }
   };
   const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);
@@ -729,11 +757,13 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) ka[(kk + 1) & 1][nb] = lds16(Kt + (bq ^ ((kk + 1) << 5)) + nb * 16 * kD);
         }
+        if (OPT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           st[0][nb] = mfma16(ka[kk & 1][nb], qf[0][kk], st[0][nb]);
           st[1][nb] = mfma16(ka[kk & 1][nb], qf[1][kk], st[1][nb]);
         }
+        if (OPT & 1) __builtin_amdgcn_s_setprio(0);
       }
     }
     // Online softmax, written for the VALU (the unit that bounds this kernel: 32 scores per lane per tile against 64 MFMAs): the row
@@ -771,8 +801,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
       }
       l[cb] = l[cb] * alpha + ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));  // per-lane partial row sum; reduced across lq at the end
       m[cb] = m_new;
+      if (!(OPT & 2) || !__all(alpha == 1.0f)) {
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
+        for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
+      }
     }
     // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
 #pragma unroll
@@ -785,12 +817,14 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_v4_kernel(const bf16_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) va[i] = lds_tr_pair(Vt + kk2 * 32 * kD + (bt ^ ((h4 * 4 + i) << 4)));
         __builtin_amdgcn_sched_barrier(0);
+        if (OPT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int nb = h4 * 4 + i;
           ot[0][nb] = mfma16(va[i], pb0, ot[0][nb]);
           ot[1][nb] = mfma16(va[i], pb1, ot[1][nb]);
         }
+        if (OPT & 1) __builtin_amdgcn_s_setprio(0);
       }
     }
   }
