@@ -117,6 +117,7 @@ SIGNATURES: dict[str, tuple] = {
     "pm_comm_group_start": (I, []),
     "pm_comm_group_end": (I, []),
     "pm_mfma_probe_16x16x32": (I, [P, P, P, P]),
+    "pm_attn_debug_set_variant": (I, [I32, I32]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
 }
 

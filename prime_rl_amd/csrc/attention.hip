@@ -95,9 +95,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 #include "attention_v4.cuh"
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
+constexpr int kFwdDefaultVar = 412;
+static int g_fwd_var_override = -1;  // set through pm_attn_debug_set_variant (microbenchmark A/B only)
+static int g_bwd_var_override = -1;
 }  // namespace pm
 
 using namespace pm;
+
+// A/B hook for tools/microbench.py: kernel == 0 selects the forward variant (100 * waves + OPT bits), value < 0 restores the default.
+extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
+  if (kernel == 0) g_fwd_var_override = value;
+  else if (kernel == 1) g_bwd_var_override = value;
+  else return PM_ERR_INVALID_ARG;
+  return PM_OK;
+}
 
 extern "C" int pm_mfma_probe_16x16x32(const void* a, const void* b, float* c, void* stream) {
   PM_REQUIRE(a && b && c, PM_ERR_INVALID_ARG, "pm_mfma_probe_16x16x32: null pointer");
@@ -128,12 +139,15 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   PM_REQUIRE(n_tokens >= 0 && n_tokens < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
              "pm_attn_varlen_fwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
+  PM_REQUIRE(n_tokens * v_row_stride * 2 < (1ll << 31) && n_tokens * (int64_t)n_kv_heads * kD * 2 < (1ll << 31), PM_ERR_UNSUPPORTED,
+             "pm_attn_varlen_fwd: K / V beyond the 2 GiB a 32-bit buffer offset addresses (%lld tokens)", (long long)n_tokens);
   (void)workspace; (void)workspace_bytes;
   hipStream_t st = as_stream(stream);
   {  // V^T fragments are LDS transpose-reads of the row-major V tile
-    // PM_ATTN_FWD_VAR (A/B, tools/microbench.py attn16k): tens digit = waves per workgroup (4 | 8), units digit = OPT bits
-    // (1 = s_setprio around the MFMA clusters, 2 = skip the exact-no-op O rescale).  Default 40 = round 1's kernel.
-    static const int var = getenv("PM_ATTN_FWD_VAR") ? atoi(getenv("PM_ATTN_FWD_VAR")) : 40;
+    // PM_ATTN_FWD_VAR = 100 * waves per workgroup + OPT bits (attention_v4.cuh): A/B with tools/microbench.py attnfwd, which times every
+    // variant in one process.
+    static const int var_env = getenv("PM_ATTN_FWD_VAR") ? atoi(getenv("PM_ATTN_FWD_VAR")) : -1;
+    const int var = g_fwd_var_override >= 0 ? g_fwd_var_override : (var_env >= 0 ? var_env : kFwdDefaultVar);
 #define PM_LAUNCH_FWD_V4(MINW_, NW_, OPT_)                                                                                                        \
   do {                                                                                                                                            \
     static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_v4_kernel<MINW_, NW_, OPT_>),                             \
@@ -144,13 +158,17 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
                        n_kv_heads, softmax_scale, (bf16_t*)out, lse);                                                                             \
   } while (0)
     switch (var) {
-      case 41: PM_LAUNCH_FWD_V4(2, 4, 1); break;
-      case 42: PM_LAUNCH_FWD_V4(2, 4, 2); break;
-      case 43: PM_LAUNCH_FWD_V4(2, 4, 3); break;
-      case 80: PM_LAUNCH_FWD_V4(2, 8, 0); break;  // one 8-wave workgroup per CU (the ~212 VGPRs of this kernel allow 2 waves per SIMD)
-      case 82: PM_LAUNCH_FWD_V4(2, 8, 2); break;
-      case 83: PM_LAUNCH_FWD_V4(2, 8, 3); break;
-      default: PM_LAUNCH_FWD_V4(2, 4, 0); break;
+      case 400: PM_LAUNCH_FWD_V4(2, 4, 0); break;
+      case 404: PM_LAUNCH_FWD_V4(2, 4, 4); break;
+      case 408: PM_LAUNCH_FWD_V4(2, 4, 8); break;
+      case 412: PM_LAUNCH_FWD_V4(2, 4, 12); break;
+      case 414: PM_LAUNCH_FWD_V4(2, 4, 14); break;
+      case 415: PM_LAUNCH_FWD_V4(2, 4, 15); break;
+      case 428: PM_LAUNCH_FWD_V4(2, 4, 28); break;
+      case 444: PM_LAUNCH_FWD_V4(2, 4, 44); break;
+      case 460: PM_LAUNCH_FWD_V4(2, 4, 60); break;
+      case 462: PM_LAUNCH_FWD_V4(2, 4, 62); break;
+      default: PM_LAUNCH_FWD_V4(2, 4, 12); break;
     }
 #undef PM_LAUNCH_FWD_V4
   }

@@ -45,6 +45,15 @@ __device__ __forceinline__ void st8_bf16(bf16_t* p, const f32x4& c, float mul) {
   *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16_hw(c[0] * mul, c[1] * mul), pack_bf16_hw(c[2] * mul, c[3] * mul)};
 }
 
+// Pin a loop-invariant register operand that was loaded from global memory in the prologue: the empty asm takes the value as a read-write
+// operand, so the load must have COMPLETED here and the compiler cannot sink it towards its first use inside the main loop.  Without it
+// hipcc placed the Q-fragment loads after the first K/V prefetch and left them pending at loop entry; its waitcnt pass then guarded every
+// use of those registers inside the loop with `s_waitcnt vmcnt(3..0)` — and vmcnt counts in order, so in steady state each of those waits
+// drained the K/V PREFETCH issued a few instructions earlier: the memory latency the prefetch exists to hide was paid in every iteration.
+__device__ __forceinline__ void pin_loaded(u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_loaded(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_loaded(int& v) { asm volatile("" : "+v"(v)); }
+
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
 
@@ -78,6 +87,16 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 }
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
 }
 __device__ __forceinline__ float xrow_max_swap(float v) {
   float a = v, b = v;
@@ -207,6 +226,11 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4_kerne
     stage(0);
   }
   if (total_iters > 1) issue();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    pin_loaded(kf[kk]);
+    pin_loaded(vf[kk]);
+  }
   for (int j = 0; j < total_iters; ++j) {
     const int qi0 = kv0 + 32 * c_cur.tile;
     advance(c_cur);
@@ -403,6 +427,11 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void attn_bwd_dkdv_v4q_kern
     stage(0);
   }
   if (total_iters > 1) issue();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    pin_loaded(kf[kk]);
+    pin_loaded(vf[kk]);
+  }
   for (int j = 0; j < total_iters; ++j) {
     const int qi0 = kv0 + QT * c_cur.tile;
     advance(c_cur);
@@ -569,6 +598,17 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_v4_kernel(const bf16_t*
   issue(kv_begin);
   stage(0);
   if (n_iters > 1) issue(kv_begin + KT);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    pin_loaded(lo[cb]);
+    pin_loaded(L2[cb]);
+    pin_loaded(Dl[cb]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      pin_loaded(qf[cb][kk]);
+      pin_loaded(dof[cb][kk]);
+    }
+  }
   for (int j = 0; j < n_iters; ++j) {
     const int kvt = kv_begin + KT * j;
     const int buf = j & 1;
@@ -656,8 +696,12 @@ constexpr int kV4FwdOffV = 2 * kV4FwdTile * 2;   // bytes: K[2] then V[2]
 constexpr int kV4FwdSmemBytes = 2 * kV4FwdOffV;  // 64 KB
 
 // NW waves x 32 q rows per workgroup (4 -> 128-row q tiles, two workgroups per CU; 8 -> 256-row q tiles: every staged K/V tile feeds twice the
-// MFMA work and the same 64 KB of LDS hosts 16 waves per CU).  OPT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O-accumulator
-// rescale when no lane's running max moved (alpha == 1 exactly for the whole wave: bit-identical results, 64 fewer VALU multiplies per tile).
+// MFMA work).  OPT bits (A/B through PM_ATTN_FWD_VAR = 100 * NW + OPT, measured in ONE process per comparison: boxes differ by ~5 %):
+//   1  s_setprio(1) around the MFMA clusters;
+//   2  skip the O-accumulator rescale when no lane's running max moved (alpha == 1 for the whole wave: bit-identical results);
+//   4  K / V staging through buffer loads with 32-bit offsets (no 64-bit address arithmetic, no row clamps in the loop);
+//   8  wave-uniform mask branch (one scalar branch per tile instead of per-lane exec-mask sequences);
+//  16  row max as 16 inline-asm v_max3_f32;   32  precomputed transpose-read offsets.
 template <int MINW, int NW = 4, int OPT = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                   int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
@@ -704,15 +748,34 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t
   const int n_iters = (tile_last - kv_begin) / 64 + 1;
   const float sc2 = scale * 1.44269504088896340736f;
 
+  // K / V staging through buffer loads: a wave-uniform descriptor per tensor + ONE 32-bit byte offset per thread and pass that advances by
+  // a scalar per tile (the flat-pointer form cost ~45 VALU per tile in 64-bit address arithmetic and row clamps — on a kernel whose VALU,
+  // not its MFMA pipe, is the busy unit).  Rows past the end of the tensor read as zeros (hardware range check), which the causal /
+  // document mask discards like any other kv > q.
   const int kr = t >> 4, kc = (t & 15) * 8;
   u32x4 kreg[SPASS], vreg[SPASS];
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(k), 0, (int)((int64_t)n * hkv * kD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(v), 0, (int)(((int64_t)(n - 1) * v_stride + (int64_t)hkv * kD) * 2), 0x00020000);
+  int koff[SPASS], voff[SPASS];
+#pragma unroll
+  for (int i = 0; i < SPASS; ++i) {
+    koff[i] = (((kr + SROWS * i) * hkv + kvh) * kD + kc) * 2;
+    voff[i] = (int)(((int64_t)(kr + SROWS * i) * v_stride + (int64_t)kvh * kD + kc) * 2);
+  }
+  const int ktile = hkv * kD * 2, vtile = (int)(v_stride * 2);  // bytes per kv row
   auto issue = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < SPASS; ++i) {
-      int krow = kv0 + kr + SROWS * i;
-      if (krow > n - 1) krow = n - 1;
-      kreg[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + kc);
-      vreg[i] = ldg16(v + (int64_t)krow * v_stride + (int64_t)kvh * kD + kc);
+      if (OPT & 4) {
+        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff[i] + kv0 * ktile, 0, 0);
+        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff[i] + kv0 * vtile, 0, 0);
+      } else {
+        int krow = kv0 + kr + SROWS * i;
+        if (krow > n - 1) krow = n - 1;
+        kreg[i] = ldg16(k + ((int64_t)krow * hkv + kvh) * kD + kc);
+        vreg[i] = ldg16(v + (int64_t)krow * v_stride + (int64_t)kvh * kD + kc);
+      }
     }
   };
   const int st_off = swz_off(kr, t & 15);  // rows kr + SROWS i share row & 15 (SROWS is a multiple of 16), hence the swizzle
@@ -726,9 +789,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t
   const int bq = lr * kD + ((lq ^ swz_f(lr)) << 3);
   const int r0 = lq * 4 + (lr >> 2);
   const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));
+  int bt8[8];  // the 8 column-block offsets of the V^T transpose-reads, XOR-swizzled once instead of once per read per tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bt8[i] = bt ^ (i << 4);
   issue(kv_begin);
   stage(0);
   if (n_iters > 1) issue(kv_begin + 64);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    pin_loaded(lo[cb]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) pin_loaded(qf[cb][kk]);
+  }
   for (int j = 0; j < n_iters; ++j) {
     const int kv0 = kv_begin + 64 * j;
     const int buf = j & 1;
@@ -770,19 +842,42 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t
     // max is taken on the RAW scores (scale > 0 commutes with max), scale and subtraction are one fma feeding v_exp_f32, the f32x4
     // accumulators are rescaled with vector multiplies (v_pk_mul_f32), and the max crosses the four 16-lane rows of the wave through
     // v_permlane32_swap / v_permlane16_swap (VALU) instead of two ds_bpermute round trips through the LDS pipe.
-    const bool need_mask = (kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]);  // per lane; cheap and exact either way
+    // wave-uniform: one scalar branch per tile (a per-lane condition made hipcc emit an exec-mask branch sequence per pair of scores — 16 of
+    // them per tile — plus unconditional compare / select code); masking a score that needs no mask is exact, so "any lane" is enough
+    const bool lane_mask = (kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]);
+    const bool need_mask = (OPT & 8) ? (bool)__any(lane_mask) : lane_mask;
+    if (need_mask) {  // a separate pass, so that the common (interior-tile) path below carries no mask code at all
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      float mx = -INFINITY;
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (need_mask) {
+          for (int r = 0; r < 4; ++r) {
             const int kv = kv0 + nb * 16 + lq * 4 + r;
             st[cb][nb][r] = ((kv <= qi[cb]) && (kv >= lo[cb])) ? st[cb][nb][r] : -INFINITY;
           }
-          mx = fmaxf(mx, st[cb][nb][r]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float mx;
+      if (OPT & 16) {  // 16 single-instruction v_max3 for the 32 scores (plain fmaxf on MFMA outputs gets a canonicalising v_max each)
+        mx = st[cb][0][0];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          if (nb == 0) {
+            mx = max3_f32(mx, st[cb][0][1], st[cb][0][2]);
+            mx = fmax_raw(mx, st[cb][0][3]);
+          } else {
+            mx = max3_f32(mx, st[cb][nb][0], st[cb][nb][1]);
+            mx = max3_f32(mx, st[cb][nb][2], st[cb][nb][3]);
+          }
+        }
+      } else {
+        mx = -INFINITY;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[cb][nb][r]);
         }
       }
       mx = xrow_max_swap(mx) * sc2;
@@ -815,7 +910,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_v4_kernel(const bf16_t
       for (int h4 = 0; h4 < 2; ++h4) {
         u32x4 va[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) va[i] = lds_tr_pair(Vt + kk2 * 32 * kD + (bt ^ ((h4 * 4 + i) << 4)));
+        for (int i = 0; i < 4; ++i)
+          va[i] = (OPT & 32) ? lds_tr_pair(Vt + kk2 * 32 * kD + bt8[h4 * 4 + i]) : lds_tr_pair(Vt + kk2 * 32 * kD + (bt ^ ((h4 * 4 + i) << 4)));
         __builtin_amdgcn_sched_barrier(0);
         if (OPT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll

@@ -195,9 +195,48 @@ def bench_lmhead(out, n=16384, h=4096, v=151936):
     out.append(dict(kernel="library path: K1 bwd in place", ms=med * 1e3, best_ms=best * 1e3))
 
 
+def bench_attn_variants(out, kernel, variants, n=16384, seqs=(2048,) * 8, rounds=5):
+    """In-process interleaved A/B of attention kernel variants (boxes differ by ~5 %, so variants must share a process)."""
+    from prime_rl_amd import _lib
+
+    lib = _lib.load()
+    hq, hkv, d = 32, 8, 128
+    q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+    k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(torch.tensor(seqs).cumsum(0)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    o, lse = ops.attn_varlen_fwd(q, k, v, ss, d**-0.5)
+    go = torch.randn_like(o)
+    fn = (lambda: ops.attn_varlen_fwd(q, k, v, ss, d**-0.5)) if kernel == 0 else (lambda: ops.attn_varlen_bwd(go, q, k, v, o, lse, ss, d**-0.5))
+    ref = None
+    times = {var: [] for var in variants}
+    for _ in range(rounds):
+        for var in variants:
+            lib.pm_attn_debug_set_variant(kernel, var)
+            res = fn()
+            if ref is None:
+                ref = [t.clone() for t in res]
+            elif _ == 0:
+                for a, b in zip(res, ref):
+                    assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2), f"variant {var} differs"
+            med, best = timeit(fn, iters=10, warmup=2)
+            times[var].append(med)
+    lib.pm_attn_debug_set_variant(kernel, -1)
+    flops = sum(2 * s * s * hq * d for s in seqs) * (1.0 if kernel == 0 else 2.5)
+    for var in variants:
+        ts = sorted(times[var])
+        out.append(dict(kernel=f"attn_{'fwd' if kernel == 0 else 'bwd'} variant {var}", median_ms=ts[len(ts) // 2] * 1e3, min_ms=ts[0] * 1e3,
+                        TFLOPs=flops / ts[len(ts) // 2] / 1e12))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
+    if which == "attnfwd":
+        bench_attn_variants(out, 0, [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [400, 404, 408, 412, 414, 415, 812])
+    if which == "attnbwd":
+        bench_attn_variants(out, 1, [int(x) for x in sys.argv[2].split(",")])
     if which == "lmhead":
         bench_lmhead(out)
     if which == "lmhead4k":
