@@ -7,14 +7,14 @@
 // P = softmax_row(S), O = P V; backward dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(dO o O)), dQ = scale dS K,
 // dK = scale dS^T Q.
 //
-// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_v4.cuh; the earlier
-// generations — correct-first v1, LDS-round-trip v2, padded-LDS / transposed-global-copy v3 — are in the git history only):
+// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_kernels.cuh; earlier
+// generations are in the git history only):
 //   * tiles live on the GLOBAL token grid of the packed row: row i may attend to j in [seq_start[i], i].  No per-document
 //     tile scheduling on the host, no max_seqlen, no host sync: grid = ceil(N/BM) * heads.
 //   * v_mfma_f32_16x16x32_bf16; every A/B fragment is 16 bytes along the contraction dim (lane l: row l&15,
 //     k = (l>>4)*8..+8), C layout row = (l>>4)*4 + r, col = l&15 (guide §3, verified by pm_mfma_probe_16x16x32).
 //   * TRANSPOSED products (S^T = K.Q^T, ...): probabilities stay in registers, the C layout is the B-fragment layout up to a
-//     permutation of the contraction index (attention_v4.cuh header).
+//     permutation of the contraction index (attention_kernels.cuh).
 //   * operands whose contraction dim is the token axis (V in PV; Q, dO in dK/dV; K in dQ) are read out of the row-major LDS
 //     tile with ds_read_b64_tr_b16 (pinned by pm_ds_read_tr16_probe): no transposed copies in global memory, no pre-pass.
 //   * blockIdx -> (kv head fastest): the workgroups that share K/V land on the same XCD (block b runs on XCD b%8),
@@ -68,9 +68,12 @@ __global__ void ds_read_tr16_probe_kernel(const int32_t* elem_index, uint16_t* o
 }
 
 // ---------------------------------------------------------------------------------------------
-// delta[h][i] = sum_d dO[i,h,d] * O[i,h,d]   (16 lanes per (token, head))
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, int64_t n, int hq,
-                                                        float* __restrict__ delta) {
+// Row statistics of the backward pass, [hq][n] each (16 lanes per (token, head)):
+//   ndelta[h][i] = -sum_d dO[i,h,d] * O[i,h,d]      nlse[h][i] = -lse[h][i] / scale
+// negated (and the lse pre-divided by the softmax scale) because the dK/dV and dQ kernels START their dP and S accumulators from these
+// rows instead of zero: P = exp2((S - lse / scale) * scale * log2 e), dS = P * (dP - delta) * scale.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, const float* __restrict__ lse,
+                                                        int64_t n, int hq, float inv_scale, float* __restrict__ ndelta, float* __restrict__ nlse) {
   const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int sub = threadIdx.x & 15;
   const bool valid = item < n * hq;
@@ -88,24 +91,28 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   if (valid && sub == 0) {
     const int64_t tok = it / hq;
     const int h = (int)(it - tok * hq);
-    delta[(int64_t)h * n + tok] = s;
+    const int64_t o = (int64_t)h * n + tok;
+    ndelta[o] = -s;
+    nlse[o] = -lse[o] * inv_scale;
   }
 }
 
-#include "attention_v4.cuh"
+#include "attention_kernels.cuh"
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
-constexpr int kFwdDefaultVar = 412;
-static int g_fwd_var_override = -1;  // set through pm_attn_debug_set_variant (microbenchmark A/B only)
-static int g_bwd_var_override = -1;
+// Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
+// boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
+// workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
+static int g_dkdv_var = 0;
+static int g_dq_var = 0;
 }  // namespace pm
 
 using namespace pm;
 
-// A/B hook for tools/microbench.py: kernel == 0 selects the forward variant (100 * waves + OPT bits), value < 0 restores the default.
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
-  if (kernel == 0) g_fwd_var_override = value;
-  else if (kernel == 1) g_bwd_var_override = value;
+  if (kernel == 0) return value <= 0 ? PM_OK : PM_ERR_INVALID_ARG;  // the forward kernel has a single build
+  if (kernel == 1) g_dkdv_var = value < 0 ? 0 : value;
+  else if (kernel == 2) g_dq_var = value < 0 ? 0 : value;
   else return PM_ERR_INVALID_ARG;
   return PM_OK;
 }
@@ -124,7 +131,11 @@ extern "C" int pm_ds_read_tr16_probe(const int32_t* elem_index, void* out_u16, v
   return PM_OK;
 }
 
-// Workspace: none in forward (the entry point keeps the argument for ABI stability), delta[h][n] f32 in backward.
+// The kernels address K / V / Q / dO through buffer descriptors with 32-bit byte offsets.
+static bool fits_buffer_range(int64_t n, int64_t row_elems) { return n * row_elems * 2 < (int64_t)1 << 31; }
+
+// Workspace: none in forward (the entry point keeps the argument for ABI stability); backward: the two row-statistics arrays of
+// attn_delta_kernel, [hq][n] f32 each.
 extern "C" int64_t pm_attn_fwd_workspace_bytes(int64_t n_tokens, int32_t n_kv_heads, int32_t head_dim) {
   (void)n_kv_heads; (void)head_dim;
   return n_tokens <= 0 ? 0 : 256;
@@ -138,40 +149,12 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: bad head counts");
   PM_REQUIRE(n_tokens >= 0 && n_tokens < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
              "pm_attn_varlen_fwd: bad sizes");
-  if (n_tokens == 0) return PM_OK;
-  PM_REQUIRE(n_tokens * v_row_stride * 2 < (1ll << 31) && n_tokens * (int64_t)n_kv_heads * kD * 2 < (1ll << 31), PM_ERR_UNSUPPORTED,
-             "pm_attn_varlen_fwd: K / V beyond the 2 GiB a 32-bit buffer offset addresses (%lld tokens)", (long long)n_tokens);
   (void)workspace; (void)workspace_bytes;
-  hipStream_t st = as_stream(stream);
-  {  // V^T fragments are LDS transpose-reads of the row-major V tile
-    // PM_ATTN_FWD_VAR = 100 * waves per workgroup + OPT bits (attention_v4.cuh): A/B with tools/microbench.py attnfwd, which times every
-    // variant in one process.
-    static const int var_env = getenv("PM_ATTN_FWD_VAR") ? atoi(getenv("PM_ATTN_FWD_VAR")) : -1;
-    const int var = g_fwd_var_override >= 0 ? g_fwd_var_override : (var_env >= 0 ? var_env : kFwdDefaultVar);
-#define PM_LAUNCH_FWD_V4(MINW_, NW_, OPT_)                                                                                                        \
-  do {                                                                                                                                            \
-    static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_v4_kernel<MINW_, NW_, OPT_>),                             \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kV4FwdSmemBytes) == hipSuccess;                       \
-    PM_REQUIRE(ok_, PM_ERR_LAUNCH, "pm_attn_varlen_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                                 \
-    hipLaunchKernelGGL((attn_fwd_v4_kernel<MINW_, NW_, OPT_>), dim3((unsigned)(cdiv(n_tokens, NW_ * 32) * n_q_heads)), dim3(NW_ * 64),            \
-                       kV4FwdSmemBytes, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads,   \
-                       n_kv_heads, softmax_scale, (bf16_t*)out, lse);                                                                             \
-  } while (0)
-    switch (var) {
-      case 400: PM_LAUNCH_FWD_V4(2, 4, 0); break;
-      case 404: PM_LAUNCH_FWD_V4(2, 4, 4); break;
-      case 408: PM_LAUNCH_FWD_V4(2, 4, 8); break;
-      case 412: PM_LAUNCH_FWD_V4(2, 4, 12); break;
-      case 414: PM_LAUNCH_FWD_V4(2, 4, 14); break;
-      case 415: PM_LAUNCH_FWD_V4(2, 4, 15); break;
-      case 428: PM_LAUNCH_FWD_V4(2, 4, 28); break;
-      case 444: PM_LAUNCH_FWD_V4(2, 4, 44); break;
-      case 460: PM_LAUNCH_FWD_V4(2, 4, 60); break;
-      case 462: PM_LAUNCH_FWD_V4(2, 4, 62); break;
-      default: PM_LAUNCH_FWD_V4(2, 4, 12); break;
-    }
-#undef PM_LAUNCH_FWD_V4
-  }
+  if (n_tokens == 0) return PM_OK;
+  PM_REQUIRE(fits_buffer_range(n_tokens, v_row_stride) && fits_buffer_range(n_tokens, (int64_t)n_kv_heads * kD), PM_ERR_UNSUPPORTED,
+             "pm_attn_varlen_fwd: k / v exceed the 2 GiB buffer-offset range");
+  hipLaunchKernelGGL((attn_fwd_kernel<2>), dim3((unsigned)(cdiv(n_tokens, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
   PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
   return PM_OK;
 }
@@ -179,7 +162,7 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
 extern "C" int64_t pm_attn_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim) {
   if (n_tokens <= 0) return 0;
   (void)n_kv_heads; (void)head_dim;
-  return align256((int64_t)n_q_heads * n_tokens * 4);
+  return 2 * align256((int64_t)n_q_heads * n_tokens * 4);
 }
 
 extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
@@ -189,69 +172,40 @@ extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const voi
   PM_REQUIRE(grad_out && q && k && v && out && lse && seq_start && grad_q && grad_k && grad_v, PM_ERR_INVALID_ARG, "pm_attn_varlen_bwd: null pointer");
   PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "pm_attn_varlen_bwd: head_dim=%d (only 128 is built)", head_dim);
   PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_bwd: bad head counts");
-  PM_REQUIRE(n_tokens >= 0 && v_row_stride % 8 == 0 && grad_v_row_stride >= (int64_t)n_kv_heads * kD, PM_ERR_INVALID_ARG, "pm_attn_varlen_bwd: bad sizes");
+  PM_REQUIRE(n_tokens >= 0 && v_row_stride % 8 == 0 && grad_v_row_stride >= (int64_t)n_kv_heads * kD && softmax_scale > 0.f, PM_ERR_INVALID_ARG,
+             "pm_attn_varlen_bwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
   const int64_t need = pm_attn_bwd_workspace_bytes(n_tokens, n_q_heads, n_kv_heads, head_dim);
   PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_attn_varlen_bwd: workspace %lld < %lld", (long long)workspace_bytes,
              (long long)need);
-  hipStream_t st = as_stream(stream);
   const int64_t n = n_tokens;
-  float* delta = (float*)workspace;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, n,
-                     n_q_heads, delta);
+  PM_REQUIRE(fits_buffer_range(n, (int64_t)n_q_heads * kD) && fits_buffer_range(n, v_row_stride), PM_ERR_UNSUPPORTED,
+             "pm_attn_varlen_bwd: q / k / v exceed the 2 GiB buffer-offset range");
+  hipStream_t st = as_stream(stream);
+  float* ndelta = (float*)workspace;
+  float* nlse = ndelta + align256(n * n_q_heads * 4) / 4;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, lse, n,
+                     n_q_heads, 1.0f / softmax_scale, ndelta, nlse);
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(delta)");
 
-  // ---- dK / dV
-  {
-    // PM_ATTN_DKDV_V4_VAR (A/B; whole backward per 16k-token layer): 4 (default) = 64-row q tiles, 4 waves, 2 workgroups/CU (1.37 ms);
-    // 0 = 32-row q tiles (1.47 ms); 1 / 2 = 3 workgroups/CU with 2- / 4-fragment batches (register spills: +9 % / +34 % over 0);
-    // 3 = one 8-wave workgroup with 128 kv rows (+5 % over 0)
-    static const int var = getenv("PM_ATTN_DKDV_V4_VAR") ? atoi(getenv("PM_ATTN_DKDV_V4_VAR")) : 4;
-#define PM_LAUNCH_DKDV_V4(NW_, MINB_, FB_)                                                                                                       \
-  hipLaunchKernelGGL((attn_bwd_dkdv_v4_kernel<NW_, MINB_, FB_>), dim3((unsigned)(cdiv(n, NW_ * 16) * n_kv_heads)), dim3(NW_ * 64), kV4SmemBytes, st, \
-                     (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,        \
-                     n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride)
-    if (var == 1) PM_LAUNCH_DKDV_V4(4, 3, 2);
-    else if (var == 2) PM_LAUNCH_DKDV_V4(4, 3, 4);
-    else if (var == 3) PM_LAUNCH_DKDV_V4(8, 1, 4);
-    else if (var == 0) PM_LAUNCH_DKDV_V4(4, 2, 4);
-    else if (var == 5) {  // 64-row q tiles, one 8-wave workgroup per CU with 128 kv rows (half the staging traffic of the default)
-      constexpr int kSmemQ64 = 4 * 64 * kD * 2 + 6 * 64 * 4 + 16;
-      static const bool ok8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v4q_kernel<8, 1, 4, 64>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSmemQ64) == hipSuccess;
-      PM_REQUIRE(ok8, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-      hipLaunchKernelGGL((attn_bwd_dkdv_v4q_kernel<8, 1, 4, 64>), dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(512), kSmemQ64, st, (const bf16_t*)q,
-                         (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
-                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
-    } else {
-      constexpr int kSmemQ64 = 4 * 64 * kD * 2 + 6 * 64 * 4 + 16;
-      static const bool q64_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_v4q_kernel<4, 2, 4, 64>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kSmemQ64) == hipSuccess;
-      PM_REQUIRE(q64_ok, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-      hipLaunchKernelGGL((attn_bwd_dkdv_v4q_kernel<4, 2, 4, 64>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), kSmemQ64, st, (const bf16_t*)q,
-                         (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n, n_q_heads, n_kv_heads,
-                         softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride);
-    }
-#undef PM_LAUNCH_DKDV_V4
-  }
+#define PM_LAUNCH_DKDV(MINB_, FB_, QT_)                                                                                                           \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q,     \
+                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
+                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride)
+  if (g_dkdv_var == 1) PM_LAUNCH_DKDV(2, 2, 64);
+  else if (g_dkdv_var == 2) PM_LAUNCH_DKDV(2, 8, 64);
+  else if (g_dkdv_var == 3) PM_LAUNCH_DKDV(3, 4, 32);
+  else PM_LAUNCH_DKDV(2, 4, 64);
+#undef PM_LAUNCH_DKDV
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
 
-  // ---- dQ
-  {
-    static const bool kt64 = getenv("PM_ATTN_DQ_KT32") == nullptr;  // default: 64 kv rows per barrier (backward 1.41 -> 1.37 ms per layer); PM_ATTN_DQ_KT32 = A/B
-    if (kt64) {
-      static const bool ok64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_v4_kernel<2, 64>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kV4DqSmemBytes<64>) == hipSuccess;
-      PM_REQUIRE(ok64, PM_ERR_LAUNCH, "pm_attn_varlen_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-      hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2, 64>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes<64>, st,
-                         (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,
-                         n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_q);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<2, 32>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), kV4DqSmemBytes<32>, st,
-                         (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, lse, delta, seq_start, n,
-                         n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)grad_q);
-    }
-  }
+#define PM_LAUNCH_DQ(KT_)                                                                                                                        \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<2, KT_>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, \
+                     (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, softmax_scale,    \
+                     (bf16_t*)grad_q)
+  if (g_dq_var == 1) PM_LAUNCH_DQ(32);
+  else PM_LAUNCH_DQ(64);
+#undef PM_LAUNCH_DQ
   PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dq)");
   return PM_OK;
 }
