@@ -357,6 +357,49 @@ int pm_comm_group_start(void);
 int pm_comm_group_end(void);
 
 /* --------------------------------------------------------------------------------------------
+ * MoE routing / permutation / combine (the expert-parallel half) — src/prime_rl/trainer/models/layers/moe.py.
+ * Token-major tensors; a "slot" is one (token, j < top_k) selection, flattened slot = token * top_k + j; "sorted row" = position of a
+ * slot after the stable sort by expert (TokenReorderer, moe.py:769-809).  The expert GEMMs stay library calls (grouped GEMM).
+ *
+ * pm_moe_router_fwd — TokenChoiceTopKRouter.forward after the gate GEMM (moe.py:707-746):
+ *     scores[N,E] f32 = softmax (score_func 0) | sigmoid (1) of gate_logits (bf16 or f32); selection = forced_idx[N,k] (routed_experts,
+ *     moe.py:718-720) | top-k of scores + expert_bias[E] (moe.py:726-728) | top-k of scores (ties -> lowest expert index);
+ *     top_scores[N,k] = unbiased selected scores, / (their sum + 1e-20) if route_norm, * route_scale; top_idx[N,k];
+ *     counts[E] (zeroed by the call) = selections per expert (histc, moe.py:739-744); confidence[N] = selected probability mass per token
+ *     (_selected_probability_mass_sum, moe.py:634-641: the caller sums it).
+ * pm_moe_router_bwd — d top_scores -> d gate_logits [N,E] f32 through normalisation, scale, gather and softmax / sigmoid.
+ * pm_moe_sort — stable counting sort of top_idx (flattened, n_slots = N*k) by expert: dest_of_slot[n_slots], slot_of_dest[n_slots]
+ *     (= torch.argsort(stable=True), moe.py:801), offsets[E+1] (exclusive scan of counts).  Three launches, no host sync.
+ * pm_moe_gather_rows — out[r] = x[row_map[r] / divisor] (* scale[row_map[r]] in f32, rounded to bf16): the expert-sorted gather
+ *     (moe.py:891-895, divisor = top_k, row_map = slot_of_dest, scale = top_scores when score_before_experts) and, with divisor 1, any
+ *     row permutation (expert-parallel regrouping).  row_map[r] < 0 -> zero row.
+ * pm_moe_combine — out[t] = bf16(base[t] + sum over the token's k slots of bf16(y[dest_of_slot[t*k+j]] * scores[t*k+j])), added in ascending
+ *     sorted-row order in f32 and rounded once: the reference's bf16 scatter_add (moe.py:1043-1051) as a deterministic gather.
+ *     scores / base nullable (plain sum = backward of the gather).
+ * pm_moe_slot_grads — per sorted row r (slot s = slot_of_dest[r], token t = s / k): rows_out[r] = bf16(a[t] * scores[s]) and
+ *     dscore[s] = <a[t], b[r]> in f32: the two gradients of the per-row score multiply (moe.py:894-900).  Either output nullable.
+ * pm_moe_ep_row_map — expert-parallel regrouping after the row all-to-all (torchtitan ExpertParallel._token_dispatch, used by
+ *     trainer/distributed/expert_parallel.py:47-63): recv_counts[ep][n_local] -> row_map (expert-major row -> received row), its
+ *     inverse, and local_offsets[n_local+1]. */
+int pm_moe_router_fwd(const void* gate_logits, int32_t logits_dtype, const float* expert_bias /* nullable */, const int32_t* forced_idx /* nullable */,
+                      int64_t n_tokens, int32_t n_experts, int32_t top_k, int32_t score_func, int32_t route_norm, float route_scale,
+                      float* scores, float* top_scores, int32_t* top_idx, int32_t* counts, float* confidence, void* stream);
+int pm_moe_router_bwd(const float* scores, const int32_t* top_idx, const float* grad_top_scores, int64_t n_tokens, int32_t n_experts, int32_t top_k,
+                      int32_t score_func, int32_t route_norm, float route_scale, float* grad_logits, void* stream);
+int64_t pm_moe_sort_workspace_bytes(int64_t n_slots, int32_t n_experts);
+int pm_moe_sort(const int32_t* top_idx, int64_t n_slots, int32_t n_experts, int32_t* dest_of_slot, int32_t* slot_of_dest, int32_t* offsets,
+                void* workspace, int64_t workspace_bytes, void* stream);
+int pm_moe_gather_rows(const void* x_bf16, const int32_t* row_map, int32_t divisor, const float* scale /* nullable */, int64_t n_rows,
+                       int64_t row_elems, void* out_bf16, void* stream);
+int pm_moe_combine(const void* y_bf16, const int32_t* dest_of_slot, const float* scores /* nullable */, const void* base_bf16 /* nullable */,
+                   int64_t n_tokens, int32_t top_k, int64_t row_elems, void* out_bf16, void* stream);
+int pm_moe_slot_grads(const void* a_bf16, const void* b_bf16 /* nullable iff dscore is */, const int32_t* slot_of_dest, int32_t top_k,
+                      const float* scores /* nullable */, int64_t n_rows, int64_t row_elems, void* rows_out_bf16 /* nullable */,
+                      float* dscore /* nullable */, void* stream);
+int pm_moe_ep_row_map(const int32_t* recv_counts, int32_t ep_size, int32_t n_local_experts, int32_t* row_map, int32_t* inv_map,
+                      int32_t* local_offsets, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
  * C[16,16] = A[16,32] @ B[32,16]^T-free form: c = sum_k a[i][k]*b[j][k]  (both operands K-contiguous, bf16). */
 int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);

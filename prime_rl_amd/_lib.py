@@ -118,6 +118,14 @@ SIGNATURES: dict[str, tuple] = {
     "pm_comm_group_end": (I, []),
     "pm_mfma_probe_16x16x32": (I, [P, P, P, P]),
     "pm_attn_debug_set_variant": (I, [I32, I32]),
+    "pm_moe_router_fwd": (I, [P, I32, P, P, I64, I32, I32, I32, I32, F, P, P, P, P, P, P]),
+    "pm_moe_router_bwd": (I, [P, P, P, I64, I32, I32, I32, I32, F, P, P]),
+    "pm_moe_sort_workspace_bytes": (I64, [I64, I32]),
+    "pm_moe_sort": (I, [P, I64, I32, P, P, P, P, I64, P]),
+    "pm_moe_gather_rows": (I, [P, P, I32, P, I64, I64, P, P]),
+    "pm_moe_combine": (I, [P, P, P, P, I64, I32, I64, P, P]),
+    "pm_moe_slot_grads": (I, [P, P, P, I32, P, I64, I64, P, P, P]),
+    "pm_moe_ep_row_map": (I, [P, I32, I32, P, P, P, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
 }
 

@@ -376,9 +376,9 @@ extern "C" int pm_lmhead_logprob_fwd(const void* hidden_bf16, const void* weight
   hipStream_t st = as_stream(stream);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)lmhead_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-    hipFuncSetAttribute((const void*)lmhead_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-    hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
     attr_done = true;
   }
   const int grid = grid_blocks(a);
@@ -407,7 +407,7 @@ extern "C" int pm_lmhead_logprob_bwd(const void* hidden_bf16, const void* weight
   a.ld = dlogits_ld;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
     attr_done = true;
   }
   hipLaunchKernelGGL((lmhead_kernel<true, true>), dim3(grid_blocks(a)), dim3(kThreads), kSmemBytes, as_stream(stream), a);

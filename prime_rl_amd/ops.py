@@ -513,3 +513,113 @@ def device_arch() -> str:
     buf = ctypes.create_string_buffer(128)
     check(lib.pm_device_arch(buf, 128), "pm_device_arch")
     return buf.value.decode()
+
+
+# ------------------------------------------------------------------------------------------------ MoE (row f4)
+def moe_router_fwd(gate_logits: Tensor, top_k: int, score_func: str = "softmax", route_norm: bool = False, route_scale: float = 1.0,
+                   expert_bias: Tensor | None = None, forced_idx: Tensor | None = None):
+    """TokenChoiceTopKRouter.forward after the gate GEMM (pm_moe_router_fwd).  gate_logits [N, E] bf16 | f32 ->
+    (scores [N,E] f32, top_scores [N,k] f32, top_idx [N,k] i32, counts [E] i32, confidence [N] f32)."""
+    lib = _lib.load()
+    _req(gate_logits, None, "gate_logits")
+    if gate_logits.dtype not in (torch.bfloat16, torch.float32) or gate_logits.dim() != 2:
+        raise PrimeMI355XError(f"gate_logits must be [N, E] bf16 or f32, got {gate_logits.dtype} {tuple(gate_logits.shape)}")
+    if score_func not in ("softmax", "sigmoid"):
+        raise PrimeMI355XError(f"unknown score function {score_func!r}")
+    n, e = gate_logits.shape
+    dev = gate_logits.device
+    if expert_bias is not None:
+        _req(expert_bias, torch.float32, "expert_bias")
+    if forced_idx is not None:
+        _req(forced_idx, torch.int32, "forced_idx")
+        if tuple(forced_idx.shape) != (n, top_k):
+            raise PrimeMI355XError(f"forced_idx must be [N, top_k], got {tuple(forced_idx.shape)}")
+    scores = torch.empty((n, e), dtype=torch.float32, device=dev)
+    top_scores = torch.empty((n, top_k), dtype=torch.float32, device=dev)
+    top_idx = torch.empty((n, top_k), dtype=torch.int32, device=dev)
+    counts = torch.empty(e, dtype=torch.int32, device=dev)
+    conf = torch.empty(n, dtype=torch.float32, device=dev)
+    dt = _lib.PM_DTYPE_BF16 if gate_logits.dtype == torch.bfloat16 else _lib.PM_DTYPE_F32
+    check(lib.pm_moe_router_fwd(_p(gate_logits), dt, _p(expert_bias), _p(forced_idx), n, e, top_k, 1 if score_func == "sigmoid" else 0,
+                                1 if route_norm else 0, float(route_scale), _p(scores), _p(top_scores), _p(top_idx), _p(counts), _p(conf), _stream()),
+          "pm_moe_router_fwd")
+    return scores, top_scores, top_idx, counts, conf
+
+
+def moe_router_bwd(scores: Tensor, top_idx: Tensor, grad_top_scores: Tensor, score_func: str, route_norm: bool, route_scale: float) -> Tensor:
+    """d top_scores [N,k] -> d gate_logits [N,E] f32 (pm_moe_router_bwd)."""
+    lib = _lib.load()
+    _req(scores, torch.float32, "scores"); _req(top_idx, torch.int32, "top_idx"); _req(grad_top_scores, torch.float32, "grad_top_scores")
+    n, e = scores.shape
+    k = top_idx.shape[1]
+    out = torch.empty_like(scores)
+    check(lib.pm_moe_router_bwd(_p(scores), _p(top_idx), _p(grad_top_scores), n, e, k, 1 if score_func == "sigmoid" else 0, 1 if route_norm else 0,
+                                float(route_scale), _p(out), _stream()), "pm_moe_router_bwd")
+    return out
+
+
+def moe_sort(top_idx: Tensor, n_experts: int):
+    """Stable sort of the flattened (token, slot) pairs by expert (pm_moe_sort) -> (dest_of_slot [N*k], slot_of_dest [N*k], offsets [E+1]), i32."""
+    lib = _lib.load()
+    _req(top_idx, torch.int32, "top_idx")
+    m = top_idx.numel()
+    dev = top_idx.device
+    dest = torch.empty(m, dtype=torch.int32, device=dev)
+    slot = torch.empty(m, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n_experts + 1, dtype=torch.int32, device=dev)
+    ws = workspace(lib.pm_moe_sort_workspace_bytes(m, n_experts), dev, "moe_sort")
+    check(lib.pm_moe_sort(_p(top_idx), m, n_experts, _p(dest), _p(slot), _p(offsets), _p(ws), ws.numel(), _stream()), "pm_moe_sort")
+    return dest, slot, offsets
+
+
+def moe_gather_rows(x: Tensor, row_map: Tensor, divisor: int = 1, scale: Tensor | None = None) -> Tensor:
+    """out[r] = x[row_map[r] // divisor] (* scale[row_map[r]]), bf16 rows (pm_moe_gather_rows); row_map[r] < 0 -> zero row."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x"); _req(row_map, torch.int32, "row_map")
+    if scale is not None:
+        _req(scale, torch.float32, "scale")
+    h = x.shape[-1]
+    out = torch.empty((row_map.numel(), h), dtype=torch.bfloat16, device=x.device)
+    check(lib.pm_moe_gather_rows(_p(x), _p(row_map), divisor, _p(scale), row_map.numel(), h, _p(out), _stream()), "pm_moe_gather_rows")
+    return out
+
+
+def moe_combine(y: Tensor, dest_of_slot: Tensor, top_k: int, scores: Tensor | None = None, base: Tensor | None = None) -> Tensor:
+    """out[t] = base[t] + sum_j bf16(y[dest_of_slot[t*k+j]] * scores[t*k+j]) accumulated in f32 in sorted-row order, rounded once (pm_moe_combine)."""
+    lib = _lib.load()
+    _req(y, torch.bfloat16, "y"); _req(dest_of_slot, torch.int32, "dest_of_slot")
+    if scores is not None:
+        _req(scores, torch.float32, "scores")
+    if base is not None:
+        _req(base, torch.bfloat16, "base")
+    n = dest_of_slot.numel() // top_k
+    h = y.shape[-1]
+    out = torch.empty((n, h), dtype=torch.bfloat16, device=y.device)
+    check(lib.pm_moe_combine(_p(y), _p(dest_of_slot), _p(scores), _p(base), n, top_k, h, _p(out), _stream()), "pm_moe_combine")
+    return out
+
+
+def moe_slot_grads(a: Tensor, b: Tensor | None, slot_of_dest: Tensor, top_k: int, scores: Tensor | None, want_rows: bool, want_dscore: bool):
+    """Per sorted row r (slot s, token t = s // k): rows[r] = bf16(a[t] * scores[s]), dscore[s] = <a[t], b[r]> (pm_moe_slot_grads)."""
+    lib = _lib.load()
+    _req(a, torch.bfloat16, "a"); _req(slot_of_dest, torch.int32, "slot_of_dest")
+    m, h = slot_of_dest.numel(), a.shape[-1]
+    rows = torch.empty((m, h), dtype=torch.bfloat16, device=a.device) if want_rows else None
+    dscore = torch.zeros(m, dtype=torch.float32, device=a.device) if want_dscore else None
+    if want_dscore:
+        _req(b, torch.bfloat16, "b")
+    check(lib.pm_moe_slot_grads(_p(a), _p(b), _p(slot_of_dest), top_k, _p(scores), m, h, _p(rows), _p(dscore), _stream()), "pm_moe_slot_grads")
+    return rows, dscore
+
+
+def moe_ep_row_map(recv_counts: Tensor, total_rows: int):
+    """recv_counts [ep, n_local] i32 (rows received per (source rank, local expert)) -> (row_map, inv_map [total_rows], local_offsets [n_local+1])."""
+    lib = _lib.load()
+    _req(recv_counts, torch.int32, "recv_counts")
+    ep, le = recv_counts.shape
+    dev = recv_counts.device
+    row_map = torch.empty(total_rows, dtype=torch.int32, device=dev)
+    inv_map = torch.empty(total_rows, dtype=torch.int32, device=dev)
+    offs = torch.empty(le + 1, dtype=torch.int32, device=dev)
+    check(lib.pm_moe_ep_row_map(_p(recv_counts), ep, le, _p(row_map), _p(inv_map), _p(offs), _stream()), "pm_moe_ep_row_map")
+    return row_map, inv_map, offs

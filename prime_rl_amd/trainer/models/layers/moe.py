@@ -1,0 +1,253 @@
+"""Token-choice MoE layer on the HIP seams — mirrors `prime_rl.trainer.models.layers.moe`
+(src/prime_rl/trainer/models/layers/moe.py): `MoEArgs` (:21-37), `BCFeedForward` (:71-90, the shared expert), `GroupedExperts` (:431-485,
+parameters `w1 [E, hidden, dim]`, `w2 [E, dim, hidden]`, `w3 [E, hidden, dim]`), `TokenChoiceTopKRouter` (:644-751, `gate`),
+`TokenReorderer` (:754-809), `MoE` (:812-1054: `experts`, `router`, `reorderer`, `shared_expert`, buffers `expert_bias`,
+`tokens_per_expert`, `routing_confidence_sum`) — same module tree, parameter names and forward contract (`x [bs, slen, dim]`, optional
+`routed_experts [bs, slen, top_k]`).
+
+What runs where: the gate and expert GEMMs are library calls (the expert GEMMs grouped: `torch._grouped_mm` with device-side offsets,
+or a per-expert loop when `use_grouped_mm=False`, exactly the reference's two paths); everything between them is `moe.hip`:
+score function + top-k + normalisation + histogram in one launch per layer (`pm_moe_router_fwd`, the reference: softmax, topk, gather,
+sum, div, mul, histc), a three-launch stable counting sort (`pm_moe_sort`; the reference: histc + argsort + index + floor-divide), the
+expert-sorted row gather with the optional score multiply (`pm_moe_gather_rows`) and the weighted combine as a deterministic gather with
+f32 accumulation (`pm_moe_combine`; the reference: f32 multiply, cast, zeros_like, scatter_add with atomics).
+Expert parallelism (`ep_group`): `prime_rl_amd.trainer.distributed.expert_parallel` dispatches the sorted rows to the ranks that own
+the experts and brings the outputs back (all-to-all over xGMI), the experts module then holds `E / ep` experts.
+
+Not built (the reference's other branches): DeepEP, the fused Triton MoE kernel, FP8 / MXFP8 experts, GPT-OSS and non-gated experts,
+NemotronH router."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from .... import ops
+from ...distributed import expert_parallel as EP
+
+
+@dataclass
+class MoEArgs:
+    num_experts: int = 8
+    num_shared_experts: int = 1
+    # router
+    score_func: str = "sigmoid"
+    route_norm: bool = False
+    route_scale: float = 1.0
+    score_before_experts: bool = True
+    # token-choice
+    top_k: int = 1
+    use_grouped_mm: bool = True
+    load_balance_coeff: float | None = 1e-3
+    fp8: bool = False
+
+
+class BCFeedForward(nn.Module):
+    """The shared expert: w2(silu(w1 x) * w3 x) with bare parameter matrices (moe.py:71-90)."""
+
+    def __init__(self, dim: int, hidden_dim: int) -> None:
+        super().__init__()
+        self.w1 = nn.Parameter(torch.empty(hidden_dim, dim))
+        self.w2 = nn.Parameter(torch.empty(dim, hidden_dim))
+        self.w3 = nn.Parameter(torch.empty(hidden_dim, dim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.matmul(F.silu(torch.matmul(x, self.w1.T)) * torch.matmul(x, self.w3.T), self.w2.T)
+
+    def init_weights(self, init_std: float):
+        nn.init.trunc_normal_(self.w1, mean=0.0, std=0.02)
+        nn.init.trunc_normal_(self.w2, mean=0.0, std=init_std)
+        nn.init.trunc_normal_(self.w3, mean=0.0, std=init_std)
+
+
+def _experts_grouped(w1, w2, w3, x, offsets):
+    """_run_experts_grouped_mm_impl (moe.py:161-188): three grouped GEMMs over the expert-sorted rows, offsets stay on the device."""
+    offs = offsets[1:]  # cumulative END of every group, int32
+    h = F.silu(torch._grouped_mm(x, w1.transpose(-2, -1), offs=offs))
+    h = h * torch._grouped_mm(x, w3.transpose(-2, -1), offs=offs)
+    return torch._grouped_mm(h, w2.transpose(-2, -1), offs=offs)
+
+
+def _experts_for_loop(w1, w2, w3, x, offsets):
+    """_run_experts_for_loop_impl (moe.py:93-126); like the reference this path synchronises with the host for the group sizes."""
+    bounds = offsets.tolist()
+    outs = []
+    for e in range(len(bounds) - 1):
+        xe = x[bounds[e]:bounds[e + 1]]
+        h = F.silu(torch.matmul(xe, w1[e].transpose(-2, -1))) * torch.matmul(xe, w3[e].transpose(-2, -1))
+        outs.append(torch.matmul(h, w2[e].transpose(-2, -1)))
+    return torch.cat(outs, dim=0) if outs else x.new_zeros((0, w2.shape[1]))
+
+
+class GroupedExperts(nn.Module):
+    def __init__(self, dim: int, hidden_dim: int, num_experts: int, use_grouped_mm: bool, fp8: bool = False):
+        super().__init__()
+        if fp8:
+            raise NotImplementedError("FP8 expert GEMMs (moe.py:151-158) are not built")
+        self.num_experts = num_experts  # the LOCAL expert count under expert parallelism
+        self.w1 = nn.Parameter(torch.empty(num_experts, hidden_dim, dim))
+        self.w2 = nn.Parameter(torch.empty(num_experts, dim, hidden_dim))
+        self.w3 = nn.Parameter(torch.empty(num_experts, hidden_dim, dim))
+        self.use_grouped_mm = use_grouped_mm
+
+    def forward(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+        """x: rows sorted by (local) expert; offsets [E_local + 1] i32 on the device."""
+        fn = _experts_grouped if self.use_grouped_mm else _experts_for_loop
+        return fn(self.w1, self.w2, self.w3, x, offsets)
+
+    def init_weights(self, init_std: float):
+        nn.init.trunc_normal_(self.w1, mean=0.0, std=0.02)
+        nn.init.trunc_normal_(self.w2, mean=0.0, std=init_std)
+        nn.init.trunc_normal_(self.w3, mean=0.0, std=init_std)
+
+
+class _RouterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, expert_bias, forced, top_k, score_func, route_norm, route_scale):
+        scores, top_scores, top_idx, counts, conf = ops.moe_router_fwd(logits, top_k, score_func, route_norm, route_scale, expert_bias, forced)
+        ctx.save_for_backward(scores, top_idx)
+        ctx.cfg = (score_func, route_norm, route_scale, logits.dtype)
+        ctx.mark_non_differentiable(top_idx, counts, conf)
+        return top_scores, top_idx, counts, conf
+
+    @staticmethod
+    def backward(ctx, g_top, *_):
+        scores, top_idx = ctx.saved_tensors
+        score_func, route_norm, route_scale, dtype = ctx.cfg
+        g = ops.moe_router_bwd(scores, top_idx, g_top.contiguous().float(), score_func, route_norm, route_scale)
+        return g.to(dtype), None, None, None, None, None, None
+
+
+class TokenChoiceTopKRouter(nn.Module):
+    def __init__(self, dim: int, num_experts: int, top_k: int, score_func: str, route_norm: bool, route_scale: float):
+        super().__init__()
+        self.gate = nn.Linear(dim, num_experts, bias=False)
+        self.num_experts, self.top_k = num_experts, top_k
+        self.score_func, self.route_norm, self.route_scale = score_func, route_norm, route_scale
+        self.fp32_gate = False  # model.moe_router_dtype = 'float32' (moe.py:674-676)
+
+    def forward(self, x: torch.Tensor, expert_bias: torch.Tensor | None = None, routed_experts: torch.Tensor | None = None):
+        """-> (top_scores [N,k] f32, selected_experts_indices [N,k] i32, num_tokens_per_expert [E] i32, routing_confidence_sum)."""
+        if routed_experts is not None and routed_experts.shape[-1] != self.top_k:
+            raise AssertionError(f"routed_experts shape: {routed_experts.shape}, top_k: {self.top_k}")
+        logits = self.gate(x.to(torch.float32)) if self.fp32_gate else self.gate(x)
+        forced = None if routed_experts is None else routed_experts.reshape(-1, self.top_k).to(torch.int32).contiguous()
+        top_scores, idx, counts, conf = _RouterFn.apply(logits.contiguous(), expert_bias, forced, self.top_k, self.score_func, self.route_norm,
+                                                        self.route_scale)
+        return top_scores, idx, counts, conf.sum()
+
+    def init_weights(self, init_std: float):
+        nn.init.trunc_normal_(self.gate.weight, mean=0.0, std=init_std)
+
+
+class TokenReorderer(nn.Module):
+    """Stable sort of the (token, slot) pairs by expert (moe.py:754-809).  Returns the reference's triple plus the two index maps the
+    permutation kernels consume (`slot_of_dest` = the argsort, `dest_of_slot` = its inverse) and the device-side group offsets."""
+
+    def __init__(self, num_experts: int, top_k: int):
+        super().__init__()
+        self.num_experts, self.top_k = num_experts, top_k
+
+    def forward(self, top_scores: torch.Tensor, selected_experts_indices: torch.Tensor):
+        dest_of_slot, slot_of_dest, offsets = ops.moe_sort(selected_experts_indices.reshape(-1).contiguous(), self.num_experts)
+        return dest_of_slot, slot_of_dest, offsets
+
+
+class _GatherFn(torch.autograd.Function):
+    """routed_input = x[token of every sorted row] (* score, rounded to bf16): moe.py:891-895."""
+
+    @staticmethod
+    def forward(ctx, x, scores_flat, slot_of_dest, dest_of_slot, top_k):
+        ctx.save_for_backward(x, scores_flat, slot_of_dest, dest_of_slot)
+        ctx.top_k = top_k
+        return ops.moe_gather_rows(x, slot_of_dest, top_k, scores_flat)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, scores_flat, slot_of_dest, dest_of_slot = ctx.saved_tensors
+        g = g.contiguous()
+        gx = ops.moe_combine(g, dest_of_slot, ctx.top_k, scores=scores_flat)  # the gather's scatter_add backward, fixed order
+        gs = None
+        if scores_flat is not None:
+            _, gs = ops.moe_slot_grads(x, g, slot_of_dest, ctx.top_k, None, want_rows=False, want_dscore=True)
+        return gx, gs, None, None, None
+
+
+class _CombineFn(torch.autograd.Function):
+    """out = base + scatter_add of bf16(routed_output * score) over token rows: moe.py:899-900, 1043-1051."""
+
+    @staticmethod
+    def forward(ctx, y, scores_flat, base, slot_of_dest, dest_of_slot, top_k):
+        ctx.save_for_backward(y, scores_flat, slot_of_dest)
+        ctx.top_k, ctx.has_base = top_k, base is not None
+        return ops.moe_combine(y, dest_of_slot, top_k, scores=scores_flat, base=base)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, scores_flat, slot_of_dest = ctx.saved_tensors
+        g = g.contiguous()
+        gy, gs = ops.moe_slot_grads(g, y, slot_of_dest, ctx.top_k, scores_flat, want_rows=True, want_dscore=scores_flat is not None)
+        return gy, gs, (g if ctx.has_base else None), None, None, None
+
+
+class MoE(nn.Module):
+    def __init__(self, moe_args: MoEArgs, dim: int, hidden_dim: int, ep_group: dist.ProcessGroup | None = None):
+        super().__init__()
+        num_experts = moe_args.num_experts
+        self.ep_group = ep_group
+        self.ep_size = dist.get_world_size(ep_group) if ep_group is not None else 1
+        if num_experts % self.ep_size:
+            raise ValueError(f"num_experts {num_experts} is not divisible by the expert-parallel degree {self.ep_size}")
+        self.experts = GroupedExperts(dim=dim, hidden_dim=hidden_dim, num_experts=num_experts // self.ep_size, use_grouped_mm=moe_args.use_grouped_mm,
+                                      fp8=moe_args.fp8)
+        self.router = TokenChoiceTopKRouter(dim=dim, num_experts=num_experts, top_k=moe_args.top_k, score_func=moe_args.score_func,
+                                            route_norm=moe_args.route_norm, route_scale=moe_args.route_scale)
+        self.reorderer = TokenReorderer(num_experts=num_experts, top_k=moe_args.top_k)
+        self.shared_expert = BCFeedForward(dim=dim, hidden_dim=hidden_dim * moe_args.num_shared_experts) if moe_args.num_shared_experts > 0 else None
+        self.score_before_experts = moe_args.score_before_experts
+        self.top_k, self.num_experts = moe_args.top_k, num_experts
+        self.load_balance_coeff = moe_args.load_balance_coeff
+        if self.load_balance_coeff is not None:
+            assert self.load_balance_coeff > 0.0
+            self.register_buffer("expert_bias", torch.zeros(num_experts, dtype=torch.float32), persistent=True)
+        else:
+            self.expert_bias = None
+        self.register_buffer("tokens_per_expert", torch.zeros(num_experts, dtype=torch.float32), persistent=False)
+        self.register_buffer("routing_confidence_sum", torch.tensor(0.0, dtype=torch.float32), persistent=False)
+
+    def forward(self, x: torch.Tensor, routed_experts: torch.Tensor | None = None) -> torch.Tensor:
+        bs, slen, dim = x.shape
+        x = x.reshape(-1, dim)
+        if x.dtype != torch.bfloat16:
+            raise NotImplementedError("the HIP MoE permutation kernels move bf16 rows (the reference trains in bf16)")
+        if routed_experts is not None:
+            routed_experts = routed_experts.reshape(-1, routed_experts.shape[-1])
+        top_scores, idx, counts, conf = self.router(x, self.expert_bias, routed_experts=routed_experts)
+        with torch.no_grad():  # moe.py:1010-1012
+            self.tokens_per_expert.add_(counts)
+            self.routing_confidence_sum.add_(conf)
+        dest_of_slot, slot_of_dest, offsets = self.reorderer(top_scores, idx)
+        scores_flat = top_scores.reshape(-1)
+        routed_in = _GatherFn.apply(x, scores_flat if self.score_before_experts else None, slot_of_dest, dest_of_slot, self.top_k)
+        if self.ep_size > 1:
+            routed_out = EP.run_experts(self.experts, routed_in, counts, self.ep_group)
+        else:
+            routed_out = self.experts(routed_in, offsets)
+        base = self.shared_expert(x) if self.shared_expert is not None else None
+        out = _CombineFn.apply(routed_out.contiguous(), None if self.score_before_experts else scores_flat, base, slot_of_dest, dest_of_slot, self.top_k)
+        return out.reshape(bs, slen, dim)
+
+    def init_weights(self, init_std: float, buffer_device: torch.device | None = None):
+        self.experts.init_weights(init_std)
+        self.router.init_weights(init_std)
+        if self.shared_expert is not None:
+            self.shared_expert.init_weights(init_std)
+        with torch.no_grad():
+            self.tokens_per_expert.zero_()
+            self.routing_confidence_sum.zero_()
+            if self.expert_bias is not None:
+                self.expert_bias.zero_()
