@@ -24,7 +24,7 @@ constexpr int kMaxTopK = 16;
 //   selection = forced indices (moe.py:718-720) | top-k of scores + bias (moe.py:726-728) | top-k of scores (moe.py:730); ties -> lowest index;
 //   gating value = unbiased score, optionally normalised over the selected k and scaled (moe.py:734-737);
 //   confidence[token] = selected probability mass before normalisation (moe.py:634-641); counts[e] += 1 per selection (moe.py:739-744).
-template <typename T>
+template <typename T, int kPer>  // kPer = experts per lane (E <= 64 * kPer): the score registers of a token
 __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ bias, const int32_t* __restrict__ forced,
                                                             int64_t n, int E, int k, int sigmoid, int route_norm, float route_scale,
                                                             float* __restrict__ scores, float* __restrict__ top_scores, int32_t* __restrict__ top_idx,
@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= n) return;
-  const int per = (E + 63) / 64;
-  float s[kMaxPerLane], key[kMaxPerLane];
+  constexpr int per = kPer;
+  float s[kPer], key[kPer];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < kPer; ++i) {
     const int e = i * 64 + lane;
     s[i] = -INFINITY;
     if (i < per && e < E) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
   float total = 0.f;
   if (sigmoid) {
 #pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i) {
+    for (int i = 0; i < kPer; ++i) {
       const int e = i * 64 + lane;
       if (i < per && e < E) {
         s[i] = 1.0f / (1.0f + expf(-s[i]));
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
     mx = wave_max(mx);
     float z = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i) {
+    for (int i = 0; i < kPer; ++i) {
       const int e = i * 64 + lane;
       if (i < per && e < E) {
         s[i] = expf(s[i] - mx);
@@ -70,12 +70,12 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
     z = wave_sum(z);
     const float inv = 1.0f / z;
 #pragma unroll
-    for (int i = 0; i < kMaxPerLane; ++i)
+    for (int i = 0; i < kPer; ++i)
       if (i < per && i * 64 + lane < E) s[i] *= inv;
     total = 1.0f;
   }
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) {
+  for (int i = 0; i < kPer; ++i) {
     const int e = i * 64 + lane;
     key[i] = -INFINITY;
     if (i < per && e < E) {
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
       be = forced[tok * k + j];
       float mine = 0.f;
 #pragma unroll
-      for (int i = 0; i < kMaxPerLane; ++i)
+      for (int i = 0; i < kPer; ++i)
         if (i < per && i * 64 + lane == be) mine = s[i];
       bs = wave_sum(mine);  // exactly one lane holds it
     } else {
       float bk = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int i = 0; i < kMaxPerLane; ++i) {
+      for (int i = 0; i < kPer; ++i) {
         const int e = i * 64 + lane;
         if (i < per && e < E && (key[i] > bk)) {  // strict: the lowest index of a lane's equal keys wins (i ascending)
           bk = key[i];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
       be = bi;
       float mine = 0.f;
 #pragma unroll
-      for (int i = 0; i < kMaxPerLane; ++i)
+      for (int i = 0; i < kPer; ++i)
         if (i < per && i * 64 + lane == be) {
           mine = s[i];
           key[i] = -INFINITY;  // taken
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void moe_router_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Stable counting sort of the flattened (token, slot) pairs by expert (TokenReorderer, moe.py:769-809: argsort(stable=True)).
-constexpr int kSortChunk = 1024;  // slots per block (4 rounds of 256)
+constexpr int kSortChunk = 256;  // slots per block (one round of 4 waves: 512 blocks for 16k tokens x 8 slots)
 
 __global__ __launch_bounds__(256) void moe_sort_hist_kernel(const int32_t* __restrict__ idx, int64_t m, int E, int32_t* __restrict__ block_hist) {
   extern __shared__ int32_t hist[];
@@ -424,12 +424,21 @@ extern "C" int pm_moe_router_fwd(const void* gate_logits, int32_t logits_dtype, 
   if (hipMemsetAsync(counts, 0, (size_t)n_experts * 4, st) != hipSuccess) return PM_ERR_LAUNCH;
   if (n_tokens == 0) return PM_OK;
   const dim3 grid((unsigned)cdiv(n_tokens, 4));
-  if (logits_dtype == PM_DTYPE_BF16)
-    hipLaunchKernelGGL(moe_router_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)gate_logits, expert_bias, forced_idx, n_tokens, n_experts, top_k,
-                       score_func, route_norm, route_scale, scores, top_scores, top_idx, counts, confidence);
-  else
-    hipLaunchKernelGGL(moe_router_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)gate_logits, expert_bias, forced_idx, n_tokens, n_experts, top_k,
-                       score_func, route_norm, route_scale, scores, top_scores, top_idx, counts, confidence);
+#define PM_LAUNCH_ROUTER(T_, PER_)                                                                                                                 \
+  hipLaunchKernelGGL((moe_router_fwd_kernel<T_, PER_>), grid, dim3(256), 0, st, (const T_*)gate_logits, expert_bias, forced_idx, n_tokens, n_experts, \
+                     top_k, score_func, route_norm, route_scale, scores, top_scores, top_idx, counts, confidence)
+#define PM_LAUNCH_ROUTER_T(T_)                                 \
+  do {                                                        \
+    if (n_experts <= 64) PM_LAUNCH_ROUTER(T_, 1);             \
+    else if (n_experts <= 128) PM_LAUNCH_ROUTER(T_, 2);       \
+    else if (n_experts <= 256) PM_LAUNCH_ROUTER(T_, 4);       \
+    else if (n_experts <= 512) PM_LAUNCH_ROUTER(T_, 8);       \
+    else PM_LAUNCH_ROUTER(T_, 16);                            \
+  } while (0)
+  if (logits_dtype == PM_DTYPE_BF16) PM_LAUNCH_ROUTER_T(bf16_t);
+  else PM_LAUNCH_ROUTER_T(float);
+#undef PM_LAUNCH_ROUTER_T
+#undef PM_LAUNCH_ROUTER
   PM_CHECK_LAUNCH("pm_moe_router_fwd");
   return PM_OK;
 }

@@ -210,3 +210,89 @@ def adamw_step(master, exp_avg, exp_avg_sq, grad, param_bf16, lr, beta1, beta2, 
         param_bf16.copy_(master.to(BF16))
     if zero_grad:
         grad.zero_()
+
+
+# ------------------------------------------------------------------------------------------------ MoE stand-ins (tests/test_moe_ep_gloo_cpu.py)
+def moe_router_fwd(gate_logits, top_k, score_func="softmax", route_norm=False, route_scale=1.0, expert_bias=None, forced_idx=None):
+    scores = torch.sigmoid(gate_logits.float()) if score_func == "sigmoid" else torch.softmax(gate_logits.float(), dim=1)
+    if forced_idx is not None:
+        idx = forced_idx.long()
+    else:
+        idx = torch.topk(scores if expert_bias is None else scores + expert_bias, top_k, dim=1).indices
+    top = scores.gather(1, idx)
+    conf = top.sum(-1) if score_func == "softmax" else top.sum(-1) / (scores.sum(-1) + 1e-20)
+    if route_norm:
+        top = top / (top.sum(-1, keepdim=True) + 1e-20)
+    top = top * route_scale
+    counts = torch.bincount(idx.reshape(-1), minlength=gate_logits.shape[1]).to(torch.int32)
+    return scores, top, idx.to(torch.int32), counts, conf
+
+
+def moe_router_bwd(scores, top_idx, grad_top, score_func, route_norm, route_scale):
+    idx = top_idx.long()
+    s = scores.gather(1, idx)
+    g = grad_top * route_scale
+    if route_norm:
+        tot = s.sum(-1, keepdim=True) + 1e-20
+        g = (g - (g * s).sum(-1, keepdim=True) / tot) / tot
+    ds = torch.zeros_like(scores).scatter_add(1, idx, g)
+    if score_func == "sigmoid":
+        return scores * (1 - scores) * ds
+    return scores * (ds - (s * g).sum(-1, keepdim=True))
+
+
+def moe_sort(top_idx, n_experts):
+    flat = top_idx.reshape(-1).long()
+    order = torch.argsort(flat, stable=True)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel())
+    counts = torch.bincount(flat, minlength=n_experts)
+    offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+    return inv.to(torch.int32), order.to(torch.int32), offsets
+
+
+def moe_gather_rows(x, row_map, divisor=1, scale=None):
+    m = row_map.long()
+    out = x[(m.clamp(min=0) // divisor)]
+    if scale is not None:
+        out = (out.float() * scale[m.clamp(min=0)][:, None]).to(BF16)
+    return torch.where((m < 0)[:, None], torch.zeros_like(out), out)
+
+
+def moe_combine(y, dest_of_slot, top_k, scores=None, base=None):
+    n = dest_of_slot.numel() // top_k
+    rows = y[dest_of_slot.long()].float()
+    if scores is not None:
+        rows = (rows * scores[:, None]).to(BF16).float()
+    acc = rows.reshape(n, top_k, -1).sum(1)
+    if base is not None:
+        acc = acc + base.float()
+    return acc.to(BF16)
+
+
+def moe_slot_grads(a, b, slot_of_dest, top_k, scores, want_rows, want_dscore):
+    slot = slot_of_dest.long()
+    at = a[slot // top_k]
+    rows = dscore = None
+    if want_rows:
+        rows = at if scores is None else (at.float() * scores[slot][:, None]).to(BF16)
+    if want_dscore:
+        dscore = torch.zeros(slot.numel())
+        dscore[slot] = (at.float() * b.float()).sum(-1)
+    return rows, dscore
+
+
+def moe_ep_row_map(recv_counts, total_rows):
+    ep, le = recv_counts.shape
+    c = recv_counts.long()
+    src_off = torch.cat([c.new_zeros(1), c.reshape(-1).cumsum(0)])[:-1].reshape(ep, le)
+    row_map = []
+    for j in range(le):
+        for s in range(ep):
+            row_map += list(range(int(src_off[s, j]), int(src_off[s, j]) + int(c[s, j])))
+    row_map = torch.tensor(row_map, dtype=torch.int64)
+    inv = torch.empty_like(row_map)
+    inv[row_map] = torch.arange(row_map.numel())
+    tot = c.sum(0)
+    offs = torch.cat([tot.new_zeros(1), tot.cumsum(0)]).to(torch.int32)
+    return row_map.to(torch.int32), inv.to(torch.int32), offs

@@ -1,0 +1,94 @@
+"""Expert parallelism of the MoE layer over gloo (world 2 and 4) with CPU stand-in kernels: the UNCHANGED
+`prime_rl_amd.trainer.models.layers.moe.MoE` + `trainer/distributed/expert_parallel.py` (counts all-to-all, row all-to-all, regrouping,
+local experts, inverse) must give every rank exactly what the single-rank layer with all experts gives for that rank's tokens —
+outputs, input gradients, and the local experts' weight gradients summed over every rank's tokens."""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _patch_ops():
+    sys.path.insert(0, str(ROOT))
+    from prime_rl_amd import ops
+    from tests import cpu_standin_ops as S
+
+    for name in ("moe_router_fwd", "moe_router_bwd", "moe_sort", "moe_gather_rows", "moe_combine", "moe_slot_grads", "moe_ep_row_map"):
+        setattr(ops, name, getattr(S, name))
+
+
+def _make(world_experts, dim, hidden, k, ep_group, seed):
+    from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
+
+    args = MoEArgs(num_experts=world_experts, num_shared_experts=1, score_func="softmax", route_norm=True, route_scale=1.0, score_before_experts=False,
+                   top_k=k, use_grouped_mm=False, load_balance_coeff=None)
+    torch.manual_seed(seed)
+    full = MoE(args, dim, hidden)  # every rank builds the SAME full layer first (same seed), then keeps its expert slice
+    for p in full.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    full = full.to(torch.bfloat16)
+    if ep_group is None:
+        return full, full
+    local = MoE(args, dim, hidden, ep_group=ep_group).to(torch.bfloat16)
+    ep, r = dist.get_world_size(ep_group), dist.get_rank(ep_group)
+    le = world_experts // ep
+    sd = {k_: v for k_, v in full.state_dict().items() if not k_.startswith("experts.")}
+    for w in ("w1", "w2", "w3"):
+        sd[f"experts.{w}"] = getattr(full.experts, w).detach()[r * le:(r + 1) * le].clone()
+    local.load_state_dict(sd)
+    return local, full
+
+
+def _worker(rank, world, port, n_experts):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_ops()
+        dim, hidden, k = 32, 16, 2
+        local, full = _make(n_experts, dim, hidden, k, dist.group.WORLD, seed=7)
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 24 + 5 * rank  # ragged token counts across ranks
+        x = torch.randn(1, n, dim, generator=g).to(torch.bfloat16)
+        gy = torch.randn(1, n, dim, generator=g).to(torch.bfloat16)
+        xa = x.clone().requires_grad_(True)
+        ya = local(xa)
+        ya.backward(gy)
+        xb = x.clone().requires_grad_(True)
+        yb = full(xb)  # single-rank layer with all experts on this rank's tokens (same stand-in kernels, no communication)
+        yb.backward(gy)
+        assert torch.equal(ya, yb), f"rank {rank}: outputs differ by {(ya.float() - yb.float()).abs().max()}"
+        assert torch.equal(xa.grad, xb.grad), f"rank {rank}: input gradients differ"
+        assert torch.equal(local.router.gate.weight.grad, full.router.gate.weight.grad)
+        assert torch.equal(local.tokens_per_expert, full.tokens_per_expert)
+        # expert weight gradients: the local slice holds the sum over EVERY rank's tokens; the full layer only this rank's -> all-reduce it
+        le = n_experts // world
+        for w in ("w1", "w2", "w3"):
+            ref = getattr(full.experts, w).grad.float()
+            dist.all_reduce(ref)
+            got = getattr(local.experts, w).grad.float()
+            want = ref[rank * le:(rank + 1) * le]
+            # each side rounds to bf16 at a different point of the sum over ranks: one bf16 ulp of the largest entry
+            assert (got - want).abs().max() <= 2.0 ** -7 * want.abs().max(), f"rank {rank} {w}: {(got - want).abs().max()} of {want.abs().max()}"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_experts", [(2, 8), (4, 8), (2, 2)])
+def test_expert_parallel_layer_equals_single_rank_layer(world, n_experts):
+    mp.spawn(_worker, args=(world, _free_port(), n_experts), nprocs=world, join=True)

@@ -232,6 +232,40 @@ def bench_attn_variants(out, kernel, variants, n=16384, seqs=(2048,) * 8, rounds
                         TFLOPs=flops / ts[len(ts) // 2] / 1e12, max_abs_diff_vs_first=diffs.get(var, 0.0)))
 
 
+def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
+    """Qwen3-30B-A3B layer shapes: routing / permutation kernels, and the expert GEMMs as torch._grouped_mm vs the per-expert loop."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    logits = (torch.randn(n, e, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    x = torch.randn(n, h, generator=g).to(torch.bfloat16).to(DEV)
+    med, _ = timeit(lambda: ops.moe_router_fwd(logits, k, "softmax", True, 1.0), iters=20)
+    out.append(dict(kernel=f"moe_router_fwd[n={n},E={e},k={k}]", us=med * 1e6, GBs=(n * e * (2 + 4) + n * k * 8) / med / 1e9))
+    scores, top, idx, counts, conf = ops.moe_router_fwd(logits, k, "softmax", True, 1.0)
+    med, _ = timeit(lambda: ops.moe_sort(idx.reshape(-1), e), iters=20)
+    out.append(dict(kernel=f"moe_sort[{n * k} slots] (3 launches)", us=med * 1e6))
+    dest, slot, offsets = ops.moe_sort(idx.reshape(-1), e)
+    med, _ = timeit(lambda: ops.moe_gather_rows(x, slot, k), iters=20)
+    out.append(dict(kernel=f"moe_gather_rows[{n * k} x {h}]", us=med * 1e6, GBs=2 * n * k * h * 2 / med / 1e9))
+    y = ops.moe_gather_rows(x, slot, k)
+    med, _ = timeit(lambda: ops.moe_combine(y, dest, k, top.reshape(-1)), iters=20)
+    out.append(dict(kernel=f"moe_combine[{n} x {k} x {h}]", us=med * 1e6, GBs=(n * k * h * 2 + n * h * 2) / med / 1e9))
+    w1 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
+    w3 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
+    w2 = (torch.randn(e, h, hidden, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
+    from prime_rl_amd.trainer.models.layers.moe import _experts_for_loop, _experts_grouped
+
+    flops = 3 * 2 * n * k * h * hidden
+    med, _ = timeit(lambda: _experts_for_loop(w1, w2, w3, y, offsets), iters=5, warmup=1)
+    out.append(dict(kernel="experts per-expert loop (3 x 128 library GEMMs + host sync)", ms=med * 1e3, TFLOPs=flops / med / 1e12))
+    try:
+        ref = _experts_for_loop(w1, w2, w3, y, offsets)
+        got = _experts_grouped(w1, w2, w3, y, offsets)
+        err = float((got.float() - ref.float()).abs().max())
+        med, _ = timeit(lambda: _experts_grouped(w1, w2, w3, y, offsets), iters=5, warmup=1)
+        out.append(dict(kernel="experts torch._grouped_mm (3 grouped GEMMs)", ms=med * 1e3, TFLOPs=flops / med / 1e12, max_abs_diff_vs_loop=err))
+    except Exception as ex:  # noqa: BLE001
+        out.append(dict(kernel="experts torch._grouped_mm", error=repr(ex)[:200]))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
@@ -241,6 +275,8 @@ def main():
         bench_attn_variants(out, 1, [int(x) for x in sys.argv[2].split(",")])
     if which == "attndq":
         bench_attn_variants(out, 2, [int(x) for x in sys.argv[2].split(",")])
+    if which == "moe":
+        bench_moe(out)
     if which == "lmhead":
         bench_lmhead(out)
     if which == "lmhead4k":
