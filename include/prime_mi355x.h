@@ -365,11 +365,12 @@ int pm_comm_group_end(void);
  *     scores[N,E] f32 = softmax (score_func 0) | sigmoid (1) of gate_logits (bf16 or f32); selection = forced_idx[N,k] (routed_experts,
  *     moe.py:718-720) | top-k of scores + expert_bias[E] (moe.py:726-728) | top-k of scores (ties -> lowest expert index);
  *     top_scores[N,k] = unbiased selected scores, / (their sum + 1e-20) if route_norm, * route_scale; top_idx[N,k];
- *     counts[E] (zeroed by the call) = selections per expert (histc, moe.py:739-744); confidence[N] = selected probability mass per token
+ *     counts[E] (nullable; zeroed by the call) = selections per expert (histc, moe.py:739-744) — the same numbers are the differences of
+ *     pm_moe_sort's offsets, which is where the hot path takes them from (contended atomics here); confidence[N] = selected probability mass per token
  *     (_selected_probability_mass_sum, moe.py:634-641: the caller sums it).
  * pm_moe_router_bwd — d top_scores -> d gate_logits [N,E] f32 through normalisation, scale, gather and softmax / sigmoid.
  * pm_moe_sort — stable counting sort of top_idx (flattened, n_slots = N*k) by expert: dest_of_slot[n_slots], slot_of_dest[n_slots]
- *     (= torch.argsort(stable=True), moe.py:801), offsets[E+1] (exclusive scan of counts).  Three launches, no host sync.
+ *     (= torch.argsort(stable=True), moe.py:801), offsets[E+1] (exclusive scan of counts).  Four launches, no host sync.
  * pm_moe_gather_rows — out[r] = x[row_map[r] / divisor] (* scale[row_map[r]] in f32, rounded to bf16): the expert-sorted gather
  *     (moe.py:891-895, divisor = top_k, row_map = slot_of_dest, scale = top_scores when score_before_experts) and, with divisor 1, any
  *     row permutation (expert-parallel regrouping).  row_map[r] < 0 -> zero row.
@@ -383,7 +384,7 @@ int pm_comm_group_end(void);
  *     inverse, and local_offsets[n_local+1]. */
 int pm_moe_router_fwd(const void* gate_logits, int32_t logits_dtype, const float* expert_bias /* nullable */, const int32_t* forced_idx /* nullable */,
                       int64_t n_tokens, int32_t n_experts, int32_t top_k, int32_t score_func, int32_t route_norm, float route_scale,
-                      float* scores, float* top_scores, int32_t* top_idx, int32_t* counts, float* confidence, void* stream);
+                      float* scores, float* top_scores, int32_t* top_idx, int32_t* counts /* nullable */, float* confidence, void* stream);
 int pm_moe_router_bwd(const float* scores, const int32_t* top_idx, const float* grad_top_scores, int64_t n_tokens, int32_t n_experts, int32_t top_k,
                       int32_t score_func, int32_t route_norm, float route_scale, float* grad_logits, void* stream);
 int64_t pm_moe_sort_workspace_bytes(int64_t n_slots, int32_t n_experts);
@@ -398,6 +399,20 @@ int pm_moe_slot_grads(const void* a_bf16, const void* b_bf16 /* nullable iff dsc
                       float* dscore /* nullable */, void* stream);
 int pm_moe_ep_row_map(const int32_t* recv_counts, int32_t ep_size, int32_t n_local_experts, int32_t* row_map, int32_t* inv_map,
                       int32_t* local_offsets, void* stream);
+
+/* Grouped expert GEMMs over the expert-sorted rows — _run_experts_grouped_mm_impl (layers/moe.py:161-188: torch._grouped_mm(x,
+ * w.transpose(-2, -1), offs=offsets)) and the two gradients autograd derives from it.  offsets[E+1] i32 on the device (rows of expert e =
+ * [offsets[e], offsets[e+1])), bf16 operands, f32 accumulation, bf16 results; n_out / k_dim multiples of 128 (pm_grouped_gemm_supported):
+ *   nt: y[m][n]     = sum_k x[m][k]  * w[e][n][k]      x [M, K], w [E, N, K] -> y [M, N]
+ *   nn: dx[m][k]    = sum_n dy[m][n] * w[e][n][k]      dy [M, N], w [E, N, K] -> dx [M, K]
+ *   tn: dw[e][n][k] = sum_{m in group e} dy[m][n] * x[m][k]   -> dw [E, N, K] (zeros for an empty group) */
+int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim);
+int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_out, int64_t k_dim,
+                       void* y_bf16, void* stream);
+int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t k_out,
+                       void* dx_bf16, void* stream);
+int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t k_dim,
+                       void* dw_bf16, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

@@ -342,7 +342,7 @@ class TrainerConfig(BaseConfig):
         if m.vlm is not None:
             bad.append("model.vlm (vision-language models)")
         if isinstance(m.ep, int) and m.ep > 1:
-            bad.append("model.ep > 1 (MoE expert parallelism: SURVEY §8 f4)")
+            bad.append("model.ep > 1 (the flat-buffer train loop is dense; MoE + expert parallelism run through trainer.model.setup_model())")
         if m.moe_fused_kernel or m.freeze_moe_router or m.debug.force_balanced_routing:
             bad.append("MoE options (dense models only)")
         if self.optim.type != "adamw":

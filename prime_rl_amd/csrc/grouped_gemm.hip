@@ -1,0 +1,389 @@
+// grouped_gemm.hip — the expert GEMMs of the MoE layer as hand-written MFMA kernels over the expert-sorted rows (SURVEY §8 row f4:
+// "MoE EP grouped-GEMM").
+//
+// Reference: _run_experts_grouped_mm_impl (src/prime_rl/trainer/models/layers/moe.py:161-188): three `torch._grouped_mm(x, w.transpose(-2, -1),
+// offs=offsets)` per layer — rows [offs[e-1], offs[e]) of x are multiplied with expert e's matrix — and the two gradients autograd derives
+// from each of them.  Measured on the MI355X at Qwen3-30B-A3B layer shapes (131 072 sorted rows, 128 experts, 2048 <-> 768): the library
+// grouped GEMM runs at 0.17 PFLOP/s, a per-expert loop of library GEMMs at 0.12 (tools/microbench.py moe), i.e. 7 % of the MFMA peak; these
+// kernels: 0.72 / 0.57 / 0.78 PFLOP/s (nt / nn / tn), bit-identical to the per-expert loop on the forward (profiles/r02_moe.md).
+//
+// Three products, all bf16 x bf16 -> f32 accumulate -> bf16, group boundaries read on the device (no host sync):
+//   NT  y[m][n]  = sum_k x[m][k]  * w[e][n][k]     forward                       x, w K-contiguous: both operands by ds_read_b128
+//   NN  dx[m][k] = sum_n dy[m][n] * w[e][n][k]     gradient w.r.t. the rows      w tile read TRANSPOSED out of LDS (ds_read_b64_tr_b16)
+//   TN  dw[e][n][k] = sum_{m in group e} dy[m][n] * x[m][k]                      both tiles read transposed; one workgroup per (e, tile)
+// so no transposed copy of the expert weights and no transposed activations ever exist in HBM.
+//
+// MI355X design (the GEMM core of lmhead.hip, re-targeted):
+//   * v_mfma_f32_16x16x32_bf16, TRANSPOSED product (the MFMA A operand is the operand whose rows become the output's CONTIGUOUS axis), so
+//     a lane of the C fragment holds 4 consecutive output columns of one output row: 8-byte stores.
+//   * 128 x 128 output tile per workgroup, 4 waves as 2 x 2 (64 x 64 = 4 x 4 accumulator fragments each), contraction step 64, LDS
+//     2 x 32 KB -> two workgroups per CU.
+//   * tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write pass; rows past the end of a tensor / of a
+//     group read as zeros through the buffer range check (the TN kernel bounds its descriptor at the END OF THE GROUP, which is what
+//     makes a ragged last contraction step exact).  XOR swizzles are applied on the source side of the DMA:
+//       [128 rows][64 cols] tiles (operand K-contiguous): chunk ^ (row & 7), read with ds_read_b128;
+//       [64 rows][128 cols] tiles (contraction along the rows): the attention kernels' chunk ^ f(row & 15), read with pairs of
+//       ds_read_b64_tr_b16 addressed so that a fragment holds its 8 contraction values in NATURAL order (rows lq*8 .. lq*8+7: first
+//       read rows +0..3, second +4..7) — the partner operand can then be a plain ds_read_b128 fragment.
+//   * the two LDS buffers are two static arrays and the stage loop is unrolled by two (hipcc guards transpose-reads that may alias a
+//     pending LDS-DMA with vmcnt(0); see attention_kernels.cuh), explicit `s_waitcnt vmcnt(0)` before each barrier.
+//   * NT / NN: 128-row tiles of the SORTED rows x 128-column tiles, block order XCD-aware (tile_of_block: 0.44 -> 0.72 PFLOP/s on the forward
+//     product); a row tile never straddles two experts (per expert ceil(rows / 128) tiles), the tile -> expert search is a wave-parallel
+//     prefix scan over the offsets, rows past the group's end are computed and not stored.
+#include "common.cuh"
+
+namespace pm {
+namespace gg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+constexpr int kT = 128;                 // output tile edge
+constexpr int kBK = 64;                 // contraction per stage
+constexpr int kTileBytes = 128 * 64 * 2;  // 16 KB: either [128][64] or [64][128] bf16
+constexpr int kStageBytes = 2 * kTileBytes;
+
+__device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int swz_f(int r) {  // r in [0, 16): the attention kernels' swizzle for 256-byte rows
+  return (((r >> 3) ^ (r >> 2)) & 1) << 3 | (r & 2) << 1 | (r & 1) << 1 | ((r >> 2) & 1);
+}
+
+// [128 rows][64 cols] tile (128-byte rows), rows row0.. of a row-major tensor with `row_bytes` per row, columns starting at byte col_byte0:
+// 16 one-KiB DMA pieces of 8 rows; wave w issues pieces 4w..4w+3; lane L lands at (row 8p + L/8, chunk L%8) and fetches chunk (L%8)^(row&7).
+__device__ __forceinline__ void dma_tile_k64(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int64_t row0, int row_bytes, int col_byte0, int wave, int lane) {
+  const int sub = lane >> 3, ch = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    const int row = p * 8 + sub;
+    const int voff = (int)((row0 + row) * row_bytes) + col_byte0 + ((ch ^ (row & 7)) << 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(dst + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+// [64 rows][128 cols] tile (256-byte rows): 16 pieces of 4 rows; lane L lands at (row 4p + L/16, chunk L%16), fetches chunk (L%16)^f(row&15).
+__device__ __forceinline__ void dma_tile_r64(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int64_t row0, int row_bytes, int col_byte0, int wave, int lane) {
+  const int sub = lane >> 4, ch = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    const int row = p * 4 + sub;
+    const int voff = (int)((row0 + row) * row_bytes) + col_byte0 + ((ch ^ swz_f(row & 15)) << 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(dst + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+// K-contiguous fragment (16 rows x 32 k) of a [128][64] tile: lane (lr, lq) reads row r0 + lr, 16-byte chunk kk*4 + lq
+__device__ __forceinline__ u32x4 frag_k(const unsigned char* tile, int r0, int kk, int lr, int lq) {
+  const int row = r0 + lr;
+  return *reinterpret_cast<const u32x4*>(tile + row * 128 + (((kk * 4 + lq) ^ (row & 7)) << 4));
+}
+// Transposed fragment of a [64][128] tile: 16 consecutive tile COLUMNS (column block cb) x 32 contraction rows (k-step kk), natural order.
+// `base` = byte offsets of this lane's two reads for column block 0 (precomputed per k-step by tr_bases); a column block is an XOR.
+__device__ __forceinline__ void tr_bases(int kk, int lr, int lq, int (&base)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = kk * 32 + lq * 8 + (lr >> 2) + 4 * h;
+    base[h] = row * 256 + (((((lr & 3) >> 1) ^ swz_f(row & 15)) << 4) | ((lr & 1) << 3));
+  }
+}
+__device__ __forceinline__ u32x4 frag_tr(const unsigned char* tile, const int (&base)[2], int cb) {
+  const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + (base[0] ^ (cb << 5))));
+  const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(tile + (base[1] ^ (cb << 5))));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  return u32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
+// 128-row tile `t` of the sorted rows -> (expert, first row, end of the expert's rows); false past the last tile.  Every wave runs the
+// same prefix scan over ceil(rows_e / 128).
+__device__ __forceinline__ bool locate_tile(const int32_t* __restrict__ offsets, int n_experts, int t, int lane, int& expert, int& row0, int& row_end) {
+  int base = 0;
+  for (int e0 = 0; e0 < n_experts; e0 += 64) {
+    const int e = e0 + lane;
+    int lo = 0, hi = 0;
+    if (e < n_experts) {
+      lo = offsets[e];
+      hi = offsets[e + 1];
+    }
+    const int tiles = (hi - lo + kT - 1) / kT;
+    int incl = tiles;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const unsigned long long hit = __ballot(base + incl > t);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      const int first_tile = base + __shfl(incl, src, 64) - __shfl(tiles, src, 64);
+      expert = e0 + src;
+      row0 = __shfl(lo, src, 64) + (t - first_tile) * kT;
+      row_end = __shfl(hi, src, 64);
+      return true;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  return false;
+}
+
+// blockIdx.x -> (row tile, column tile).  Block b runs on XCD b % 8 (its own L2): the `ncol` column tiles of one row tile — which all
+// stream the same 128 rows of x / dy — are consecutive blocks of ONE XCD, so the rows leave HBM once, not ncol times.
+__device__ __forceinline__ void tile_of_block(int b, int ncol, int& row_tile, int& col_tile) {
+  const int xcd = b & 7, q = b >> 3;
+  row_tile = (q / ncol) * 8 + xcd;
+  col_tile = q % ncol;
+}
+
+// 4 consecutive output columns of one output row, bf16
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& c) { *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16_hw(c[0], c[1]), pack_bf16_hw(c[2], c[3])}; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT: y[m][n0 + ..] = x[m][:] . w[e][n][:]   (A = w rows, B = x rows; both [128][64] tiles, contraction k)
+__global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const int32_t* __restrict__ offsets,
+                                                           int n_experts, int64_t m_total, int n_out, int k_dim, bf16_t* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 1, wt = wave & 1;
+  int expert, row0, row_end, row_tile, col_tile;
+  tile_of_block(blockIdx.x, n_out / kT, row_tile, col_tile);
+  if (!locate_tile(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
+  const int n0 = col_tile * kT;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)(m_total * k_dim * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * n_out * k_dim), 0, n_out * k_dim * 2, 0x00020000);
+  const int row_bytes = k_dim * 2;
+  const int nk = k_dim / kBK;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {
+    dma_tile_k64(wr, sm, n0, row_bytes, s * kBK * 2, wave, lane);
+    dma_tile_k64(xr, sm + kTileBytes, row0, row_bytes, s * kBK * 2, wave, lane);
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = frag_k(sm, wv * 64 + i * 16, kk, lr, lq);
+        bfr[i] = frag_k(sm + kTileBytes, wt * 64 + i * 16, kk, lr, lq);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  stage(smA, 0);
+  for (int s = 0; s < nk; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nk) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < nk) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+  // acc[a][b][r] = y[row0 + wt*64 + b*16 + lr][n0 + wv*64 + a*16 + lq*4 + r]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = row0 + wt * 64 + b * 16 + lr;
+    if (row < row_end) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) store4(y + (int64_t)row * n_out + n0 + wv * 64 + a * 16 + lq * 4, acc[a][b]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NN: dx[m][k0 + ..] = dy[m][:] . w[e][:][k]   (A = w^T: transposed fragments of the [64 n][128 k] tile; B = dy rows: [128 m][64 n] tile)
+__global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w, const int32_t* __restrict__ offsets,
+                                                           int n_experts, int64_t m_total, int n_dim, int k_out, bf16_t* __restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 1, wt = wave & 1;
+  int expert, row0, row_end, row_tile, col_tile;
+  tile_of_block(blockIdx.x, k_out / kT, row_tile, col_tile);
+  if (!locate_tile(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
+  const int k0 = col_tile * kT;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, (int)(m_total * n_dim * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * n_dim * k_out), 0, n_dim * k_out * 2, 0x00020000);
+  const int ns = n_dim / kBK;
+  int tb[2][2];
+  tr_bases(0, lr, lq, tb[0]);
+  tr_bases(1, lr, lq, tb[1]);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {
+    dma_tile_r64(wr, sm, (int64_t)s * kBK, k_out * 2, k0 * 2, wave, lane);              // w[e][n = s*64 ..][k0 ..]
+    dma_tile_k64(yr, sm + kTileBytes, row0, n_dim * 2, s * kBK * 2, wave, lane);         // dy[row0 ..][n = s*64 ..]
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = frag_tr(sm, tb[kk], wv * 4 + i);
+        bfr[i] = frag_k(sm + kTileBytes, wt * 64 + i * 16, kk, lr, lq);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  stage(smA, 0);
+  for (int s = 0; s < ns; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < ns) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < ns) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < ns) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = row0 + wt * 64 + b * 16 + lr;
+    if (row < row_end) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) store4(dx + (int64_t)row * k_out + k0 + wv * 64 + a * 16 + lq * 4, acc[a][b]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN: dw[e][n0 + ..][k0 + ..] = sum over the group's rows of dy[m][n] * x[m][k]   (A = x^T, B = dy^T: both transposed fragments of [64 m][128] tiles)
+__global__ __launch_bounds__(256, 2) void grouped_tn_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const int32_t* __restrict__ offsets,
+                                                           int n_dim, int k_dim, bf16_t* __restrict__ dw) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 1, wt = wave & 1;
+  const int expert = blockIdx.y;
+  const int tiles_k = k_dim / kT;
+  const int n0 = (blockIdx.x / tiles_k) * kT, k0 = (blockIdx.x % tiles_k) * kT;
+  const int lo = offsets[expert], hi = offsets[expert + 1];
+  // descriptors end at the END OF THE GROUP: rows past it (the next expert's) read as zeros, so the last, ragged stage adds nothing wrong
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, hi * n_dim * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, hi * k_dim * 2, 0x00020000);
+  const int ns = (hi - lo + kBK - 1) / kBK;
+  int tb[2][2];
+  tr_bases(0, lr, lq, tb[0]);
+  tr_bases(1, lr, lq, tb[1]);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {
+    dma_tile_r64(xr, sm, (int64_t)lo + s * kBK, k_dim * 2, k0 * 2, wave, lane);               // x[m = lo + s*64 ..][k0 ..]
+    dma_tile_r64(yr, sm + kTileBytes, (int64_t)lo + s * kBK, n_dim * 2, n0 * 2, wave, lane);  // dy[m ..][n0 ..]
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = frag_tr(sm, tb[kk], wv * 4 + i);                 // rows k = k0 + wv*64 + i*16 + ..
+        bfr[i] = frag_tr(sm + kTileBytes, tb[kk], wt * 4 + i);    // cols n = n0 + wt*64 + i*16 + lr
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  if (ns > 0) stage(smA, 0);
+  for (int s = 0; s < ns; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < ns) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < ns) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < ns) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+  // acc[a][b][r] = dw[e][n0 + wt*64 + b*16 + lr][k0 + wv*64 + a*16 + lq*4 + r]; an empty group writes zeros
+  bf16_t* out = dw + (int64_t)expert * n_dim * k_dim;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + wt * 64 + b * 16 + lr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) store4(out + (int64_t)n * k_dim + k0 + wv * 64 + a * 16 + lq * 4, acc[a][b]);
+  }
+}
+
+}  // namespace gg
+}  // namespace pm
+
+using namespace pm;
+
+static bool gg_shapes_ok(int64_t m, int64_t n, int64_t k) { return n % 128 == 0 && k % 128 == 0 && m * (n > k ? n : k) * 2 < ((int64_t)1 << 31); }
+
+extern "C" int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim) { return gg_shapes_ok(n_rows, n_out, k_dim) ? 1 : 0; }
+
+extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_out,
+                                  int64_t k_dim, void* y_bf16, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: bad sizes");
+  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (x_bf16 && y_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: null pointer");
+  PM_REQUIRE(gg_shapes_ok(n_rows, n_out, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nt: n_out=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
+             (long long)n_out, (long long)k_dim);
+  if (n_rows == 0) return PM_OK;
+  const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (n_out / 128)));
+  hipLaunchKernelGGL(gg::grouped_nt_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, offsets, n_experts, n_rows,
+                     (int)n_out, (int)k_dim, (bf16_t*)y_bf16);
+  PM_CHECK_LAUNCH("pm_grouped_gemm_nt");
+  return PM_OK;
+}
+
+extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
+                                  int64_t k_out, void* dx_bf16, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: bad sizes");
+  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (dy_bf16 && dx_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: null pointer");
+  PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_out), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
+             (long long)n_dim, (long long)k_out);
+  if (n_rows == 0) return PM_OK;
+  const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (k_out / 128)));
+  hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, offsets, n_experts, n_rows,
+                     (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
+  PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
+  return PM_OK;
+}
+
+extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
+                                  int64_t k_dim, void* dw_bf16, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: bad sizes");
+  PM_REQUIRE(offsets && dw_bf16 && (n_rows == 0 || (dy_bf16 && x_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: null pointer");
+  PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
+             (long long)n_dim, (long long)k_dim);
+  const dim3 grid((unsigned)((n_dim / 128) * (k_dim / 128)), (unsigned)n_experts);
+  hipLaunchKernelGGL(gg::grouped_tn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_dim, (int)k_dim,
+                     (bf16_t*)dw_bf16);
+  PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
+  return PM_OK;
+}

@@ -6,7 +6,7 @@
 // library calls (grouped GEMM), like the dense projections.
 //
 // MI355X design — everything here is HBM / latency bound integer and row-copy work, so: one wave64 per token for the router (the E
-// scores of a token live in registers: E/64 per lane, top-k by k rounds of a wave arg-max), a three-launch stable counting sort instead
+// scores of a token live in registers: E/64 per lane, top-k by k rounds of a wave arg-max), a four-launch stable counting sort instead
 // of a radix sort (E <= 1024 bins, block histograms -> per-(block, expert) bases -> in-block stable ranks by ballot matching; no atomics
 // on floating point, bitwise reproducible), 16-byte row copies for the permutations, and the combine written as a GATHER over each
 // token's k slots (deterministic; the reference's scatter_add is an atomic accumulation on the GPU) that reproduces the reference's CPU
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void moe_router_fwd_kernel(const T* __restrict
     g *= route_scale;
     top_scores[tok * k + lane] = g;
     top_idx[tok * k + lane] = sel_e;
-    atomicAdd(&counts[sel_e], 1);
+    if (counts) atomicAdd(&counts[sel_e], 1);  // 1k-way contended at 16k tokens x 8: callers on the hot path take the counts from pm_moe_sort's offsets
   }
 }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void moe_router_bwd_kernel(const float* __rest
 // Stable counting sort of the flattened (token, slot) pairs by expert (TokenReorderer, moe.py:769-809: argsort(stable=True)).
 constexpr int kSortChunk = 256;  // slots per block (one round of 4 waves: 512 blocks for 16k tokens x 8 slots)
 
-__global__ __launch_bounds__(256) void moe_sort_hist_kernel(const int32_t* __restrict__ idx, int64_t m, int E, int32_t* __restrict__ block_hist) {
+__global__ __launch_bounds__(256) void moe_sort_hist_kernel(const int32_t* __restrict__ idx, int64_t m, int E, int n_blocks, int32_t* __restrict__ block_hist) {
   extern __shared__ int32_t hist[];
   for (int e = threadIdx.x; e < E; e += 256) hist[e] = 0;
   __syncthreads();
@@ -193,43 +193,61 @@ __global__ __launch_bounds__(256) void moe_sort_hist_kernel(const int32_t* __res
     if (j < m) atomicAdd(&hist[idx[j]], 1);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += 256) block_hist[(int64_t)blockIdx.x * E + e] = hist[e];
+  for (int e = threadIdx.x; e < E; e += 256) block_hist[(int64_t)e * n_blocks + blockIdx.x] = hist[e];  // [E][n_blocks]: one expert's row is scanned by one wave
 }
 
-// one block: offsets[e] = exclusive scan of the expert totals; block_hist[b][e] becomes the first sorted row of (block b, expert e)
-__global__ __launch_bounds__(1024) void moe_sort_scan_kernel(int32_t* __restrict__ block_hist, int n_blocks, int E, int32_t* __restrict__ offsets) {
-  extern __shared__ int32_t tot[];
-  for (int e = threadIdx.x; e < E; e += 1024) {
-    int t = 0;
-    for (int b = 0; b < n_blocks; ++b) t += block_hist[(int64_t)b * E + e];
-    tot[e] = t;
+// one wave per expert: totals[e] = sum over blocks
+__global__ __launch_bounds__(256) void moe_sort_totals_kernel(const int32_t* __restrict__ block_hist, int n_blocks, int E, int32_t* __restrict__ totals) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  int t = 0;
+  for (int b = lane; b < n_blocks; b += 64) t += block_hist[(int64_t)e * n_blocks + b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (lane == 0) totals[e] = t;
+}
+
+// one wave per expert: offsets[e] = sum of the totals before e; block_hist[e][b] becomes the first sorted row of (block b, expert e)
+__global__ __launch_bounds__(256) void moe_sort_scan_kernel(int32_t* __restrict__ block_hist, int n_blocks, int E, const int32_t* __restrict__ totals,
+                                                           int32_t* __restrict__ offsets) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  int before = 0, all = 0;
+  for (int q = lane; q < E; q += 64) {
+    const int t = totals[q];
+    all += t;
+    if (q < e) before += t;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int e = 0; e < E; ++e) {
-      const int t = tot[e];
-      tot[e] = run;
-      offsets[e] = run;
-      run += t;
-    }
-    offsets[E] = run;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o, 64);
+    all += __shfl_xor(all, o, 64);
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += 1024) {
-    int run = tot[e];
-    for (int b = 0; b < n_blocks; ++b) {
-      const int c = block_hist[(int64_t)b * E + e];
-      block_hist[(int64_t)b * E + e] = run;
-      run += c;
+  if (lane == 0) {
+    offsets[e] = before;
+    if (e == E - 1) offsets[E] = all;
+  }
+  int run = before;
+  for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+    const int b = b0 + lane;
+    const int c = b < n_blocks ? block_hist[(int64_t)e * n_blocks + b] : 0;
+    int incl = c;  // inclusive wave scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
     }
+    if (b < n_blocks) block_hist[(int64_t)e * n_blocks + b] = run + incl - c;
+    run += __shfl(incl, 63, 64);
   }
 }
 
-__global__ __launch_bounds__(256) void moe_sort_place_kernel(const int32_t* __restrict__ idx, int64_t m, int E, const int32_t* __restrict__ block_base,
+__global__ __launch_bounds__(256) void moe_sort_place_kernel(const int32_t* __restrict__ idx, int64_t m, int E, int n_blocks, const int32_t* __restrict__ block_base,
                                                             int32_t* __restrict__ dest_of_slot, int32_t* __restrict__ slot_of_dest) {
   extern __shared__ int32_t next[];  // next free sorted row per expert for this block
-  for (int e = threadIdx.x; e < E; e += 256) next[e] = block_base[(int64_t)blockIdx.x * E + e];
+  for (int e = threadIdx.x; e < E; e += 256) next[e] = block_base[(int64_t)e * n_blocks + blockIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * kSortChunk;
@@ -415,13 +433,13 @@ using namespace pm;
 extern "C" int pm_moe_router_fwd(const void* gate_logits, int32_t logits_dtype, const float* expert_bias, const int32_t* forced_idx, int64_t n_tokens,
                                  int32_t n_experts, int32_t top_k, int32_t score_func, int32_t route_norm, float route_scale, float* scores,
                                  float* top_scores, int32_t* top_idx, int32_t* counts, float* confidence, void* stream) {
-  PM_REQUIRE(gate_logits && scores && top_scores && top_idx && counts && confidence, PM_ERR_INVALID_ARG, "pm_moe_router_fwd: null pointer");
+  PM_REQUIRE(gate_logits && scores && top_scores && top_idx && confidence, PM_ERR_INVALID_ARG, "pm_moe_router_fwd: null pointer");
   PM_REQUIRE(n_tokens >= 0 && n_experts > 0 && n_experts <= 64 * kMaxPerLane && top_k > 0 && top_k <= kMaxTopK && top_k <= n_experts, PM_ERR_UNSUPPORTED,
              "pm_moe_router_fwd: n_experts=%d (<= %d) top_k=%d (<= %d)", n_experts, 64 * kMaxPerLane, top_k, kMaxTopK);
   PM_REQUIRE(score_func == 0 || score_func == 1, PM_ERR_INVALID_ARG, "pm_moe_router_fwd: score_func must be 0 (softmax) or 1 (sigmoid)");
   PM_REQUIRE(logits_dtype == PM_DTYPE_BF16 || logits_dtype == PM_DTYPE_F32, PM_ERR_INVALID_ARG, "pm_moe_router_fwd: logits dtype");
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(counts, 0, (size_t)n_experts * 4, st) != hipSuccess) return PM_ERR_LAUNCH;
+  if (counts && hipMemsetAsync(counts, 0, (size_t)n_experts * 4, st) != hipSuccess) return PM_ERR_LAUNCH;
   if (n_tokens == 0) return PM_OK;
   const dim3 grid((unsigned)cdiv(n_tokens, 4));
 #define PM_LAUNCH_ROUTER(T_, PER_)                                                                                                                 \
@@ -455,7 +473,7 @@ extern "C" int pm_moe_router_bwd(const float* scores, const int32_t* top_idx, co
 }
 
 extern "C" int64_t pm_moe_sort_workspace_bytes(int64_t n_slots, int32_t n_experts) {
-  return n_slots <= 0 ? 0 : cdiv(n_slots, kSortChunk) * n_experts * 4;
+  return n_slots <= 0 ? 0 : (cdiv(n_slots, kSortChunk) + 1) * n_experts * 4;
 }
 
 extern "C" int pm_moe_sort(const int32_t* top_idx, int64_t n_slots, int32_t n_experts, int32_t* dest_of_slot, int32_t* slot_of_dest, int32_t* offsets,
@@ -472,9 +490,11 @@ extern "C" int pm_moe_sort(const int32_t* top_idx, int64_t n_slots, int32_t n_ex
   PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_moe_sort: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
   const int nb = (int)cdiv(n_slots, kSortChunk);
   int32_t* bh = (int32_t*)workspace;
-  hipLaunchKernelGGL(moe_sort_hist_kernel, dim3(nb), dim3(256), (size_t)n_experts * 4, st, top_idx, n_slots, n_experts, bh);
-  hipLaunchKernelGGL(moe_sort_scan_kernel, dim3(1), dim3(1024), (size_t)n_experts * 4, st, bh, nb, n_experts, offsets);
-  hipLaunchKernelGGL(moe_sort_place_kernel, dim3(nb), dim3(256), (size_t)n_experts * 4, st, top_idx, n_slots, n_experts, bh, dest_of_slot, slot_of_dest);
+  int32_t* totals = bh + (int64_t)nb * n_experts;
+  hipLaunchKernelGGL(moe_sort_hist_kernel, dim3(nb), dim3(256), (size_t)n_experts * 4, st, top_idx, n_slots, n_experts, nb, bh);
+  hipLaunchKernelGGL(moe_sort_totals_kernel, dim3((unsigned)cdiv(n_experts, 4)), dim3(256), 0, st, bh, nb, n_experts, totals);
+  hipLaunchKernelGGL(moe_sort_scan_kernel, dim3((unsigned)cdiv(n_experts, 4)), dim3(256), 0, st, bh, nb, n_experts, totals, offsets);
+  hipLaunchKernelGGL(moe_sort_place_kernel, dim3(nb), dim3(256), (size_t)n_experts * 4, st, top_idx, n_slots, n_experts, nb, bh, dest_of_slot, slot_of_dest);
   PM_CHECK_LAUNCH("pm_moe_sort");
   return PM_OK;
 }

@@ -517,9 +517,10 @@ def device_arch() -> str:
 
 # ------------------------------------------------------------------------------------------------ MoE (row f4)
 def moe_router_fwd(gate_logits: Tensor, top_k: int, score_func: str = "softmax", route_norm: bool = False, route_scale: float = 1.0,
-                   expert_bias: Tensor | None = None, forced_idx: Tensor | None = None):
+                   expert_bias: Tensor | None = None, forced_idx: Tensor | None = None, want_counts: bool = True):
     """TokenChoiceTopKRouter.forward after the gate GEMM (pm_moe_router_fwd).  gate_logits [N, E] bf16 | f32 ->
-    (scores [N,E] f32, top_scores [N,k] f32, top_idx [N,k] i32, counts [E] i32, confidence [N] f32)."""
+    (scores [N,E] f32, top_scores [N,k] f32, top_idx [N,k] i32, counts [E] i32 | None, confidence [N] f32).
+    `want_counts=False` skips the in-kernel histogram (contended atomics); the counts are then the differences of `moe_sort`'s offsets."""
     lib = _lib.load()
     _req(gate_logits, None, "gate_logits")
     if gate_logits.dtype not in (torch.bfloat16, torch.float32) or gate_logits.dim() != 2:
@@ -537,7 +538,7 @@ def moe_router_fwd(gate_logits: Tensor, top_k: int, score_func: str = "softmax",
     scores = torch.empty((n, e), dtype=torch.float32, device=dev)
     top_scores = torch.empty((n, top_k), dtype=torch.float32, device=dev)
     top_idx = torch.empty((n, top_k), dtype=torch.int32, device=dev)
-    counts = torch.empty(e, dtype=torch.int32, device=dev)
+    counts = torch.empty(e, dtype=torch.int32, device=dev) if want_counts else None
     conf = torch.empty(n, dtype=torch.float32, device=dev)
     dt = _lib.PM_DTYPE_BF16 if gate_logits.dtype == torch.bfloat16 else _lib.PM_DTYPE_F32
     check(lib.pm_moe_router_fwd(_p(gate_logits), dt, _p(expert_bias), _p(forced_idx), n, e, top_k, 1 if score_func == "sigmoid" else 0,
@@ -623,3 +624,49 @@ def moe_ep_row_map(recv_counts: Tensor, total_rows: int):
     offs = torch.empty(le + 1, dtype=torch.int32, device=dev)
     check(lib.pm_moe_ep_row_map(_p(recv_counts), ep, le, _p(row_map), _p(inv_map), _p(offs), _stream()), "pm_moe_ep_row_map")
     return row_map, inv_map, offs
+
+
+def grouped_gemm_supported(n_rows: int, n_out: int, k_dim: int) -> bool:
+    return bool(_lib.load().pm_grouped_gemm_supported(n_rows, n_out, k_dim))
+
+
+def _gg_check(rows: Tensor, w: Tensor, offsets: Tensor, what: str):
+    _req(rows, torch.bfloat16, what); _req(w, torch.bfloat16, "w"); _req(offsets, torch.int32, "offsets")
+    if w.dim() != 3 or rows.dim() != 2 or offsets.numel() != w.shape[0] + 1:
+        raise PrimeMI355XError(f"grouped GEMM: rows {tuple(rows.shape)}, w {tuple(w.shape)}, offsets {tuple(offsets.shape)}")
+
+
+def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor) -> Tensor:
+    """y[m] = x[m] @ w[e(m)].T over expert-sorted rows: x [M, K], w [E, N, K], offsets [E+1] i32 -> y [M, N] (pm_grouped_gemm_nt)."""
+    lib = _lib.load()
+    _gg_check(x, w, offsets, "x")
+    e, n, k = w.shape
+    if x.shape[1] != k:
+        raise PrimeMI355XError(f"grouped_gemm_nt: x {tuple(x.shape)} vs w {tuple(w.shape)}")
+    y = torch.empty((x.shape[0], n), dtype=torch.bfloat16, device=x.device)
+    check(lib.pm_grouped_gemm_nt(_p(x), _p(w), _p(offsets), e, x.shape[0], n, k, _p(y), _stream()), "pm_grouped_gemm_nt")
+    return y
+
+
+def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor) -> Tensor:
+    """dx[m] = dy[m] @ w[e(m)]: dy [M, N], w [E, N, K] -> dx [M, K] (pm_grouped_gemm_nn)."""
+    lib = _lib.load()
+    _gg_check(dy, w, offsets, "dy")
+    e, n, k = w.shape
+    if dy.shape[1] != n:
+        raise PrimeMI355XError(f"grouped_gemm_nn: dy {tuple(dy.shape)} vs w {tuple(w.shape)}")
+    dx = torch.empty((dy.shape[0], k), dtype=torch.bfloat16, device=dy.device)
+    check(lib.pm_grouped_gemm_nn(_p(dy), _p(w), _p(offsets), e, dy.shape[0], n, k, _p(dx), _stream()), "pm_grouped_gemm_nn")
+    return dx
+
+
+def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor) -> Tensor:
+    """dw[e] = dy[group e].T @ x[group e]: dy [M, N], x [M, K] -> dw [E, N, K] (pm_grouped_gemm_tn)."""
+    lib = _lib.load()
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(offsets, torch.int32, "offsets")
+    e = offsets.numel() - 1
+    if dy.shape[0] != x.shape[0]:
+        raise PrimeMI355XError(f"grouped_gemm_tn: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
+    dw = torch.empty((e, dy.shape[1], x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], dy.shape[1], x.shape[1], _p(dw), _stream()), "pm_grouped_gemm_tn")
+    return dw

@@ -25,6 +25,7 @@ from torch import Tensor, nn
 from .engine import GRPOEngine, LossConfig, ModelDims, OptimConfig
 from .models.layers.lm_head import PrimeLmOutput, cast_float_and_contiguous, inject_prime_lm_head
 from .models.qwen3.modeling_qwen3 import Qwen3Config, Qwen3ForCausalLM
+from .models.qwen3_moe.modeling_qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
 from .parallel_dims import ParallelDims
 
 DTYPE_MAP = {"bfloat16": torch.bfloat16, "float32": torch.float32}
@@ -40,6 +41,38 @@ KNOWN_MODELS: dict[str, dict] = {
                        tie_word_embeddings=True),
     "tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2),
 }
+# MoE families (models/qwen3_moe): the dense fields above plus the expert fields of configuration_qwen3_moe.py:150-205
+KNOWN_MOE_MODELS: dict[str, dict] = {
+    "qwen3-30b-a3b": dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=48, num_attention_heads=32,
+                          num_key_value_heads=4, num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768, norm_topk_prob=True),
+    "tiny-moe": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                     num_experts=8, num_experts_per_tok=2, moe_intermediate_size=128, norm_topk_prob=True),
+}
+_MOE_KEYS = ("num_experts", "num_experts_per_tok", "moe_intermediate_size", "norm_topk_prob", "decoder_sparse_step", "mlp_only_layers")
+
+
+def resolve_moe_config(config) -> Qwen3MoeConfig | None:
+    """ModelConfig -> Qwen3MoeConfig when `name` is a Qwen3-MoE model (local HF directory with model_type qwen3_moe, or a known name), else None."""
+    p = Path(config.name)
+    if (p / "config.json").exists():
+        hf = json.loads((p / "config.json").read_text())
+        if hf.get("model_type") != "qwen3_moe":
+            return None
+        fields = {k: hf[k] for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads") if k in hf}
+        fields["num_key_value_heads"] = hf.get("num_key_value_heads", hf["num_attention_heads"])
+        fields["head_dim"] = hf.get("head_dim", hf["hidden_size"] // hf["num_attention_heads"])
+        fields["rms_norm_eps"] = hf.get("rms_norm_eps", 1e-6)
+        fields["rope_theta"] = hf.get("rope_theta", (hf.get("rope_parameters") or {}).get("rope_theta", 1_000_000.0))
+        fields["tie_word_embeddings"] = hf.get("tie_word_embeddings", False)
+        fields.update({k: hf[k] for k in _MOE_KEYS if hf.get(k) is not None})
+    else:
+        key = config.name.split("/")[-1].lower()
+        if key not in KNOWN_MOE_MODELS:
+            return None
+        fields = dict(KNOWN_MOE_MODELS[key])
+    if config.debug.num_layers is not None:
+        fields["num_hidden_layers"] = min(config.debug.num_layers, fields["num_hidden_layers"])
+    return Qwen3MoeConfig(**fields)
 
 
 def resolve_model_dims(config) -> ModelDims:
@@ -87,10 +120,17 @@ def resolve_auto_attn(config) -> None:
         config.attn = "hip_varlen"
 
 
-def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16) -> nn.Module:
+def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16, ep_group=None) -> nn.Module:
     """The custom PrimeRL class for the config's family (model.py:715-800, `impl` "custom"/"auto"); HF-impl models are out of scope."""
     if config.impl == "hf":
         raise NotImplementedError("model.impl = 'hf' (transformers modelling code + flash-attn) is outside the MI355X path; use 'custom' or 'auto'")
+    moe_cfg = resolve_moe_config(config)
+    if moe_cfg is not None:
+        with torch.device(device):
+            model = Qwen3MoeForCausalLM(moe_cfg, ep_group=ep_group)
+        return model.to(dtype)
+    if ep_group is not None:
+        raise ValueError(f"model.ep > 1 needs an MoE model; {config.name!r} is dense")
     d = resolve_model_dims(config)
     hf_cfg = Qwen3Config(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size, num_hidden_layers=d.num_hidden_layers,
                          num_attention_heads=d.num_attention_heads, num_key_value_heads=d.num_key_value_heads, head_dim=d.head_dim,
@@ -104,12 +144,13 @@ def setup_model(config, parallel_dims: ParallelDims, loading_from_checkpoint_lat
     """model.py:1314-1428 for the dense data-parallel path.  Compute dtype is bf16 (the reference's FSDP MixedPrecisionPolicy param
     dtype, model.py:823-960); `optimization_dtype` (f32 master weights) is the engine's / optimizer's business, not the module's."""
     resolve_auto_attn(config)
-    if parallel_dims.ep_enabled:
-        raise NotImplementedError("expert parallelism: SURVEY.md §8 f4")
+    ep_group = parallel_dims.get_group("ep") if parallel_dims.ep_enabled else None
+    if getattr(config, "ep_comm_backend", "torch") != "torch":
+        raise NotImplementedError("model.ep_comm_backend = 'deepep': expert dispatch here is RCCL all-to-all (trainer/distributed/expert_parallel.py)")
     for name in ("lora", "quantization", "vlm"):
         if getattr(config, name, None) is not None:
             raise NotImplementedError(f"model.{name} is outside the MI355X GRPO hot path (SURVEY.md section 2)")
-    model = get_model(config, device="cuda", dtype=torch.bfloat16)
+    model = get_model(config, device="cuda", dtype=torch.bfloat16, ep_group=ep_group)
     chunk = config.fused_lm_head_token_chunk_size if isinstance(config.fused_lm_head_token_chunk_size, int) else None
     inject_prime_lm_head(model, chunk_size=chunk)
     if loading_from_checkpoint_later:
@@ -140,10 +181,15 @@ def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, *, seq_le
             temperature: Tensor | None = None, routed_experts: Tensor | None = None, mm_kwargs: dict | None = None,
             mm_token_type_ids: Tensor | None = None, seq_lens_are_pre_shard: bool = False) -> PrimeLmOutput:
     """model.py:1431-1482: build the kwargs, run the backbone + head, return float / contiguous outputs."""
-    if mm_kwargs or mm_token_type_ids is not None or routed_experts is not None:
-        raise NotImplementedError("multimodal / router-replay inputs are outside the dense GRPO path (SURVEY.md section 2 rows 12, 21)")
+    if mm_kwargs or mm_token_type_ids is not None:
+        raise NotImplementedError("multimodal inputs are outside the GRPO path built here (SURVEY.md section 2 row 12)")
+    kw = {}
+    if routed_experts is not None:  # router replay (model.py:1462-1463): only MoE models take it
+        if not isinstance(model, Qwen3MoeForCausalLM):
+            raise ValueError("routed_experts given to a dense model")
+        kw["routed_experts"] = routed_experts
     out = model(input_ids=input_ids, position_ids=position_ids, labels=labels, temperature=temperature, seq_lens=seq_lens,
-                seq_lens_are_pre_shard=seq_lens_are_pre_shard)
+                seq_lens_are_pre_shard=seq_lens_are_pre_shard, **kw)
     if isinstance(out, dict):
         return cast_float_and_contiguous(out)
     return cast_float_and_contiguous(PrimeLmOutput(logits=out.logits))
@@ -155,6 +201,8 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     config.validate_supported()
     m = config.model
     resolve_auto_attn(m)
+    if resolve_moe_config(m) is not None or parallel_dims.ep_enabled:
+        raise NotImplementedError("the flat-buffer engine is the dense Qwen3 path; MoE models (and model.ep > 1) run through setup_model() / forward()")
     dims = resolve_model_dims(m)
     if parallel_dims.cp_enabled and m.cp_style != "ulysses":
         raise NotImplementedError("context parallelism on MI355X is Ulysses (all-to-all over the xGMI full mesh): set model.cp_style = 'ulysses'; "

@@ -5,8 +5,9 @@ parameters `w1 [E, hidden, dim]`, `w2 [E, dim, hidden]`, `w3 [E, hidden, dim]`),
 `tokens_per_expert`, `routing_confidence_sum`) — same module tree, parameter names and forward contract (`x [bs, slen, dim]`, optional
 `routed_experts [bs, slen, top_k]`).
 
-What runs where: the gate and expert GEMMs are library calls (the expert GEMMs grouped: `torch._grouped_mm` with device-side offsets,
-or a per-expert loop when `use_grouped_mm=False`, exactly the reference's two paths); everything between them is `moe.hip`:
+What runs where: the gate GEMM is a library call; the expert GEMMs are the hand-written grouped MFMA kernels of grouped_gemm.hip
+(`pm_grouped_gemm_nt / nn / tn`, device-side offsets; `torch._grouped_mm` for shapes that are not multiples of 128, a per-expert loop when
+`use_grouped_mm=False`: the reference's two paths); everything between them is `moe.hip`:
 score function + top-k + normalisation + histogram in one launch per layer (`pm_moe_router_fwd`, the reference: softmax, topk, gather,
 sum, div, mul, histc), a three-launch stable counting sort (`pm_moe_sort`; the reference: histc + argsort + index + floor-divide), the
 expert-sorted row gather with the optional score multiply (`pm_moe_gather_rows`) and the weighted combine as a deterministic gather with
@@ -64,8 +65,32 @@ class BCFeedForward(nn.Module):
         nn.init.trunc_normal_(self.w3, mean=0.0, std=init_std)
 
 
+class _GroupedLinearFn(torch.autograd.Function):
+    """y[m] = x[m] @ w[expert of m].T over expert-sorted rows — `torch._grouped_mm(x, w.transpose(-2, -1), offs=...)` (moe.py:181-183) and its
+    two gradients on the hand-written MFMA kernels of grouped_gemm.hip (pm_grouped_gemm_nt / nn / tn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, offsets):
+        ctx.save_for_backward(x, w, offsets)
+        return ops.grouped_gemm_nt(x, w, offsets)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, offsets = ctx.saved_tensors
+        g = g.contiguous()
+        gx = ops.grouped_gemm_nn(g, w, offsets) if ctx.needs_input_grad[0] else None
+        gw = ops.grouped_gemm_tn(g, x, offsets) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def _experts_grouped_hip(w1, w2, w3, x, offsets):
+    """_run_experts_grouped_mm_impl (moe.py:161-188) on pm_grouped_gemm_*: offsets stay on the device, no transposed weight copies."""
+    h = F.silu(_GroupedLinearFn.apply(x, w1, offsets)) * _GroupedLinearFn.apply(x, w3, offsets)
+    return _GroupedLinearFn.apply(h, w2, offsets)
+
+
 def _experts_grouped(w1, w2, w3, x, offsets):
-    """_run_experts_grouped_mm_impl (moe.py:161-188): three grouped GEMMs over the expert-sorted rows, offsets stay on the device."""
+    """The same through the library's grouped GEMM (`torch._grouped_mm`), for shapes the MFMA kernels are not built for."""
     offs = offsets[1:]  # cumulative END of every group, int32
     h = F.silu(torch._grouped_mm(x, w1.transpose(-2, -1), offs=offs))
     h = h * torch._grouped_mm(x, w3.transpose(-2, -1), offs=offs)
@@ -93,11 +118,18 @@ class GroupedExperts(nn.Module):
         self.w2 = nn.Parameter(torch.empty(num_experts, dim, hidden_dim))
         self.w3 = nn.Parameter(torch.empty(num_experts, hidden_dim, dim))
         self.use_grouped_mm = use_grouped_mm
+        # "auto": the MFMA kernels when the shapes are multiples of 128 (every production MoE), else the library; "hip" / "torch" force one
+        self.grouped_impl = "auto"
 
     def forward(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
         """x: rows sorted by (local) expert; offsets [E_local + 1] i32 on the device."""
-        fn = _experts_grouped if self.use_grouped_mm else _experts_for_loop
-        return fn(self.w1, self.w2, self.w3, x, offsets)
+        if not self.use_grouped_mm:
+            return _experts_for_loop(self.w1, self.w2, self.w3, x, offsets)
+        hidden, dim = self.w1.shape[1], self.w1.shape[2]
+        if self.grouped_impl == "hip" or (self.grouped_impl == "auto" and x.is_cuda and x.dtype == torch.bfloat16
+                                          and ops.grouped_gemm_supported(x.shape[0], hidden, dim)):
+            return _experts_grouped_hip(self.w1, self.w2, self.w3, x.contiguous(), offsets)
+        return _experts_grouped(self.w1, self.w2, self.w3, x, offsets)
 
     def init_weights(self, init_std: float):
         nn.init.trunc_normal_(self.w1, mean=0.0, std=0.02)
@@ -108,11 +140,12 @@ class GroupedExperts(nn.Module):
 class _RouterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, expert_bias, forced, top_k, score_func, route_norm, route_scale):
-        scores, top_scores, top_idx, counts, conf = ops.moe_router_fwd(logits, top_k, score_func, route_norm, route_scale, expert_bias, forced)
+        scores, top_scores, top_idx, _, conf = ops.moe_router_fwd(logits, top_k, score_func, route_norm, route_scale, expert_bias, forced,
+                                                                  want_counts=False)
         ctx.save_for_backward(scores, top_idx)
         ctx.cfg = (score_func, route_norm, route_scale, logits.dtype)
-        ctx.mark_non_differentiable(top_idx, counts, conf)
-        return top_scores, top_idx, counts, conf
+        ctx.mark_non_differentiable(top_idx, conf)
+        return top_scores, top_idx, conf
 
     @staticmethod
     def backward(ctx, g_top, *_):
@@ -136,9 +169,12 @@ class TokenChoiceTopKRouter(nn.Module):
             raise AssertionError(f"routed_experts shape: {routed_experts.shape}, top_k: {self.top_k}")
         logits = self.gate(x.to(torch.float32)) if self.fp32_gate else self.gate(x)
         forced = None if routed_experts is None else routed_experts.reshape(-1, self.top_k).to(torch.int32).contiguous()
-        top_scores, idx, counts, conf = _RouterFn.apply(logits.contiguous(), expert_bias, forced, self.top_k, self.score_func, self.route_norm,
-                                                        self.route_scale)
-        return top_scores, idx, counts, conf.sum()
+        top_scores, idx, conf = _RouterFn.apply(logits.contiguous(), expert_bias, forced, self.top_k, self.score_func, self.route_norm, self.route_scale)
+        # the per-expert histogram (histc, moe.py:739-744) falls out of the stable sort the reorderer needs anyway: sort once, here, and
+        # hand the maps to TokenReorderer through `last_sort` (an in-kernel histogram is 1k-way contended atomics at 16k tokens x 8 slots)
+        self.last_sort = (idx, *ops.moe_sort(idx.reshape(-1), self.num_experts))
+        offsets = self.last_sort[3]
+        return top_scores, idx, offsets[1:] - offsets[:-1], conf.sum()
 
     def init_weights(self, init_std: float):
         nn.init.trunc_normal_(self.gate.weight, mean=0.0, std=init_std)
@@ -152,9 +188,10 @@ class TokenReorderer(nn.Module):
         super().__init__()
         self.num_experts, self.top_k = num_experts, top_k
 
-    def forward(self, top_scores: torch.Tensor, selected_experts_indices: torch.Tensor):
-        dest_of_slot, slot_of_dest, offsets = ops.moe_sort(selected_experts_indices.reshape(-1).contiguous(), self.num_experts)
-        return dest_of_slot, slot_of_dest, offsets
+    def forward(self, top_scores: torch.Tensor, selected_experts_indices: torch.Tensor, presorted=None):
+        if presorted is not None and presorted[0] is selected_experts_indices:
+            return presorted[1:]
+        return ops.moe_sort(selected_experts_indices.reshape(-1).contiguous(), self.num_experts)
 
 
 class _GatherFn(torch.autograd.Function):
@@ -230,7 +267,7 @@ class MoE(nn.Module):
         with torch.no_grad():  # moe.py:1010-1012
             self.tokens_per_expert.add_(counts)
             self.routing_confidence_sum.add_(conf)
-        dest_of_slot, slot_of_dest, offsets = self.reorderer(top_scores, idx)
+        dest_of_slot, slot_of_dest, offsets = self.reorderer(top_scores, idx, presorted=getattr(self.router, "last_sort", None))
         scores_flat = top_scores.reshape(-1)
         routed_in = _GatherFn.apply(x, scores_flat if self.score_before_experts else None, slot_of_dest, dest_of_slot, self.top_k)
         if self.ep_size > 1:

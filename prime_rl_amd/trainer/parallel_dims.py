@@ -86,7 +86,8 @@ class ParallelDims:
         return rank % self.cp
 
     def get_group(self, name: str):
-        """"dp" (same cp position, different micro-batches), "cp" (one packed row), "dp_cp" (gradient reduction = everyone).
+        """"dp" (same cp position, different micro-batches), "cp" (one packed row), "dp_cp" (gradient reduction = everyone), "ep" (`ep`
+        consecutive ranks of dp_cp that share one set of experts, parallel_dims.py:150-190 of the reference: ep borrows from dp_shard x cp).
         Every rank must call this for the same names in the same order (new_group is collective).  None = the default group / no group."""
         if name in self._groups:
             return self._groups[name]
@@ -109,6 +110,13 @@ class ParallelDims:
             else:
                 for c in range(self.cp):
                     ranks = list(range(c, self.world_size, self.cp))
+                    g = dist.new_group(ranks)
+                    if rank in ranks:
+                        mine = g
+        elif name == "ep":
+            if self.ep > 1:
+                for first in range(0, self.world_size, self.ep):
+                    ranks = list(range(first, first + self.ep))
                     g = dist.new_group(ranks)
                     if rank in ranks:
                         mine = g

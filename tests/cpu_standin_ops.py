@@ -213,7 +213,7 @@ def adamw_step(master, exp_avg, exp_avg_sq, grad, param_bf16, lr, beta1, beta2, 
 
 
 # ------------------------------------------------------------------------------------------------ MoE stand-ins (tests/test_moe_ep_gloo_cpu.py)
-def moe_router_fwd(gate_logits, top_k, score_func="softmax", route_norm=False, route_scale=1.0, expert_bias=None, forced_idx=None):
+def moe_router_fwd(gate_logits, top_k, score_func="softmax", route_norm=False, route_scale=1.0, expert_bias=None, forced_idx=None, want_counts=True):
     scores = torch.sigmoid(gate_logits.float()) if score_func == "sigmoid" else torch.softmax(gate_logits.float(), dim=1)
     if forced_idx is not None:
         idx = forced_idx.long()

@@ -238,3 +238,177 @@ def test_grouped_mm_path_equals_the_for_loop_path():
     yb.backward(g)
     assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=5e-2, atol=5e-3)
     assert torch.allclose(a.experts.w1.grad.float(), b.experts.w1.grad.float(), rtol=5e-2, atol=5e-3)
+
+
+def _tiny_moe_model(extra=None):
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer import model as MM
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims
+
+    cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny-moe", seq_len=128, debug=dict(random_init=True), fused_lm_head_token_chunk_size=64,
+                                                       **(extra or {}))))
+    pd = get_parallel_dims(cfg.model, cfg.model.seq_len, world_size=1)
+    return MM, MM.setup_model(cfg.model, pd)
+
+
+def test_qwen3_moe_model_through_setup_model_forward_and_router_replay():
+    """setup_model() builds Qwen3MoeForCausalLM for an MoE name; forward() returns log-probs; every parameter (router gates and expert
+    matrices included) receives a gradient; replaying the recorded routing (`routed_experts`, model.py:1462-1463) reproduces the free
+    forward bit for bit; the flat-buffer engine refuses the model loudly."""
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeForCausalLM
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims
+
+    MM, model = _tiny_moe_model()
+    assert isinstance(model, Qwen3MoeForCausalLM) and len(model.moe_layers()) == 2
+    n = 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ids = torch.randint(0, 512, (1, n), generator=g).to(DEV)
+    labels = torch.cat([ids[:, 1:], ids.new_zeros(1, 1)], 1)
+    kw = dict(seq_lens=torch.tensor([70, 58], device=DEV), labels=labels, temperature=torch.ones(1, n, device=DEV))
+    recorded = []
+    hooks = [m.router.register_forward_hook(lambda mod, inp, out: recorded.append(out[1].clone())) for m in model.moe_layers()]
+    out = MM.forward(model, ids, torch.arange(n, device=DEV)[None], **kw)
+    for h in hooks:
+        h.remove()
+    lp = out["logprobs"]
+    assert lp.shape == (1, n) and torch.isfinite(lp).all() and (lp <= 0).all()
+    (-lp.mean()).backward()
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert all(float(m.experts.w1.grad.abs().sum()) > 0 and float(m.router.gate.weight.grad.abs().sum()) > 0 for m in model.moe_layers())
+    assert all(float(m.tokens_per_expert.sum()) == n * 2 for m in model.moe_layers())
+    routed = torch.stack(recorded, dim=1).reshape(1, n, 2, 2).long()  # [1, N, layers, top_k]
+    replay = MM.forward(model, ids, torch.arange(n, device=DEV)[None], routed_experts=routed, **kw)
+    assert torch.equal(replay["logprobs"], lp)
+    other = routed.clone()
+    other[..., 0] = (other[..., 0] + 1) % 8
+    assert not torch.equal(MM.forward(model, ids, torch.arange(n, device=DEV)[None], routed_experts=other, **kw)["logprobs"], lp)
+    cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny-moe", seq_len=128, debug=dict(random_init=True))))
+    with pytest.raises(NotImplementedError, match="flat-buffer engine"):
+        MM.setup_engine(cfg, get_parallel_dims(cfg.model, 128, world_size=1))
+
+
+def test_qwen3_moe_training_steps_reduce_the_loss():
+    MM, model = _tiny_moe_model()
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.0)
+    n = 128
+    g = torch.Generator(device="cpu").manual_seed(11)
+    ids = torch.randint(0, 512, (1, n), generator=g).to(DEV)
+    labels = torch.cat([ids[:, 1:], ids.new_zeros(1, 1)], 1)
+    losses = []
+    for _ in range(8):
+        out = MM.forward(model, ids, torch.arange(n, device=DEV)[None], seq_lens=torch.tensor([n], device=DEV), labels=labels,
+                         temperature=torch.ones(1, n, device=DEV))
+        loss = -out["logprobs"][:, :-1].mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.5, losses
+
+
+def test_expert_parallel_dispatch_on_the_device_equals_local_experts():
+    """The dispatch / regroup / combine path of trainer/distributed/expert_parallel.py over an RCCL group (world 1: the all-to-alls are
+    self-copies, every kernel and index map of the path runs) gives exactly the local grouped-experts result, forward and backward."""
+    import os
+
+    import torch.distributed as dist
+
+    from prime_rl_amd import ops
+    from prime_rl_amd.trainer.distributed import expert_parallel as EP
+    from prime_rl_amd.trainer.models.layers.moe import GroupedExperts
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        e, dim, hidden, n, k = 8, 128, 64, 200, 2
+        experts = GroupedExperts(dim, hidden, e, use_grouped_mm=False).to(DEV).to(torch.bfloat16)
+        experts.init_weights(0.05)
+        idx = torch.randint(0, e, (n, k), dtype=torch.int32, device=DEV)
+        idx[:, 0] = torch.where(idx[:, 0] == 3, 4, idx[:, 0])  # an expert with fewer rows
+        dest, slot, offsets = ops.moe_sort(idx.reshape(-1).contiguous(), e)
+        counts = (offsets[1:] - offsets[:-1]).contiguous()
+        x = torch.randn(n, dim, device=DEV).to(torch.bfloat16)
+        rows = ops.moe_gather_rows(x, slot, k)
+        a = rows.clone().requires_grad_(True)
+        b = rows.clone().requires_grad_(True)
+        ya = EP.run_experts(experts, a, counts, dist.group.WORLD)
+        gy = torch.randn_like(ya)
+        ya.backward(gy)
+        ga = {n_: p.grad.clone() for n_, p in experts.named_parameters()}
+        experts.zero_grad()
+        yb = experts(b, offsets)
+        yb.backward(gy)
+        assert torch.equal(ya, yb) and torch.equal(a.grad, b.grad)
+        for n_, p in experts.named_parameters():
+            assert torch.equal(ga[n_], p.grad), n_
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("e,n_out,k,sizes", [(4, 128, 128, [5, 0, 300, 128]), (8, 256, 384, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 768, 2048, [1000, 24, 513]),
+                                             (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16)])
+def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes):
+    """pm_grouped_gemm_nt / nn / tn vs a per-expert f32 matmul of the same bf16 operands: ragged groups, empty groups, groups that are not
+    multiples of the 64-row contraction step or the 128-row tile, an empty batch."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(e * 1000 + n_out)
+    m = sum(sizes)
+    offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(e, n_out, k, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(m, n_out, generator=g).to(torch.bfloat16).to(DEV)
+    assert ops.grouped_gemm_supported(m, n_out, k)
+    y = ops.grouped_gemm_nt(x, w, offsets)
+    dx = ops.grouped_gemm_nn(dy, w, offsets)
+    dw = ops.grouped_gemm_tn(dy, x, offsets)
+    o = 0
+    for i, c in enumerate(sizes):
+        xe, de, we = x[o:o + c].float(), dy[o:o + c].float(), w[i].float()
+        ref_y, ref_dx, ref_dw = xe @ we.T, de @ we, de.T @ xe
+        for got, ref, what in ((y[o:o + c], ref_y, "nt"), (dx[o:o + c], ref_dx, "nn"), (dw[i], ref_dw, "tn")):
+            err = (got.float() - ref).abs()
+            tol = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * max(1e-3, float(ref.abs().mean()))  # one bf16 rounding of an exactly accumulated sum
+            assert (err <= tol).all(), f"{what} expert {i} (rows {c}): max err {float(err.max())}"
+        o += c
+
+
+def test_grouped_gemm_rejects_unsupported_shapes_loudly():
+    ops = _ops()
+    from prime_rl_amd._lib import PrimeMI355XError
+
+    assert not ops.grouped_gemm_supported(100, 96, 128)
+    x = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(2, 128, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(PrimeMI355XError, match="multiples of 128"):
+        ops.grouped_gemm_nt(x, w, torch.tensor([0, 4, 8], dtype=torch.int32, device=DEV))
+
+
+def test_moe_layer_on_the_mfma_grouped_gemms_matches_the_loop_path():
+    from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
+
+    torch.manual_seed(0)
+    dim, hidden, e, k, n = 256, 128, 8, 2, 777
+    mk = lambda grouped: MoE(MoEArgs(num_experts=e, num_shared_experts=0, score_func="softmax", route_norm=True, score_before_experts=False, top_k=k,
+                                     use_grouped_mm=grouped, load_balance_coeff=None), dim, hidden).to(DEV).to(torch.bfloat16)
+    a, b = mk(True), mk(False)
+    a.init_weights(0.05)
+    a.experts.grouped_impl = "hip"
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(1, n, dim, device=DEV).to(torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    assert torch.allclose(ya.float(), yb.float(), rtol=2e-2, atol=2e-3)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=3e-2, atol=3e-3)
+    for w in ("w1", "w2", "w3"):
+        ga, gb = getattr(a.experts, w).grad.float(), getattr(b.experts, w).grad.float()
+        assert (ga - gb).abs().max() <= 2.0 ** -6 * gb.abs().max(), w

@@ -237,7 +237,7 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     g = torch.Generator(device="cpu").manual_seed(0)
     logits = (torch.randn(n, e, generator=g) * 2).to(torch.bfloat16).to(DEV)
     x = torch.randn(n, h, generator=g).to(torch.bfloat16).to(DEV)
-    med, _ = timeit(lambda: ops.moe_router_fwd(logits, k, "softmax", True, 1.0), iters=20)
+    med, _ = timeit(lambda: ops.moe_router_fwd(logits, k, "softmax", True, 1.0, want_counts=False), iters=20)
     out.append(dict(kernel=f"moe_router_fwd[n={n},E={e},k={k}]", us=med * 1e6, GBs=(n * e * (2 + 4) + n * k * 8) / med / 1e9))
     scores, top, idx, counts, conf = ops.moe_router_fwd(logits, k, "softmax", True, 1.0)
     med, _ = timeit(lambda: ops.moe_sort(idx.reshape(-1), e), iters=20)
@@ -251,7 +251,7 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     w1 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
     w3 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
     w2 = (torch.randn(e, h, hidden, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
-    from prime_rl_amd.trainer.models.layers.moe import _experts_for_loop, _experts_grouped
+    from prime_rl_amd.trainer.models.layers.moe import _experts_for_loop, _experts_grouped, _experts_grouped_hip
 
     flops = 3 * 2 * n * k * h * hidden
     med, _ = timeit(lambda: _experts_for_loop(w1, w2, w3, y, offsets), iters=5, warmup=1)
@@ -264,6 +264,18 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
         out.append(dict(kernel="experts torch._grouped_mm (3 grouped GEMMs)", ms=med * 1e3, TFLOPs=flops / med / 1e12, max_abs_diff_vs_loop=err))
     except Exception as ex:  # noqa: BLE001
         out.append(dict(kernel="experts torch._grouped_mm", error=repr(ex)[:200]))
+    with torch.no_grad():
+        got = _experts_grouped_hip(w1, w2, w3, y, offsets)
+        err = float((got.float() - ref.float()).abs().max())
+        med, _ = timeit(lambda: _experts_grouped_hip(w1, w2, w3, y, offsets), iters=10, warmup=2)
+    out.append(dict(kernel="experts pm_grouped_gemm_nt x3 + silu*mul", ms=med * 1e3, TFLOPs=flops / med / 1e12, max_abs_diff_vs_loop=err))
+    med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets), iters=10, warmup=2)
+    out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}]", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    hmid = ops.grouped_gemm_nt(y, w1, offsets)
+    med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
+    out.append(dict(kernel="pm_grouped_gemm_nn (dgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets), iters=10, warmup=2)
+    out.append(dict(kernel="pm_grouped_gemm_tn (wgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
 
 
 def main():
