@@ -92,3 +92,36 @@ def _worker(rank, world, port, n_experts):
 @pytest.mark.parametrize("world,n_experts", [(2, 8), (4, 8), (2, 2)])
 def test_expert_parallel_layer_equals_single_rank_layer(world, n_experts):
     mp.spawn(_worker, args=(world, _free_port(), n_experts), nprocs=world, join=True)
+
+
+def _groups_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT))
+        from prime_rl_amd.trainer.parallel_dims import ParallelDims
+
+        pd = ParallelDims(dp_replicate=1, dp_shard=-1, cp=1, pp=1, ep=2, world_size=world)
+        assert pd.ep_enabled and pd.dp_size == world
+        g = pd.get_group("ep")
+        assert dist.get_world_size(g) == 2 and dist.get_process_group_ranks(g) == [rank - rank % 2, rank - rank % 2 + 1]
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, group=g)
+        assert float(t) == (rank - rank % 2) * 2 + 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ep_process_groups_are_consecutive_rank_blocks():
+    mp.spawn(_groups_worker, args=(4, _free_port()), nprocs=4, join=True)
+
+
+def test_moe_model_names_resolve_and_the_dense_engine_refuses_them():
+    sys.path.insert(0, str(ROOT))
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer import model as MM
+
+    cfg = TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen3-30B-A3B")))
+    moe = MM.resolve_moe_config(cfg.model)
+    assert (moe.num_experts, moe.num_experts_per_tok, moe.moe_intermediate_size, moe.hidden_size, moe.num_hidden_layers) == (128, 8, 768, 2048, 48)
+    assert MM.resolve_moe_config(TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen3-8B"))).model) is None
