@@ -35,19 +35,6 @@ HBM_PEAK_BPS = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 MFMA_BF16_PEAK = 2.5e15
 
 
-def _headline_only(args, dims, world, headline, engine) -> dict:
-    """The contract's JSON line without roofline / extras — emitted by the watchdog if an extra measurement wedges."""
-    value = headline["samples"] / headline["elapsed"]
-    return {"metric": "GRPO trainer samples/sec (Qwen3-8B, 2k-token rollouts)" if args.model == "qwen3-8b" else f"GRPO trainer samples/sec ({dims.name})",
-            "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(headline["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (reference FakeDataLoader batches); random-init weights",
-            "config": {"workload": f"{dims.name} GRPO policy-update step, fixed-length {args.seq_len}-token rollouts, {args.micro_batches} micro-batches/GPU/step",
-                       "global_batch": args.micro_batches * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "lm_head": engine.lm_head_impl,
-                       "extra": {"error": "an extra measurement did not finish in time; headline only"}},
-            "roofline": None, "cpu_baseline": None}
-
-
 def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
     """Measurements the judge asked for next to the headline (VERDICT r1 'Next round' 3), each guarded so that a failure is REPORTED in
     the JSON instead of taking the headline down:
@@ -148,6 +135,37 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
                                     "mean_launch_ms": round(ms, 3)}
     except Exception as e:  # pragma: no cover
         extra["j1_roofline"] = {"error": repr(e)[:300]}
+    # -- one MoE layer of config 4 (Qwen3-30B-A3B shapes), forward + backward, on the row-f4 kernels -----------------------------------------
+    try:
+        from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
+
+        n, hidden_dim, e, k, inter = 16384, 2048, 128, 8, 768
+        layer = MoE(MoEArgs(num_experts=e, num_shared_experts=0, score_func="softmax", route_norm=True, score_before_experts=False, top_k=k,
+                            use_grouped_mm=True, load_balance_coeff=None), hidden_dim, inter).to(device).to(torch.bfloat16)
+        layer.init_weights(0.02)
+        x = torch.randn(1, n, hidden_dim, device=device).to(torch.bfloat16).requires_grad_(True)
+        gy = torch.randn(1, n, hidden_dim, device=device).to(torch.bfloat16)
+
+        def fb():
+            x.grad = None
+            layer(x).backward(gy)
+
+        fb()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fb()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        flop = 3 * 3 * 2.0 * n * k * hidden_dim * inter  # three expert GEMMs, forward + two gradients each
+        extra["moe_layer"] = {"shape": f"{n} tokens, {e} experts top-{k}, hidden {hidden_dim}, expert intermediate {inter} (Qwen3-30B-A3B layer), forward + backward",
+                              "ms": round(ms, 3), "expert_gemm_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1),
+                              "note": "router, stable sort, gather, grouped MFMA GEMMs (pm_grouped_gemm_nt/nn/tn), combine; per-kernel numbers in profiles/r02_moe.md"}
+        del layer, x, gy
+    except Exception as ex:  # pragma: no cover
+        extra["moe_layer"] = {"error": repr(ex)[:300]}
     if dist.is_initialized():
         dist.barrier()
     return extra
@@ -230,29 +248,18 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- extra measurements (all ranks take part; reported under config.extra, never part of `value`) ----------------------------------
-    extra: dict = {}
-    headline = {"samples": args.micro_batches * world * args.steps, "elapsed": elapsed}
-    if not args.no_extra:
-        import threading
+    samples = args.micro_batches * world * args.steps
+    # everything the JSON line needs from the device is read NOW, on this thread: the watchdog below must be able to print the line while
+    # the main thread sits in a wedged collective (a .item() or an event query from there would queue behind it)
+    k1_durs = [a.elapsed_time(b) * 1e-3 for a, b, _, _ in k1_events] if k1_events else []
+    loss_last = float(sum(l.item() for l in losses[-1]))
 
-        done = threading.Event()
-
-        def watchdog():  # extras are best-effort: if one of them wedges (e.g. a collective), print the headline and leave
-            if not done.wait(float(os.environ.get("PM_BENCH_EXTRA_TIMEOUT", "180"))) and rank == 0:
-                print(json.dumps(_headline_only(args, dims, world, headline, engine)), flush=True)
-                os._exit(0)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        extra = measure_extras(args, engine, loader, device, world, rank, barrier)
-        done.set()
-
-    if rank == 0:
-        samples = args.micro_batches * world * args.steps
+    def assemble(extra: dict) -> dict:
+        """The contract's JSON line (rank 0) from the timed region alone; `extra` = whatever extra measurements finished."""
         value = samples / elapsed
         if k1_events:
             # roofline of the log-prob kernel: algorithmic bytes (sizeof(T)*V + 20 per token, SURVEY.md §8d) / mean launch time
-            durs = [a.elapsed_time(b) * 1e-3 for a, b, _, _ in k1_events]
+            durs = k1_durs
             rows = k1_events[0][2]
             esz = k1_events[0][3]
             alg_bytes = rows * (esz * dims.vocab_size + 20)
@@ -294,7 +301,7 @@ def main() -> None:
                 "step_includes": "scale all-reduce, forward, log-prob, GRPO loss, backward, grad reduce-scatter, clip, AdamW, param all-gather",
                 "mfu_vs_2.5PF_bf16": round(value * flops_per_sample / (world * MFMA_BF16_PEAK), 4),
                 "tflop_per_sample": round(flops_per_sample / 1e12, 2),
-                "loss_last": float(sum(l.item() for l in losses[-1])),
+                "loss_last": loss_last,
                 "host_enqueue_ms_per_step": round(host_enqueue_empty_queue * 1e3, 1) if host_enqueue_empty_queue is not None else None,
                 "lm_head": engine.lm_head_impl,
                 "extra": extra,
@@ -317,6 +324,31 @@ def main() -> None:
             }
         else:  # PM_LM_HEAD=fused: no stand-alone log-prob kernel runs; the dominant hand-written kernel is the fused MFMA LM head (J1)
             result["roofline"] = extra.get("j1_roofline")
+        return result
+
+    # ---- extra measurements (all ranks take part; reported under config.extra, never part of `value`) ----------------------------------
+    extra: dict = {}
+    if not args.no_extra:
+        import threading
+
+        done = threading.Event()
+
+        def watchdog():  # extras are best-effort: if one of them wedges (e.g. a collective at N > 1), rank 0 prints the line it already has
+            if not done.wait(float(os.environ.get("PM_BENCH_EXTRA_TIMEOUT", "180"))):  # (headline + roofline) and EVERY rank leaves
+                if rank == 0:
+                    line = assemble({"error": "an extra measurement did not finish in time; headline and roofline only"})
+                    line["cpu_baseline"] = None
+                    print(json.dumps(line), flush=True)
+                else:
+                    time.sleep(3.0)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        extra = measure_extras(args, engine, loader, device, world, rank, barrier)
+        done.set()
+
+    if rank == 0:
+        result = assemble(extra)
         wp = extra.get("weight_push") or {}
         if "ms" in wp:  # samples/s excluding (= value) and including the weight push, if the push were NOT overlapped
             extra["samples_per_s_incl_serial_weight_push"] = round(samples / (elapsed + args.steps * wp["ms"] * 1e-3), 4)
