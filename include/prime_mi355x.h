@@ -418,8 +418,8 @@ int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* o
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
  * C[16,16] = A[16,32] @ B[32,16]^T-free form: c = sum_k a[i][k]*b[j][k]  (both operands K-contiguous, bf16). */
 int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);
-/* Kernel-variant switch for in-process A/B timing (tools/microbench.py): kernel 0 = attention forward (single build: only value <= 0 is
- * accepted), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles), 2 = dQ (1: 32 kv rows per barrier); value <= 0
+/* Kernel-variant switch for in-process A/B timing (tools/microbench.py): kernel 0 = attention forward (bits: 1 = asm row max, 2 = skip the O rescale
+ * when no row max moved; default 3), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles), 2 = dQ (1: 32 kv rows per barrier); value <= 0
  * restores the default.  Not part of the training path. */
 int pm_attn_debug_set_variant(int32_t kernel, int32_t value);
 /* gfx950 LDS transpose-read (`ds_read_b64_tr_b16`): one wave, LDS image lds[i] = i (u16, 4096 entries); lane l reads at element

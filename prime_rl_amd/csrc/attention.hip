@@ -103,6 +103,8 @@ static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
 // boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
 // workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
+constexpr int kFwdDefaultOpt = 3;
+static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.cuh); -1 = the default build
 static int g_dkdv_var = 0;
 static int g_dq_var = 0;
 }  // namespace pm
@@ -110,7 +112,11 @@ static int g_dq_var = 0;
 using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
-  if (kernel == 0) return value <= 0 ? PM_OK : PM_ERR_INVALID_ARG;  // the forward kernel has a single build
+  if (kernel == 0) {
+    if (value > 3) return PM_ERR_INVALID_ARG;
+    g_fwd_var = value;
+    return PM_OK;
+  }
   if (kernel == 1) g_dkdv_var = value < 0 ? 0 : value;
   else if (kernel == 2) g_dq_var = value < 0 ? 0 : value;
   else return PM_ERR_INVALID_ARG;
@@ -153,8 +159,16 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
   if (n_tokens == 0) return PM_OK;
   PM_REQUIRE(fits_buffer_range(n_tokens, v_row_stride) && fits_buffer_range(n_tokens, (int64_t)n_kv_heads * kD), PM_ERR_UNSUPPORTED,
              "pm_attn_varlen_fwd: k / v exceed the 2 GiB buffer-offset range");
-  hipLaunchKernelGGL((attn_fwd_kernel<2>), dim3((unsigned)(cdiv(n_tokens, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse);
+#define PM_LAUNCH_FWD(OPT_)                                                                                                                       \
+  hipLaunchKernelGGL((attn_fwd_kernel<2, OPT_>), dim3((unsigned)(cdiv(n_tokens, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, \
+                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse)
+  switch (g_fwd_var < 0 ? kFwdDefaultOpt : g_fwd_var) {
+    case 0: PM_LAUNCH_FWD(0); break;
+    case 1: PM_LAUNCH_FWD(1); break;
+    case 2: PM_LAUNCH_FWD(2); break;
+    default: PM_LAUNCH_FWD(3); break;
+  }
+#undef PM_LAUNCH_FWD
   PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
   return PM_OK;
 }

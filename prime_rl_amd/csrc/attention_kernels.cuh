@@ -90,6 +90,17 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
+// v_max3_f32 / v_max_f32 as inline asm: a plain fmaxf on an MFMA output gets a canonicalising v_max_f32 in front of it (32 extra VALU per tile)
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ float xrow_max_swap(float v) {
   float a = v, b = v;
   permlane32_swap(a, b);  // a = [v.lo, v.lo], b = [v.hi, v.hi]
@@ -520,6 +531,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
 // lane of the wave needs it for (diagonal / document-boundary tiles), so interior tiles carry no compare / select code.
 constexpr int kV5FwdBufBytes = 2 * 64 * kD * 2;  // K [64][128] then V [64][128]
 
+template <int OPT>  // A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved (default 3:
+                    // 0.3314 -> 0.3257 ms, bit-identical; an explicit v_pk_fma_f32 for the scale-and-subtract was 4 % SLOWER: pair-building moves)
 __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[2][4],
                                          const int (&qi)[2], const int (&lo)[2], float (&m)[2], float (&l)[2], f32x4 (&ot)[2][8]) {
   const bf16_t* Kt = reinterpret_cast<const bf16_t*>(sm);
@@ -565,11 +578,22 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
   // 16-lane rows of the wave through v_permlane32_swap / v_permlane16_swap (VALU) instead of ds_bpermute round trips.
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    float mx = -INFINITY;
+    float mx;
+    if constexpr (OPT & 1) {
+      mx = max3_f32(st[cb][0][0], st[cb][0][1], st[cb][0][2]);
+      mx = fmax_raw(mx, st[cb][0][3]);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+      for (int nb = 1; nb < 4; ++nb) {
+        mx = max3_f32(mx, st[cb][nb][0], st[cb][nb][1]);
+        mx = max3_f32(mx, st[cb][nb][2], st[cb][nb][3]);
+      }
+    } else {
+      mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[cb][nb][r]);
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[cb][nb][r]);
+    }
     mx = xrow_max_swap(mx) * sc2;
     const float m_new = fmaxf(m[cb], mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -577,7 +601,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
     f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      const f32x4 e = st[cb][nb] * sc2 - m_use;  // contracted to (packed) fma
+      const f32x4 e = st[cb][nb] * sc2 - m_use;  // contracted to four fmas
       f32x4 p;
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[r] = fast_exp2(e[r]);
@@ -586,8 +610,10 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
     }
     l[cb] = l[cb] * alpha + ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));  // per-lane partial row sum; reduced across lq at the end
     m[cb] = m_new;
+    if (!(OPT & 2) || !__all(alpha == 1.0f)) {  // alpha == 1 for the whole wave: the rescale would multiply by one (bit-identical to skip it)
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
+      for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
+    }
   }
   // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
 #pragma unroll
@@ -610,7 +636,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
   }
 }
 
-template <int MINW>
+template <int MINW, int OPT = 0>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
                                                                float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
@@ -683,7 +709,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (j + 1 < n_iters) dma_pieces<PPW>(krsrc, vrsrc, wr + w * PPW * 1024, 64 * kD * 2, koff, voff, (kv0 + 64) * krow, (kv0 + 64) * vrow);
-    if (active && kv0 <= wave_last) fwd_tile(rd, kv0, q0, sc2, bq, bt, lq, qf, qi, lo, m, l, ot);
+    if (active && kv0 <= wave_last) fwd_tile<OPT>(rd, kv0, q0, sc2, bq, bt, lq, qf, qi, lo, m, l, ot);
   };
   for (int j = 0; j < n_iters; j += 2) {
     step(smA, smB, j);

@@ -282,7 +282,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
     if which == "attnfwd":
-        bench_attn_variants(out, 0, [0])
+        bench_attn_variants(out, 0, [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3, 0, 1, 2])
     if which == "attnbwd":
         bench_attn_variants(out, 1, [int(x) for x in sys.argv[2].split(",")])
     if which == "attndq":
