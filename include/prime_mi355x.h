@@ -405,14 +405,17 @@ int pm_moe_ep_row_map(const int32_t* recv_counts, int32_t ep_size, int32_t n_loc
  * [offsets[e], offsets[e+1])), bf16 operands, f32 accumulation, bf16 results; n_out / k_dim multiples of 128 (pm_grouped_gemm_supported):
  *   nt: y[m][n]     = sum_k x[m][k]  * w[e][n][k]      x [M, K], w [E, N, K] -> y [M, N]
  *   nn: dx[m][k]    = sum_n dy[m][n] * w[e][n][k]      dy [M, N], w [E, N, K] -> dx [M, K]
- *   tn: dw[e][n][k] = sum_{m in group e} dy[m][n] * x[m][k]   -> dw [E, N, K] (zeros for an empty group) */
+ *   tn: dw[e][n][k] = sum_{m in group e} dy[m][n] * x[m][k]   -> dw [E, N, K] (zeros for an empty group)
+ * Each takes an optional SECOND weight set for the columns [n_first, N) (w2 [E, N - n_first, K]; n_first = N and w2 = NULL for one set), so
+ * the experts' gate and up projections (w1, w3 of GroupedExperts, moe.py:436-440) run as one product whose output is the gate|up layout
+ * pm_swiglu_fwd consumes, their row gradients as one contraction over both, and their weight gradients as one launch with two outputs. */
 int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim);
-int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_out, int64_t k_dim,
-                       void* y_bf16, void* stream);
-int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t k_out,
-                       void* dx_bf16, void* stream);
-int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t k_dim,
-                       void* dw_bf16, void* stream);
+int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
+                       int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream);
+int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
+                       int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream);
+int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
+                       int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

@@ -142,8 +142,11 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& c) { *reinterpret
 
 // ---------------------------------------------------------------------------------------------------------------------
 // NT: y[m][n0 + ..] = x[m][:] . w[e][n][:]   (A = w rows, B = x rows; both [128][64] tiles, contraction k)
-__global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const int32_t* __restrict__ offsets,
-                                                           int n_experts, int64_t m_total, int n_out, int k_dim, bf16_t* __restrict__ y) {
+// Two weight sets: output columns [0, n_a) come from w_a [E, n_a, K], columns [n_a, n_out) from w_b [E, n_out - n_a, K] (the gate and up
+// projections of the experts in ONE launch, written side by side as the gate|up layout pm_swiglu_fwd consumes); w_b unused when n_a == n_out.
+__global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w_a, const bf16_t* __restrict__ w_b,
+                                                           const int32_t* __restrict__ offsets, int n_experts, int64_t m_total, int n_a, int n_out, int k_dim,
+                                                           bf16_t* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -152,9 +155,13 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __rest
   int expert, row0, row_end, row_tile, col_tile;
   tile_of_block(blockIdx.x, n_out / kT, row_tile, col_tile);
   if (!locate_tile(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
-  const int n0 = col_tile * kT;
+  const int n0 = col_tile * kT;                    // output column
+  const bool second = n0 >= n_a;
+  const int wn = second ? n_out - n_a : n_a;        // rows of the selected weight set
+  const int nw0 = second ? n0 - n_a : n0;           // first row inside it
+  const bf16_t* w = second ? w_b : w_a;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)(m_total * k_dim * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * n_out * k_dim), 0, n_out * k_dim * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * wn * k_dim), 0, wn * k_dim * 2, 0x00020000);
   const int row_bytes = k_dim * 2;
   const int nk = k_dim / kBK;
   f32x4 acc[4][4];
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __rest
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto stage = [&](unsigned char* sm, int s) {
-    dma_tile_k64(wr, sm, n0, row_bytes, s * kBK * 2, wave, lane);
+    dma_tile_k64(wr, sm, nw0, row_bytes, s * kBK * 2, wave, lane);
     dma_tile_k64(xr, sm + kTileBytes, row0, row_bytes, s * kBK * 2, wave, lane);
   };
   auto compute = [&](const unsigned char* sm) {
@@ -207,8 +214,10 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __rest
 
 // ---------------------------------------------------------------------------------------------------------------------
 // NN: dx[m][k0 + ..] = dy[m][:] . w[e][:][k]   (A = w^T: transposed fragments of the [64 n][128 k] tile; B = dy rows: [128 m][64 n] tile)
-__global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w, const int32_t* __restrict__ offsets,
-                                                           int n_experts, int64_t m_total, int n_dim, int k_out, bf16_t* __restrict__ dx) {
+// Two weight sets: the contraction runs over dy's n_dim columns, the first n_a against w_a, the rest against w_b (dx = d_gate . w1 + d_up . w3).
+__global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w_a, const bf16_t* __restrict__ w_b,
+                                                           const int32_t* __restrict__ offsets, int n_experts, int64_t m_total, int n_a, int n_dim, int k_out,
+                                                           bf16_t* __restrict__ dx) {
   __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -219,7 +228,10 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __rest
   if (!locate_tile(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
   const int k0 = col_tile * kT;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, (int)(m_total * n_dim * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * n_dim * k_out), 0, n_dim * k_out * 2, 0x00020000);
+  const int n_b = n_dim - n_a;
+  const __amdgpu_buffer_rsrc_t wra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w_a + (int64_t)expert * n_a * k_out), 0, n_a * k_out * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(n_b ? w_b + (int64_t)expert * n_b * k_out : w_a), 0, n_b * k_out * 2, 0x00020000);
   const int ns = n_dim / kBK;
   int tb[2][2];
   tr_bases(0, lr, lq, tb[0]);
@@ -230,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __rest
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto stage = [&](unsigned char* sm, int s) {
-    dma_tile_r64(wr, sm, (int64_t)s * kBK, k_out * 2, k0 * 2, wave, lane);              // w[e][n = s*64 ..][k0 ..]
+    if (s * kBK < n_a) dma_tile_r64(wra, sm, (int64_t)s * kBK, k_out * 2, k0 * 2, wave, lane);        // w_a[e][n = s*64 ..][k0 ..]
+    else dma_tile_r64(wrb, sm, (int64_t)s * kBK - n_a, k_out * 2, k0 * 2, wave, lane);
     dma_tile_k64(yr, sm + kTileBytes, row0, n_dim * 2, s * kBK * 2, wave, lane);         // dy[row0 ..][n = s*64 ..]
   };
   auto compute = [&](const unsigned char* sm) {
@@ -273,8 +286,9 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __rest
 
 // ---------------------------------------------------------------------------------------------------------------------
 // TN: dw[e][n0 + ..][k0 + ..] = sum over the group's rows of dy[m][n] * x[m][k]   (A = x^T, B = dy^T: both transposed fragments of [64 m][128] tiles)
+// Two outputs: dy columns [0, n_a) give dw_a [E, n_a, K], columns [n_a, n_dim) give dw_b [E, n_dim - n_a, K].
 __global__ __launch_bounds__(256, 2) void grouped_tn_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const int32_t* __restrict__ offsets,
-                                                           int n_dim, int k_dim, bf16_t* __restrict__ dw) {
+                                                           int n_a, int n_dim, int k_dim, bf16_t* __restrict__ dw_a, bf16_t* __restrict__ dw_b) {
   __shared__ __attribute__((aligned(16))) unsigned char smA[kStageBytes];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kStageBytes];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -329,10 +343,11 @@ __global__ __launch_bounds__(256, 2) void grouped_tn_kernel(const bf16_t* __rest
     }
   }
   // acc[a][b][r] = dw[e][n0 + wt*64 + b*16 + lr][k0 + wv*64 + a*16 + lq*4 + r]; an empty group writes zeros
-  bf16_t* out = dw + (int64_t)expert * n_dim * k_dim;
+  const bool second = n0 >= n_a;
+  bf16_t* out = second ? dw_b + (int64_t)expert * (n_dim - n_a) * k_dim : dw_a + (int64_t)expert * n_a * k_dim;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    const int n = n0 + wt * 64 + b * 16 + lr;
+    const int n = (second ? n0 - n_a : n0) + wt * 64 + b * 16 + lr;
 #pragma unroll
     for (int a = 0; a < 4; ++a) store4(out + (int64_t)n * k_dim + k0 + wv * 64 + a * 16 + lq * 4, acc[a][b]);
   }
@@ -347,43 +362,46 @@ static bool gg_shapes_ok(int64_t m, int64_t n, int64_t k) { return n % 128 == 0 
 
 extern "C" int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim) { return gg_shapes_ok(n_rows, n_out, k_dim) ? 1 : 0; }
 
-extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_out,
-                                  int64_t k_dim, void* y_bf16, void* stream) {
+extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
+                                  int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream) {
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: bad sizes");
-  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (x_bf16 && y_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: null pointer");
+  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (x_bf16 && y_bf16)) && (n_first == n_out || w2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: null pointer");
+  PM_REQUIRE(n_first > 0 && n_first <= n_out && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: n_first must be a multiple of 128 in (0, n_out]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_out, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nt: n_out=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_out, (long long)k_dim);
   if (n_rows == 0) return PM_OK;
   const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (n_out / 128)));
-  hipLaunchKernelGGL(gg::grouped_nt_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, offsets, n_experts, n_rows,
-                     (int)n_out, (int)k_dim, (bf16_t*)y_bf16);
+  hipLaunchKernelGGL(gg::grouped_nt_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
+                     n_experts, n_rows, (int)n_first, (int)n_out, (int)k_dim, (bf16_t*)y_bf16);
   PM_CHECK_LAUNCH("pm_grouped_gemm_nt");
   return PM_OK;
 }
 
-extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
-                                  int64_t k_out, void* dx_bf16, void* stream) {
+extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
+                                  int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream) {
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: bad sizes");
-  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (dy_bf16 && dx_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: null pointer");
+  PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (dy_bf16 && dx_bf16)) && (n_first == n_dim || w2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: null pointer");
+  PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: n_first must be a multiple of 128 in (0, n_dim]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_out), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_out);
   if (n_rows == 0) return PM_OK;
   const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (k_out / 128)));
-  hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, offsets, n_experts, n_rows,
-                     (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
+  hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
+                     n_experts, n_rows, (int)n_first, (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
   PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
   return PM_OK;
 }
 
-extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
-                                  int64_t k_dim, void* dw_bf16, void* stream) {
+extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first,
+                                  int64_t n_dim, int64_t k_dim, void* dw_bf16, void* dw2_bf16, void* stream) {
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: bad sizes");
-  PM_REQUIRE(offsets && dw_bf16 && (n_rows == 0 || (dy_bf16 && x_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: null pointer");
+  PM_REQUIRE(offsets && dw_bf16 && (n_rows == 0 || (dy_bf16 && x_bf16)) && (n_first == n_dim || dw2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: null pointer");
+  PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: n_first must be a multiple of 128 in (0, n_dim]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
   const dim3 grid((unsigned)((n_dim / 128) * (k_dim / 128)), (unsigned)n_experts);
-  hipLaunchKernelGGL(gg::grouped_tn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_dim, (int)k_dim,
-                     (bf16_t*)dw_bf16);
+  hipLaunchKernelGGL(gg::grouped_tn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_first, (int)n_dim,
+                     (int)k_dim, (bf16_t*)dw_bf16, (bf16_t*)dw2_bf16);
   PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
   return PM_OK;
 }

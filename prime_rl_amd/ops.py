@@ -636,37 +636,51 @@ def _gg_check(rows: Tensor, w: Tensor, offsets: Tensor, what: str):
         raise PrimeMI355XError(f"grouped GEMM: rows {tuple(rows.shape)}, w {tuple(w.shape)}, offsets {tuple(offsets.shape)}")
 
 
-def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor) -> Tensor:
-    """y[m] = x[m] @ w[e(m)].T over expert-sorted rows: x [M, K], w [E, N, K], offsets [E+1] i32 -> y [M, N] (pm_grouped_gemm_nt)."""
+def _gg_second(w: Tensor, w2: Tensor | None):
+    if w2 is None:
+        return 0
+    _req(w2, torch.bfloat16, "w2")
+    if w2.dim() != 3 or w2.shape[0] != w.shape[0] or w2.shape[2] != w.shape[2]:
+        raise PrimeMI355XError(f"grouped GEMM: second weight set {tuple(w2.shape)} does not match {tuple(w.shape)}")
+    return w2.shape[1]
+
+
+def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None) -> Tensor:
+    """y[m] = x[m] @ [w | w2][e(m)].T over expert-sorted rows: x [M, K], w [E, N1, K] (, w2 [E, N2, K]), offsets [E+1] i32 -> y [M, N1 + N2]."""
     lib = _lib.load()
     _gg_check(x, w, offsets, "x")
     e, n, k = w.shape
+    n2 = _gg_second(w, w2)
     if x.shape[1] != k:
         raise PrimeMI355XError(f"grouped_gemm_nt: x {tuple(x.shape)} vs w {tuple(w.shape)}")
-    y = torch.empty((x.shape[0], n), dtype=torch.bfloat16, device=x.device)
-    check(lib.pm_grouped_gemm_nt(_p(x), _p(w), _p(offsets), e, x.shape[0], n, k, _p(y), _stream()), "pm_grouped_gemm_nt")
+    y = torch.empty((x.shape[0], n + n2), dtype=torch.bfloat16, device=x.device)
+    check(lib.pm_grouped_gemm_nt(_p(x), _p(w), _p(w2), _p(offsets), e, x.shape[0], n, n + n2, k, _p(y), _stream()), "pm_grouped_gemm_nt")
     return y
 
 
-def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor) -> Tensor:
-    """dx[m] = dy[m] @ w[e(m)]: dy [M, N], w [E, N, K] -> dx [M, K] (pm_grouped_gemm_nn)."""
+def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None) -> Tensor:
+    """dx[m] = dy[m] @ [w ; w2][e(m)]: dy [M, N1 + N2], w [E, N1, K] (, w2 [E, N2, K]) -> dx [M, K]."""
     lib = _lib.load()
     _gg_check(dy, w, offsets, "dy")
     e, n, k = w.shape
-    if dy.shape[1] != n:
-        raise PrimeMI355XError(f"grouped_gemm_nn: dy {tuple(dy.shape)} vs w {tuple(w.shape)}")
+    n2 = _gg_second(w, w2)
+    if dy.shape[1] != n + n2:
+        raise PrimeMI355XError(f"grouped_gemm_nn: dy {tuple(dy.shape)} vs w {tuple(w.shape)} (+ {n2})")
     dx = torch.empty((dy.shape[0], k), dtype=torch.bfloat16, device=dy.device)
-    check(lib.pm_grouped_gemm_nn(_p(dy), _p(w), _p(offsets), e, dy.shape[0], n, k, _p(dx), _stream()), "pm_grouped_gemm_nn")
+    check(lib.pm_grouped_gemm_nn(_p(dy), _p(w), _p(w2), _p(offsets), e, dy.shape[0], n, n + n2, k, _p(dx), _stream()), "pm_grouped_gemm_nn")
     return dx
 
 
-def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor) -> Tensor:
-    """dw[e] = dy[group e].T @ x[group e]: dy [M, N], x [M, K] -> dw [E, N, K] (pm_grouped_gemm_tn)."""
+def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None = None):
+    """dw[e] = dy[group e].T @ x[group e]: dy [M, N], x [M, K] -> dw [E, N, K]; with n_first: (dw [E, n_first, K], dw2 [E, N - n_first, K])."""
     lib = _lib.load()
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(offsets, torch.int32, "offsets")
     e = offsets.numel() - 1
     if dy.shape[0] != x.shape[0]:
         raise PrimeMI355XError(f"grouped_gemm_tn: dy {tuple(dy.shape)} vs x {tuple(x.shape)}")
-    dw = torch.empty((e, dy.shape[1], x.shape[1]), dtype=torch.bfloat16, device=x.device)
-    check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], dy.shape[1], x.shape[1], _p(dw), _stream()), "pm_grouped_gemm_tn")
-    return dw
+    n, k = dy.shape[1], x.shape[1]
+    n1 = n if n_first is None else n_first
+    dw = torch.empty((e, n1, k), dtype=torch.bfloat16, device=x.device)
+    dw2 = torch.empty((e, n - n1, k), dtype=torch.bfloat16, device=x.device) if n1 < n else None
+    check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), _stream()), "pm_grouped_gemm_tn")
+    return dw if n_first is None else (dw, dw2)

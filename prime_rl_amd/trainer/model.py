@@ -120,6 +120,29 @@ def resolve_auto_attn(config) -> None:
         config.attn = "hip_varlen"
 
 
+def get_load_balance_stats(model: nn.Module, reset_stats: bool = True, try_to_avoid_padding_experts: bool = True) -> dict[str, Tensor | None]:
+    """model.py:561-592: per MoE layer, the maximal load violation `(max tokens_per_expert - mean) / mean` (optionally without the top_k most loaded
+    experts, which absorb padding) and the routing confidence `routing_confidence_sum / routed tokens`; resets the layer counters."""
+    per_layer_max_vio, per_layer_conf = [], []
+    for block in model.model.layers:
+        mlp = getattr(block, "mlp", None)
+        if mlp is None or not hasattr(mlp, "tokens_per_expert"):
+            continue
+        tpe = mlp.tokens_per_expert
+        routed = tpe.sum() / mlp.router.top_k
+        if try_to_avoid_padding_experts:
+            tpe = tpe.sort(dim=0, descending=True).values[mlp.router.top_k:]
+        balanced = tpe.mean()
+        per_layer_max_vio.append(((tpe.max() - balanced) / balanced).detach())
+        per_layer_conf.append((mlp.routing_confidence_sum / routed).detach())
+        if reset_stats:
+            mlp.tokens_per_expert.zero_()
+            mlp.routing_confidence_sum.zero_()
+    if not per_layer_max_vio:
+        return {"max_vio": None, "routing_confidence": None}
+    return {"max_vio": torch.stack(per_layer_max_vio), "routing_confidence": torch.stack(per_layer_conf)}
+
+
 def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = torch.bfloat16, ep_group=None) -> nn.Module:
     """The custom PrimeRL class for the config's family (model.py:715-800, `impl` "custom"/"auto"); HF-impl models are out of scope."""
     if config.impl == "hf":

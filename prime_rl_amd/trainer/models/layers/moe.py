@@ -83,10 +83,31 @@ class _GroupedLinearFn(torch.autograd.Function):
         return gx, gw, None
 
 
+class _GroupedSwiGLUFn(torch.autograd.Function):
+    """h = silu(x @ w1[e].T) * (x @ w3[e].T) (moe.py:181-182) with both projections in ONE grouped GEMM that writes the gate|up layout, the
+    activation as `pm_swiglu_fwd`; backward: `pm_swiglu_bwd`, one row-gradient GEMM contracting over gate and up, one weight-gradient launch
+    with two outputs.  Saves, per layer, two [rows, hidden] round trips, the silu / mul / silu-backward / add kernels and one read of x."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w3, offsets):
+        gate_up = ops.grouped_gemm_nt(x, w1, offsets, w2=w3)
+        ctx.save_for_backward(x, w1, w3, offsets, gate_up)
+        return ops.swiglu_fwd(gate_up)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w3, offsets, gate_up = ctx.saved_tensors
+        d_gate_up = ops.swiglu_bwd(g.contiguous(), gate_up)
+        gx = ops.grouped_gemm_nn(d_gate_up, w1, offsets, w2=w3) if ctx.needs_input_grad[0] else None
+        gw1 = gw3 = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])
+        return gx, gw1, gw3, None
+
+
 def _experts_grouped_hip(w1, w2, w3, x, offsets):
     """_run_experts_grouped_mm_impl (moe.py:161-188) on pm_grouped_gemm_*: offsets stay on the device, no transposed weight copies."""
-    h = F.silu(_GroupedLinearFn.apply(x, w1, offsets)) * _GroupedLinearFn.apply(x, w3, offsets)
-    return _GroupedLinearFn.apply(h, w2, offsets)
+    return _GroupedLinearFn.apply(_GroupedSwiGLUFn.apply(x, w1, w3, offsets), w2, offsets)
 
 
 def _experts_grouped(w1, w2, w3, x, offsets):

@@ -268,7 +268,8 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
         got = _experts_grouped_hip(w1, w2, w3, y, offsets)
         err = float((got.float() - ref.float()).abs().max())
         med, _ = timeit(lambda: _experts_grouped_hip(w1, w2, w3, y, offsets), iters=10, warmup=2)
-    out.append(dict(kernel="experts pm_grouped_gemm_nt x3 + silu*mul", ms=med * 1e3, TFLOPs=flops / med / 1e12, max_abs_diff_vs_loop=err))
+    out.append(dict(kernel="experts pm_grouped_gemm_nt (gate|up in one launch) + pm_swiglu_fwd + pm_grouped_gemm_nt", ms=med * 1e3, TFLOPs=flops / med / 1e12,
+                    max_abs_diff_vs_loop=err))
     med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets), iters=10, warmup=2)
     out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}]", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
     hmid = ops.grouped_gemm_nt(y, w1, offsets)
@@ -276,6 +277,24 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     out.append(dict(kernel="pm_grouped_gemm_nn (dgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
     med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets), iters=10, warmup=2)
     out.append(dict(kernel="pm_grouped_gemm_tn (wgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+
+
+def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
+    """One Qwen3-30B-A3B MoE layer, forward + backward (for rocprofv3 --kernel-trace)."""
+    from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
+
+    layer = MoE(MoEArgs(num_experts=e, num_shared_experts=0, score_func="softmax", route_norm=True, score_before_experts=False, top_k=k, use_grouped_mm=True,
+                        load_balance_coeff=None), h, hidden).to(DEV).to(torch.bfloat16)
+    layer.init_weights(0.02)
+    x = torch.randn(1, n, h, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(1, n, h, device=DEV).to(torch.bfloat16)
+
+    def fb():
+        x.grad = None
+        layer(x).backward(gy)
+
+    med, _ = timeit(fb, iters=iters, warmup=2)
+    out.append(dict(kernel=f"MoE layer fwd+bwd [{n} tokens, {e} experts top-{k}, {h}/{hidden}]", ms=med * 1e3))
 
 
 def main():
@@ -289,6 +308,8 @@ def main():
         bench_attn_variants(out, 2, [int(x) for x in sys.argv[2].split(",")])
     if which == "moe":
         bench_moe(out)
+    if which == "moelayer":
+        bench_moe_layer(out)
     if which == "lmhead":
         bench_lmhead(out)
     if which == "lmhead4k":
