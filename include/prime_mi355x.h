@@ -410,6 +410,7 @@ int pm_moe_ep_row_map(const int32_t* recv_counts, int32_t ep_size, int32_t n_loc
  * the experts' gate and up projections (w1, w3 of GroupedExperts, moe.py:436-440) run as one product whose output is the gate|up layout
  * pm_swiglu_fwd consumes, their row gradients as one contraction over both, and their weight gradients as one launch with two outputs. */
 int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim);
+int pm_grouped_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): 0 = default tiling, 1 = force 128 x 128 tiles in the forward kernel */
 int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
                        int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream);
 int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,

@@ -127,6 +127,7 @@ SIGNATURES: dict[str, tuple] = {
     "pm_moe_slot_grads": (I, [P, P, P, I32, P, I64, I64, P, P, P]),
     "pm_moe_ep_row_map": (I, [P, I32, I32, P, P, P, P]),
     "pm_grouped_gemm_supported": (I, [I64, I64, I64]),
+    "pm_grouped_gemm_debug_set_variant": (I, [I32]),
     "pm_grouped_gemm_nt": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
     "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
     "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, P]),

@@ -97,8 +97,9 @@ __device__ __forceinline__ u32x4 frag_tr(const unsigned char* tile, const int (&
   return u32x4{l2.x, l2.y, h2.x, h2.y};
 }
 
-// 128-row tile `t` of the sorted rows -> (expert, first row, end of the expert's rows); false past the last tile.  Every wave runs the
-// same prefix scan over ceil(rows_e / 128).
+// ROWS-row tile `t` of the sorted rows -> (expert, first row, end of the expert's rows); false past the last tile.  Every wave runs the
+// same prefix scan over ceil(rows_e / ROWS).
+template <int ROWS = kT>
 __device__ __forceinline__ bool locate_tile(const int32_t* __restrict__ offsets, int n_experts, int t, int lane, int& expert, int& row0, int& row_end) {
   int base = 0;
   for (int e0 = 0; e0 < n_experts; e0 += 64) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ bool locate_tile(const int32_t* __restrict__ offsets,
       lo = offsets[e];
       hi = offsets[e + 1];
     }
-    const int tiles = (hi - lo + kT - 1) / kT;
+    const int tiles = (hi - lo + ROWS - 1) / ROWS;
     int incl = tiles;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -120,7 +121,7 @@ __device__ __forceinline__ bool locate_tile(const int32_t* __restrict__ offsets,
       const int src = __ffsll((long long)hit) - 1;
       const int first_tile = base + __shfl(incl, src, 64) - __shfl(tiles, src, 64);
       expert = e0 + src;
-      row0 = __shfl(lo, src, 64) + (t - first_tile) * kT;
+      row0 = __shfl(lo, src, 64) + (t - first_tile) * ROWS;
       row_end = __shfl(hi, src, 64);
       return true;
     }
@@ -208,6 +209,89 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(const bf16_t* __rest
     if (row < row_end) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) store4(y + (int64_t)row * n_out + n0 + wv * 64 + a * 16 + lq * 4, acc[a][b]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT on 256 x 256 tiles: 8 waves (2 along the weight rows x 4 along the tokens), 128 x 64 accumulators per wave (8 x 4 fragments = 128
+// VGPRs), one workgroup per CU (two waves per SIMD), LDS 2 x 64 KB.  Against the 128 x 128 kernel: half the L2 -> LDS bytes per flop (the
+// 128 x 128 tile saturates a CU's 64 B/clk L2 port at the full MFMA rate), 12 instead of 16 fragment reads per 32 MFMAs, 64 MFMAs per
+// wave between barriers instead of 32, and a DMA stage has 2048 MFMA cycles to land.
+constexpr int kBigTile = 256;
+constexpr int kBigOperand = kBigTile * kBK * 2;  // 32 KB
+constexpr int kBigStage = 2 * kBigOperand;       // 64 KB
+
+__global__ __launch_bounds__(512, 1) void grouped_nt_big_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w_a, const bf16_t* __restrict__ w_b,
+                                                               const int32_t* __restrict__ offsets, int n_experts, int64_t m_total, int n_a, int n_out, int k_dim,
+                                                               bf16_t* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kBigStage];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kBigStage];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 2, wt = wave & 3;  // wv: 128 weight rows, wt: 64 tokens
+  int expert, row0, row_end, row_tile, col_tile;
+  tile_of_block(blockIdx.x, n_out / kBigTile, row_tile, col_tile);
+  if (!locate_tile<kBigTile>(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
+  const int n0 = col_tile * kBigTile;
+  const bool second = n0 >= n_a;
+  const int wn = second ? n_out - n_a : n_a;
+  const int nw0 = second ? n0 - n_a : n0;
+  const bf16_t* w = second ? w_b : w_a;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)(m_total * k_dim * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w + (int64_t)expert * wn * k_dim), 0, wn * k_dim * 2, 0x00020000);
+  const int row_bytes = k_dim * 2;
+  const int nk = k_dim / kBK;
+  const int sub = lane >> 3, ch = lane & 7;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {  // 32 + 32 one-KiB pieces (8 rows x 8 chunks): wave w issues pieces 4w..4w+3 of each operand
+    const int kb = s * kBK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave * 4 + i, row = p * 8 + sub;
+      const int swz = (ch ^ (row & 7)) << 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(sm + p * 1024), 16, (nw0 + row) * row_bytes + kb + swz, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sm + kBigOperand + p * 1024), 16, (int)((int64_t)(row0 + row) * row_bytes) + kb + swz, 0, 0, 0);
+    }
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = frag_k(sm, wv * 128 + i * 16, kk, lr, lq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bfr[i] = frag_k(sm + kBigOperand, wt * 64 + i * 16, kk, lr, lq);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  stage(smA, 0);
+  for (int s = 0; s < nk; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nk) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < nk) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+  // acc[a][b][r] = y[row0 + wt*64 + b*16 + lr][n0 + wv*128 + a*16 + lq*4 + r]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = row0 + wt * 64 + b * 16 + lr;
+    if (row < row_end) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) store4(y + (int64_t)row * n_out + n0 + wv * 128 + a * 16 + lq * 4, acc[a][b]);
     }
   }
 }
@@ -358,6 +442,12 @@ __global__ __launch_bounds__(256, 2) void grouped_tn_kernel(const bf16_t* __rest
 
 using namespace pm;
 
+static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = 256 x 256 tiles where the shape allows, 1 = 128 x 128 tiles
+extern "C" int pm_grouped_gemm_debug_set_variant(int32_t value) {
+  g_nt_variant = value;
+  return PM_OK;
+}
+
 static bool gg_shapes_ok(int64_t m, int64_t n, int64_t k) { return n % 128 == 0 && k % 128 == 0 && m * (n > k ? n : k) * 2 < ((int64_t)1 << 31); }
 
 extern "C" int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim) { return gg_shapes_ok(n_rows, n_out, k_dim) ? 1 : 0; }
@@ -370,6 +460,13 @@ extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const 
   PM_REQUIRE(gg_shapes_ok(n_rows, n_out, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nt: n_out=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_out, (long long)k_dim);
   if (n_rows == 0) return PM_OK;
+  if (g_nt_variant != 1 && n_first % 256 == 0 && n_out % 256 == 0) {
+    const dim3 gridb((unsigned)(cdiv(cdiv(n_rows, 256) + n_experts, 8) * 8 * (n_out / 256)));
+    hipLaunchKernelGGL(gg::grouped_nt_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16,
+                       offsets, n_experts, n_rows, (int)n_first, (int)n_out, (int)k_dim, (bf16_t*)y_bf16);
+    PM_CHECK_LAUNCH("pm_grouped_gemm_nt");
+    return PM_OK;
+  }
   const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (n_out / 128)));
   hipLaunchKernelGGL(gg::grouped_nt_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
                      n_experts, n_rows, (int)n_first, (int)n_out, (int)k_dim, (bf16_t*)y_bf16);

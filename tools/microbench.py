@@ -270,8 +270,17 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
         med, _ = timeit(lambda: _experts_grouped_hip(w1, w2, w3, y, offsets), iters=10, warmup=2)
     out.append(dict(kernel="experts pm_grouped_gemm_nt (gate|up in one launch) + pm_swiglu_fwd + pm_grouped_gemm_nt", ms=med * 1e3, TFLOPs=flops / med / 1e12,
                     max_abs_diff_vs_loop=err))
-    med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets), iters=10, warmup=2)
-    out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}]", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    from prime_rl_amd import _lib as _l
+
+    for variant, label in ((1, "128 x 128 tiles"), (0, "256 x 256 tiles")):
+        _l.load().pm_grouped_gemm_debug_set_variant(variant)
+        ts = []
+        for _ in range(3):
+            med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets), iters=10, warmup=2)
+            ts.append(med)
+        med = sorted(ts)[1]
+        out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}] ({label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    _l.load().pm_grouped_gemm_debug_set_variant(0)
     hmid = ops.grouped_gemm_nt(y, w1, offsets)
     med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
     out.append(dict(kernel="pm_grouped_gemm_nn (dgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
