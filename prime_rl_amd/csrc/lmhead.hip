@@ -36,13 +36,23 @@ typedef __attribute__((ext_vector_type(4))) float lm_f32x4;
 
 namespace {
 
-constexpr int BV = 128;          // vocab rows per tile (MFMA A operand)
-constexpr int BT = 128;          // tokens per tile (MFMA B operand)
 constexpr int BK = 64;           // k per stage
-constexpr int kThreads = 256;    // 4 waves, 2 (vocab) x 2 (tokens)
-constexpr int kTileBytes = BV * BK * 2;            // 16 KB per operand per stage
-constexpr int kStageBytes = 2 * kTileBytes;        // A then B
-constexpr int kSmemBytes = 2 * kStageBytes;        // double buffer: 64 KB
+// Two tile configurations of the same kernel:
+//   small  128 (vocab) x 128 (tokens), 4 waves 2 x 2, 64 x 64 accumulators per wave, LDS 64 KB, two workgroups per CU;
+//   big    256 x 256, 8 waves 2 (vocab) x 4 (tokens), 128 x 64 accumulators per wave (128 VGPRs), LDS 128 KB, one workgroup per CU —
+//          half the L2 -> LDS bytes per flop (a 128 x 128 tile streams 64 flop/byte: at the full MFMA rate that is a CU's whole 64 B/clk L2
+//          port), 12 instead of 16 fragment reads per 32 MFMAs, 64 MFMAs per wave between barriers; used from 1024 tokens up.
+template <bool BIG>
+struct Cfg {
+  static constexpr int BV = BIG ? 256 : 128;            // vocab rows per tile (MFMA A operand)
+  static constexpr int BT = BIG ? 256 : 128;            // tokens per tile (MFMA B operand)
+  static constexpr int NVI = BV / 32;                   // 16-row vocab fragments per wave (2 waves along the vocab)
+  static constexpr int NWT = BT / 64;                   // waves along the tokens (64 tokens = 4 fragments each)
+  static constexpr int kThreads = 2 * NWT * 64;
+  static constexpr int kTileBytes = BV * BK * 2;        // bytes per operand per stage (BV == BT)
+  static constexpr int kStageBytes = 2 * kTileBytes;    // A then B
+  static constexpr int kSmemBytes = 2 * kStageBytes;    // double buffer
+};
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -3.0e38f;
 
@@ -70,10 +80,12 @@ struct Args {
   int round_bf16;         // round the GEMM result to bf16 before the epilogue (the reference's bf16 logits)
 };
 
-// One stage = the [128 x 64] k-slice of the W tile and of the hidden tile, 16 KB each, as 16 one-KiB DMA pieces per operand:
+// One stage = the [BV x 64] k-slice of the W tile and of the hidden tile as BV / 8 one-KiB DMA pieces per operand (4 per wave):
 // piece p covers tile rows 8p..8p+7; lane L of the issuing wave lands at LDS byte p*1024 + L*16 = (row 8p + L/8, chunk L%8) and must
 // therefore FETCH chunk (L%8) ^ (row & 7) of that row.  Wave w issues pieces 4w..4w+3 of each operand.
+template <bool BIG>
 __device__ __forceinline__ void stage_tiles(const Args& a, unsigned char* smem, int buf, int v0, int t0, int k0, int wave, int lane) {
+  constexpr int kStageBytes = Cfg<BIG>::kStageBytes, kTileBytes = Cfg<BIG>::kTileBytes;
   const int sub = lane >> 3, ch = lane & 7;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -99,8 +111,10 @@ __device__ __forceinline__ u32x4 frag(const unsigned char* tile, int r0, int kk,
   return *reinterpret_cast<const u32x4*>(tile + row * 128 + (((kk * 4 + lq) ^ (row & 7)) << 4));
 }
 
-template <bool BWD, bool STORE>
-__global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
+template <bool BWD, bool STORE, bool BIG>
+__global__ __launch_bounds__(Cfg<BIG>::kThreads, BIG ? 1 : 2) void lmhead_kernel(const Args a) {
+  constexpr int BV = Cfg<BIG>::BV, BT = Cfg<BIG>::BT, NVI = Cfg<BIG>::NVI, NWT = Cfg<BIG>::NWT;
+  constexpr int kStageBytes = Cfg<BIG>::kStageBytes, kTileBytes = Cfg<BIG>::kTileBytes;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // ---- blockIdx -> (token block, super-chunk): 8 x 8 patches per XCD (block b runs on XCD b % 8; speed only, any mapping is correct)
   const int patches_t = (a.tb_count + 7) >> 3, patches_s = (a.n_super + 7) >> 3;
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
-  const int wv = wave >> 1, wt = wave & 1;
+  const int wv = wave / NWT, wt = wave % NWT;
   const int t0 = tb * BT;
   const int tile_first = sc * a.tiles_per_super;
   const int n_vtiles = (a.v + BV - 1) / BV;
@@ -151,15 +165,15 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
     }
   }
 
-  lm_f32x4 acc[4][4];
+  lm_f32x4 acc[NVI][4];
 #pragma unroll
-  for (int vi = 0; vi < 4; ++vi)
+  for (int vi = 0; vi < NVI; ++vi)
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) acc[vi][ti] = lm_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- software pipeline over the flattened (tile, k) space: stage s+1 is in flight while stage s is multiplied
   const int total = (tile_last - tile_first) * nk;
-  stage_tiles(a, smem, 0, tile_first * BV, t0, 0, wave, lane);
+  stage_tiles<BIG>(a, smem, 0, tile_first * BV, t0, 0, wave, lane);
   int tile = tile_first, k = 0;
   for (int s = 0; s < total; ++s) {
     const int buf = s & 1;
@@ -171,31 +185,30 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
     if (s + 1 < total) {
       int nt = tile, nkk = k + 1;
       if (nkk == nk) { nkk = 0; ++nt; }
-      stage_tiles(a, smem, buf ^ 1, nt * BV, t0, nkk * BK, wave, lane);
+      stage_tiles<BIG>(a, smem, buf ^ 1, nt * BV, t0, nkk * BK, wave, lane);
     }
     const unsigned char* ta = smem + buf * kStageBytes;
     const unsigned char* tbp = ta + kTileBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      u32x4 af[4], bfr[4];
+      u32x4 af[NVI], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = frag(ta, wv * 64 + i * 16, kk, lr, lq);
-        bfr[i] = frag(tbp, wt * 64 + i * 16, kk, lr, lq);
-      }
+      for (int i = 0; i < NVI; ++i) af[i] = frag(ta, wv * (NVI * 16) + i * 16, kk, lr, lq);
 #pragma unroll
-      for (int vi = 0; vi < 4; ++vi)
+      for (int i = 0; i < 4; ++i) bfr[i] = frag(tbp, wt * 64 + i * 16, kk, lr, lq);
+#pragma unroll
+      for (int vi = 0; vi < NVI; ++vi)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[vi][ti] = mfma(af[vi], bfr[ti], acc[vi][ti]);
     }
     if (++k == nk) {
-      // ---- epilogue of vocab tile `tile`: acc[vi][ti][r] = logits[token(ti)][vocab = v0 + wv*64 + vi*16 + lq*4 + r]
-      const int vbase = tile * BV + wv * 64 + lq * 4;
+      // ---- epilogue of vocab tile `tile`: acc[vi][ti][r] = logits[token(ti)][vocab = v0 + wv*(NVI*16) + vi*16 + lq*4 + r]
+      const int vbase = tile * BV + wv * (NVI * 16) + lq * 4;
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        float l[16];
+        float l[NVI * 4];
 #pragma unroll
-        for (int vi = 0; vi < 4; ++vi)
+        for (int vi = 0; vi < NVI; ++vi)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = acc[vi][ti][r];
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
         const int tok = t0 + wt * 64 + ti * 16 + lr;
         if (STORE && !BWD && tok < a.n) {  // optional raw-logits tile (bf16), 8 bytes per (token, 4 vocab entries)
 #pragma unroll
-          for (int vi = 0; vi < 4; ++vi) {
+          for (int vi = 0; vi < NVI; ++vi) {
             const int vc = vbase + vi * 16;
             bf16_t* dst = a.tile_out + (int64_t)tok * a.ld + vc;
             if (vc + 3 < a.v) {
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
         if (!BWD) {
           float mx = kNegBig;
 #pragma unroll
-          for (int vi = 0; vi < 4; ++vi)
+          for (int vi = 0; vi < NVI; ++vi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int vc = vbase + vi * 16 + r;
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
           const float sc_old = __builtin_amdgcn_exp2f((st_m[ti] - m_new) * kLog2e);
           float ssum = 0.f, tsum = 0.f;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
+          for (int j = 0; j < NVI * 4; ++j) {
             const float e = __builtin_amdgcn_exp2f((l[j] - m_new) * kLog2e);  // exp(-huge) = 0 for masked entries
             ssum += e;
             tsum = fmaf(e, l[j] > kNegBig ? l[j] : 0.f, tsum);
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
         } else if (tok < a.n) {
           // dl = g * inv_t * (onehot(label) - exp(l * inv_t - logz))   (lm_head.py:184-191)
 #pragma unroll
-          for (int vi = 0; vi < 4; ++vi) {
+          for (int vi = 0; vi < NVI; ++vi) {
             const int vc = vbase + vi * 16;
             float d[4];
 #pragma unroll
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kThreads, 2) void lmhead_kernel(const Args a) {
         }
       }
 #pragma unroll
-      for (int vi = 0; vi < 4; ++vi)
+      for (int vi = 0; vi < NVI; ++vi)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) acc[vi][ti] = lm_f32x4{0.f, 0.f, 0.f, 0.f};
       k = 0;
@@ -318,12 +331,16 @@ __global__ void lmhead_finalize_kernel(const float* __restrict__ partial, int n,
   entropy[tok] = lzv - tt / s;
 }
 
+bool use_big(int64_t n_tokens) { return n_tokens >= 1024; }  // 256 x 256 tiles once there are at least four 256-token blocks
+
 int choose_super(int64_t n_tokens, int64_t vocab) {
+  const int BT = use_big(n_tokens) ? 256 : 128, BV = BT;
   // ~2 workgroups per CU per round: token blocks x S close to a multiple of 512, S a multiple of 8 (8 x 8 XCD patches), capped so that
   // a super-chunk keeps >= 8 vocab tiles (the k-pipeline restarts only at workgroup start)
   const int64_t tb = cdiv(n_tokens, BT), vt = cdiv(vocab, BV);
+  const int64_t want = use_big(n_tokens) ? 512 : 1024;  // workgroups: ~2 rounds of (one | two) per CU
   int s = 8;
-  while (s < 64 && tb * s < 1024 && vt / (s * 2) >= 8) s *= 2;
+  while (s < 64 && tb * s < want && vt / (s * 2) >= 8) s *= 2;
   return s;
 }
 
@@ -337,9 +354,10 @@ int fill_args(Args& a, const void* hidden, const void* weight, int64_t n, int64_
   a.labels = labels;
   a.inv_temp = inv_temp;
   a.n = (int)n; a.h = (int)h; a.v = (int)v;
+  const int tile = use_big(n) ? 256 : 128;
   a.n_super = choose_super(n, v);
-  a.tiles_per_super = (int)cdiv(cdiv(v, BV), a.n_super);
-  a.tb_count = (int)cdiv(n, BT);
+  a.tiles_per_super = (int)cdiv(cdiv(v, tile), a.n_super);
+  a.tb_count = (int)cdiv(n, tile);
   a.round_bf16 = round_logits_bf16 ? 1 : 0;
   a.logz = nullptr; a.grad = nullptr; a.partial = nullptr; a.tile_out = nullptr; a.ld = 0;
   return PM_OK;
@@ -376,16 +394,20 @@ extern "C" int pm_lmhead_logprob_fwd(const void* hidden_bf16, const void* weight
   hipStream_t st = as_stream(stream);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<false>::kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<false>::kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<true>::kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<true>::kSmemBytes);
     attr_done = true;
   }
   const int grid = grid_blocks(a);
-  if (logits_out_bf16)
-    hipLaunchKernelGGL((lmhead_kernel<false, true>), dim3(grid), dim3(kThreads), kSmemBytes, st, a);
-  else
-    hipLaunchKernelGGL((lmhead_kernel<false, false>), dim3(grid), dim3(kThreads), kSmemBytes, st, a);
+  if (use_big(n_tokens)) {
+    if (logits_out_bf16) hipLaunchKernelGGL((lmhead_kernel<false, true, true>), dim3(grid), dim3(Cfg<true>::kThreads), Cfg<true>::kSmemBytes, st, a);
+    else hipLaunchKernelGGL((lmhead_kernel<false, false, true>), dim3(grid), dim3(Cfg<true>::kThreads), Cfg<true>::kSmemBytes, st, a);
+  } else {
+    if (logits_out_bf16) hipLaunchKernelGGL((lmhead_kernel<false, true, false>), dim3(grid), dim3(Cfg<false>::kThreads), Cfg<false>::kSmemBytes, st, a);
+    else hipLaunchKernelGGL((lmhead_kernel<false, false, false>), dim3(grid), dim3(Cfg<false>::kThreads), Cfg<false>::kSmemBytes, st, a);
+  }
   PM_CHECK_LAUNCH("lmhead_kernel<fwd>");
   hipLaunchKernelGGL(lmhead_finalize_kernel, dim3((unsigned)cdiv(n_tokens, 256)), dim3(256), 0, st, a.partial, a.n, 2 * a.n_super, logprobs, entropy, logz);
   PM_CHECK_LAUNCH("lmhead_finalize_kernel");
@@ -407,10 +429,14 @@ extern "C" int pm_lmhead_logprob_bwd(const void* hidden_bf16, const void* weight
   a.ld = dlogits_ld;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<false>::kSmemBytes);
+    (void)hipFuncSetAttribute((const void*)lmhead_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<true>::kSmemBytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((lmhead_kernel<true, true>), dim3(grid_blocks(a)), dim3(kThreads), kSmemBytes, as_stream(stream), a);
+  if (use_big(n_tokens))
+    hipLaunchKernelGGL((lmhead_kernel<true, true, true>), dim3(grid_blocks(a)), dim3(Cfg<true>::kThreads), Cfg<true>::kSmemBytes, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL((lmhead_kernel<true, true, false>), dim3(grid_blocks(a)), dim3(Cfg<false>::kThreads), Cfg<false>::kSmemBytes, as_stream(stream), a);
   PM_CHECK_LAUNCH("lmhead_kernel<bwd>");
   return PM_OK;
 }
