@@ -76,6 +76,38 @@ __device__ __forceinline__ void dma_tile_r64(__amdgpu_buffer_rsrc_t rsrc, unsign
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(dst + p * 1024), 16, voff, 0, 0, 0);
   }
 }
+// [64 rows][256 cols] tile (512-byte rows) for the 256 x 256 kernels: 32 pieces of 2 rows; lane L lands at (row 2p + L/32, chunk L%32) and fetches
+// chunk (L%32) ^ f(row & 15) (the 4-bit XOR stays inside a 256-byte half row, so the bank picture is the one of the 256-byte rows).  Wave w of 8
+// issues pieces 4w..4w+3.
+__device__ __forceinline__ void dma_tile_r64w(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int64_t row0, int row_bytes, int col_byte0, int wave, int lane) {
+  const int sub = lane >> 5, ch = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    const int row = p * 2 + sub;
+    const int voff = (int)((row0 + row) * row_bytes) + col_byte0 + ((ch ^ swz_f(row & 15)) << 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(dst + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+// [256 rows][64 cols] K-contiguous tile: 32 pieces of 8 rows, wave w of 8 issues pieces 4w..4w+3
+__device__ __forceinline__ void dma_tile_k64w(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int64_t row0, int row_bytes, int col_byte0, int wave, int lane) {
+  const int sub = lane >> 3, ch = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    const int row = p * 8 + sub;
+    const int voff = (int)((row0 + row) * row_bytes) + col_byte0 + ((ch ^ (row & 7)) << 4);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(dst + p * 1024), 16, voff, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void tr_bases_w(int kk, int lr, int lq, int (&base)[2]) {  // tr_bases for 512-byte rows
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = kk * 32 + lq * 8 + (lr >> 2) + 4 * h;
+    base[h] = row * 512 + (((((lr & 3) >> 1) ^ swz_f(row & 15)) << 4) | ((lr & 1) << 3));
+  }
+}
+
 // K-contiguous fragment (16 rows x 32 k) of a [128][64] tile: lane (lr, lq) reads row r0 + lr, 16-byte chunk kk*4 + lq
 __device__ __forceinline__ u32x4 frag_k(const unsigned char* tile, int r0, int kk, int lr, int lq) {
   const int row = r0 + lr;
@@ -368,6 +400,75 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(const bf16_t* __rest
   }
 }
 
+// NN on 256 x 256 tiles (see grouped_nt_big_kernel): A = transposed fragments of the [64 n][256 k] weight tile, B = [256 m][64 n] rows of dy.
+__global__ __launch_bounds__(512, 1) void grouped_nn_big_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w_a, const bf16_t* __restrict__ w_b,
+                                                               const int32_t* __restrict__ offsets, int n_experts, int64_t m_total, int n_a, int n_dim, int k_out,
+                                                               bf16_t* __restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kBigStage];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kBigStage];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 2, wt = wave & 3;  // wv: 128 output columns k, wt: 64 rows m
+  int expert, row0, row_end, row_tile, col_tile;
+  tile_of_block(blockIdx.x, k_out / kBigTile, row_tile, col_tile);
+  if (!locate_tile<kBigTile>(offsets, n_experts, row_tile, lane, expert, row0, row_end)) return;
+  const int k0 = col_tile * kBigTile;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, (int)(m_total * n_dim * 2), 0x00020000);
+  const int n_b = n_dim - n_a;
+  const __amdgpu_buffer_rsrc_t wra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(w_a + (int64_t)expert * n_a * k_out), 0, n_a * k_out * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(n_b ? w_b + (int64_t)expert * n_b * k_out : w_a), 0, n_b * k_out * 2, 0x00020000);
+  const int ns = n_dim / kBK;
+  int tb[2][2];
+  tr_bases_w(0, lr, lq, tb[0]);
+  tr_bases_w(1, lr, lq, tb[1]);
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {
+    if (s * kBK < n_a) dma_tile_r64w(wra, sm, (int64_t)s * kBK, k_out * 2, k0 * 2, wave, lane);
+    else dma_tile_r64w(wrb, sm, (int64_t)s * kBK - n_a, k_out * 2, k0 * 2, wave, lane);
+    dma_tile_k64w(yr, sm + kBigOperand, row0, n_dim * 2, s * kBK * 2, wave, lane);
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = frag_tr(sm, tb[kk], wv * 8 + i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bfr[i] = frag_k(sm + kBigOperand, wt * 64 + i * 16, kk, lr, lq);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  stage(smA, 0);
+  for (int s = 0; s < ns; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < ns) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < ns) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < ns) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = row0 + wt * 64 + b * 16 + lr;
+    if (row < row_end) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) store4(dx + (int64_t)row * k_out + k0 + wv * 128 + a * 16 + lq * 4, acc[a][b]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // TN: dw[e][n0 + ..][k0 + ..] = sum over the group's rows of dy[m][n] * x[m][k]   (A = x^T, B = dy^T: both transposed fragments of [64 m][128] tiles)
 // Two outputs: dy columns [0, n_a) give dw_a [E, n_a, K], columns [n_a, n_dim) give dw_b [E, n_dim - n_a, K].
@@ -437,12 +538,76 @@ __global__ __launch_bounds__(256, 2) void grouped_tn_kernel(const bf16_t* __rest
   }
 }
 
+// TN on 256 x 256 tiles: A = x^T, B = dy^T, both transposed fragments of [64 m][256] tiles; one workgroup per (expert, 256 n x 256 k tile).
+__global__ __launch_bounds__(512, 1) void grouped_tn_big_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const int32_t* __restrict__ offsets,
+                                                               int n_a, int n_dim, int k_dim, bf16_t* __restrict__ dw_a, bf16_t* __restrict__ dw_b) {
+  __shared__ __attribute__((aligned(16))) unsigned char smA[kBigStage];
+  __shared__ __attribute__((aligned(16))) unsigned char smB[kBigStage];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wv = wave >> 2, wt = wave & 3;  // wv: 128 columns k, wt: 64 rows n
+  const int expert = blockIdx.y;
+  const int tiles_k = k_dim / kBigTile;
+  const int n0 = (blockIdx.x / tiles_k) * kBigTile, k0 = (blockIdx.x % tiles_k) * kBigTile;
+  const int lo = offsets[expert], hi = offsets[expert + 1];
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, hi * n_dim * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, hi * k_dim * 2, 0x00020000);
+  const int ns = (hi - lo + kBK - 1) / kBK;
+  int tb[2][2];
+  tr_bases_w(0, lr, lq, tb[0]);
+  tr_bases_w(1, lr, lq, tb[1]);
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](unsigned char* sm, int s) {
+    dma_tile_r64w(xr, sm, (int64_t)lo + s * kBK, k_dim * 2, k0 * 2, wave, lane);
+    dma_tile_r64w(yr, sm + kBigOperand, (int64_t)lo + s * kBK, n_dim * 2, n0 * 2, wave, lane);
+  };
+  auto compute = [&](const unsigned char* sm) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = frag_tr(sm, tb[kk], wv * 8 + i);                  // rows k = k0 + wv*128 + i*16 + ..
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bfr[i] = frag_tr(sm + kBigOperand, tb[kk], wt * 4 + i);   // cols n = n0 + wt*64 + i*16 + lr
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma(af[a], bfr[b], acc[a][b]);
+    }
+  };
+  if (ns > 0) stage(smA, 0);
+  for (int s = 0; s < ns; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < ns) stage(smB, s + 1);
+    compute(smA);
+    if (s + 1 < ns) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < ns) stage(smA, s + 2);
+      compute(smB);
+    }
+  }
+  const bool second = n0 >= n_a;
+  bf16_t* out = second ? dw_b + (int64_t)expert * (n_dim - n_a) * k_dim : dw_a + (int64_t)expert * n_a * k_dim;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = (second ? n0 - n_a : n0) + wt * 64 + b * 16 + lr;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) store4(out + (int64_t)n * k_dim + k0 + wv * 128 + a * 16 + lq * 4, acc[a][b]);
+  }
+}
+
 }  // namespace gg
 }  // namespace pm
 
 using namespace pm;
 
-static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = 256 x 256 tiles where the shape allows, 1 = 128 x 128 tiles
+static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = 256 x 256 tiles where the shape allows, 1 = 128 x 128 tiles everywhere
 extern "C" int pm_grouped_gemm_debug_set_variant(int32_t value) {
   g_nt_variant = value;
   return PM_OK;
@@ -482,6 +647,13 @@ extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_out), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_out);
   if (n_rows == 0) return PM_OK;
+  if (g_nt_variant != 1 && k_out % 256 == 0) {
+    const dim3 gridb((unsigned)(cdiv(cdiv(n_rows, 256) + n_experts, 8) * 8 * (k_out / 256)));
+    hipLaunchKernelGGL(gg::grouped_nn_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16,
+                       offsets, n_experts, n_rows, (int)n_first, (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
+    PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
+    return PM_OK;
+  }
   const dim3 grid((unsigned)(cdiv(cdiv(n_rows, 128) + n_experts, 8) * 8 * (k_out / 128)));
   hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
                      n_experts, n_rows, (int)n_first, (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
@@ -496,6 +668,13 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: n_first must be a multiple of 128 in (0, n_dim]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
+  if (g_nt_variant != 1 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
+    const dim3 gridb((unsigned)((n_dim / 256) * (k_dim / 256)), (unsigned)n_experts);
+    hipLaunchKernelGGL(gg::grouped_tn_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_first,
+                       (int)n_dim, (int)k_dim, (bf16_t*)dw_bf16, (bf16_t*)dw2_bf16);
+    PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
+    return PM_OK;
+  }
   const dim3 grid((unsigned)((n_dim / 128) * (k_dim / 128)), (unsigned)n_experts);
   hipLaunchKernelGGL(gg::grouped_tn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_first, (int)n_dim,
                      (int)k_dim, (bf16_t*)dw_bf16, (bf16_t*)dw2_bf16);

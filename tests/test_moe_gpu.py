@@ -358,8 +358,10 @@ def test_expert_parallel_dispatch_on_the_device_equals_local_experts():
 
 
 @pytest.mark.parametrize("e,n_out,k,sizes", [(4, 128, 128, [5, 0, 300, 128]), (8, 256, 384, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 768, 2048, [1000, 24, 513]),
-                                             (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16)])
-def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes):
+                                             (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16), (5, 512, 256, [300, 0, 257, 255, 1]),
+                                             (3, 256, 768, [600, 256, 31])])
+@pytest.mark.parametrize("variant", [0, 1])  # 0: 256 x 256 tiles where the shape allows; 1: 128 x 128 tiles everywhere
+def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes, variant):
     """pm_grouped_gemm_nt / nn / tn vs a per-expert f32 matmul of the same bf16 operands: ragged groups, empty groups, groups that are not
     multiples of the 64-row contraction step or the 128-row tile, an empty batch."""
     ops = _ops()
@@ -370,9 +372,15 @@ def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes):
     w = (torch.randn(e, n_out, k, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
     dy = torch.randn(m, n_out, generator=g).to(torch.bfloat16).to(DEV)
     assert ops.grouped_gemm_supported(m, n_out, k)
-    y = ops.grouped_gemm_nt(x, w, offsets)
-    dx = ops.grouped_gemm_nn(dy, w, offsets)
-    dw = ops.grouped_gemm_tn(dy, x, offsets)
+    from prime_rl_amd import _lib
+
+    _lib.load().pm_grouped_gemm_debug_set_variant(variant)
+    try:
+        y = ops.grouped_gemm_nt(x, w, offsets)
+        dx = ops.grouped_gemm_nn(dy, w, offsets)
+        dw = ops.grouped_gemm_tn(dy, x, offsets)
+    finally:
+        _lib.load().pm_grouped_gemm_debug_set_variant(0)
     o = 0
     for i, c in enumerate(sizes):
         xe, de, we = x[o:o + c].float(), dy[o:o + c].float(), w[i].float()

@@ -282,10 +282,13 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
         out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}] ({label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
     _l.load().pm_grouped_gemm_debug_set_variant(0)
     hmid = ops.grouped_gemm_nt(y, w1, offsets)
-    med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
-    out.append(dict(kernel="pm_grouped_gemm_nn (dgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
-    med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets), iters=10, warmup=2)
-    out.append(dict(kernel="pm_grouped_gemm_tn (wgrad of the same)", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    for variant, label in ((1, "128 x 128 tiles"), (0, "256 x 256 tiles")):
+        _l.load().pm_grouped_gemm_debug_set_variant(variant)
+        med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
+        out.append(dict(kernel=f"pm_grouped_gemm_nn (row gradient of the same; {label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+        med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets), iters=10, warmup=2)
+        out.append(dict(kernel=f"pm_grouped_gemm_tn (weight gradient of the same; {label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
+    _l.load().pm_grouped_gemm_debug_set_variant(0)
 
 
 def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
