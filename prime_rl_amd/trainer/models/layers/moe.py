@@ -9,7 +9,7 @@ What runs where: the gate GEMM is a library call; the expert GEMMs are the hand-
 (`pm_grouped_gemm_nt / nn / tn`, device-side offsets; `torch._grouped_mm` for shapes that are not multiples of 128, a per-expert loop when
 `use_grouped_mm=False`: the reference's two paths); everything between them is `moe.hip`:
 score function + top-k + normalisation + histogram in one launch per layer (`pm_moe_router_fwd`, the reference: softmax, topk, gather,
-sum, div, mul, histc), a three-launch stable counting sort (`pm_moe_sort`; the reference: histc + argsort + index + floor-divide), the
+sum, div, mul, histc), a four-launch stable counting sort (`pm_moe_sort`; the reference: histc + argsort + index + floor-divide), the
 expert-sorted row gather with the optional score multiply (`pm_moe_gather_rows`) and the weighted combine as a deterministic gather with
 f32 accumulation (`pm_moe_combine`; the reference: f32 multiply, cast, zeros_like, scatter_add with atomics).
 Expert parallelism (`ep_group`): `prime_rl_amd.trainer.distributed.expert_parallel` dispatches the sorted rows to the ranks that own

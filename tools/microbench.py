@@ -241,7 +241,7 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     out.append(dict(kernel=f"moe_router_fwd[n={n},E={e},k={k}]", us=med * 1e6, GBs=(n * e * (2 + 4) + n * k * 8) / med / 1e9))
     scores, top, idx, counts, conf = ops.moe_router_fwd(logits, k, "softmax", True, 1.0)
     med, _ = timeit(lambda: ops.moe_sort(idx.reshape(-1), e), iters=20)
-    out.append(dict(kernel=f"moe_sort[{n * k} slots] (3 launches)", us=med * 1e6))
+    out.append(dict(kernel=f"moe_sort[{n * k} slots] (4 launches)", us=med * 1e6))
     dest, slot, offsets = ops.moe_sort(idx.reshape(-1), e)
     med, _ = timeit(lambda: ops.moe_gather_rows(x, slot, k), iters=20)
     out.append(dict(kernel=f"moe_gather_rows[{n * k} x {h}]", us=med * 1e6, GBs=2 * n * k * h * 2 / med / 1e9))
