@@ -223,6 +223,43 @@ def test_engine_step_matches_oracle(packed):
     assert torch.equal(eng.store.params, eng.store.master.to(torch.bfloat16))
 
 
+def test_engine_three_optimizer_steps_follow_the_f32_cpu_trainer():
+    """Trajectory check: three full policy updates (forward, loss, backward, clip, AdamW, next forward on the UPDATED bf16 weights) of the
+    shipped engine against oracle/cpu_trainer.py::train_step (f32 torch-CPU, torch.optim.AdamW, clip_grad_norm_) from the same weights on
+    the same rollouts.  Per step: loss within 5e-4, pre-clip gradient norm within 3 %; after three steps the f32 master weights agree with the
+    oracle's parameters to a few bf16-compute-noise units of the update size."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=512)
+    lr = 2e-4
+    eng = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=lr, weight_decay=0.01, max_norm=1.0), loss=LossConfig(), seed=3)
+    sd = {k: v.detach().cpu().clone() for k, v in eng.store.state_dict().items()}
+    cfg = _oracle_cfg(dims)
+    params = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    start = {k: v.detach().clone() for k, v in params.items()}
+    for step in range(3):
+        mbs = _mbs(dims.vocab_size, 256, 4, packed=True, seed_shift=step)
+        for mb in mbs:  # a sampling policy close to the current one, so that the ratios stay near 1 like in training
+            mb["inference_logprobs"] = torch.full_like(mb["inference_logprobs"], -6.2)
+        out = eng.step([pack_micro_batches(mbs, DEV)])
+        loss_e, norm_e = float(sum(l.item() for l in out["loss"])), float(out["grad_norm"].item())
+        loss_o, norm_o, _, _ = C.train_step(params, cfg, mbs, opt, O.LossConfig(), max_norm=1.0)
+        print(f"[trajectory step {step}] loss engine {loss_e:+.6f} oracle {float(loss_o):+.6f} | grad norm engine {norm_e:.5f} oracle {float(norm_o):.5f}")
+        assert abs(loss_e - float(loss_o)) <= 5e-4, (step, loss_e, float(loss_o))
+        assert abs(norm_e - float(norm_o)) <= 3e-2 * float(norm_o), (step, norm_e, float(norm_o))
+    eng.wait_params_ready()
+    got = eng.store.state_dict()
+    worst = 0.0
+    for k, p in params.items():
+        upd = (p.detach() - start[k]).abs().mean().item()
+        diff = (got[k].float().cpu() - p.detach()).abs().mean().item()
+        # the engine's master is f32 but its forward runs on bf16(master): parameters agree to bf16 resolution of the weights plus a fraction of the update
+        assert diff <= 0.25 * upd + 2.0 ** -9 * p.detach().abs().mean().item() + 1e-7, (k, diff, upd)
+        worst = max(worst, diff / max(upd, 1e-12))
+    print(f"[trajectory] worst mean |param(engine) - param(oracle)| / mean |update| over tensors: {worst:.3f}")
+
+
 def test_engine_qwen3_8b_width_parity():
     """The same gate at the BASELINE shape: Qwen3-8B width (H=4096, 32 q / 8 kv heads, I=12288, V=151936), 2 layers, 4 x 2048-token
     rollouts of the parity variant (256 masked prompt + 1792 trained tokens), against the oracles run with torch ON the device.  At this
