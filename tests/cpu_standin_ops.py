@@ -52,6 +52,7 @@ def rmsnorm_fwd(x, weight, eps, residual=None):
     return y, rstd.reshape(-1), s
 
 
+@torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
 def rmsnorm_bwd(grad_y, x, weight, rstd, grad_weight_f32, dresidual=None):
     xf = x.float().requires_grad_(True)
     wf = weight.float().requires_grad_(True)
@@ -84,6 +85,7 @@ def qknorm_rope_fwd(qkv, q_norm_w, k_norm_w, cos, sin, n_q_heads, n_kv_heads, he
     return q.to(BF16), k.to(BF16), rstd
 
 
+@torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
 def qknorm_rope_bwd(grad_q, grad_k, qkv, q_norm_w, k_norm_w, cos, sin, rstd, grad_qkv, gqw, gkw, n_q_heads, n_kv_heads, head_dim):
     x = qkv.float().requires_grad_(True)
     qw, kw = q_norm_w.float().requires_grad_(True), k_norm_w.float().requires_grad_(True)
@@ -107,6 +109,7 @@ def attn_varlen_fwd(q, k, v, seq_start, softmax_scale):
     return o.to(BF16), torch.zeros(q.shape[1], q.shape[0])
 
 
+@torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
 def attn_varlen_bwd(grad_out, q, k, v, out, lse, seq_start, softmax_scale, grad_v_out=None):
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
     o = O.varlen_causal_attention(qf, kf, vf, _seq_lens(seq_start), softmax_scale)
@@ -121,6 +124,7 @@ def swiglu_fwd(gate_up):
     return (torch.nn.functional.silu(gate_up[:, :i].float()).to(BF16).float() * gate_up[:, i:].float()).to(BF16)
 
 
+@torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
 def swiglu_bwd(grad_act, gate_up):
     x = gate_up.float().requires_grad_(True)
     i = x.shape[1] // 2

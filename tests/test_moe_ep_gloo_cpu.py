@@ -125,3 +125,71 @@ def test_moe_model_names_resolve_and_the_dense_engine_refuses_them():
     moe = MM.resolve_moe_config(cfg.model)
     assert (moe.num_experts, moe.num_experts_per_tok, moe.moe_intermediate_size, moe.hidden_size, moe.num_hidden_layers) == (128, 8, 768, 2048, 48)
     assert MM.resolve_moe_config(TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen3-8B"))).model) is None
+
+
+def _patch_all_ops():
+    """Every stand-in of tests/cpu_standin_ops.py replaces its namesake in prime_rl_amd.ops (worker processes only)."""
+    import inspect
+
+    sys.path.insert(0, str(ROOT))
+    from prime_rl_amd import ops
+    from tests import cpu_standin_ops as S
+
+    for name, fn in inspect.getmembers(S, inspect.isfunction):
+        if not name.startswith("_") and hasattr(ops, name):
+            setattr(ops, name, fn)
+
+
+def _model_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_all_ops()
+        from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+        from prime_rl_amd.trainer.parallel_dims import ParallelDims
+
+        cfg = Qwen3MoeConfig(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                             num_experts=4, num_experts_per_tok=2, moe_intermediate_size=32, mlp_only_layers=[0], use_grouped_mm=False)
+        pd = ParallelDims(dp_replicate=1, dp_shard=-1, cp=1, pp=1, ep=2, world_size=world)
+        group = pd.get_group("ep")
+        torch.manual_seed(11)
+        full = Qwen3MoeForCausalLM(cfg)
+        for p in full.parameters():
+            torch.nn.init.normal_(p, std=0.3 if p.dim() == 3 else 0.08)
+        for n_, p in full.named_parameters():
+            if n_.endswith("norm.weight") or n_.endswith("layernorm.weight"):
+                torch.nn.init.ones_(p)
+        full = full.to(torch.bfloat16)
+        local = Qwen3MoeForCausalLM(cfg, ep_group=group).to(torch.bfloat16)
+        er, le = dist.get_rank(group), cfg.num_experts // 2
+        sd = {}
+        for k_, v in full.state_dict().items():
+            sd[k_] = v[er * le:(er + 1) * le].clone() if ".experts.w" in k_ else v
+        local.load_state_dict(sd)
+        g = torch.Generator().manual_seed(50 + rank)
+        n = 40 + 8 * rank
+        ids = torch.randint(0, 64, (1, n), generator=g)
+        gy = torch.randn(1, n, 64, generator=g)
+        outs = []
+        for m_ in (local, full):
+            logits = m_(input_ids=ids, position_ids=torch.arange(n)[None], seq_lens=torch.tensor([n - 12, 12]))["logits"]
+            (logits.float() * gy).sum().backward()
+            outs.append(logits.detach())
+        assert torch.equal(outs[0], outs[1]), f"rank {rank}: logits differ by {(outs[0].float() - outs[1].float()).abs().max()}"
+        for (na, pa), (nb, pb) in zip(local.named_parameters(), full.named_parameters()):
+            ga, gb = pa.grad.float(), pb.grad.float()
+            if ".experts.w" in na:  # local experts see every rank's tokens: compare with the all-reduced single-rank gradient
+                dist.all_reduce(gb, group=group)
+                gb = gb[er * le:(er + 1) * le]
+                assert (ga - gb).abs().max() <= 2.0 ** -6 * gb.abs().max() + 1e-6, (rank, na)
+            else:
+                assert torch.equal(ga, gb), (rank, na)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_qwen3_moe_model_with_expert_parallelism_equals_the_single_rank_model():
+    """The whole Qwen3-MoE autograd model (dense layer 0, MoE layer 1) with its experts sharded over ParallelDims' "ep" group (world 2) against
+    the same model holding all experts, on each rank's own ragged packed batch: logits and every replicated gradient bit-identical,
+    expert gradients equal to the all-reduced single-rank ones."""
+    mp.spawn(_model_worker, args=(2, _free_port()), nprocs=2, join=True)
