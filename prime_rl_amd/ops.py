@@ -8,7 +8,6 @@ stream, and raises `PrimeMI355XError` on any non-zero return.  No function here 
 from __future__ import annotations
 
 import ctypes
-import math
 
 import torch
 from torch import Tensor

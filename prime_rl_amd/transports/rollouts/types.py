@@ -7,7 +7,7 @@ exists in the reference (wire bytes unpinned), so the pin here i
 
 from __future__ import annotations
 
-from dataclasses import dataclass, field, fields
+from dataclasses import dataclass, fields
 from typing import Any
 
 

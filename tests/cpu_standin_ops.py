@@ -9,7 +9,6 @@ test's worker processes only."""
 
 from __future__ import annotations
 
-import math
 
 import torch
 

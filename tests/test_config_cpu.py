@@ -5,7 +5,6 @@ benchmarks/scripts/run_single_benchmark.py:111-191), its defaults, its scheduler
 import math
 
 import pytest
-import torch
 
 from prime_rl_amd.configs.trainer import TrainerConfig, parse_argv
 from prime_rl_amd.trainer.parallel_dims import ParallelDims, get_parallel_dims

@@ -9,7 +9,6 @@ width (H=4096, 32q/8kv, I=12288, V=151936) on BASELINE.md's parity variant."""
 
 import math
 
-import numpy as np
 import pytest
 import torch
 
@@ -346,7 +345,6 @@ def test_fused_lm_head_engine_equals_library_engine():
 def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
     """train(config) end to end on the tiny model: reference step/version indexing (startup v0 + one broadcast per step), the
     console line and metric keys dashboards regex, metrics.jsonl."""
-    import json
     import re
 
     from prime_rl_amd.configs.trainer import parse_argv
