@@ -120,6 +120,23 @@ def resolve_auto_attn(config) -> None:
         config.attn = "hip_varlen"
 
 
+def apply_moe_options(model: nn.Module, config) -> None:
+    """The MoE switches of setup_model (model.py:1358-1375): `moe_router_dtype = "float32"` (the default: f32 gate weight and gate GEMM,
+    moe.py:674-676 / model.py:863-872), `freeze_moe_router` (model.py:395-420), `debug.force_balanced_routing` (model.py:522-540).  The fused
+    Triton MoE kernel has no counterpart here: the expert path already runs on the grouped MFMA kernels."""
+    if getattr(config, "moe_fused_kernel", False):
+        raise NotImplementedError("model.moe_fused_kernel selects the reference's Triton kernel; the experts here always run on pm_grouped_gemm_*")
+    for mlp in model.moe_layers():
+        if config.moe_router_dtype == "float32":
+            mlp.router.gate.float()
+            mlp.router.fp32_gate = True
+        if config.freeze_moe_router:
+            for p in mlp.router.parameters():
+                p.requires_grad = False
+        if config.debug.force_balanced_routing:
+            mlp.router.force_balanced = True
+
+
 def get_load_balance_stats(model: nn.Module, reset_stats: bool = True, try_to_avoid_padding_experts: bool = True) -> dict[str, Tensor | None]:
     """model.py:561-592: per MoE layer, the maximal load violation `(max tokens_per_expert - mean) / mean` (optionally without the top_k most loaded
     experts, which absorb padding) and the routing confidence `routing_confidence_sum / routed tokens`; resets the layer counters."""
@@ -174,6 +191,8 @@ def setup_model(config, parallel_dims: ParallelDims, loading_from_checkpoint_lat
         if getattr(config, name, None) is not None:
             raise NotImplementedError(f"model.{name} is outside the MI355X GRPO hot path (SURVEY.md section 2)")
     model = get_model(config, device="cuda", dtype=torch.bfloat16, ep_group=ep_group)
+    if isinstance(model, Qwen3MoeForCausalLM):
+        apply_moe_options(model, config)
     chunk = config.fused_lm_head_token_chunk_size if isinstance(config.fused_lm_head_token_chunk_size, int) else None
     inject_prime_lm_head(model, chunk_size=chunk)
     if loading_from_checkpoint_later:

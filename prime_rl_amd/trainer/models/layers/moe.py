@@ -182,7 +182,8 @@ class TokenChoiceTopKRouter(nn.Module):
         self.gate = nn.Linear(dim, num_experts, bias=False)
         self.num_experts, self.top_k = num_experts, top_k
         self.score_func, self.route_norm, self.route_scale = score_func, route_norm, route_scale
-        self.fp32_gate = False  # model.moe_router_dtype = 'float32' (moe.py:674-676)
+        self.force_balanced = False  # debug.force_balanced_routing (moe.py:721-725): round-robin experts instead of the top-k
+        self.fp32_gate = False  # model.moe_router_dtype = 'float32' (moe.py:674-676): f32 gate weight and gate GEMM
 
     def forward(self, x: torch.Tensor, expert_bias: torch.Tensor | None = None, routed_experts: torch.Tensor | None = None):
         """-> (top_scores [N,k] f32, selected_experts_indices [N,k] i32, num_tokens_per_expert [E] i32, routing_confidence_sum)."""
@@ -190,6 +191,9 @@ class TokenChoiceTopKRouter(nn.Module):
             raise AssertionError(f"routed_experts shape: {routed_experts.shape}, top_k: {self.top_k}")
         logits = self.gate(x.to(torch.float32)) if self.fp32_gate else self.gate(x)
         forced = None if routed_experts is None else routed_experts.reshape(-1, self.top_k).to(torch.int32).contiguous()
+        if forced is None and self.force_balanced:
+            n = logits.shape[0]
+            forced = (torch.arange(n * self.top_k, device=logits.device, dtype=torch.int32) % self.num_experts).view(n, self.top_k)
         top_scores, idx, conf = _RouterFn.apply(logits.contiguous(), expert_bias, forced, self.top_k, self.score_func, self.route_norm, self.route_scale)
         # the per-expert histogram (histc, moe.py:739-744) falls out of the stable sort the reorderer needs anyway: sort once, here, and
         # hand the maps to TokenReorderer through `last_sort` (an in-kernel histogram is 1k-way contended atomics at 16k tokens x 8 slots)

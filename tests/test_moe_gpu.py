@@ -294,6 +294,30 @@ def test_qwen3_moe_model_through_setup_model_forward_and_router_replay():
         MM.setup_engine(cfg, get_parallel_dims(cfg.model, 128, world_size=1))
 
 
+def test_qwen3_moe_setup_model_switches():
+    """model.moe_router_dtype (default float32: f32 gate weight and gate GEMM), model.freeze_moe_router, model.debug.force_balanced_routing."""
+    MM, model = _tiny_moe_model()
+    assert all(m.router.gate.weight.dtype == torch.float32 and m.router.fp32_gate for m in model.moe_layers())
+    assert model.model.layers[0].mlp.experts.w1.dtype == torch.bfloat16
+    _, m16 = _tiny_moe_model(dict(moe_router_dtype="bfloat16"))
+    assert all(m.router.gate.weight.dtype == torch.bfloat16 and not m.router.fp32_gate for m in m16.moe_layers())
+    _, frozen = _tiny_moe_model(dict(freeze_moe_router=True))
+    assert all(not p.requires_grad for m in frozen.moe_layers() for p in m.router.parameters())
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims
+
+    cfg = TrainerConfig.model_validate(dict(model=dict(name="tiny-moe", seq_len=128, debug=dict(random_init=True, force_balanced_routing=True))))
+    bal = MM.setup_model(cfg.model, get_parallel_dims(cfg.model, 128, world_size=1))
+    n = 128
+    ids = torch.randint(0, 512, (1, n), device=DEV)
+    out = MM.forward(bal, ids, torch.arange(n, device=DEV)[None], seq_lens=torch.tensor([n], device=DEV), labels=ids, temperature=torch.ones(1, n, device=DEV))
+    out["logprobs"].sum().backward()
+    for m in bal.moe_layers():  # 128 tokens x top-2 over 8 experts, round robin: exactly 32 rows per expert
+        assert m.tokens_per_expert.tolist() == [32.0] * 8
+    with pytest.raises(NotImplementedError, match="moe_fused_kernel"):
+        _tiny_moe_model(dict(moe_fused_kernel=True))
+
+
 def test_qwen3_moe_training_steps_reduce_the_loss():
     MM, model = _tiny_moe_model()
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.0)
