@@ -281,6 +281,16 @@ class MoE(nn.Module):
         self.register_buffer("tokens_per_expert", torch.zeros(num_experts, dtype=torch.float32), persistent=False)
         self.register_buffer("routing_confidence_sum", torch.tensor(0.0, dtype=torch.float32), persistent=False)
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to(torch.bfloat16)` / `.bfloat16()` on the model must not round the routing buffers: token counts above 256 and the load-balance bias are
+        f32 quantities (the reference keeps buffers out of its bf16 cast, model.py:1079-1083)."""
+        super()._apply(fn, *args, **kwargs)
+        for name in ("tokens_per_expert", "routing_confidence_sum", "expert_bias"):
+            buf = getattr(self, name, None)
+            if isinstance(buf, torch.Tensor) and buf.is_floating_point() and buf.dtype != torch.float32:
+                self._buffers[name] = buf.float()
+        return self
+
     def forward(self, x: torch.Tensor, routed_experts: torch.Tensor | None = None) -> torch.Tensor:
         bs, slen, dim = x.shape
         x = x.reshape(-1, dim)
