@@ -435,7 +435,11 @@ def _attn_case(n, seq_lens, hq, hkv, seed):
     return q, k, v
 
 
-@pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([300, 212], 8, 8), ([5], 2, 1)])
+@pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([300, 212], 8, 8), ([5], 2, 1),
+                                             # tile edges of the LDS-DMA kernels: one token, exactly one 64 / 128-row tile, one row past it, documents
+                                             # ending on and straddling tile boundaries, many one- and two-token documents inside one tile
+                                             ([1], 2, 2), ([64], 2, 1), ([128], 4, 2), ([129], 4, 2), ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1),
+                                             ([255, 257], 8, 2)])
 def test_attention_forward_backward(ops, seq_lens, hq, hkv):
     n, d = sum(seq_lens), 128
     q, k, v = _attn_case(n, seq_lens, hq, hkv, n)
