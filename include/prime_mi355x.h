@@ -225,6 +225,13 @@ int pm_embedding_fwd(const void* table_bf16, const int64_t* ids, int64_t n_token
 /* grad_table_f32[id] += sum of grad_out rows with that id.  `order` = argsort(ids) (stable), ids_sorted = ids[order]. */
 int pm_embedding_bwd(const void* grad_out_bf16, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens,
                      int64_t hidden, int64_t vocab, float* grad_table_f32, void* stream);  /* ids outside [0, vocab) are skipped */
+/* The same scatter-add into a WINDOW of the flattened [vocab, hidden] gradient: grad_window_f32 points at element `elem_lo` and holds
+ * `elem_count` elements (both multiples of 8; the window may start and end inside a row).  Rows outside the window and ids < 0 (padding)
+ * are skipped.  Under ZeRO sharding the last pass's embedding gradient — n_tokens rows, not vocab rows — is all-gathered and each rank adds
+ * the rows of its own shard, so the dense reduce-scatter of the embedding bucket (FSDP's reduce-scatter of the embedding gradient,
+ * trainer/model.py:823-960) is issued one pass early and overlaps the last pass instead of trailing it (trainer/engine.py). */
+int pm_embedding_bwd_window(const void* grad_out_bf16, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens,
+                            int64_t hidden, int64_t vocab, int64_t elem_lo, int64_t elem_count, float* grad_window_f32, void* stream);
 
 /* 2-D transpose of 16-bit elements: dst[c*dst_ld + r] = src[r*src_ld + c].  Replaces the `.transpose(1, 2)` / `.t().contiguous()`
  * copies around the attention and linear layers (models/layers/attn.py:147-158) and feeds the library GEMMs the operand

@@ -81,6 +81,7 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grpo_loss_fwd_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I32, I64, POINTER(LossParams), P, P, P, P, P]),
     "pm_embedding_fwd": (I, [P, P, I64, I64, I64, P, P]),
     "pm_embedding_bwd": (I, [P, P, P, I64, I64, I64, P, P]),
+    "pm_embedding_bwd_window": (I, [P, P, P, I64, I64, I64, I64, I64, P, P]),
     "pm_rmsnorm_fwd": (I, [P, P, P, I64, I64, F, P, P, P, P]),
     "pm_rmsnorm_bwd_workspace_bytes": (I64, [I64, I64]),
     "pm_rmsnorm_bwd": (I, [P, P, P, P, P, I64, I64, P, P, P, I64, P]),

@@ -117,17 +117,25 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const bf16_t* __rest
 }
 
 // one workgroup per sorted position; only the first position of each run of equal ids does work, summing the run in order.
+// The destination is a WINDOW [elem_lo, elem_hi) of the flattened [vocab, hidden] table (both multiples of 8): `gwin` points at element
+// elem_lo.  The whole table is the window [0, vocab * hidden); a ZeRO shard of the embedding bucket is a window that may start and end
+// inside a row (trainer/engine.py: the last pass's embedding gradient goes to the rank that owns the rows instead of through the dense
+// reduce-scatter).  Rows outside the window, negative ids (padding of the gathered id lists) and ids >= vocab are skipped.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ ids_sorted,
                                                            const int64_t* __restrict__ order, int64_t n_tokens, int64_t hidden, int64_t vocab,
-                                                           float* __restrict__ gtable) {
+                                                           int64_t elem_lo, int64_t elem_hi, float* __restrict__ gwin) {
   const int64_t p = blockIdx.x;
   const int64_t id = ids_sorted[p];
   if (id < 0 || id >= vocab) return;  // never write outside the table
   if (p > 0 && ids_sorted[p - 1] == id) return;
+  const int64_t row0 = id * hidden;
+  if (row0 + hidden <= elem_lo || row0 >= elem_hi) return;
   int64_t e = p + 1;
   while (e < n_tokens && ids_sorted[e] == id) ++e;
   const int64_t vec_per_row = hidden >> 3;
   for (int64_t c = threadIdx.x; c < vec_per_row; c += 256) {
+    const int64_t at = row0 + c * 8;
+    if (at < elem_lo || at >= elem_hi) continue;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* __rest
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += g[k];
     }
-    float4* dst = reinterpret_cast<float4*>(gtable + id * hidden + c * 8);
+    float4* dst = reinterpret_cast<float4*>(gwin + (at - elem_lo));
     float4 a = dst[0], b = dst[1];
     a.x += acc[0]; a.y += acc[1]; a.z += acc[2]; a.w += acc[3];
     b.x += acc[4]; b.y += acc[5]; b.z += acc[6]; b.w += acc[7];
@@ -365,8 +373,22 @@ extern "C" int pm_embedding_bwd(const void* grad_out, const int64_t* ids_sorted,
   PM_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden % 8 == 0, PM_ERR_UNSUPPORTED, "pm_embedding_bwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_out, ids_sorted, order,
-                     n_tokens, hidden, vocab, grad_table);
+                     n_tokens, hidden, vocab, (int64_t)0, vocab * hidden, grad_table);
   PM_CHECK_LAUNCH("pm_embedding_bwd");
+  return PM_OK;
+}
+
+extern "C" int pm_embedding_bwd_window(const void* grad_out, const int64_t* ids_sorted, const int64_t* order, int64_t n_tokens, int64_t hidden,
+                                       int64_t vocab, int64_t elem_lo, int64_t elem_count, float* grad_window, void* stream) {
+  PM_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden % 8 == 0 && vocab > 0, PM_ERR_UNSUPPORTED, "pm_embedding_bwd_window: bad sizes");
+  PM_REQUIRE(elem_lo >= 0 && elem_count >= 0 && elem_lo % 8 == 0 && elem_count % 8 == 0, PM_ERR_INVALID_ARG,
+             "pm_embedding_bwd_window: the window must start and end on a multiple of 8 elements");
+  if (n_tokens == 0 || elem_count == 0) return PM_OK;
+  PM_REQUIRE(grad_out && ids_sorted && order && grad_window, PM_ERR_INVALID_ARG, "pm_embedding_bwd_window: null pointer");
+  PM_REQUIRE((reinterpret_cast<uintptr_t>(grad_window) & 15) == 0, PM_ERR_INVALID_ARG, "pm_embedding_bwd_window: grad_window must be 16-byte aligned");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)grad_out, ids_sorted, order,
+                     n_tokens, hidden, vocab, elem_lo, elem_lo + elem_count, grad_window);
+  PM_CHECK_LAUNCH("pm_embedding_bwd_window");
   return PM_OK;
 }
 

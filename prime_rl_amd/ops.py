@@ -272,6 +272,17 @@ def embedding_bwd(grad_out: Tensor, ids: Tensor, grad_table_f32: Tensor) -> None
     check(lib.pm_embedding_bwd(_p(grad_out), _p(ids_sorted), _p(order), n, h, grad_table_f32.shape[0], _p(grad_table_f32), _stream()), "pm_embedding_bwd")
 
 
+def embedding_bwd_window(grad_out: Tensor, ids: Tensor, grad_window_f32: Tensor, elem_lo: int, vocab: int) -> None:
+    """grad_window_f32 (elements [elem_lo, elem_lo + numel) of the flattened [vocab, hidden] gradient) += rows of grad_out whose id falls in the
+    window; ids < 0 are padding.  Deterministic (sorted run reduction, rows summed in the order they appear in `ids`)."""
+    lib = _lib.load()
+    _req(grad_out, torch.bfloat16, "grad_out"); _req(ids, torch.int64, "ids"); _req(grad_window_f32, torch.float32, "grad_window")
+    ids_sorted, order = torch.sort(ids.reshape(-1), stable=True)  # plumbing: index sort only
+    n, h = grad_out.shape
+    check(lib.pm_embedding_bwd_window(_p(grad_out), _p(ids_sorted), _p(order), n, h, vocab, elem_lo, grad_window_f32.numel(), _p(grad_window_f32),
+                                      _stream()), "pm_embedding_bwd_window")
+
+
 def rmsnorm_fwd(x: Tensor, weight: Tensor, eps: float, residual: Tensor | None = None) -> tuple[Tensor, Tensor, Tensor | None]:
     """Returns (y, rstd, x_plus_residual | None)."""
     lib = _lib.load()

@@ -412,6 +412,14 @@ class GRPOEngine:
         # stand-in kernels) issues them synchronously
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_collectives and self.device.type == "cuda") else None
         self._gather_events: dict[str, torch.cuda.Event] = {}
+        # The embedding bucket's gradient is complete only when the LAST pass's backward ends, so its dense reduce-scatter (vocab x hidden f32,
+        # 2.5 GB for Qwen3-8B) would trail the step with nothing to hide behind.  With sharding on, step() splits it: the dense part (earlier
+        # passes; the tied head gradient) is reduce-scattered while the last pass still runs, and the last pass's own embedding gradient —
+        # n_tokens rows — is all-gathered as (ids, bf16 rows) and added by the rank that owns the rows (ops.embedding_bwd_window).
+        # PM_EMBED_SPLIT=0 keeps the single trailing reduce-scatter (A/B switch).
+        self.embed_split = self.use_collectives and os.environ.get("PM_EMBED_SPLIT", "1") != "0"
+        self._embed_plan: dict | None = None
+        self._embed_bufs: dict | None = None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._wgrad_direct = self._probe_wgrad_direct()
         # keep GEMM-friendly operand layouts (K-contiguous weight copies for dgrad, transposed MLP inputs for wgrad); PM_GEMM_LAYOUTS=0 is the A/B switch
@@ -654,6 +662,9 @@ class GRPOEngine:
         emb_accumulate = accumulate or d.tie_word_embeddings
         dpend = ops.rmsnorm_bwd(dhf, ctx["x_last"], w["model.norm.weight"], ctx["rstd_f"], self._norm_grad(g["model.norm.weight"], accumulate))
         self._bucket_done("head", last_pass)
+        split = last_pass and self._embed_plan is not None
+        if split and d.tie_word_embeddings:  # the tied head gradient is the last dense write into the embedding bucket
+            self._bucket_done("embed", True)
         # dpend = gradient w.r.t. (x + mlp_out) of the last layer = gradient of both the residual stream and the mlp output
         dx = dpend
         scale = d.head_dim**-0.5
@@ -689,6 +700,9 @@ class GRPOEngine:
                                  self._norm_grad(g[p + "input_layernorm.weight"], accumulate), dresidual=dx2)
             ctx["layers"][i] = None
             self._bucket_done(f"layer{i}", last_pass)
+        if split:
+            self._embed_rows_to_owners(dx, ids)
+            return
         if not emb_accumulate:
             g["model.embed_tokens.weight"].zero_()
         ops.embedding_bwd(dx, ids, g["model.embed_tokens.weight"])
@@ -706,6 +720,66 @@ class GRPOEngine:
             return
         b = next(bk for bk in self.store.buckets if bk.name == name)
         zero.reduce_scatter_bucket(self.store, b, self.shard_group, self.comm_stream)
+
+    def _plan_embed_split(self, passes: list) -> dict | None:
+        """Exchange (tokens of the last pass, number of passes) over the shard group: the row all-gather needs one capacity on every rank, and the
+        early dense reduce-scatter is a collective, so every rank must take the same branch even when pass counts differ."""
+        if not self.embed_split:
+            return None
+        n_last = passes[-1].n_tokens // self.cp_size if self.cp_size > 1 else passes[-1].n_tokens
+        mine = torch.tensor([n_last, len(passes)], dtype=torch.int64, device=self.device)
+        every = torch.empty(self.shard_size * 2, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(every, mine, group=self.shard_group)
+        every = every.view(self.shard_size, 2).tolist()
+        return {"capacity": max(r[0] for r in every), "dense": self.dims.tie_word_embeddings or any(r[1] > 1 for r in every), "passes": len(passes)}
+
+    def _embed_dense_early(self) -> None:
+        """Untied embeddings, just before the last pass: reduce-scatter what the earlier passes accumulated.  A rank with a single pass joins the
+        collective with zeros when some other rank has earlier passes."""
+        plan = self._embed_plan
+        if plan is None or self.dims.tie_word_embeddings or not plan["dense"]:
+            return
+        if plan["passes"] == 1:
+            self.store.g["model.embed_tokens.weight"].zero_()
+        self._bucket_done("embed", True)
+
+    def _embed_rows_to_owners(self, dx: Tensor, ids: Tensor) -> None:
+        """grad_shard[embedding shard] (+)= the last pass's embedding gradient of EVERY rank, restricted to this rank's window of the table."""
+        plan, st, d = self._embed_plan, self.store, self.dims
+        cap, world, n = plan["capacity"], self.shard_size, ids.numel()
+        bufs = self._embed_bufs
+        if bufs is None or bufs["cap"] < cap:
+            bufs = self._embed_bufs = {
+                "cap": cap,
+                "ids": torch.empty(cap, dtype=torch.int64, device=self.device),
+                "rows": torch.empty(cap, d.hidden_size, dtype=torch.bfloat16, device=self.device),
+                "all_ids": torch.empty(world * cap, dtype=torch.int64, device=self.device),
+                "all_rows": torch.empty(world * cap, d.hidden_size, dtype=torch.bfloat16, device=self.device),
+            }
+        cap = bufs["cap"]
+        bufs["ids"][:n].copy_(ids.reshape(-1))
+        bufs["ids"][n:].fill_(-1)  # padding up to the common capacity: skipped by the kernel (the rows behind it are never read)
+        bufs["rows"][:n].copy_(dx)
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_gather_into_tensor(bufs["all_ids"], bufs["ids"], group=self.shard_group)
+                dist.all_gather_into_tensor(bufs["all_rows"], bufs["rows"], group=self.shard_group)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+            torch.cuda.current_stream().wait_event(done)  # also orders this after the early dense reduce-scatter (same stream)
+        else:
+            dist.all_gather_into_tensor(bufs["all_ids"], bufs["ids"], group=self.shard_group)
+            dist.all_gather_into_tensor(bufs["all_rows"], bufs["rows"], group=self.shard_group)
+        bucket = st.buckets[0]
+        assert bucket.name == "embed" and bucket.params[0][1] == bucket.offset
+        _, local = st.shard_slices(bucket)
+        window = st.grad_shard[local]
+        if not plan["dense"]:
+            window.zero_()
+        ops.embedding_bwd_window(bufs["all_rows"], bufs["all_ids"], window, self.shard_rank * window.numel(), d.vocab_size)
 
     def wait_params_ready(self) -> None:
         """Make the current stream wait for every in-flight parameter all-gather (issued on the comm stream by the last optimizer
@@ -756,7 +830,10 @@ class GRPOEngine:
         counts = tuple(sum(p.local_counts[k] for p in passes) for k in range(3))
         scales = self.global_scales(counts)
         out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": []}
+        self._embed_plan = self._plan_embed_split(passes)
         for idx, p in enumerate(passes):
+            if idx == len(passes) - 1:
+                self._embed_dense_early()
             ctx = self.forward(p)
             self.loss(ctx, scales)
             out["loss"].append(ctx["loss"])
@@ -766,6 +843,7 @@ class GRPOEngine:
             out["sample_stats"].append(ctx["sample_stats"])
             self.backward(ctx, accumulate=idx > 0, last_pass=idx == len(passes) - 1)
             del ctx
+        self._embed_plan = None
         out["grad_norm"] = self.optimizer_step()
         out["scales"] = scales
         return out

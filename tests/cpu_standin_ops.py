@@ -29,6 +29,16 @@ def embedding_bwd(grad_out, ids, grad_table_f32):
     grad_table_f32.index_add_(0, ids.reshape(-1), grad_out.float())
 
 
+def embedding_bwd_window(grad_out, ids, grad_window_f32, elem_lo, vocab):
+    h = grad_out.shape[1]
+    ids = ids.reshape(-1)
+    keep = (ids >= 0) & (ids < vocab)
+    elems = (ids[keep, None] * h + torch.arange(h)[None, :]).reshape(-1) - elem_lo  # flat element index of every gradient entry, window-relative
+    vals = grad_out.float()[keep].reshape(-1)
+    inside = (elems >= 0) & (elems < grad_window_f32.numel())
+    grad_window_f32.index_add_(0, elems[inside], vals[inside])
+
+
 def rope_table(position_ids, inv_freq):
     ang = position_ids.to(F32)[:, None] * inv_freq[None, :]
     return ang.cos().to(BF16), ang.sin().to(BF16)

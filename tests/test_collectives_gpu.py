@@ -41,10 +41,17 @@ def _batches(vocab, n_steps):
     return out
 
 
-def test_forced_collectives_step_equals_plain_step(rccl_world1):
+@pytest.mark.parametrize("one_pass,tied", [(False, False), (True, False), (False, True)])
+def test_forced_collectives_step_equals_plain_step(rccl_world1, one_pass, tied):
+    """Also the split reduction of the embedding bucket (engine._plan_embed_split) on the device, comm stream and all: dense part of the earlier
+    pass reduce-scattered before the last pass, the last pass's rows all-gathered and added by pm_embedding_bwd_window — same f32 additions
+    in the same order as the plain engine's accumulate-in-place, so still bit for bit.  `one_pass`: nothing dense; `tied`: the head gradient
+    is the dense part."""
+    import dataclasses
+
     from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig
 
-    dims = ModelDims.tiny(layers=2, vocab=512)
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), tie_word_embeddings=tied)
     optim = OptimConfig(lr=1e-3, max_norm=0.5)
     plain = GRPOEngine(dims, device=DEV, optim=optim, seed=5)
     forced = GRPOEngine(dims, device=DEV, optim=optim, seed=5, force_collectives=True)
@@ -52,9 +59,11 @@ def test_forced_collectives_step_equals_plain_step(rccl_world1):
     assert forced.comm_stream is not None and forced.store.grad_shard.data_ptr() != forced.store.main_grad.data_ptr()
     assert torch.equal(plain.store.params, forced.store.params)
     for passes in _batches(dims.vocab_size, 3):
+        passes = passes[:1] if one_pass else passes
         a = plain.step(passes)
         b = forced.step(passes)
         torch.cuda.synchronize()
+        assert forced.embed_split and forced._embed_bufs is not None
         assert torch.equal(a["grad_norm"], b["grad_norm"])
         for la, lb in zip(a["loss"], b["loss"]):
             assert torch.equal(la, lb)

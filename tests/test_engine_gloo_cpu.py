@@ -28,12 +28,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _engine(dp_group=None, **kw):
+def _engine(dp_group=None, tied=False, **kw):
+    import dataclasses
+
     import tests.cpu_standin_ops as standin
     from prime_rl_amd.trainer import engine as E
 
     E.ops = standin  # the engine module resolves its kernels through this name
     dims = E.ModelDims.tiny(layers=2, vocab=320)
+    if tied:
+        dims = dataclasses.replace(dims, tie_word_embeddings=True)
     return E, E.GRPOEngine(dims, device="cpu", optim=E.OptimConfig(lr=LR), seed=5, dp_group=dp_group, gemm_layouts=False, **kw)
 
 
@@ -50,7 +54,15 @@ def _batches(E, dims, world, rank, step):
     return mbs
 
 
-def _worker(rank, world, port, out_dir, cp=1):
+def _passes(E, mbs, mode, rank):
+    """"two": one pass per micro-batch (gradient accumulation, reduce-scatter only after the last one); "one": both micro-batches packed into a
+    single pass on every rank (no earlier pass: the embedding bucket has no dense part); "ragged": rank 0 runs one pass, the others two."""
+    if mode == "one" or (mode == "ragged" and rank == 0):
+        return [E.pack_micro_batches(mbs, "cpu")]
+    return [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
+
+
+def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,7 +70,7 @@ def _worker(rank, world, port, out_dir, cp=1):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dp = world // cp
     if cp == 1:
-        E, eng = _engine()
+        E, eng = _engine(tied=tied)
         assert eng.dp_size == world and eng.use_collectives and eng.comm_stream is None
     else:  # the trainer's own construction path: ParallelDims -> dp / cp / dp_cp groups -> engine
         from prime_rl_amd.trainer.parallel_dims import ParallelDims
@@ -70,9 +82,10 @@ def _worker(rank, world, port, out_dir, cp=1):
     rec = {"loss": [], "grad_norm": [], "shards": None}
     for step in range(STEPS):
         mbs = _batches(E, eng.dims, dp, rank // cp, step)
-        # two passes per step: gradient accumulation across passes, reduce-scatter only after the last one
-        passes = [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
+        passes = _passes(E, mbs, mode, rank)
         out = eng.step(passes)
+        # the embedding bucket went the split way: last pass's rows all-gathered to their owners, dense part (if any) reduce-scattered early
+        assert eng.embed_split and eng._embed_bufs is not None and eng._embed_plan is None
         rec["loss"].append(sum(l.item() for l in out["loss"]))
         rec["grad_norm"].append(out["grad_norm"].item())
         own = sum(p.local_counts[0] for p in passes)
@@ -88,15 +101,18 @@ def _worker(rank, world, port, out_dir, cp=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cp", [(2, 1), (2, 2), (4, 2)])
-def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp):
+@pytest.mark.parametrize("world,cp,mode,tied", [(2, 1, "two", False), (2, 2, "two", False), (4, 2, "two", False), (2, 1, "ragged", False),
+                                                 (2, 1, "one", False), (2, 1, "two", True)])
+def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode, tied):
     """(2, 1): ZeRO-2 data parallel.  (2, 2): one dp position, Ulysses context parallel over two ranks (heads <-> sequence all-to-all around
-    attention, log-probs gathered for the full-pass loss, gradients reduce-scattered over dp x cp).  (4, 2): both at once."""
+    attention, log-probs gathered for the full-pass loss, gradients reduce-scattered over dp x cp).  (4, 2): both at once.  The "ragged" / "one" /
+    tied cases walk the branches of the split embedding-bucket reduction (engine._plan_embed_split): ranks with different pass counts, no
+    dense part at all, and tied embeddings whose head gradient is the dense part."""
     dp = world // cp
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp, mode, tied), nprocs=world, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"r{k}.pt") for k in range(world)]
     # single process, same global batch (rank 0's micro-batches then rank 1's), one pass per rank-pass to keep the same accumulation units
-    E, eng = _engine()
+    E, eng = _engine(tied=tied)
     assert eng.dp_size == 1 and not eng.use_collectives
     ref = {"loss": [], "grad_norm": [], "grad": None}
     for step in range(STEPS):

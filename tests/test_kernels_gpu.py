@@ -425,6 +425,39 @@ def test_embedding(ops):
     assert torch.equal(gt2, 2 * gt), "embedding bwd is not deterministic/accumulating"
 
 
+def test_embedding_bwd_window(ops):
+    """Windows of the flattened [vocab, hidden] gradient (a ZeRO shard of the embedding bucket): pieced together they are the whole-table
+    scatter-add bit for bit; windows that start / end inside a row, padding ids (-1) and ids >= vocab."""
+    torch.manual_seed(3)
+    v, h, n = 90, 256, 700
+    ids = torch.randint(0, v, (n,))
+    ids[::17] = -1  # padding of the gathered id lists
+    ids[5] = v + 3  # outside the table: skipped
+    go = torch.randn(n, h).to(torch.bfloat16)
+    keep = (ids >= 0) & (ids < v)
+    whole = torch.zeros(v, h, device=DEV)
+    ops.embedding_bwd(go[keep].to(DEV), ids[keep].to(DEV), whole)
+    total = v * h
+    for parts in (1, 3, 8, 45):  # 3 and 45 cut rows: 23040 / 3 = 7680 = 30 rows, / 45 = 512 = 2 rows; use uneven 8-aligned cuts below as well
+        per = total // parts
+        assert per % 8 == 0
+        got = torch.zeros(total, device=DEV)
+        for r in range(parts):
+            ops.embedding_bwd_window(go.to(DEV), ids.to(DEV), got[r * per:(r + 1) * per], r * per, v)
+        assert torch.equal(got.view(v, h), whole), parts
+    cuts = [0, 8, 8 + 256 * 3 + 40, 8 + 256 * 3 + 48, total - 264, total]  # windows starting and ending mid-row, one 8-element window
+    got = torch.zeros(total, device=DEV)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ops.embedding_bwd_window(go.to(DEV), ids.to(DEV), got[lo:hi], lo, v)
+    assert torch.equal(got.view(v, h), whole)
+    before = got.clone()
+    ops.embedding_bwd_window(go.to(DEV), ids.to(DEV), got[:0], 0, v)  # empty window: nothing to do
+    ops.embedding_bwd_window(go[:0].to(DEV), ids[:0].to(DEV), got, 0, v)  # no tokens
+    assert torch.equal(got, before)
+    with pytest.raises(Exception):
+        ops.embedding_bwd_window(go.to(DEV), ids.to(DEV), got[4:12], 4, v)
+
+
 # ================================================================================================ attention
 def _attn_case(n, seq_lens, hq, hkv, seed):
     torch.manual_seed(seed)
