@@ -262,7 +262,9 @@ int pm_rope_table(const int64_t* position_ids, int64_t n_tokens, const float* in
  * (models/layers/attn.py:123-160) + apply_rotary_pos_emb (rotary_emb.py:83-118).
  * qkv: [n_tokens, (hq+2*hkv)*128] bf16 (fused q|k|v projection output).  Writes q_out [n,hq,128], k_out [n,hkv,128]
  * (normed+roped), and keeps per-(token,head) rstd for backward.  bf16 rounding points follow the reference
- * (norm -> bf16, *w -> bf16, *cos -> bf16, *sin -> bf16, add -> bf16). */
+ * (norm -> bf16, *w -> bf16, *cos -> bf16, *sin -> bf16, add -> bf16).
+ * q_norm_w = k_norm_w = NULL: `use_qk_norm = False` (the Llama block, models/llama/modeling_llama.py:59-60, and HF Qwen2): RoPE
+ * only; rstd is not written (may be NULL) and the backward needs neither qkv, rstd, the weight gradients nor a workspace. */
 int pm_qknorm_rope_fwd(const void* qkv_bf16, const void* q_norm_w_bf16, const void* k_norm_w_bf16,
                        const void* cos_bf16, const void* sin_bf16,
                        int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float eps,
@@ -274,6 +276,13 @@ int pm_qknorm_rope_bwd(const void* grad_q_bf16, const void* grad_k_bf16, const v
                        const void* cos_bf16, const void* sin_bf16, const float* rstd,
                        int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
                        void* grad_qkv_bf16, float* grad_q_norm_w_f32, float* grad_k_norm_w_f32,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out_accumulate_f32[c] += sum over rows of x[r, c] (x bf16 [n_rows, n_cols], row stride ld elements; n_cols, ld multiples of 8):
+ * the bias gradient of the q/k/v projections when `attention_bias = True` (nn.Linear(bias=True), models/layers/attn.py:64-72).
+ * Deterministic two-stage reduction. */
+int64_t pm_column_sum_workspace_bytes(int64_t n_cols);
+int pm_column_sum_bf16(const void* x_bf16, int64_t n_rows, int64_t n_cols, int64_t ld, float* out_accumulate_f32,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* token -> start index of its document; cu_seqlens from get_cu_seqlens_from_seq_lens (utils/sequence.py:38-52)

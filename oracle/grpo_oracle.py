@@ -374,23 +374,30 @@ class TinyQwen3Config:
     vocab_size: int = 512
     rms_norm_eps: float = 1e-6
     rope_theta: float = 1_000_000.0
+    qk_norm: bool = True  # AttentionConfig.use_qk_norm (models/layers/attn.py:37): Qwen3 True, Llama / Qwen2 False
+    attention_bias: bool = False  # AttentionConfig.attention_bias (attn.py:36,64-72): bias on q/k/v_proj — Qwen2 True
 
 
-def exact_mm(a, w):
-    """a @ w.T with exact products and f32 accumulation, rounded ONCE to a's dtype: the GEMM every bf16 implementation of the
+def exact_mm(a, w, bias=None):
+    """a @ w.T (+ bias, added to the f32 accumulator as F.linear does) with exact products and f32 accumulation, rounded ONCE to a's dtype: the GEMM every bf16 implementation of the
     reference approximates (cuBLAS / hipBLASLt / CPU differ only in accumulation order).  Used as the `mm` hook of qwen3_forward to
     take GEMM summation order out of an engine-vs-oracle comparison while keeping the reference's bf16 rounding points."""
     torch = _torch()
-    return (a.to(torch.float32) @ w.to(torch.float32).T).to(a.dtype)
+    y = a.to(torch.float32) @ w.to(torch.float32).T
+    return (y if bias is None else y + bias.to(torch.float32)).to(a.dtype)
 
 
 def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int], mm=None):
     """Qwen3Model.forward + Qwen3DecoderLayer.forward (trainer/models/qwen3/modeling_qwen3.py:65-85,155-196) with
     FlashAttention.attn_projections (trainer/models/layers/attn.py:123-160).  `params` uses HF names
     (model.layers.{i}.self_attn.q_proj.weight, ...); returns the final-norm hidden states [N, H] in the params' dtype.
-    Runs on whatever device the tensors live on; `mm(a, w) -> a @ w.T` overrides the linear layers' GEMM (default: torch's)."""
+    The same function is the Llama block (models/llama/modeling_llama.py:52-100: use_qk_norm=False) and HF Qwen2 (bias on q/k/v, no q/k
+    norm — the class the reference loads for Qwen2.5): a `q_proj.bias` in `params` is added after the projection
+    (nn.Linear, attn.py:64-72), a missing `q_norm.weight` skips the per-head norm (attn.py:143-145).
+    Runs on whatever device the tensors live on; `mm(a, w[, bias]) -> a @ w.T (+ bias)` overrides the linear layers' GEMM (default: torch's
+    F.linear); the three-argument form is only used for projections that have a bias."""
     torch = _torch()
-    mm = mm or (lambda a, w: a @ w.T)
+    mm = mm or (lambda a, w, b=None: torch.nn.functional.linear(a, w, b))
     hq, hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     x = params["model.embed_tokens.weight"][input_ids]
     cos, sin = rope_cos_sin(position_ids, d, cfg.rope_theta, x.dtype)
@@ -399,11 +406,15 @@ def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int
         pre = f"model.layers.{i}."
         res = x
         h = rmsnorm(x, params[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
-        q = mm(h, params[pre + "self_attn.q_proj.weight"]).view(n, hq, d)
-        k = mm(h, params[pre + "self_attn.k_proj.weight"]).view(n, hkv, d)
-        v = mm(h, params[pre + "self_attn.v_proj.weight"]).view(n, hkv, d)
-        q = rmsnorm(q, params[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
-        k = rmsnorm(k, params[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
+        def proj(name):
+            b = params.get(pre + f"self_attn.{name}_proj.bias")
+            wt = params[pre + f"self_attn.{name}_proj.weight"]
+            return mm(h, wt) if b is None else mm(h, wt, b)  # nn.Linear: the bias joins the accumulator before the single rounding
+
+        q, k, v = proj("q").view(n, hq, d), proj("k").view(n, hkv, d), proj("v").view(n, hkv, d)
+        if pre + "self_attn.q_norm.weight" in params:
+            q = rmsnorm(q, params[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
+            k = rmsnorm(k, params[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
         a = varlen_causal_attention(q, k, v, seq_lens, d**-0.5).to(x.dtype).reshape(n, hq * d)
         x = res + mm(a, params[pre + "self_attn.o_proj.weight"])
@@ -433,8 +444,12 @@ def init_qwen3_params(cfg, seed: int = 0, dtype=None, std: float = 0.02) -> dict
         p[pre + "self_attn.k_proj.weight"] = w(hkv * d, h)
         p[pre + "self_attn.v_proj.weight"] = w(hkv * d, h)
         p[pre + "self_attn.o_proj.weight"] = w(h, hq * d)
-        p[pre + "self_attn.q_norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
-        p[pre + "self_attn.k_norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+        if getattr(cfg, "qk_norm", True):
+            p[pre + "self_attn.q_norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+            p[pre + "self_attn.k_norm.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+        if getattr(cfg, "attention_bias", False):
+            for nm, rows in (("q", hq * d), ("k", hkv * d), ("v", hkv * d)):
+                p[pre + f"self_attn.{nm}_proj.bias"] = (torch.randn(rows, generator=g) * 0.1).to(dtype)
         p[pre + "mlp.gate_proj.weight"] = w(inter, h)
         p[pre + "mlp.up_proj.weight"] = w(inter, h)
         p[pre + "mlp.down_proj.weight"] = w(h, inter)

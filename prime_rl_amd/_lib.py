@@ -89,6 +89,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_qknorm_rope_fwd": (I, [P, P, P, P, P, I64, I32, I32, I32, F, P, P, P, P]),
     "pm_qknorm_rope_bwd_workspace_bytes": (I64, [I64, I32, I32]),
     "pm_qknorm_rope_bwd": (I, [P, P, P, P, P, P, P, P, I64, I32, I32, I32, P, P, P, P, I64, P]),
+    "pm_column_sum_workspace_bytes": (I64, [I64]),
+    "pm_column_sum_bf16": (I, [P, I64, I64, I64, P, P, I64, P]),
     "pm_seq_start_from_cu": (I, [P, I32, I64, P, P]),
     "pm_attn_fwd_workspace_bytes": (I64, [I64, I32, I32]),
     "pm_attn_varlen_fwd": (I, [P, P, P, I64, P, I64, I32, I32, I32, F, P, P, P, I64, P]),

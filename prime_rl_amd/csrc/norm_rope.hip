@@ -238,6 +238,45 @@ __global__ void column_reduce_stage2_kernel(const float* __restrict__ stage, int
   out[c] += (s0 + s1) + (s2 + s3);
 }
 
+// Column sums of a bf16 matrix (the bias gradient of a linear layer: grad_bias = sum over tokens of grad_out, nn.Linear(bias=True) in
+// models/layers/attn.py:64-72).  Row slice blockIdx.y of kColSumSlices sums its rows in f32 (8 columns per lane, 16-byte loads) into one
+// partial row; the two column_reduce stages above add the partial rows into `out` in a fixed order.
+constexpr int kColSumSlices = 256;
+
+__global__ __launch_bounds__(256) void column_sum_bf16_kernel(const bf16_t* __restrict__ x, int64_t n_rows, int64_t n_cols, int64_t ld,
+                                                             float* __restrict__ partials) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= n_cols) return;
+  const int64_t per = (n_rows + kColSumSlices - 1) / kColSumSlices;
+  const int64_t r0 = (int64_t)blockIdx.y * per;
+  const int64_t r1 = r0 + per < n_rows ? r0 + per : n_rows;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int64_t r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const u32x4*>(x + (r + j) * ld + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f[8];
+      unpack8(v[j], f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f[k];
+    }
+  }
+  for (; r < r1; ++r) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + r * ld + c), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+  }
+  float4* dst = reinterpret_cast<float4*>(partials + (int64_t)blockIdx.y * n_cols + c);
+  dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
 // 4 workgroups (16 waves) per CU keep enough row loads in flight for HBM; 1024 = 4 x 256 CUs, so the grid is one full residency
 static int64_t rms_bwd_num_wg(int64_t n_rows) {
   int64_t g = cdiv(n_rows, 8);
@@ -266,6 +305,9 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, int64_t n_tok
 // [0,64), lanes 8-15 hold [64,128): the rotate_half partner is lane ^ 8 = DPP row_ror:8; row sums are DPP too (VALU, no LDS).
 constexpr int kQkBatch = 4;
 
+// NORM = false is the Llama / Qwen2 attention block (AttentionConfig.use_qk_norm = False, models/llama/modeling_llama.py:59-60): RoPE only, on the
+// projection output as it is (norm weights, rstd unused).
+template <bool NORM>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
                                                              const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
                                                              const bf16_t* __restrict__ sinb, int64_t n_tokens, int hq, int hkv, float eps,
@@ -276,8 +318,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
   if (tok >= n_tokens) return;  // a whole 16-lane row leaves together; the DPP row ops never cross rows
   const int64_t row_stride = (int64_t)(hq + 2 * hkv) * 128;
   float wq[8], wk[8], cf[8], sf[8];
-  unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
-  unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+  if constexpr (NORM) {
+    unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
+    unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+  }
   const int cs = (sub & 7) * 8;
   unpack8(*reinterpret_cast<const u32x4*>(cosb + tok * 64 + cs), cf);
   unpack8(*reinterpret_cast<const u32x4*>(sinb + tok * 64 + cs), sf);
@@ -293,19 +337,25 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
       if (h >= nh) break;
       float xf[8];
       unpack8(xv[j], xf);
-      float ss = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ss = fmaf(xf[k], xf[k], ss);
-      ss = row16_sum(ss);
-      const float r = rsqrtf(ss / 128.0f + eps);
-      const float* wf = h < hq ? wq : wk;
       float yv[8], o[8];
+      float r = 0.f;
+      if constexpr (NORM) {
+        float ss = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) yv[k] = xf[k] * r;
-      round8_bf16(yv);
+        for (int k = 0; k < 8; ++k) ss = fmaf(xf[k], xf[k], ss);
+        ss = row16_sum(ss);
+        r = rsqrtf(ss / 128.0f + eps);
+        const float* wf = h < hq ? wq : wk;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) yv[k] = wf[k] * yv[k];
-      round8_bf16(yv);
+        for (int k = 0; k < 8; ++k) yv[k] = xf[k] * r;
+        round8_bf16(yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[k] = wf[k] * yv[k];
+        round8_bf16(yv);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[k] = xf[k];
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         o[k] = yv[k] * cf[k];
@@ -317,11 +367,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
       for (int k = 0; k < 8; ++k) o[k] += xf[k];
       bf16_t* dst = (h < hq) ? (qo + (tok * hq + h) * 128 + sub * 8) : (ko + (tok * hkv + (h - hq)) * 128 + sub * 8);
       *reinterpret_cast<u32x4*>(dst) = pack8(o);
-      if (sub == 0) rstd[tok * nh + h] = r;
+      if constexpr (NORM) {
+        if (sub == 0) rstd[tok * nh + h] = r;
+      }
     }
   }
 }
 
+template <bool NORM>
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __restrict__ gq, const bf16_t* __restrict__ gk,
                                                              const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
                                                              const bf16_t* __restrict__ kw, const bf16_t* __restrict__ cosb,
@@ -334,8 +387,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
   float dwq[8], dwk[8], wq[8], wk[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) dwq[k] = dwk[k] = 0.f;
-  unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
-  unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+  if constexpr (NORM) {
+    unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
+    unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+  }
   const int cs = (sub & 7) * 8;
   const float sgn = (sub < 8) ? 1.0f : -1.0f;
   for (int64_t tok = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); tok < n_tokens; tok += (int64_t)gridDim.x * 16) {
@@ -350,9 +405,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
 #pragma unroll
       for (int j = 0; j < kQkBatch; ++j) {
         const int h = h0 + j < nh ? h0 + j : nh - 1;
-        xv[j] = *reinterpret_cast<const u32x4*>(xrow + (int64_t)h * 128);
         gv[j] = *reinterpret_cast<const u32x4*>(h < hq ? (gq + (tok * hq + h) * 128 + sub * 8) : (gk + (tok * hkv + (h - hq)) * 128 + sub * 8));
-        rv[j] = rstd[tok * nh + h];
+        if constexpr (NORM) {
+          xv[j] = *reinterpret_cast<const u32x4*>(xrow + (int64_t)h * 128);
+          rv[j] = rstd[tok * nh + h];
+        }
       }
 #pragma unroll
       for (int j = 0; j < kQkBatch; ++j) {
@@ -361,6 +418,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
         const bool is_q = h < hq;
         float g[8], xf[8], dn[8], nh_[8];
         unpack8(gv[j], g);
+        if constexpr (!NORM) {  // transpose of the rotation alone
+          float o[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = g[k] * cf[k] + (sgn * dpp_f32<0x128>(g[k])) * sf[k];
+          *reinterpret_cast<u32x4*>(orow + (int64_t)h * 128) = pack8(o);
+          continue;
+        }
         unpack8(xv[j], xf);
         const float r = rv[j];
         const float* wv = is_q ? wq : wk;
@@ -383,6 +447,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
       }
     }
   }
+  if constexpr (!NORM) return;
   // the 16 groups of the block through LDS (fixed order): one partial row [q 128 | k 128] per block
   __shared__ float red[16][256];
   const int grp = threadIdx.x >> 4;
@@ -515,6 +580,33 @@ extern "C" int pm_rmsnorm_bwd(const void* grad_y, const void* x, const void* wei
   return PM_OK;
 }
 
+extern "C" int64_t pm_column_sum_workspace_bytes(int64_t n_cols) {
+  return n_cols <= 0 ? 0 : (int64_t)(kColSumSlices + kReduceSlices) * n_cols * (int64_t)sizeof(float);
+}
+
+extern "C" int pm_column_sum_bf16(const void* x, int64_t n_rows, int64_t n_cols, int64_t ld, float* out_accumulate, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols % 8 == 0 && ld >= n_cols && ld % 8 == 0, PM_ERR_UNSUPPORTED,
+             "pm_column_sum_bf16: n_cols and ld must be multiples of 8 (n_cols=%lld ld=%lld)", (long long)n_cols, (long long)ld);
+  if (n_rows == 0) return PM_OK;
+  PM_REQUIRE(x && out_accumulate, PM_ERR_INVALID_ARG, "pm_column_sum_bf16: null pointer");
+  PM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, PM_ERR_INVALID_ARG, "pm_column_sum_bf16: x must be 16-byte aligned");
+  const int64_t need = pm_column_sum_workspace_bytes(n_cols);
+  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_column_sum_bf16: workspace %lld < %lld", (long long)workspace_bytes,
+             (long long)need);
+  hipStream_t st = as_stream(stream);
+  float* partials = (float*)workspace;
+  float* stage = partials + (int64_t)kColSumSlices * n_cols;
+  hipLaunchKernelGGL(column_sum_bf16_kernel, dim3((unsigned)cdiv(n_cols, (int64_t)2048), kColSumSlices), dim3(256), 0, st, (const bf16_t*)x, n_rows,
+                     n_cols, ld, partials);
+  hipLaunchKernelGGL(column_reduce_stage1_kernel, dim3((unsigned)cdiv(n_cols, (int64_t)256), kReduceSlices), dim3(256), 0, st, (const float*)partials,
+                     (int64_t)kColSumSlices, n_cols, stage);
+  hipLaunchKernelGGL(column_reduce_stage2_kernel, dim3((unsigned)cdiv(n_cols, (int64_t)256)), dim3(256), 0, st, (const float*)stage, n_cols,
+                     out_accumulate);
+  PM_CHECK_LAUNCH("pm_column_sum_bf16");
+  return PM_OK;
+}
+
 extern "C" int pm_rope_table(const int64_t* position_ids, int64_t n_tokens, const float* inv_freq, int32_t half_dim, void* cos_bf16,
                              void* sin_bf16, void* stream) {
   PM_REQUIRE(position_ids && inv_freq && cos_bf16 && sin_bf16, PM_ERR_INVALID_ARG, "pm_rope_table: null pointer");
@@ -530,13 +622,21 @@ extern "C" int pm_rope_table(const int64_t* position_ids, int64_t n_tokens, cons
 extern "C" int pm_qknorm_rope_fwd(const void* qkv, const void* q_norm_w, const void* k_norm_w, const void* cosb, const void* sinb,
                                   int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float eps, void* q_out, void* k_out,
                                   float* rstd, void* stream) {
-  PM_REQUIRE(qkv && q_norm_w && k_norm_w && cosb && sinb && q_out && k_out && rstd, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: null pointer");
+  const bool norm = q_norm_w || k_norm_w;  // both NULL: RoPE only (use_qk_norm = False); rstd is then not written and may be NULL
+  PM_REQUIRE(qkv && cosb && sinb && q_out && k_out, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: null pointer");
+  PM_REQUIRE(!norm || (q_norm_w && k_norm_w && rstd), PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: q_norm_w, k_norm_w and rstd go together");
   PM_REQUIRE(head_dim == 128, PM_ERR_UNSUPPORTED, "pm_qknorm_rope_fwd: head_dim=%d (only 128 is built)", head_dim);
   PM_REQUIRE(n_tokens >= 0 && n_q_heads > 0 && n_kv_heads > 0, PM_ERR_INVALID_ARG, "pm_qknorm_rope_fwd: bad sizes");
   if (n_tokens == 0) return PM_OK;
-  hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)cdiv(n_tokens, (int64_t)16)), dim3(256), 0, as_stream(stream), (const bf16_t*)qkv,
-                     (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, n_tokens, n_q_heads, n_kv_heads,
-                     eps, (bf16_t*)q_out, (bf16_t*)k_out, rstd);
+  const dim3 grid((unsigned)cdiv(n_tokens, (int64_t)16));
+  if (norm)
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)q_norm_w,
+                       (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, n_tokens, n_q_heads, n_kv_heads, eps, (bf16_t*)q_out,
+                       (bf16_t*)k_out, rstd);
+  else
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, (const bf16_t*)cosb, (const bf16_t*)sinb, n_tokens, n_q_heads, n_kv_heads, eps, (bf16_t*)q_out,
+                       (bf16_t*)k_out, (float*)nullptr);
   PM_CHECK_LAUNCH("pm_qknorm_rope_fwd");
   return PM_OK;
 }
@@ -550,16 +650,26 @@ extern "C" int pm_qknorm_rope_bwd(const void* grad_q, const void* grad_k, const 
                                   const void* cosb, const void* sinb, const float* rstd, int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads,
                                   int32_t head_dim, void* grad_qkv, float* grad_q_norm_w, float* grad_k_norm_w, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
-  PM_REQUIRE(grad_q && grad_k && qkv && q_norm_w && k_norm_w && cosb && sinb && rstd && grad_qkv && grad_q_norm_w && grad_k_norm_w,
-             PM_ERR_INVALID_ARG, "pm_qknorm_rope_bwd: null pointer");
+  const bool norm = q_norm_w || k_norm_w;  // both NULL: transpose of the rotation only; qkv, rstd, the weight gradients and the workspace are unused
+  PM_REQUIRE(grad_q && grad_k && cosb && sinb && grad_qkv, PM_ERR_INVALID_ARG, "pm_qknorm_rope_bwd: null pointer");
+  PM_REQUIRE(!norm || (qkv && q_norm_w && k_norm_w && rstd && grad_q_norm_w && grad_k_norm_w), PM_ERR_INVALID_ARG,
+             "pm_qknorm_rope_bwd: null pointer (the norm weights, rstd, qkv and the weight gradients go together)");
   PM_REQUIRE(head_dim == 128, PM_ERR_UNSUPPORTED, "pm_qknorm_rope_bwd: head_dim=%d (only 128 is built)", head_dim);
   if (n_tokens == 0) return PM_OK;
+  if (!norm) {
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<false>, dim3((unsigned)qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)grad_q, (const bf16_t*)grad_k, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                       (const bf16_t*)cosb, (const bf16_t*)sinb, (const float*)nullptr, n_tokens, n_q_heads, n_kv_heads, (bf16_t*)grad_qkv,
+                       (float*)nullptr);
+    PM_CHECK_LAUNCH("pm_qknorm_rope_bwd(rope only)");
+    return PM_OK;
+  }
   const int64_t need = pm_qknorm_rope_bwd_workspace_bytes(n_tokens, n_q_heads, n_kv_heads);
   PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_qknorm_rope_bwd: workspace %lld < %lld", (long long)workspace_bytes,
              (long long)need);
   hipStream_t st = as_stream(stream);
   const int64_t grid = qk_bwd_grid(n_tokens, n_q_heads + n_kv_heads);
-  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)grad_q, (const bf16_t*)grad_k,
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, (const bf16_t*)grad_q, (const bf16_t*)grad_k,
                      (const bf16_t*)qkv, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, (const bf16_t*)cosb, (const bf16_t*)sinb, rstd, n_tokens,
                      n_q_heads, n_kv_heads, (bf16_t*)grad_qkv, (float*)workspace);
   PM_CHECK_LAUNCH("pm_qknorm_rope_bwd");

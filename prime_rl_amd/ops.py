@@ -332,7 +332,11 @@ def rope_table(position_ids: Tensor, inv_freq: Tensor) -> tuple[Tensor, Tensor]:
 def _check_qknorm_operands(q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, n: int, head_dim: int) -> None:
     """The kernels read these through raw bf16 pointers: an f32 cos/sin table (a model that is not bf16) or a mis-shaped norm weight
     would be read as garbage without any error."""
+    if (q_norm_w is None) != (k_norm_w is None):
+        raise PrimeMI355XError("q_norm_w and k_norm_w go together (both None = use_qk_norm False: RoPE only)")
     for t, nm in ((q_norm_w, "q_norm_w"), (k_norm_w, "k_norm_w")):
+        if t is None:
+            continue
         _req(t, torch.bfloat16, nm)
         if t.numel() != head_dim:
             raise PrimeMI355XError(f"{nm}: expected {head_dim} elements, got {t.numel()}")
@@ -342,8 +346,9 @@ def _check_qknorm_operands(q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin:
             raise PrimeMI355XError(f"{nm}: expected a [{n}, {head_dim // 2}] bf16 half-table (pm_rope_table layout), got {tuple(t.shape)}")
 
 
-def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, n_q_heads: int, n_kv_heads: int,
-                    head_dim: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
+def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor | None, k_norm_w: Tensor | None, cos: Tensor, sin: Tensor, n_q_heads: int, n_kv_heads: int,
+                    head_dim: int, eps: float) -> tuple[Tensor, Tensor, Tensor | None]:
+    """(q, k, rstd).  q_norm_w = k_norm_w = None: no per-head norm (Llama / Qwen2 attention) — RoPE only, rstd is None."""
     lib = _lib.load()
     _req(qkv, torch.bfloat16, "qkv")
     n = qkv.shape[0]
@@ -352,7 +357,7 @@ def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor
     _check_qknorm_operands(q_norm_w, k_norm_w, cos, sin, n, head_dim)
     q = torch.empty((n, n_q_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
     k = torch.empty((n, n_kv_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
-    rstd = torch.empty((n, n_q_heads + n_kv_heads), dtype=torch.float32, device=qkv.device)
+    rstd = None if q_norm_w is None else torch.empty((n, n_q_heads + n_kv_heads), dtype=torch.float32, device=qkv.device)
     check(
         lib.pm_qknorm_rope_fwd(_p(qkv), _p(q_norm_w), _p(k_norm_w), _p(cos), _p(sin), n, n_q_heads, n_kv_heads, head_dim, eps, _p(q), _p(k),
                                _p(rstd), _stream()),
@@ -361,14 +366,23 @@ def qknorm_rope_fwd(qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor
     return q, k, rstd
 
 
-def qknorm_rope_bwd(grad_q: Tensor, grad_k: Tensor, qkv: Tensor, q_norm_w: Tensor, k_norm_w: Tensor, cos: Tensor, sin: Tensor, rstd: Tensor,
-                    grad_qkv: Tensor, grad_q_norm_w_f32: Tensor, grad_k_norm_w_f32: Tensor, n_q_heads: int, n_kv_heads: int, head_dim: int) -> None:
-    """Writes the q|k columns of grad_qkv (the v columns are written by attention backward)."""
+def qknorm_rope_bwd(grad_q: Tensor, grad_k: Tensor, qkv: Tensor | None, q_norm_w: Tensor | None, k_norm_w: Tensor | None, cos: Tensor, sin: Tensor,
+                    rstd: Tensor | None, grad_qkv: Tensor, grad_q_norm_w_f32: Tensor | None, grad_k_norm_w_f32: Tensor | None, n_q_heads: int,
+                    n_kv_heads: int, head_dim: int) -> None:
+    """Writes the q|k columns of grad_qkv (the v columns are written by attention backward).  Without norm weights (RoPE only) qkv, rstd
+    and the weight gradients are not used."""
     lib = _lib.load()
-    for t, nm in ((grad_q, "grad_q"), (grad_k, "grad_k"), (qkv, "qkv"), (grad_qkv, "grad_qkv")):
+    for t, nm in ((grad_q, "grad_q"), (grad_k, "grad_k"), (grad_qkv, "grad_qkv")):
         _req(t, torch.bfloat16, nm)
-    n = qkv.shape[0]
+    n = grad_qkv.shape[0]
+    if grad_qkv.shape[1] != (n_q_heads + 2 * n_kv_heads) * head_dim or grad_q.numel() != n * n_q_heads * head_dim or grad_k.numel() != n * n_kv_heads * head_dim:
+        raise PrimeMI355XError("qknorm_rope_bwd: grad_q / grad_k / grad_qkv shapes do not agree")
     _check_qknorm_operands(q_norm_w, k_norm_w, cos, sin, n, head_dim)
+    if q_norm_w is None:
+        check(lib.pm_qknorm_rope_bwd(_p(grad_q), _p(grad_k), None, None, None, _p(cos), _p(sin), None, n, n_q_heads, n_kv_heads, head_dim, _p(grad_qkv),
+                                     None, None, None, 0, _stream()), "pm_qknorm_rope_bwd")
+        return
+    _req(qkv, torch.bfloat16, "qkv")
     _req(rstd, torch.float32, "rstd")
     wsb = lib.pm_qknorm_rope_bwd_workspace_bytes(n, n_q_heads, n_kv_heads)
     ws = workspace(wsb, qkv.device, "qknorm_bwd")
@@ -377,6 +391,19 @@ def qknorm_rope_bwd(grad_q: Tensor, grad_k: Tensor, qkv: Tensor, q_norm_w: Tenso
                                head_dim, _p(grad_qkv), _p(grad_q_norm_w_f32), _p(grad_k_norm_w_f32), _p(ws), ws.numel(), _stream()),
         "pm_qknorm_rope_bwd",
     )
+
+
+def column_sum(x: Tensor, out_f32: Tensor) -> None:
+    """out_f32[c] += sum_r x[r, c] for a bf16 matrix whose rows may be strided (a column block of a wider buffer): the bias gradient of a
+    linear layer.  Deterministic."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x", contiguous=False); _req(out_f32, torch.float32, "out")
+    if x.dim() != 2 or x.stride(1) != 1 or out_f32.numel() != x.shape[1]:
+        raise PrimeMI355XError(f"column_sum: x must be [rows, cols] with unit column stride and out must hold cols floats, got {tuple(x.shape)} / {tuple(out_f32.shape)}")
+    n, c = x.shape
+    wsb = lib.pm_column_sum_workspace_bytes(c)
+    ws = workspace(wsb, x.device, "column_sum")
+    check(lib.pm_column_sum_bf16(_p(x), n, c, x.stride(0) if n > 1 else c, _p(out_f32), _p(ws), ws.numel(), _stream()), "pm_column_sum_bf16")
 
 
 def seq_start_from_cu(cu_seqlens: Tensor, n_tokens: int) -> Tensor:

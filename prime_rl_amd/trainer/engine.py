@@ -37,7 +37,10 @@ from .._lib import LossParams, PrimeMI355XError
 # ---------------------------------------------------------------------------------------------------------------------
 @dataclass
 class ModelDims:
-    """Dense Qwen3 / Llama-style dimensions (HF config names)."""
+    """Dense Qwen3 / Llama / Qwen2 dimensions (HF config names).  `qk_norm` / `attention_bias` are AttentionConfig.use_qk_norm /
+    .attention_bias of the reference (models/layers/attn.py:29-40): Qwen3 = per-head q/k RMSNorm, no bias; Llama = neither
+    (models/llama/modeling_llama.py:52-62); Qwen2 / Qwen2.5 = bias on the q/k/v projections, no q/k norm (the reference runs it through
+    HF's class)."""
 
     vocab_size: int
     hidden_size: int
@@ -50,6 +53,12 @@ class ModelDims:
     rope_theta: float = 1_000_000.0
     tie_word_embeddings: bool = False
     name: str = "custom"
+    qk_norm: bool = True
+    attention_bias: bool = False
+
+    @classmethod
+    def qwen2_5_1_5b(cls) -> "ModelDims":  # public HF config of Qwen/Qwen2.5-1.5B(-Instruct) (BASELINE.json configs[1])
+        return cls(151936, 1536, 8960, 28, 12, 2, 128, tie_word_embeddings=True, name="Qwen2.5-1.5B", qk_norm=False, attention_bias=True)
 
     @classmethod
     def qwen3_8b(cls) -> "ModelDims":  # public HF config
@@ -73,7 +82,9 @@ class ModelDims:
 
     def num_params(self) -> int:
         h, i, v = self.hidden_size, self.intermediate_size, self.vocab_size
-        per_layer = 2 * h + (self.q_dim + 2 * self.kv_dim) * h + 2 * self.head_dim + h * self.q_dim + 3 * i * h
+        per_layer = 2 * h + (self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h
+        per_layer += 2 * self.head_dim if self.qk_norm else 0
+        per_layer += self.q_dim + 2 * self.kv_dim if self.attention_bias else 0
         return v * h * (1 if self.tie_word_embeddings else 2) + self.num_hidden_layers * per_layer + h
 
     def flops_per_token(self, seq_len: int) -> int:
@@ -239,19 +250,18 @@ class ParamStore:
         new_bucket("embed", [("model.embed_tokens.weight", (d.vocab_size, d.hidden_size))])
         for i in range(d.num_hidden_layers):
             p = f"model.layers.{i}."
-            new_bucket(
-                f"layer{i}",
-                [
-                    (p + "input_layernorm.weight", (d.hidden_size,)),
-                    (p + "self_attn.qkv_proj.weight", (d.q_dim + 2 * d.kv_dim, d.hidden_size)),
-                    (p + "self_attn.q_norm.weight", (d.head_dim,)),
-                    (p + "self_attn.k_norm.weight", (d.head_dim,)),
-                    (p + "self_attn.o_proj.weight", (d.hidden_size, d.q_dim)),
-                    (p + "post_attention_layernorm.weight", (d.hidden_size,)),
-                    (p + "mlp.gate_up_proj.weight", (2 * d.intermediate_size, d.hidden_size)),
-                    (p + "mlp.down_proj.weight", (d.hidden_size, d.intermediate_size)),
-                ],
-            )
+            plist = [(p + "input_layernorm.weight", (d.hidden_size,)), (p + "self_attn.qkv_proj.weight", (d.q_dim + 2 * d.kv_dim, d.hidden_size))]
+            if d.attention_bias:
+                plist.append((p + "self_attn.qkv_proj.bias", (d.q_dim + 2 * d.kv_dim,)))
+            if d.qk_norm:
+                plist += [(p + "self_attn.q_norm.weight", (d.head_dim,)), (p + "self_attn.k_norm.weight", (d.head_dim,))]
+            plist += [
+                (p + "self_attn.o_proj.weight", (d.hidden_size, d.q_dim)),
+                (p + "post_attention_layernorm.weight", (d.hidden_size,)),
+                (p + "mlp.gate_up_proj.weight", (2 * d.intermediate_size, d.hidden_size)),
+                (p + "mlp.down_proj.weight", (d.hidden_size, d.intermediate_size)),
+            ]
+            new_bucket(f"layer{i}", plist)
         head = [("model.norm.weight", (d.hidden_size,))]
         if not d.tie_word_embeddings:
             head.append(("lm_head.weight", (d.vocab_size, d.hidden_size)))
@@ -279,11 +289,11 @@ class ParamStore:
 
     # -- init ------------------------------------------------------------------------------------------------------
     def random_init(self, seed: int = 0, std: float = 0.02) -> None:
-        """`config.debug.random_init`-style init (no checkpoints offline): N(0, std) matrices, ones for norms; identical on every rank."""
+        """`config.debug.random_init`-style init (no checkpoints offline): N(0, std) matrices and biases, ones for norms; identical on every rank."""
         gen = torch.Generator(device=self.device).manual_seed(seed)
         self.params.zero_()
         for name, w in self.w.items():
-            if w.dim() == 1:
+            if w.dim() == 1 and not name.endswith(".bias"):
                 w.fill_(1.0)
             else:
                 chunk = 1 << 26  # generate in f32 chunks, round to bf16
@@ -301,6 +311,8 @@ class ParamStore:
             sd = dict(sd)
             if p + "self_attn.q_proj.weight" in sd:
                 sd[p + "self_attn.qkv_proj.weight"] = torch.cat([sd.pop(p + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+            if p + "self_attn.q_proj.bias" in sd:
+                sd[p + "self_attn.qkv_proj.bias"] = torch.cat([sd.pop(p + f"self_attn.{n}_proj.bias") for n in "qkv"], 0)
             if p + "mlp.gate_proj.weight" in sd:
                 sd[p + "mlp.gate_up_proj.weight"] = torch.cat([sd.pop(p + "mlp.gate_proj.weight"), sd.pop(p + "mlp.up_proj.weight")], 0)
         if d.tie_word_embeddings:
@@ -317,11 +329,12 @@ class ParamStore:
         """HF-named views of the bf16 parameters (no copies)."""
         d, out = self.dims, {}
         for name, w in self.w.items():
-            if name.endswith("qkv_proj.weight"):
-                base = name[: -len("qkv_proj.weight")]
-                out[base + "q_proj.weight"] = w[: d.q_dim]
-                out[base + "k_proj.weight"] = w[d.q_dim: d.q_dim + d.kv_dim]
-                out[base + "v_proj.weight"] = w[d.q_dim + d.kv_dim:]
+            if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+                kind = name.rsplit(".", 1)[1]
+                base = name[: -len("qkv_proj." + kind)]
+                out[base + "q_proj." + kind] = w[: d.q_dim]
+                out[base + "k_proj." + kind] = w[d.q_dim: d.q_dim + d.kv_dim]
+                out[base + "v_proj." + kind] = w[d.q_dim + d.kv_dim:]
             elif name.endswith("gate_up_proj.weight"):
                 base = name[: -len("gate_up_proj.weight")]
                 out[base + "gate_proj.weight"] = w[: d.intermediate_size]
@@ -463,11 +476,16 @@ class GRPOEngine:
         except Exception:
             return False
 
-    def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False) -> Tensor:
-        """y[n,out] = x[n,in] @ w[out,in]^T — the forward projection GEMM (library call)."""
+    def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False, bias: Tensor | None = None) -> Tensor:
+        """y[n,out] = x[n,in] @ w[out,in]^T (+ bias) — the forward projection GEMM (library call; the bias rides in the GEMM epilogue, added
+        to the f32 accumulator before the one rounding to bf16, as F.linear does)."""
         if self.gemm_f32:
             y = torch.mm(x.float(), w.float().t())
+            if bias is not None:
+                y += bias.float()
             return y if out_f32 else y.to(torch.bfloat16)
+        if bias is not None:
+            return torch.addmm(bias, x, w.t())
         return torch.mm(x, w.t(), out_dtype=torch.float32) if out_f32 else torch.mm(x, w.t())
 
     def _wgrad(self, dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool, k_contiguous_x: bool = False) -> None:
@@ -538,8 +556,8 @@ class GRPOEngine:
                 h1, rstd1, _ = ops.rmsnorm_fwd(x, w[p + "input_layernorm.weight"], d.rms_norm_eps)
             else:
                 h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
-            qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"])
-            q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], cos, sin,
+            qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"], bias=w.get(p + "self_attn.qkv_proj.bias"))
+            q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w.get(p + "self_attn.q_norm.weight"), w.get(p + "self_attn.k_norm.weight"), cos, sin,
                                                  d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.rms_norm_eps)
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
             if cp == 1:
@@ -690,10 +708,16 @@ class GRPOEngine:
                 dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
             else:
                 dq, dk = self._ulysses_attn_bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
-            ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
-                                L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),
-                                self._norm_grad(g[p + "self_attn.k_norm.weight"], accumulate), d.num_attention_heads, d.num_key_value_heads,
-                                d.head_dim)
+            if d.qk_norm:
+                ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
+                                    L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),
+                                    self._norm_grad(g[p + "self_attn.k_norm.weight"], accumulate), d.num_attention_heads, d.num_key_value_heads,
+                                    d.head_dim)
+            else:
+                ops.qknorm_rope_bwd(dq, dk, None, None, None, ctx["cos"], ctx["sin"], None, dqkv, None, None, d.num_attention_heads,
+                                    d.num_key_value_heads, d.head_dim)
+            if d.attention_bias:  # grad_bias = column sums of the projection's output gradient
+                ops.column_sum(dqkv, self._norm_grad(g[p + "self_attn.qkv_proj.bias"], accumulate))
             dh1 = self._dgrad(dqkv, i, "self_attn.qkv_proj.weight")
             self._wgrad(dqkv, L["h1"], g[p + "self_attn.qkv_proj.weight"], accumulate)
             dx = ops.rmsnorm_bwd(dh1, L["x"], w[p + "input_layernorm.weight"], L["rstd1"],

@@ -24,12 +24,14 @@ from torch import Tensor, nn
 
 from .engine import GRPOEngine, LossConfig, ModelDims, OptimConfig
 from .models.layers.lm_head import PrimeLmOutput, cast_float_and_contiguous, inject_prime_lm_head
+from .models.llama.modeling_llama import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM
 from .models.qwen3.modeling_qwen3 import Qwen3Config, Qwen3ForCausalLM
 from .models.qwen3_moe.modeling_qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
 from .parallel_dims import ParallelDims
 
 DTYPE_MAP = {"bfloat16": torch.bfloat16, "float32": torch.float32}
 
+_QWEN2 = dict(qk_norm=False, attention_bias=True)
 # public HF configs of the dense families the reference registers as custom PrimeRL models (trainer/models/__init__.py:41-59)
 KNOWN_MODELS: dict[str, dict] = {
     "qwen3-8b": dict(vocab_size=151936, hidden_size=4096, intermediate_size=12288, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8),
@@ -40,7 +42,20 @@ KNOWN_MODELS: dict[str, dict] = {
     "qwen3-0.6b": dict(vocab_size=151936, hidden_size=1024, intermediate_size=3072, num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8,
                        tie_word_embeddings=True),
     "tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2),
+    # Qwen2.5 (HF Qwen2: q/k/v bias, no q/k norm) — BASELINE.json configs[1] is Qwen2.5-1.5B-Instruct; only the head_dim-128 sizes run here
+    "qwen2.5-1.5b": dict(vocab_size=151936, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2,
+                         tie_word_embeddings=True, **_QWEN2),
+    "qwen2.5-3b": dict(vocab_size=151936, hidden_size=2048, intermediate_size=11008, num_hidden_layers=36, num_attention_heads=16, num_key_value_heads=2,
+                       tie_word_embeddings=True, **_QWEN2),
+    "qwen2.5-7b": dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+                       **_QWEN2),
+    "tiny-qwen2": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       tie_word_embeddings=True, **_QWEN2),
+    "tiny-llama": dict(vocab_size=512, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       qk_norm=False, rms_norm_eps=1e-5, rope_theta=500_000.0),
 }
+for _k in ("qwen2.5-1.5b", "qwen2.5-3b", "qwen2.5-7b"):
+    KNOWN_MODELS[_k + "-instruct"] = KNOWN_MODELS[_k]
 # MoE families (models/qwen3_moe): the dense fields above plus the expert fields of configuration_qwen3_moe.py:150-205
 KNOWN_MOE_MODELS: dict[str, dict] = {
     "qwen3-30b-a3b": dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=48, num_attention_heads=32,
@@ -82,14 +97,21 @@ def resolve_model_dims(config) -> ModelDims:
     p = Path(name)
     if (p / "config.json").exists():
         hf = json.loads((p / "config.json").read_text())
-        if hf.get("model_type") not in ("qwen3", "llama"):
-            raise NotImplementedError(f"model_type {hf.get('model_type')!r}: the MI355X scoring forward is built for dense Qwen3 (q/k-norm) models")
+        family = hf.get("model_type")
+        if family not in ("qwen3", "llama", "qwen2"):
+            raise NotImplementedError(f"model_type {family!r}: the MI355X scoring forward is built for the dense Qwen3, Llama and Qwen2 decoders")
+        scaling = hf.get("rope_scaling") or (hf.get("rope_parameters") or {})
+        if scaling.get("rope_type", scaling.get("type", "default")) not in ("default", None):
+            raise NotImplementedError(f"rope_scaling {scaling.get('rope_type', scaling.get('type'))!r}: pm_rope_table builds the default table only "
+                                      "(inv_freq = theta^(-2i/d), rotary_emb.py:30-45)")
+        if hf.get("mlp_bias") or (family != "qwen2" and hf.get("attention_bias")):
+            raise NotImplementedError("mlp_bias / o_proj bias are not on the MI355X path (q/k/v bias is: model_type qwen2)")
         fields = dict(vocab_size=hf["vocab_size"], hidden_size=hf["hidden_size"], intermediate_size=hf["intermediate_size"],
                       num_hidden_layers=hf["num_hidden_layers"], num_attention_heads=hf["num_attention_heads"],
                       num_key_value_heads=hf.get("num_key_value_heads", hf["num_attention_heads"]),
                       head_dim=hf.get("head_dim", hf["hidden_size"] // hf["num_attention_heads"]), rms_norm_eps=hf.get("rms_norm_eps", 1e-6),
                       rope_theta=hf.get("rope_theta", (hf.get("rope_parameters") or {}).get("rope_theta", 1_000_000.0)),
-                      tie_word_embeddings=hf.get("tie_word_embeddings", False))
+                      tie_word_embeddings=hf.get("tie_word_embeddings", False), qk_norm=family == "qwen3", attention_bias=family == "qwen2")
         label = p.name
     else:
         key = name.split("/")[-1].lower()
@@ -172,11 +194,15 @@ def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = 
     if ep_group is not None:
         raise ValueError(f"model.ep > 1 needs an MoE model; {config.name!r} is dense")
     d = resolve_model_dims(config)
-    hf_cfg = Qwen3Config(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size, num_hidden_layers=d.num_hidden_layers,
-                         num_attention_heads=d.num_attention_heads, num_key_value_heads=d.num_key_value_heads, head_dim=d.head_dim,
-                         rms_norm_eps=d.rms_norm_eps, rope_theta=d.rope_theta, tie_word_embeddings=d.tie_word_embeddings)
+    # family from the two attention switches: Qwen3 (q/k norm), Llama (neither; the reference's custom class), Qwen2 (q/k/v bias; HF's class in the
+    # reference, models/__init__.py:41-59 does not register Qwen2Config)
+    cfg_cls, model_cls = (Qwen3Config, Qwen3ForCausalLM) if d.qk_norm else ((Qwen2Config, Qwen2ForCausalLM) if d.attention_bias else (LlamaConfig, LlamaForCausalLM))
+    hf_cfg = cfg_cls(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size, num_hidden_layers=d.num_hidden_layers,
+                     num_attention_heads=d.num_attention_heads, num_key_value_heads=d.num_key_value_heads, head_dim=d.head_dim,
+                     rms_norm_eps=d.rms_norm_eps, rope_theta=d.rope_theta, tie_word_embeddings=d.tie_word_embeddings, use_qk_norm=d.qk_norm,
+                     attention_bias=d.attention_bias)
     with torch.device(device):
-        model = Qwen3ForCausalLM(hf_cfg)
+        model = model_cls(hf_cfg)
     return model.to(dtype)
 
 
@@ -208,8 +234,8 @@ def setup_model(config, parallel_dims: ParallelDims, loading_from_checkpoint_lat
     elif config.debug.random_init:
         gen = torch.Generator(device="cuda").manual_seed(0)
         with torch.no_grad():
-            for p in model.parameters():
-                if p.dim() == 1:
+            for pname, p in model.named_parameters():
+                if p.dim() == 1 and not pname.endswith(".bias"):
                     p.fill_(1.0)
                 else:
                     p.copy_((torch.randn(p.shape, device="cuda", generator=gen) * 0.02).to(p.dtype))

@@ -4,7 +4,9 @@
 forward contract `forward(hidden_states [1,N,H], position_embeddings=(cos,sin), cu_seqlens i32 [S+1], max_seqlen) ->
 (out [1,N,H], None)`; it registers itself as `ATTN_IMPL2CLASS["hip_varlen"]` so `config._attn_implementation = "hip_varlen"`
 selects it (attn.py:185-189).  Inside: fused per-head q/k RMSNorm + RoPE (no transposes, attn.py:147-158 does two) and the
-MFMA varlen causal attention kernels; `max_seqlen` is accepted and ignored (the kernels need no host-side schedule)."""
+MFMA varlen causal attention kernels; `max_seqlen` is accepted and ignored (the kernels need no host-side schedule).
+`use_qk_norm=False` (the Llama block, models/llama/modeling_llama.py:52-62) runs the same kernel as RoPE only; `attention_bias=True`
+(Qwen2) puts a bias on q/k/v_proj (attn.py:64-72) — o_proj keeps `output_bias`, False everywhere on this path."""
 
 from __future__ import annotations
 
@@ -30,6 +32,25 @@ class AttentionConfig:
     rms_norm_eps: float = 1e-6
     qk_norm_type: Literal["per_head", "per_layer"] = "per_head"
     output_bias: bool = False
+
+
+class _RopeFn(torch.autograd.Function):
+    """RoPE on the q and k column blocks of the fused projection output, no per-head norm."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, hq, hkv, d):
+        q, k, _ = ops.qknorm_rope_fwd(qkv, None, None, cos, sin, hq, hkv, d, 0.0)
+        ctx.save_for_backward(cos, sin)
+        ctx.dims = (hq, hkv, d, qkv.shape)
+        return q, k
+
+    @staticmethod
+    def backward(ctx, gq, gk):
+        cos, sin = ctx.saved_tensors
+        hq, hkv, d, shape = ctx.dims
+        gqkv = torch.zeros(shape, dtype=torch.bfloat16, device=gq.device)  # v columns carry no gradient through this op
+        ops.qknorm_rope_bwd(gq.contiguous(), gk.contiguous(), None, None, None, cos, sin, None, gqkv, None, None, hq, hkv, d)
+        return gqkv, None, None, None, None, None
 
 
 class _QKNormRopeFn(torch.autograd.Function):
@@ -75,21 +96,23 @@ def varlen_causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, c
 class HipVarlenAttention(nn.Module):
     def __init__(self, config: AttentionConfig):
         super().__init__()
-        if config.head_dim != 128 or not config.is_causal or not config.use_qk_norm or config.qk_norm_type != "per_head":
-            raise NotImplementedError("hip_varlen implements the Qwen3 attention block: head_dim 128, causal, per-head q/k RMSNorm")
-        if config.attention_bias or config.output_bias:
-            raise NotImplementedError("attention biases are not on the Qwen3 path")
+        if config.head_dim != 128 or not config.is_causal or (config.use_qk_norm and config.qk_norm_type != "per_head"):
+            raise NotImplementedError("hip_varlen implements head_dim 128 causal attention with per-head q/k RMSNorm (Qwen3) or none (Llama, Qwen2)")
+        if config.output_bias:
+            raise NotImplementedError("o_proj bias is not on this path (output_bias is False for Qwen3, Qwen2 and Llama)")
         self.head_dim = config.head_dim
         self.hq, self.hkv = config.num_attention_heads, config.num_key_value_heads
         self.num_key_value_groups = self.hq // self.hkv
         self.scaling = self.head_dim**-0.5
         self.eps = config.rms_norm_eps
-        self.q_proj = nn.Linear(config.hidden_size, self.hq * self.head_dim, bias=False)
-        self.k_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=False)
-        self.v_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=False)
+        self.q_proj = nn.Linear(config.hidden_size, self.hq * self.head_dim, bias=config.attention_bias)
+        self.k_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=config.attention_bias)
+        self.v_proj = nn.Linear(config.hidden_size, self.hkv * self.head_dim, bias=config.attention_bias)
         self.o_proj = nn.Linear(self.hq * self.head_dim, config.hidden_size, bias=False)
-        self.q_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
-        self.k_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
+        self.use_qk_norm = config.use_qk_norm
+        if self.use_qk_norm:
+            self.q_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
+            self.k_norm = RMSNorm(RMSNormConfig(hidden_size=self.head_dim, eps=config.rms_norm_eps))
 
     def forward(self, hidden_states, position_embeddings=None, cu_seqlens=None, max_seqlen=None):
         b, n, _ = hidden_states.shape
@@ -100,7 +123,10 @@ class HipVarlenAttention(nn.Module):
         half = self.head_dim // 2
         # accept the reference's cat(f,f) tables too; the kernels read bf16 (the reference casts cos/sin to x.dtype, rotary_emb.py:72-73)
         cos, sin = cos.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous(), sin.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous()
-        q, k = _QKNormRopeFn.apply(qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, self.hq, self.hkv, self.head_dim, self.eps)
+        if self.use_qk_norm:
+            q, k = _QKNormRopeFn.apply(qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, self.hq, self.hkv, self.head_dim, self.eps)
+        else:
+            q, k = _RopeFn.apply(qkv, cos, sin, self.hq, self.hkv, self.head_dim)
         v = qkv[:, (self.hq + self.hkv) * self.head_dim:].view(n, self.hkv, self.head_dim)
         out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling)
         return self.o_proj(out.view(n, self.hq * self.head_dim)).unsqueeze(0), None

@@ -37,6 +37,7 @@ class Qwen3Config:
     attention_bias: bool = False
     tie_word_embeddings: bool = False
     _attn_implementation: str = "hip_varlen"
+    use_qk_norm: bool = True  # False: the Llama decoder block (models/llama/modeling_llama.py:52-62) / HF Qwen2 with attention_bias=True
 
 
 class _EmbeddingFn(torch.autograd.Function):
@@ -60,7 +61,7 @@ class Qwen3DecoderLayer(nn.Module):
         self.hidden_size = config.hidden_size
         attn_config = AttentionConfig(hidden_size=config.hidden_size, head_dim=config.head_dim, num_attention_heads=config.num_attention_heads,
                                       num_key_value_heads=config.num_key_value_heads, is_causal=True, attention_bias=config.attention_bias,
-                                      output_bias=config.attention_bias, use_qk_norm=True, rms_norm_eps=config.rms_norm_eps)
+                                      output_bias=False, use_qk_norm=config.use_qk_norm, rms_norm_eps=config.rms_norm_eps)
         self.self_attn = ATTN_IMPL2CLASS[config._attn_implementation](attn_config)
         self.mlp = MLP(MLPConfig(hidden_size=config.hidden_size, intermediate_size=config.intermediate_size, gate_act=config.hidden_act, bias=False))
         self.input_layernorm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))

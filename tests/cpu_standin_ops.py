@@ -81,7 +81,7 @@ def _qk(qkv, qw, kw, cos, sin, hq, hkv, d, eps):
     s = torch.cat([sin, sin], -1).float()[:, None, :]
 
     def one(x, w):
-        xn = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+        xn = x if w is None else w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))  # w None: use_qk_norm False, RoPE only
         rot = torch.cat([-xn[..., d // 2:], xn[..., : d // 2]], -1)
         return xn * c + rot * s
 
@@ -89,6 +89,9 @@ def _qk(qkv, qw, kw, cos, sin, hq, hkv, d, eps):
 
 
 def qknorm_rope_fwd(qkv, q_norm_w, k_norm_w, cos, sin, n_q_heads, n_kv_heads, head_dim, eps):
+    if q_norm_w is None:
+        q, k = _qk(qkv.float(), None, None, cos, sin, n_q_heads, n_kv_heads, head_dim, eps)
+        return q.to(BF16), k.to(BF16), None
     q, k = _qk(qkv.float(), q_norm_w.float(), k_norm_w.float(), cos, sin, n_q_heads, n_kv_heads, head_dim, eps)
     rstd = torch.zeros(qkv.shape[0], n_q_heads + n_kv_heads)
     return q.to(BF16), k.to(BF16), rstd
@@ -96,6 +99,13 @@ def qknorm_rope_fwd(qkv, q_norm_w, k_norm_w, cos, sin, n_q_heads, n_kv_heads, he
 
 @torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
 def qknorm_rope_bwd(grad_q, grad_k, qkv, q_norm_w, k_norm_w, cos, sin, rstd, grad_qkv, gqw, gkw, n_q_heads, n_kv_heads, head_dim):
+    w = (n_q_heads + n_kv_heads) * head_dim
+    if q_norm_w is None:  # the rotation is linear: its transpose does not need the forward input
+        x = torch.zeros(grad_qkv.shape, dtype=F32).requires_grad_(True)
+        q, k = _qk(x, None, None, cos, sin, n_q_heads, n_kv_heads, head_dim, 1e-6)
+        (gx,) = torch.autograd.grad((q, k), (x,), (grad_q.float().reshape(q.shape), grad_k.float().reshape(k.shape)))
+        grad_qkv[:, :w] = gx[:, :w].to(BF16)
+        return
     x = qkv.float().requires_grad_(True)
     qw, kw = q_norm_w.float().requires_grad_(True), k_norm_w.float().requires_grad_(True)
     q, k = _qk(x, qw, kw, cos, sin, n_q_heads, n_kv_heads, head_dim, 1e-6)
@@ -104,6 +114,10 @@ def qknorm_rope_bwd(grad_q, grad_k, qkv, q_norm_w, k_norm_w, cos, sin, rstd, gra
     grad_qkv[:, :w] = gx[:, :w].to(BF16)
     gqw += gq
     gkw += gk
+
+
+def column_sum(x, out_f32):
+    out_f32 += x.float().sum(0)
 
 
 def _seq_lens(seq_start):

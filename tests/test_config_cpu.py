@@ -105,3 +105,23 @@ def test_model_name_resolution(tmp_path):
     assert (d.vocab_size, d.num_hidden_layers, d.tie_word_embeddings) == (1000, 3, True)
     with pytest.raises(ValueError):
         resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="meta-llama/Nope"))).model)
+    # the three dense families = two attention switches (AttentionConfig.use_qk_norm / .attention_bias, models/layers/attn.py:36-37)
+    d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen2.5-1.5B-Instruct"))).model)  # BASELINE.json configs[1]
+    assert (d.hidden_size, d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.qk_norm, d.attention_bias, d.tie_word_embeddings) == (1536, 12, 2, 128, False, True, True)
+    assert d.num_params() == 1_543_714_304  # the published parameter count of Qwen2.5-1.5B
+    d3 = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen3-8B"))).model)
+    assert d3.qk_norm and not d3.attention_bias and d3.num_params() == 8_190_735_360
+    base = dict(vocab_size=1000, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2)
+    for family, want in (("llama", (False, False)), ("qwen2", (False, True)), ("qwen3", (True, False))):
+        (tmp_path / "config.json").write_text(json.dumps(dict(model_type=family, **base)))
+        d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+        assert (d.qk_norm, d.attention_bias) == want and d.head_dim == 128
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", rope_scaling=dict(rope_type="llama3", factor=8.0), **base)))
+    with pytest.raises(NotImplementedError, match="rope_scaling"):
+        resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", mlp_bias=True, **base)))
+    with pytest.raises(NotImplementedError, match="mlp_bias"):
+        resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="mistral", **base)))
+    with pytest.raises(NotImplementedError, match="model_type"):
+        resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)

@@ -37,7 +37,8 @@ def _mbs(vocab, seq_len, n_mb, packed, seed_shift=0):
 def _oracle_cfg(dims):
     return O.TinyQwen3Config(hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=dims.num_hidden_layers,
                              num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=dims.head_dim,
-                             vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta)
+                             vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta, qk_norm=dims.qk_norm,
+                             attention_bias=dims.attention_bias)
 
 
 def _parity_variant_mbs(vocab, seq_len, n_rollouts, prompt_len, seed=0):
@@ -166,9 +167,10 @@ def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=
         d = dims
         gsd = {}
         for name, gv in eng.store.g.items():
-            if name.endswith("qkv_proj.weight"):
-                base = name[: -len("qkv_proj.weight")]
-                gsd[base + "q_proj.weight"], gsd[base + "k_proj.weight"], gsd[base + "v_proj.weight"] = gv[: d.q_dim], gv[d.q_dim: d.q_dim + d.kv_dim], gv[d.q_dim + d.kv_dim:]
+            if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+                kind = name.rsplit(".", 1)[1]
+                base = name[: -len("qkv_proj." + kind)]
+                gsd[base + "q_proj." + kind], gsd[base + "k_proj." + kind], gsd[base + "v_proj." + kind] = gv[: d.q_dim], gv[d.q_dim: d.q_dim + d.kv_dim], gv[d.q_dim + d.kv_dim:]
             elif name.endswith("gate_up_proj.weight"):
                 base = name[: -len("gate_up_proj.weight")]
                 gsd[base + "gate_proj.weight"], gsd[base + "up_proj.weight"] = gv[: d.intermediate_size], gv[d.intermediate_size:]
@@ -187,13 +189,16 @@ def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=
     return engines, None
 
 
-@pytest.mark.parametrize("packed", [False, True])
-def test_engine_step_matches_oracle(packed):
+@pytest.mark.parametrize("packed,family", [(False, "qwen3"), (True, "qwen3"), (True, "qwen2"), (False, "llama")])
+def test_engine_step_matches_oracle(packed, family):
     """Tiny model (H=256, V=512, 2 layers), 8 x 256 tokens: the loss gate, then gradients and the optimizer of the SHIPPED bf16
-    engine against f32 autograd of the same model."""
+    engine against f32 autograd of the same model.  `family`: qwen3 = per-head q/k RMSNorm; qwen2 = q/k/v bias, no q/k norm (Qwen2.5 of
+    BASELINE.json configs[0-1]); llama = neither (models/llama/modeling_llama.py)."""
+    import dataclasses
+
     from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
 
-    dims = ModelDims.tiny(layers=2, vocab=512)
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family == "qwen2")
     seed_eng = GRPOEngine(dims, device=DEV, seed=0)
     # give the model non-trivial logits (std ~1)
     sd = {k: v.detach().cpu().clone() for k, v in seed_eng.store.state_dict().items()}
@@ -204,11 +209,14 @@ def test_engine_step_matches_oracle(packed):
     for k in sd:
         if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
             sd[k] = (1 + 0.1 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
+        elif k.endswith(".bias"):
+            sd[k] = (0.1 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
+    assert any(k.endswith("q_proj.bias") for k in sd) == (family == "qwen2") and any(k.endswith("q_norm.weight") for k in sd) == (family == "qwen3")
     if packed:  # FakeDataLoader's packed-document micro-batches (data.py:87-130) with a masked prefix and mixed temperatures
         mbs = _mbs(dims.vocab_size, 256, 8, True)
     else:
         mbs = _parity_variant_mbs(dims.vocab_size, 256, 8, prompt_len=32)
-    engines, norm_o = _engine_vs_f32_oracle(dims, sd, mbs, "cpu", 256, check_grads_on="bf16", tag=f"tiny packed={packed}", assert_f32=not packed)
+    engines, norm_o = _engine_vs_f32_oracle(dims, sd, mbs, "cpu", 256, check_grads_on="bf16", tag=f"tiny {family} packed={packed}", assert_f32=not packed)
     eng, _ = engines["bf16"]
     before = eng.store.master.clone()
     norm_e = eng.optimizer_step().item()

@@ -425,6 +425,55 @@ def test_embedding(ops):
     assert torch.equal(gt2, 2 * gt), "embedding bwd is not deterministic/accumulating"
 
 
+def test_rope_without_qk_norm_and_column_sum(ops):
+    """use_qk_norm = False (Llama / Qwen2 attention, models/llama/modeling_llama.py:59-60): pm_qknorm_rope_* with NULL norm weights is
+    apply_rotary_pos_emb alone, with the reference's bf16 rounding points (x*cos -> bf16, rotate_half(x)*sin -> bf16, sum -> bf16); its
+    backward is the transposed rotation.  pm_column_sum_bf16 = the bias gradient of the q/k/v projections, also on a strided column block."""
+    torch.manual_seed(11)
+    n, hq, hkv, d = 333, 6, 2, 128
+    qkv = torch.randn(n, (hq + 2 * hkv) * d).to(torch.bfloat16)
+    pos = torch.randint(0, 5000, (n,))
+    inv_freq = ops.rope_inv_freq(d, 1e6, DEV)
+    cos, sin = ops.rope_table(pos.to(DEV), inv_freq)
+    q, k, rstd = ops.qknorm_rope_fwd(qkv.to(DEV), None, None, cos, sin, hq, hkv, d, 1e-6)
+    assert rstd is None
+    c = torch.cat([cos, cos], -1).cpu()[:, None, :]
+    s = torch.cat([sin, sin], -1).cpu()[:, None, :]
+
+    def rope(x):  # bf16 in, bf16 arithmetic like the reference (rotary_emb.py:83-118 on bf16 tensors)
+        rot = torch.cat([-x[..., d // 2:], x[..., : d // 2]], -1)
+        return x * c + rot * s
+
+    assert torch.equal(q.cpu(), rope(qkv[:, : hq * d].view(n, hq, d)))
+    assert torch.equal(k.cpu(), rope(qkv[:, hq * d: (hq + hkv) * d].view(n, hkv, d)))
+    gq = torch.randn(n, hq, d).to(torch.bfloat16)
+    gk = torch.randn(n, hkv, d).to(torch.bfloat16)
+    gqkv = torch.full((n, (hq + 2 * hkv) * d), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.qknorm_rope_bwd(gq.to(DEV), gk.to(DEV), None, None, None, cos, sin, None, gqkv, None, None, hq, hkv, d)
+    x = qkv[:, : (hq + hkv) * d].float().requires_grad_(True)
+    cf, sf = c.float(), s.float()
+    y = x.view(n, hq + hkv, d)
+    out = y * cf + torch.cat([-y[..., d // 2:], y[..., : d // 2]], -1) * sf
+    (gx,) = torch.autograd.grad(out, x, torch.cat([gq, gk], 1).float())
+    _close(gqkv[:, : (hq + hkv) * d], gx, 1e-2, 1e-2, "rope-only backward")
+    assert torch.all(gqkv[:, (hq + hkv) * d:] == 7.0), "the v columns belong to attention backward"
+    with pytest.raises(Exception):
+        ops.qknorm_rope_fwd(qkv.to(DEV), torch.ones(d, dtype=torch.bfloat16, device=DEV), None, cos, sin, hq, hkv, d, 1e-6)
+    # column sums: whole matrix, strided block, ragged row counts, accumulate semantics
+    for rows in (1, 3, 255, 256, 257, 1000):
+        xm = torch.randn(rows, 1280).to(torch.bfloat16).to(DEV)
+        out = torch.ones(1280, device=DEV)
+        ops.column_sum(xm, out)
+        _close(out, 1 + xm.float().sum(0), 1e-5, 1e-4, f"column_sum rows={rows}")
+        blk = xm[:, 256:768]
+        out2 = torch.zeros(512, device=DEV)
+        ops.column_sum(blk, out2)
+        out3 = torch.zeros(512, device=DEV)
+        ops.column_sum(blk, out3)
+        _close(out2, blk.float().sum(0), 1e-5, 1e-4, f"column_sum strided rows={rows}")
+        assert torch.equal(out2, out3), "column_sum is not deterministic"
+
+
 def test_embedding_bwd_window(ops):
     """Windows of the flattened [vocab, hidden] gradient (a ZeRO shard of the embedding bucket): pieced together they are the whole-table
     scatter-add bit for bit; windows that start / end inside a row, padding ids (-1) and ids >= vocab."""

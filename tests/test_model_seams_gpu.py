@@ -48,18 +48,29 @@ def test_layer_seams_match_oracle():
     torch.testing.assert_close(out[0].cpu().float(), (a @ w["o_proj.weight"].T).float(), rtol=3e-2, atol=3e-2)
 
 
-def test_autograd_model_equals_engine():
+@pytest.mark.parametrize("family", ["qwen3", "qwen2", "llama"])
+def test_autograd_model_equals_engine(family):
+    """`family`: the nn.Module classes of the three dense families (models/qwen3, models/llama: Llama = no q/k norm, Qwen2 = q/k/v bias + tied
+    embeddings) against the flat-buffer engine with the matching ModelDims switches."""
+    import dataclasses
+
     from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, pack_micro_batches
     from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+    from prime_rl_amd.trainer.models.llama import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM
     from prime_rl_amd.trainer.models.qwen3 import Qwen3Config, Qwen3ForCausalLM
     from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
     from prime_rl_amd.trainer.rl.loss import DefaultLossConfig, compute_loss, setup_rl_loss_fn, shift_tensor_left, shift_tensor_right
 
-    dims = ModelDims.tiny(layers=2, vocab=512)
+    cfg_cls, model_cls = {"qwen3": (Qwen3Config, Qwen3ForCausalLM), "qwen2": (Qwen2Config, Qwen2ForCausalLM), "llama": (LlamaConfig, LlamaForCausalLM)}[family]
+    tied = family == "qwen2"
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family == "qwen2", tie_word_embeddings=tied)
     eng = GRPOEngine(dims, device=DEV, seed=5)
-    cfg = Qwen3Config(vocab_size=512, hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=2,
-                      num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=128)
-    model = Qwen3ForCausalLM(cfg).to(DEV).to(torch.bfloat16)
+    cfg = cfg_cls(vocab_size=512, hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=2,
+                  num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=128, tie_word_embeddings=tied,
+                  rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta)
+    model = model_cls(cfg).to(DEV).to(torch.bfloat16)
+    sd_names = set(model.state_dict())
+    assert any(k.endswith("q_proj.bias") for k in sd_names) == (family == "qwen2") and any(k.endswith("q_norm.weight") for k in sd_names) == (family == "qwen3")
     model.load_state_dict({k: v.clone() for k, v in eng.store.state_dict().items()})
     inject_prime_lm_head(model, chunk_size=64)
     mbs = FakeDataLoader(FakeDataLoaderConfig(batch_size=2, generate_samples=True), seq_len=192).get_batch()
@@ -90,9 +101,11 @@ def test_autograd_model_equals_engine():
     assert abs(ctx["loss"].item() - total) < 1e-4
     eg = eng.store.g
     d = dims
+    seen_bias = False
     for name, p in model.named_parameters():
         if "qkv" in name:
             continue
+        seen_bias |= name.endswith("q_proj.bias")
         if any(s in name for s in ("q_proj", "k_proj", "v_proj")):
             g = eg[name.replace(name.split(".")[-2], "qkv_proj")]
             lo = {"q_proj": 0, "k_proj": d.q_dim, "v_proj": d.q_dim + d.kv_dim}[name.split(".")[-2]]
@@ -105,6 +118,7 @@ def test_autograd_model_equals_engine():
         a, b = p.grad.float().flatten(), g.float().flatten()
         rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
         assert rel < 3e-2, f"{name}: relative gradient difference {rel:.4f}"
+    assert seen_bias == (family == "qwen2")
 
 
 def test_inject_prime_lm_head_into_a_stock_hf_model():
