@@ -332,7 +332,8 @@ class TrainerConfig(BaseConfig):
         return self
 
     def validate_supported(self) -> None:
-        """Raise for keys that select subsystems outside the dense GRPO policy-update path."""
+        """Raise for keys that select subsystems outside the GRPO policy-update path.  `model.ep > 1`, `freeze_moe_router`
+        and `debug.force_balanced_routing` are served by the nn.Module trainer step (trainer/module_engine.py) for the MoE families."""
         m = self.model
         bad = []
         if m.lora is not None:
@@ -341,10 +342,8 @@ class TrainerConfig(BaseConfig):
             bad.append("model.quantization (FP8 / MXFP8 training)")
         if m.vlm is not None:
             bad.append("model.vlm (vision-language models)")
-        if isinstance(m.ep, int) and m.ep > 1:
-            bad.append("model.ep > 1 (the flat-buffer train loop is dense; MoE + expert parallelism run through trainer.model.setup_model())")
-        if m.moe_fused_kernel or m.freeze_moe_router or m.debug.force_balanced_routing:
-            bad.append("MoE options (dense models only)")
+        if m.moe_fused_kernel:
+            bad.append("model.moe_fused_kernel (the fused Triton MoE kernel; expert GEMMs here are the grouped MFMA kernels)")
         if self.optim.type != "adamw":
             bad.append(f"optim.type = {self.optim.type!r} (the fused on-GPU optimizer is AdamW)")
         if self.enable_router_replay:

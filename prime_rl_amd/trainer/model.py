@@ -20,6 +20,7 @@ import json
 from pathlib import Path
 
 import torch
+import torch.distributed as dist
 from torch import Tensor, nn
 
 from .engine import GRPOEngine, LossConfig, ModelDims, OptimConfig
@@ -227,6 +228,13 @@ def setup_model(config, parallel_dims: ParallelDims, loading_from_checkpoint_lat
     if sd is not None:
         if model.config.tie_word_embeddings:
             sd.pop("lm_head.weight", None)
+        if isinstance(model, Qwen3MoeForCausalLM):  # HF per-expert names -> stacked w1 / w2 / w3, this rank's experts only under EP
+            from .models.qwen3_moe.converting_qwen3_moe import hf_to_prime
+
+            n_exp = model.config.num_experts
+            ep = dist.get_world_size(ep_group) if ep_group is not None else 1
+            first = (dist.get_rank(ep_group) if ep_group is not None else 0) * (n_exp // ep)
+            sd = hf_to_prime(sd, n_exp, range(first, first + n_exp // ep))
         missing, unexpected = model.load_state_dict(sd, strict=False)
         missing = [k for k in missing if not (model.config.tie_word_embeddings and k == "lm_head.weight")]
         if missing or unexpected:
@@ -263,6 +271,31 @@ def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, *, seq_le
     return cast_float_and_contiguous(PrimeLmOutput(logits=out.logits))
 
 
+def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.device | str = "cuda"):
+    """TrainerConfig -> the nn.Module flavour of the trainer step (trainer/module_engine.py) on the model `setup_model` builds: the path of
+    the MoE families and of `model.ep > 1` (BASELINE.json configs[3]: Qwen3-30B-A3B, expert parallel over the node)."""
+    from .module_engine import ModuleEngine
+
+    config.validate_supported()
+    if parallel_dims.cp_enabled:
+        raise NotImplementedError("context parallelism runs in the flat-buffer engine (dense models); MoE models take model.cp = 1")
+    model = setup_model(config.model, parallel_dims)
+    o, lc = config.optim, config.loss
+    if lc.type == "custom":
+        raise NotImplementedError("custom loss plugins: call prime_rl_amd.trainer.rl.loss.compute_loss on forward(model, ...) yourself")
+    optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
+    loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
+                      kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
+    ep = parallel_dims.ep if parallel_dims.ep_enabled else 1
+    return ModuleEngine(model, device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), dp_size=parallel_dims.dp_size,
+                        ep_group=parallel_dims.get_group("ep") if ep > 1 else None, ep_size=ep,
+                        ep_replica_group=parallel_dims.get_group("ep_replica") if ep > 1 else None, name=config.model.name.split("/")[-1])
+
+
+def uses_module_engine(config, parallel_dims: ParallelDims) -> bool:
+    return resolve_moe_config(config.model) is not None or parallel_dims.ep_enabled
+
+
 def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str = "cuda") -> GRPOEngine:
     """TrainerConfig -> the flat-buffer GRPO engine: ZeRO-2 over the `dp` group, (Ulysses over the `cp` group when cp > 1), fused AdamW
     with the config's optimizer fields, the config's loss.  Weights as in `setup_model`."""
@@ -270,7 +303,8 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     m = config.model
     resolve_auto_attn(m)
     if resolve_moe_config(m) is not None or parallel_dims.ep_enabled:
-        raise NotImplementedError("the flat-buffer engine is the dense Qwen3 path; MoE models (and model.ep > 1) run through setup_model() / forward()")
+        raise NotImplementedError("the flat-buffer engine is the dense path; MoE models (and model.ep > 1) run through setup_module_engine() "
+                                  "(trainer/module_engine.py) on setup_model() / forward()")
     dims = resolve_model_dims(m)
     if parallel_dims.cp_enabled and m.cp_style != "ulysses":
         raise NotImplementedError("context parallelism on MI355X is Ulysses (all-to-all over the xGMI full mesh): set model.cp_style = 'ulysses'; "

@@ -1,0 +1,235 @@
+"""The trainer step for nn.Module models — the Qwen3-MoE family under expert parallelism (BASELINE.json configs[3]).
+
+`GRPOEngine` (trainer/engine.py) is a flat-buffer schedule written for the dense decoder; models that run through `setup_model()` /
+`forward()` (trainer/model.py — the reference's own seams, src/prime_rl/trainer/model.py:1314,1431) get the same step here, with the
+same result contract as `GRPOEngine.step`, so `train(config)`, the step statistics and the filesystem weight broadcast are shared:
+
+  scale all-reduce -> per pass: model forward (HIP layer seams, fused LM head -> log-probs + entropy) -> the fused GRPO loss kernel
+  (loss, d loss / d log-prob, per-sample metrics: the K2 launch the dense engine uses) -> autograd backward seeded with that gradient ->
+  f32 gradient accumulation -> gradient reduction -> global-norm clip -> fused AdamW on f32 master weights -> bf16 parameters.
+
+What the reference does here (train.py:337-480 micro-batch loop, FSDP2 reduce-scatter with `reduce_dtype=float32`, `scale_gradients_`,
+`clip_grad_norm_` with the expert-parallel mesh, torch AdamW on f32 master parameters; MoE specifics in model.py:823-960 and
+distributed/expert_parallel.py) maps as follows on a 288 GB part:
+
+  * replicated parameters (attention, norms, router gates, embeddings, LM head): one f32 all-reduce(SUM) of their contiguous gradient
+    region over every trainer rank.  SUM, not mean: the loss is divided by the GLOBAL token count (train.py:307-323, 557-558).
+  * expert parameters: each rank owns E / ep experts and has already seen the tokens every rank of its ep group routed to them (the
+    dispatch all-to-all), so their gradients are complete within the ep group; they are summed over the ranks that hold the SAME
+    experts in other ep groups (`ep_replica`), nothing when ep == world.
+  * the global gradient norm counts replicated parameters once and expert parameters once per ep position:
+    sum_sq(replicated) + all-reduce over the ep group of sum_sq(local experts).
+  * master weights / Adam moments: flat f32, replicated for the replicated parameters (1.5 B of Qwen3-30B-A3B's 30.5 B), local for the
+    experts — the experts are what is big, and expert parallelism already shards them.
+
+Parameters are re-pointed at one flat bf16 buffer (f32 parameters such as an f32 router gate at the f32 master buffer itself), so the
+optimizer is ONE fused `pm_adamw_step` launch and gradient reduction is one collective per class."""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .. import _lib, ops
+from .._lib import LossParams, PrimeMI355XError
+from . import zero
+from .engine import LossConfig, OptimConfig, PackedBatch
+from .models.layers.moe import GroupedExperts
+
+
+@dataclass
+class ModuleDims:
+    """What train() reads from `engine.dims`: vocabulary size and the reference's flop model (trainer/perf.py:110-215) for any HF-style config."""
+
+    config: object
+    name: str = "module"
+
+    @property
+    def vocab_size(self) -> int:
+        return self.config.vocab_size
+
+    def active_mm_params(self) -> int:
+        c = self.config
+        h, L = c.hidden_size, c.num_hidden_layers
+        attn = L * (2 * h * c.num_attention_heads * c.head_dim + 2 * h * c.num_key_value_heads * c.head_dim)
+        k = getattr(c, "num_experts_per_tok", None)
+        if k:  # every layer counted sparse, as the reference does once `num_experts_per_tok` exists (perf.py:148-150)
+            moe_i = getattr(c, "moe_intermediate_size", None) or c.intermediate_size
+            mlp = L * (k * 3 * moe_i * h + c.num_experts * h)
+        else:
+            mlp = L * 3 * c.intermediate_size * h
+        return attn + mlp + c.vocab_size * h
+
+    def flops_per_token(self, seq_len: int) -> int:
+        c = self.config
+        return 6 * self.active_mm_params() + 12 * c.num_hidden_layers * c.num_attention_heads * (c.hidden_size // c.num_attention_heads) * seq_len
+
+
+def _align(n: int, a: int = 128) -> int:
+    return (n + a - 1) // a * a
+
+
+class ModuleEngine:
+    def __init__(self, model: nn.Module, device, optim: OptimConfig | None = None, loss: LossConfig | None = None, dp_group=None, dp_size: int = 1,
+                 ep_group=None, ep_size: int = 1, ep_replica_group=None, name: str = "module"):
+        self.model, self.device = model, torch.device(device)
+        self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
+        self.dp_group, self.dp_size = dp_group, dp_size
+        self.ep_group, self.ep_size, self.ep_replica_group = ep_group, ep_size, ep_replica_group
+        if ep_size > 1 and dp_size % ep_size:
+            raise PrimeMI355XError(f"ep = {ep_size} must divide the {dp_size} trainer ranks")
+        if dp_size > ep_size > 1 and ep_replica_group is None:
+            raise PrimeMI355XError("ranks that hold the same experts in different ep groups need the `ep_replica` group to sum their gradients")
+        self.dims = ModuleDims(model.config, name)
+        self.step_count = 0
+        self.cp_size = 1
+        # -- flat storage: replicated parameters first, expert parameters after them ---------------------------------------------------
+        expert_ids = {id(p) for m in model.modules() if isinstance(m, GroupedExperts) for p in m.parameters(recurse=False)} if ep_size > 1 else set()
+        seen, replicated, experts = set(), [], []
+        for pname, p in model.named_parameters():
+            if id(p) in seen or not p.requires_grad:
+                continue
+            seen.add(id(p))
+            (experts if id(p) in expert_ids else replicated).append((pname, p))
+        self.entries: list[tuple[str, nn.Parameter, int]] = []
+        cursor = 0
+        for pname, p in replicated:
+            self.entries.append((pname, p, cursor))
+            cursor = _align(cursor + p.numel())
+        self.n_replicated = cursor = _align(cursor, 256)  # [0, n_replicated): one all-reduce over every trainer rank
+        for pname, p in experts:
+            self.entries.append((pname, p, cursor))
+            cursor = _align(cursor + p.numel())
+        self.total = _align(cursor, 256)
+        dev = self.device
+        self.params_bf16 = torch.zeros(self.total, dtype=torch.bfloat16, device=dev)
+        self.master = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.main_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self._grad_views: list[Tensor] = []
+        with torch.no_grad():
+            for pname, p, off in self.entries:
+                n = p.numel()
+                if p.dtype not in (torch.bfloat16, torch.float32):
+                    raise PrimeMI355XError(f"{pname}: parameters are bf16 (compute) or f32 (e.g. an f32 router gate), got {p.dtype}")
+                self.master[off:off + n].copy_(p.detach().reshape(-1).float())
+                if p.dtype == torch.bfloat16:
+                    self.params_bf16[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = self.params_bf16[off:off + n].view(p.shape)
+                else:  # an f32 parameter IS its master copy; its bf16 shadow is scratch for the fused kernel
+                    p.data = self.master[off:off + n].view(p.shape)
+                self._grad_views.append(self.main_grad[off:off + n].view(p.shape))
+        self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._have_grad = False
+
+    # -- GRPOEngine-compatible surface used by train() and the weight broadcast -----------------------------------------------------
+    def wait_params_ready(self) -> None:
+        return None
+
+    @property
+    def collective_state_dict(self) -> bool:
+        """True when state_dict() runs collectives (every rank must call it, not only the rank that writes the checkpoint)."""
+        return self.ep_size > 1
+
+    def state_dict(self) -> dict[str, Tensor]:
+        """HF-named bf16 tensors of the WHOLE model (what the inference engine loads, transports/weights): expert shards are all-gathered
+        over the ep group, MoE names converted like the reference's `revert_weight_conversion` (transports/weights/nccl.py:87-98)."""
+        sd = {k: v.detach() for k, v in self.model.state_dict().items()}
+        sd = {k: (v if v.dtype == torch.bfloat16 or not v.is_floating_point() else v.to(torch.bfloat16)) for k, v in sd.items()}
+        if self.ep_size > 1:
+            for key in [k for k in sd if ".mlp.experts.w" in k]:
+                local = sd[key].contiguous()
+                full = torch.empty((local.shape[0] * self.ep_size, *local.shape[1:]), dtype=local.dtype, device=local.device)
+                dist.all_gather_into_tensor(full, local, group=self.ep_group)
+                sd[key] = full
+        if getattr(self.model.config, "num_experts", None):
+            from .models.qwen3_moe.converting_qwen3_moe import prime_to_hf
+
+            sd = prime_to_hf(sd)
+        return sd
+
+    def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:
+        if self.dp_size == 1:
+            return tuple(max(int(c), 1) for c in local_counts)
+        return zero.all_reduce_counts(local_counts, self.dp_group, self.device)
+
+    # -- one pass -------------------------------------------------------------------------------------------------------------------
+    def forward_loss(self, b: PackedBatch, scales: tuple[int, int, int]) -> dict:
+        n = b.n_tokens
+        seq_lens = (b.cu_seqlens[1:] - b.cu_seqlens[:-1]).to(torch.int64)
+        out = self.model(input_ids=b.input_ids.view(1, n), position_ids=b.position_ids.view(1, n), labels=b.labels.view(1, n),
+                         temperature=(1.0 / b.inv_temp).view(1, n), seq_lens=seq_lens)
+        if not isinstance(out, dict) or "logprobs" not in out:
+            raise PrimeMI355XError("the model must return log-probs and entropy (inject_prime_lm_head with the fused head; trainer/model.py:setup_model does)")
+        logprobs = out["logprobs"].reshape(n).float()
+        entropy = out["entropy"].reshape(n).float().detach()
+        c = self.loss_cfg
+        params = LossParams(loss_type=_lib.PM_LOSS_IPO if c.type == "ipo" else _lib.PM_LOSS_DEFAULT, dppo_mask_low=c.dppo_mask_low,
+                            dppo_mask_high=c.dppo_mask_high, adv_tau=c.adv_tau, kl_tau=c.kl_tau, ipo_threshold=c.ipo_threshold,
+                            rl_scale=float(max(scales[0], 1)), ce_scale=float(max(scales[1], 1)), ref_kl_scale=float(max(scales[2], 1)), shift=1,
+                            pad_logprob=math.log(1.0 / self.dims.vocab_size))
+        loss, grad, stats, metrics = ops.grpo_loss_fwd_bwd(logprobs.detach().contiguous(), b.inference_logprobs, b.advantages, b.loss_mask, b.cu_samples,
+                                                           params, ref_logprobs=b.ref_logprobs, rl_weights=b.rl_weights, ce_weights=b.ce_weights,
+                                                           ref_kl_weights=b.ref_kl_weights, sample_starts_mb=b.sample_starts_mb)
+        return dict(loss=loss, grad_logprobs=grad, sample_stats=stats, sample_metrics=metrics, logprobs=logprobs, entropy=entropy)
+
+    def backward(self, ctx: dict) -> None:
+        """d loss / d parameters through the autograd graph, seeded with the loss kernel's d loss / d log-prob; gradients land in f32."""
+        ctx["logprobs"].backward(ctx["grad_logprobs"])
+        with torch.no_grad():
+            for (pname, p, off), gv in zip(self.entries, self._grad_views):
+                if p.grad is None:
+                    continue
+                if p.grad.dtype == torch.bfloat16 and p.numel() % 8 == 0:
+                    ops.grad_accumulate(gv.view(-1), p.grad.contiguous().view(-1))
+                else:
+                    gv.add_(p.grad)
+                p.grad = None
+        self._have_grad = True
+
+    # -- optimizer ------------------------------------------------------------------------------------------------------------------
+    def optimizer_step(self) -> Tensor:
+        self.step_count += 1
+        nr, g = self.n_replicated, self.main_grad
+        if self.dp_size > 1:
+            if nr:
+                dist.all_reduce(g[:nr], op=dist.ReduceOp.SUM, group=self.dp_group)
+            if self.total > nr and (self.ep_size == 1 or self.dp_size > self.ep_size):
+                dist.all_reduce(g[nr:], op=dist.ReduceOp.SUM, group=self.ep_replica_group if self.ep_size > 1 else self.dp_group)
+        self._sumsq.zero_()
+        if nr:
+            ops.sumsq_accumulate(g[:nr], self._sumsq[0:1])
+        if self.total > nr:
+            ops.sumsq_accumulate(g[nr:], self._sumsq[1:2])
+            if self.ep_size > 1:
+                dist.all_reduce(self._sumsq[1:2], op=dist.ReduceOp.SUM, group=self.ep_group)
+        total = self._sumsq.sum().reshape(1)
+        o = self.optim
+        coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)
+        ops.adamw_step(self.master, self.exp_avg, self.exp_avg_sq, g, self.params_bf16, o.lr, o.betas1, o.betas2, o.eps, o.weight_decay, self.step_count,
+                       1.0, coef, zero_grad=True)
+        self._have_grad = False
+        return norm
+
+    def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:
+        passes = batch if isinstance(batch, list) else [batch]
+        counts = tuple(sum(p.local_counts[k] for p in passes) for k in range(3))
+        scales = self.global_scales(counts)
+        out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": []}
+        for p in passes:
+            ctx = self.forward_loss(p, scales)
+            self.backward(ctx)
+            out["loss"].append(ctx["loss"])
+            out["entropy"].append(ctx["entropy"])
+            out["logprobs"].append(ctx["logprobs"].detach())
+            out["sample_metrics"].append(ctx["sample_metrics"])
+            out["sample_stats"].append(ctx["sample_stats"])
+            del ctx
+        out["grad_norm"] = self.optimizer_step()
+        out["scales"] = scales
+        return out

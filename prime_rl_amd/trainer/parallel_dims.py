@@ -86,7 +86,7 @@ class ParallelDims:
         return rank % self.cp
 
     def get_group(self, name: str):
-        """"dp" (same cp position, different micro-batches), "cp" (one packed row), "dp_cp" (gradient reduction = everyone), "ep" (`ep`
+        """"dp" (same cp position, different micro-batches), "cp" (one packed row), "dp_cp" (gradient reduction = everyone), "ep_replica" (same ep position in every ep group), "ep" (`ep`
         consecutive ranks of dp_cp that share one set of experts, parallel_dims.py:150-190 of the reference: ep borrows from dp_shard x cp).
         Every rank must call this for the same names in the same order (new_group is collective).  None = the default group / no group."""
         if name in self._groups:
@@ -117,6 +117,13 @@ class ParallelDims:
             if self.ep > 1:
                 for first in range(0, self.world_size, self.ep):
                     ranks = list(range(first, first + self.ep))
+                    g = dist.new_group(ranks)
+                    if rank in ranks:
+                        mine = g
+        elif name == "ep_replica":  # the ranks that hold the SAME experts in different ep groups (they sum their expert gradients)
+            if 1 < self.ep < self.world_size:
+                for pos in range(self.ep):
+                    ranks = list(range(pos, self.world_size, self.ep))
                     g = dist.new_group(ranks)
                     if rank in ranks:
                         mine = g

@@ -27,7 +27,7 @@ from ... import _lib
 from ...configs.trainer import TrainerConfig, parse_argv
 from ...transports.weights import setup_weight_broadcast
 from ..engine import pack_micro_batches
-from ..model import setup_engine
+from ..model import setup_engine, setup_module_engine, uses_module_engine
 from ..parallel_dims import get_parallel_dims
 from ..stats import STAT_SUFFIXES, Tensors, collect_step_tensors
 from .data import DataLoader, FakeDataLoader
@@ -89,7 +89,8 @@ def train(config: TrainerConfig) -> list[dict]:
     # the torchrun world holds trainer ranks only; the inference GPUs are reached through a SEPARATE raw RCCL communicator bootstrapped at
     # weight_broadcast.host:port (below), as in the reference (transports/weights/nccl.py:128-136) — ZeRO shards can never span them
     parallel_dims = get_parallel_dims(config.model, config.model.seq_len, world_size=trainer_world)
-    engine = setup_engine(config, parallel_dims, device=device)
+    # dense models: the flat-buffer engine; MoE families / expert parallelism: the same step on the nn.Module tree (trainer/module_engine.py)
+    engine = (setup_module_engine if uses_module_engine(config, parallel_dims) else setup_engine)(config, parallel_dims, device=device)
     dims = engine.dims
     dp_rank, dp_world = parallel_dims.dp_rank_of(rank), parallel_dims.dp_size
     out_dir = Path(config.output_dir)

@@ -69,10 +69,12 @@ class FileSystemWeightBroadcast(WeightBroadcast):
     def broadcast_weights(self, model, step: int) -> None:
         from safetensors.torch import save_file
 
+        # an expert-parallel model assembles its full state dict with collectives: then every rank takes part, the master writes
+        named = _named_tensors(model) if (self.is_master or getattr(model, "collective_state_dict", False)) else None
         if self.is_master:
             save_dir = get_step_path(get_broadcast_dir(self.output_dir), step)
             save_dir.mkdir(parents=True, exist_ok=True)
-            tensors = {k: v.detach().to("cpu").contiguous().clone() for k, v in _named_tensors(model).items()}
+            tensors = {k: v.detach().to("cpu").contiguous().clone() for k, v in named.items()}
             tmp = save_dir / "model.safetensors.tmp"
             save_file(tensors, str(tmp))
             tmp.rename(save_dir / "model.safetensors")

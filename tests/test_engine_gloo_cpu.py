@@ -68,6 +68,7 @@ def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)  # small tensors: a full thread pool per worker only oversubscribes the host
     dp = world // cp
     if cp == 1:
         E, eng = _engine(tied=tied)

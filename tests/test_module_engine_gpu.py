@@ -1,0 +1,114 @@
+"""GPU suite: the nn.Module flavour of the trainer step (trainer/module_engine.py — the MoE / expert-parallel path of train()):
+
+  * on a DENSE model it must reproduce the flat-buffer engine (the path every parity gate runs on) — loss, gradient norm, parameters after
+    optimizer steps — from the same weights and rollouts: same kernels underneath, different schedule (autograd graph + one fused AdamW launch
+    over flat buffers instead of the hand-scheduled backward);
+  * train(config) on a Qwen3-MoE model: the reference's launch grammar, metric keys, HF-named filesystem broadcast with per-expert tensors."""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mbs(vocab, seq_len, n_mb, shift=0):
+    from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+    dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=n_mb, generate_samples=True), seq_len=seq_len)
+    dl.batch_counter = shift
+    mbs = dl.get_batch()
+    for mb in mbs:
+        mb["input_ids"] = mb["input_ids"] % vocab
+        mb["temperatures"] = torch.where(torch.arange(seq_len)[None] % 3 == 0, 0.7, 1.0)
+    return mbs
+
+
+@pytest.mark.parametrize("family", ["qwen3", "qwen2"])
+def test_module_engine_equals_flat_engine_on_a_dense_model(family):
+    import dataclasses
+
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+    from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+    from prime_rl_amd.trainer.models.llama import Qwen2Config, Qwen2ForCausalLM
+    from prime_rl_amd.trainer.models.qwen3 import Qwen3Config, Qwen3ForCausalLM
+    from prime_rl_amd.trainer.module_engine import ModuleEngine
+
+    tied = family == "qwen2"
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family == "qwen2", tie_word_embeddings=tied)
+    optim = OptimConfig(lr=1e-3, weight_decay=0.01, max_norm=1.0)
+    flat = GRPOEngine(dims, device=DEV, optim=optim, seed=5)
+    cfg_cls, model_cls = (Qwen3Config, Qwen3ForCausalLM) if family == "qwen3" else (Qwen2Config, Qwen2ForCausalLM)
+    cfg = cfg_cls(vocab_size=512, hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=2, num_attention_heads=dims.num_attention_heads,
+                  num_key_value_heads=dims.num_key_value_heads, head_dim=128, tie_word_embeddings=tied)
+    model = model_cls(cfg).to(DEV).to(torch.bfloat16)
+    model.load_state_dict({k: v.clone() for k, v in flat.store.state_dict().items()})
+    inject_prime_lm_head(model, chunk_size=128)
+    mod = ModuleEngine(model, DEV, optim=optim)
+    sd0 = {k: v.float().clone() for k, v in flat.store.state_dict().items()}
+    # parameters now live in the flat buffers: one bf16 buffer holds every bf16 parameter
+    assert all(p.data_ptr() >= mod.params_bf16.data_ptr() and p.data_ptr() < mod.params_bf16.data_ptr() + mod.params_bf16.numel() * 2 for p in model.parameters())
+    assert mod.n_replicated == mod.total  # no expert parallelism: everything is replicated
+    for step in range(3):
+        mbs = _mbs(512, 192, 4, shift=step)
+        passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+        a = flat.step(passes)
+        b = mod.step(passes)
+        flat.wait_params_ready()
+        la, lb = sum(x.item() for x in a["loss"]), sum(x.item() for x in b["loss"])
+        # step 0: identical weights -> the only differences are GEMM shapes (fused qkv / gate|up vs separate projections).  Later steps start
+        # from parameters that differ by a few flipped AdamW updates (|delta| = lr per element at step 1)
+        assert abs(la - lb) < (1e-4 if step == 0 else 5e-4), (step, la, lb)
+        na, nb = a["grad_norm"].item(), b["grad_norm"].item()
+        assert abs(na - nb) / na < (2e-2 if step == 0 else 5e-2), (step, na, nb)
+        assert a["scales"] == b["scales"]
+        for x, y in zip(a["logprobs"], b["logprobs"]):
+            d = (x - y).abs()
+            assert d.mean() < (4e-3 if step == 0 else 2e-2), (step, d.mean().item())
+        for key in ("sample_stats", "sample_metrics"):
+            assert all(x.shape == y.shape for x, y in zip(a[key], b[key]))
+    sd_flat, sd_mod = flat.store.state_dict(), mod.state_dict()
+    assert set(sd_flat) == set(sd_mod)
+    for k in sd_flat:
+        # three AdamW steps of |update| <= lr each: the two engines move every matrix the same way (the module engine takes bf16 per-pass gradients
+        # from autograd where the flat engine accumulates f32 weight gradients, so near-zero gradient elements may step in opposite directions)
+        da, db = (sd_flat[k].float() - sd0[k]).flatten(), (sd_mod[k].float() - sd0[k]).flatten()
+        cos = torch.nn.functional.cosine_similarity(da, db, dim=0).item()
+        # (the k_proj bias barely matters to the loss — a constant added to every key moves no softmax except through RoPE — so its Adam-normalised
+        # update is mostly the sign of noise: a looser bound for vectors)
+        assert float((da - db).abs().max()) <= 6.5 * 1e-3 and cos > (0.9 if sd0[k].dim() > 1 else 0.7), (k, float((da - db).abs().max()), cos)
+    assert torch.count_nonzero(mod.main_grad) == 0  # the fused optimizer launch zeroes the f32 gradients for the next step
+
+
+def test_train_loop_on_a_qwen3_moe_model(tmp_path, capsys):
+    """`train(config)` picks the module engine for an MoE model: reference launch grammar, metric keys, loss that moves under a large lr, and a
+    filesystem broadcast in HF names (per-expert gate / up / down projections, `mlp.gate.weight` router)."""
+    from safetensors.torch import load_file
+
+    from prime_rl_amd.configs.trainer import parse_argv
+    from prime_rl_amd.trainer.module_engine import ModuleDims
+    from prime_rl_amd.trainer.rl.train import train
+
+    toml = tmp_path / "rl.toml"
+    toml.write_text('max_steps = 3\n\n[data.fake]\nbatch_size = 4\ngenerate_samples = true\n\n[model]\nseq_len = 128\n\n[optim]\nlr = 1e-3\n')
+    cfg = parse_argv(["@", str(toml), "--model.name", "tiny-moe", "--model.debug.random-init", "--output-dir", str(tmp_path), "--tokens-per-pass", "256",
+                      "--monitors.file.path", "metrics.jsonl"])
+    hist = train(cfg)
+    assert len(hist) == 3
+    for key in ("perf/throughput", "perf/mfu", "optim/lr", "optim/grad_norm", "loss/mean", "entropy/all/mean", "mismatch_kl/all/max", "is_masked/mean"):
+        assert key in hist[0] and math.isfinite(hist[2][key]), key
+    assert hist[0]["optim/grad_norm"] > 0 and hist[0]["perf/mfu"] > 0
+    assert any(abs(hist[0][k] - hist[2][k]) > 0 for k in ("loss/mean", "entropy/all/mean"))  # the parameters moved
+    sd = load_file(str(tmp_path / "broadcasts" / "step_3" / "model.safetensors"))
+    assert "model.layers.0.mlp.gate.weight" in sd and "model.layers.1.mlp.experts.7.down_proj.weight" in sd and "model.layers.0.mlp.experts.0.gate_proj.weight" in sd
+    assert not any(".experts.w1" in k or "router.gate" in k for k in sd)
+    assert sd["model.layers.0.mlp.experts.3.up_proj.weight"].shape == (128, 256) and all(v.dtype == torch.bfloat16 for v in sd.values())
+    # the reference's flop model for an MoE config (perf.py:110-175): top-k experts + router + attention + head per token
+    from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig
+
+    c = Qwen3MoeConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, num_experts=8,
+                       num_experts_per_tok=2, moe_intermediate_size=128)
+    want = 2 * (2 * 256 * 4 * 128 + 2 * 256 * 2 * 128) + 2 * (2 * 3 * 128 * 256 + 8 * 256) + 512 * 256
+    assert ModuleDims(c).active_mm_params() == want

@@ -58,6 +58,7 @@ def _make(world_experts, dim, hidden, k, ep_group, seed):
 def _worker(rank, world, port, n_experts):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)  # small tensors: a full thread pool per worker only oversubscribes the host
     try:
         _patch_ops()
         dim, hidden, k = 32, 16, 2
@@ -97,6 +98,7 @@ def test_expert_parallel_layer_equals_single_rank_layer(world, n_experts):
 def _groups_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)  # small tensors: a full thread pool per worker only oversubscribes the host
     try:
         sys.path.insert(0, str(ROOT))
         from prime_rl_amd.trainer.parallel_dims import ParallelDims
@@ -143,6 +145,7 @@ def _patch_all_ops():
 def _model_worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)  # small tensors: a full thread pool per worker only oversubscribes the host
     try:
         _patch_all_ops()
         from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
