@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import json
 import sys
+import time
 from pathlib import Path
 
 import torch
@@ -308,9 +309,50 @@ def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
     out.append(dict(kernel=f"MoE layer fwd+bwd [{n} tokens, {e} experts top-{k}, {h}/{hidden}]", ms=med * 1e3))
 
 
+def bench_moe_step(out, layers=8, n_mb=8, seq=2048, steps=3):
+    """The module-engine trainer step (trainer/module_engine.py) on a Qwen3-30B-A3B-width model cut to `layers` layers (the full 48 need the
+    expert-parallel node: 30.5 B parameters x 18 B of f32 state): forward + loss + backward + clip + fused AdamW on one GPU."""
+    from prime_rl_amd.trainer.engine import OptimConfig, pack_micro_batches
+    from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+    from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+    from prime_rl_amd.trainer.module_engine import ModuleEngine
+    from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+    cfg = Qwen3MoeConfig(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=layers, num_attention_heads=32, num_key_value_heads=4,
+                         num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768, norm_topk_prob=True)
+    with torch.device(DEV):
+        model = Qwen3MoeForCausalLM(cfg)
+    model = model.to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.02).to(p.dtype))
+    inject_prime_lm_head(model, chunk_size=8192)
+    eng = ModuleEngine(model, DEV, optim=OptimConfig())
+    dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=n_mb), seq_len=seq)
+    batches = [[pack_micro_batches(dl.get_batch(), DEV)] for _ in range(steps + 1)]
+    eng.step(batches[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        eng.step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tok = n_mb * seq
+    flops = eng.dims.flops_per_token(seq) * tok
+    out.append(dict(kernel=f"module-engine step, Qwen3-30B-A3B width, {layers} of 48 layers, {n_mb} x {seq} tokens", ms=dt * 1e3, tokens_per_s=tok / dt,
+                    samples_per_s=n_mb / dt, mfu_pct=100 * flops / dt / 2.5e15, params_B=sum(p.numel() for p in model.parameters()) / 1e9,
+                    peak_mem_GiB=torch.cuda.max_memory_allocated() / 2**30))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
+    if which == "moestep":
+        bench_moe_step(out, layers=int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     if which == "attnfwd":
         bench_attn_variants(out, 0, [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3, 0, 1, 2])
     if which == "attnbwd":
