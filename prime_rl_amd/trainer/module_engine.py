@@ -126,10 +126,15 @@ class ModuleEngine:
                 self._grad_views.append(self.main_grad[off:off + n].view(p.shape))
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
         self._have_grad = False
+        self._param_readers: list = []
 
     # -- GRPOEngine-compatible surface used by train() and the weight broadcast -----------------------------------------------------
     def wait_params_ready(self) -> None:
         return None
+
+    def add_param_reader(self, event) -> None:
+        """Completion event of an asynchronous reader of the parameters (the weight push stream): the next optimizer step waits for it."""
+        self._param_readers.append(event)
 
     @property
     def collective_state_dict(self) -> bool:
@@ -195,6 +200,10 @@ class ModuleEngine:
     # -- optimizer ------------------------------------------------------------------------------------------------------------------
     def optimizer_step(self) -> Tensor:
         self.step_count += 1
+        for ev in self._param_readers:  # an in-flight weight push still reads the parameters this step is about to overwrite
+            if self.device.type == "cuda":
+                torch.cuda.current_stream().wait_event(ev)
+        self._param_readers.clear()
         nr, g = self.n_replicated, self.main_grad
         if self.dp_size > 1:
             if nr:

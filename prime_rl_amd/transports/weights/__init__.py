@@ -212,28 +212,35 @@ class RCCLWeightBroadcast(WeightBroadcast):
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
         store = getattr(model, "store", model)
+        flat = hasattr(store, "buckets")  # GRPOEngine / ParamStore; otherwise an nn.Module engine (trainer/module_engine.py: MoE, expert parallel)
+        if not flat and self.protocol != "reference":
+            raise NotImplementedError("the sharded push walks the flat parameter buckets of the dense engine; nn.Module engines (MoE models) push with the "
+                                      "reference byte protocol: PRIME_PUSH_PROTOCOL=reference")
         if hasattr(model, "wait_params_ready"):
             model.wait_params_ready()
+        # HF-named tensors; an expert-parallel model assembles them with collectives over its ep group, so every trainer rank takes part
+        named = None if flat else (model.state_dict() if (self.rank == 0 or getattr(model, "collective_state_dict", False)) else None)
+        device = store.params.device if flat else torch.device(model.device)
         save_dir = get_step_path(get_broadcast_dir(self.output_dir), step)
         if self.rank == 0:
             save_dir.mkdir(parents=True, exist_ok=True)
-            (save_dir / "LAYOUT.json").write_text(json.dumps(build_layout(store)))
+            if flat:
+                (save_dir / "LAYOUT.json").write_text(json.dumps(build_layout(store)))
             self._notify_orchestrator(save_dir)
             sync_wait_for_path(save_dir / NCCL_READY_MARKER, interval=0.05, timeout=self.ready_timeout)
         # every trainer rank waits for the inference pool before enqueuing collectives (nccl.py:203-211)
         if self.dp > 1 and dist.is_initialized():
             dist.barrier(group=self.trainer_group)
-        on_gpu = store.params.is_cuda
-        if on_gpu:
+        if device.type == "cuda":
             if self._stream is None:
-                self._stream = torch.cuda.Stream(device=store.params.device)
+                self._stream = torch.cuda.Stream(device=device)
             final = torch.cuda.Event()
             final.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 self._stream.wait_event(final)
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self._stream)
-                self._push(store, model)
+                self._push(store, named, device)
                 t1.record(self._stream)
             self._events = (t0, t1)
             if hasattr(model, "add_param_reader"):
@@ -241,13 +248,13 @@ class RCCLWeightBroadcast(WeightBroadcast):
             else:
                 torch.cuda.current_stream().wait_event(t1)
         else:
-            self._push(store, model)
+            self._push(store, named, device)
 
-    def _push(self, store, model) -> None:
+    def _push(self, store, named, device) -> None:
         if self.protocol == "sharded":
             push_sharded(self.comm, store, self.rank, self.dp, self.n_inf)
         elif self.rank == 0:
-            send_reference_protocol(self.comm, store.state_dict(), store.params.device)
+            send_reference_protocol(self.comm, named if named is not None else store.state_dict(), device)
 
     def last_transfer_seconds(self) -> float | None:
         """Device time of the most recent push (synchronises with its completion)."""

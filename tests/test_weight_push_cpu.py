@@ -154,3 +154,64 @@ def test_filesystem_broadcast(tmp_path):
     sd = load_file(str(tmp_path / "broadcasts" / "step_3" / "model.safetensors"))
     assert torch.equal(sd["model.layers.0.mlp.up_proj.weight"], store.state_dict()["model.layers.0.mlp.up_proj.weight"])
     assert (tmp_path / "broadcasts" / "step_3" / "STABLE").exists() and not (tmp_path / "broadcasts" / "step_1").exists()
+
+
+def _moe_worker(rank, world, port, out_dir):
+    """2 expert-parallel trainer ranks (each holds half of the experts of a Qwen3-MoE model in a ModuleEngine) + 1 inference rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from prime_rl_amd.comm import TorchGroupCommunicator
+    from prime_rl_amd.transports.weights import NCCL_READY_MARKER, RCCLWeightBroadcast, RCCLWeightReceiver
+
+    grp = dist.new_group([0, 2])  # the reference protocol's communicator: trainer master + inference ranks
+    comm = TorchGroupCommunicator(grp) if rank in (0, 2) else None
+    trainers = dist.new_group([0, 1])
+    out = Path(out_dir)
+    step_dir = out / "broadcasts" / "step_3"
+    if rank < 2:
+        from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+        from prime_rl_amd.trainer.models.qwen3_moe.converting_qwen3_moe import prime_to_hf
+        from prime_rl_amd.trainer.module_engine import ModuleEngine
+
+        cfg = Qwen3MoeConfig(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                             num_experts=4, num_experts_per_tok=2, moe_intermediate_size=32, use_grouped_mm=False)
+        torch.manual_seed(3)
+        full = Qwen3MoeForCausalLM(cfg)
+        for p in full.parameters():
+            torch.nn.init.normal_(p, std=0.1)
+        full = full.to(torch.bfloat16)
+        local = Qwen3MoeForCausalLM(cfg, ep_group=trainers).to(torch.bfloat16)
+        local.load_state_dict({k: (v[rank * 2:(rank + 1) * 2].clone() if ".experts.w" in k else v.clone()) for k, v in full.state_dict().items()})
+        eng = ModuleEngine(local, "cpu", dp_group=trainers, dp_size=2, ep_group=trainers, ep_size=2)
+        if rank == 0:
+            torch.save({k: v.clone() for k, v in prime_to_hf({k: v.detach() for k, v in full.state_dict().items()}).items()}, out / "sent.pt")
+        wb = RCCLWeightBroadcast(out, comm, rank, 2, 1, protocol="reference", ready_timeout=60, trainer_group=trainers)
+        wb.broadcast_weights(eng, 3)
+        if rank == 0:
+            import pytest as _pytest
+
+            with _pytest.raises(NotImplementedError, match="reference byte protocol"):
+                RCCLWeightBroadcast(out, comm, rank, 2, 1, protocol="sharded").broadcast_weights(eng, 4)
+    else:
+        t0 = time.time()
+        while not (step_dir / "STABLE").exists():
+            time.sleep(0.05)
+            assert time.time() - t0 < 60
+        (step_dir / NCCL_READY_MARKER).touch()
+        got = {name: t.clone() for name, t in RCCLWeightReceiver(comm, 2, "cpu", "reference").receive_state_dict(step_dir)}
+        torch.save(got, out / "received.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_push_of_an_expert_parallel_moe_model(tmp_path):
+    """The module engine's push (MoE models always speak the reference byte protocol): the expert shards of the two ep ranks are gathered, names
+    converted to HF's per-expert form (what vLLM's `load_weights` expects; the reference does this with `revert_weight_conversion`,
+    transports/weights/nccl.py:87-98), and the inference rank receives the WHOLE model bit-exactly, layer by layer."""
+    mp.start_processes(_moe_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True, start_method="spawn")
+    sent, got = torch.load(tmp_path / "sent.pt"), torch.load(tmp_path / "received.pt")
+    assert set(sent) == set(got) and "model.layers.1.mlp.experts.3.down_proj.weight" in got and "model.layers.0.mlp.gate.weight" in got
+    for k in sent:
+        assert got[k].shape == sent[k].shape and torch.equal(got[k], sent[k].to(got[k].dtype)), k
+    assert not (tmp_path / "broadcasts" / "step_3" / "LAYOUT.json").exists()  # the manifest belongs to the sharded protocol
