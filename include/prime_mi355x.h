@@ -307,6 +307,21 @@ int pm_attn_varlen_bwd(const void* grad_out_bf16, const void* q_bf16, const void
                        void* grad_q_bf16, void* grad_k_bf16, void* grad_v_bf16, int64_t grad_v_row_stride,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Row-window forms of the two calls above — one rank's share of a pass under context parallelism with gathered K / V (the reference's
+ * `ring_fa3_varlen_func`, models/layers/ring_attn.py:99-280: all-gather K / V over the cp group, attend with the local q chunk
+ * against `local_k_slice`, reduce-scatter dK / dV).  k, v, seq_start (and grad_k, grad_v) hold rows [0, q_row0 + n_q) of the pass,
+ * the q-side arrays (q, out, lse [hq][n_q], grad_out, grad_q) only the n_q rows from q_row0 on; q_row0 must be a multiple of 128.
+ * grad_k / grad_v receive THIS q window's contribution for every kv row (zeros where no q row of the window attends): the caller
+ * sums them over the cp ranks.  q_row0 = 0 is exactly pm_attn_varlen_fwd / _bwd; the workspace is pm_attn_bwd_workspace_bytes(n_q). */
+int pm_attn_varlen_fwd_rows(const void* q_bf16, const void* k_bf16, const void* v_bf16, int64_t v_row_stride, const int32_t* seq_start,
+                            int64_t q_row0, int64_t n_q, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale,
+                            void* out_bf16, float* lse, void* stream);
+int pm_attn_varlen_bwd_rows(const void* grad_out_bf16, const void* q_bf16, const void* k_bf16, const void* v_bf16, int64_t v_row_stride,
+                            const void* out_bf16, const float* lse, const int32_t* seq_start, int64_t q_row0, int64_t n_q,
+                            int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale,
+                            void* grad_q_bf16, void* grad_k_bf16, void* grad_v_bf16, int64_t grad_v_row_stride,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 /* SwiGLU — MLP.forward (models/layers/mlp.py:27-29): act = bf16(silu(gate)) * up, on the fused [n, 2*inter] gate|up. */
 int pm_swiglu_fwd(const void* gate_up_bf16, int64_t n_rows, int64_t inter, void* act_bf16, void* stream);
 int pm_swiglu_bwd(const void* grad_act_bf16, const void* gate_up_bf16, int64_t n_rows, int64_t inter,

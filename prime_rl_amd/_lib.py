@@ -96,6 +96,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_attn_varlen_fwd": (I, [P, P, P, I64, P, I64, I32, I32, I32, F, P, P, P, I64, P]),
     "pm_attn_bwd_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "pm_attn_varlen_bwd": (I, [P, P, P, P, I64, P, P, P, I64, I32, I32, I32, F, P, P, P, I64, P, I64, P]),
+    "pm_attn_varlen_fwd_rows": (I, [P, P, P, I64, P, I64, I64, I32, I32, I32, F, P, P, P]),
+    "pm_attn_varlen_bwd_rows": (I, [P, P, P, P, I64, P, P, P, I64, I64, I32, I32, I32, F, P, P, P, I64, P, I64, P]),
     "pm_transpose_2d": (I, [P, I64, I64, I64, P, I64, P]),
     "pm_swiglu_fwd": (I, [P, I64, I64, P, P]),
     "pm_swiglu_bwd": (I, [P, P, I64, I64, P, P]),

@@ -147,21 +147,25 @@ extern "C" int64_t pm_attn_fwd_workspace_bytes(int64_t n_tokens, int32_t n_kv_he
   return n_tokens <= 0 ? 0 : 256;
 }
 
-extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t v_row_stride, const int32_t* seq_start, int64_t n_tokens,
-                                  int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale, void* out, float* lse,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
-  PM_REQUIRE(q && k && v && seq_start && out && lse, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: null pointer");
-  PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "pm_attn_varlen_fwd: head_dim=%d (only 128 is built)", head_dim);
-  PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_fwd: bad head counts");
-  PM_REQUIRE(n_tokens >= 0 && n_tokens < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
-             "pm_attn_varlen_fwd: bad sizes");
-  (void)workspace; (void)workspace_bytes;
-  if (n_tokens == 0) return PM_OK;
-  PM_REQUIRE(fits_buffer_range(n_tokens, v_row_stride) && fits_buffer_range(n_tokens, (int64_t)n_kv_heads * kD), PM_ERR_UNSUPPORTED,
-             "pm_attn_varlen_fwd: k / v exceed the 2 GiB buffer-offset range");
-#define PM_LAUNCH_FWD(OPT_)                                                                                                                       \
-  hipLaunchKernelGGL((attn_fwd_kernel<2, OPT_>), dim3((unsigned)(cdiv(n_tokens, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, \
-                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n_tokens, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse)
+// One implementation for the ordinary call (q_row0 = 0, n_q = n_tokens) and the row-window call: k, v, seq_start hold rows [0, q_row0 + n_q),
+// q / out / lse the n_q rows from q_row0 on.
+static int attn_fwd_impl(const char* who, const void* q, const void* k, const void* v, int64_t v_row_stride, const int32_t* seq_start, int64_t q_row0,
+                         int64_t n_q, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale, void* out, float* lse, void* stream) {
+  PM_REQUIRE(q && k && v && seq_start && out && lse, PM_ERR_INVALID_ARG, "%s: null pointer", who);
+  PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", who, head_dim);
+  PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "%s: bad head counts", who);
+  const int64_t n = q_row0 + n_q;
+  PM_REQUIRE(n_q >= 0 && q_row0 >= 0 && n < (1ll << 31) - 256 && v_row_stride >= (int64_t)n_kv_heads * kD && v_row_stride % 8 == 0, PM_ERR_INVALID_ARG,
+             "%s: bad sizes", who);
+  PM_REQUIRE(q_row0 % 128 == 0, PM_ERR_UNSUPPORTED, "%s: q_row0=%lld must be a multiple of 128 (q tiles must not straddle the window start)", who,
+             (long long)q_row0);
+  if (n_q == 0) return PM_OK;
+  PM_REQUIRE(fits_buffer_range(n, v_row_stride) && fits_buffer_range(n, (int64_t)n_kv_heads * kD), PM_ERR_UNSUPPORTED,
+             "%s: k / v exceed the 2 GiB buffer-offset range", who);
+#define PM_LAUNCH_FWD(OPT_)                                                                                                                  \
+  hipLaunchKernelGGL((attn_fwd_kernel<2, OPT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, \
+                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse,  \
+                     (int)q_row0)
   switch (g_fwd_var < 0 ? kFwdDefaultOpt : g_fwd_var) {
     case 0: PM_LAUNCH_FWD(0); break;
     case 1: PM_LAUNCH_FWD(1); break;
@@ -169,8 +173,22 @@ extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, i
     default: PM_LAUNCH_FWD(3); break;
   }
 #undef PM_LAUNCH_FWD
-  PM_CHECK_LAUNCH("pm_attn_varlen_fwd");
+  PM_CHECK_LAUNCH(who);
   return PM_OK;
+}
+
+extern "C" int pm_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t v_row_stride, const int32_t* seq_start, int64_t n_tokens,
+                                  int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale, void* out, float* lse,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  return attn_fwd_impl("pm_attn_varlen_fwd", q, k, v, v_row_stride, seq_start, 0, n_tokens, n_q_heads, n_kv_heads, head_dim, softmax_scale, out, lse, stream);
+}
+
+extern "C" int pm_attn_varlen_fwd_rows(const void* q, const void* k, const void* v, int64_t v_row_stride, const int32_t* seq_start, int64_t q_row0,
+                                       int64_t n_q, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float softmax_scale, void* out, float* lse,
+                                       void* stream) {
+  return attn_fwd_impl("pm_attn_varlen_fwd_rows", q, k, v, v_row_stride, seq_start, q_row0, n_q, n_q_heads, n_kv_heads, head_dim, softmax_scale, out, lse,
+                       stream);
 }
 
 extern "C" int64_t pm_attn_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim) {
@@ -179,47 +197,63 @@ extern "C" int64_t pm_attn_bwd_workspace_bytes(int64_t n_tokens, int32_t n_q_hea
   return 2 * align256((int64_t)n_q_heads * n_tokens * 4);
 }
 
-extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
-                                  const float* lse, const int32_t* seq_start, int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads,
-                                  int32_t head_dim, float softmax_scale, void* grad_q, void* grad_k, void* grad_v, int64_t grad_v_row_stride,
-                                  void* workspace, int64_t workspace_bytes, void* stream) {
-  PM_REQUIRE(grad_out && q && k && v && out && lse && seq_start && grad_q && grad_k && grad_v, PM_ERR_INVALID_ARG, "pm_attn_varlen_bwd: null pointer");
-  PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "pm_attn_varlen_bwd: head_dim=%d (only 128 is built)", head_dim);
-  PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "pm_attn_varlen_bwd: bad head counts");
-  PM_REQUIRE(n_tokens >= 0 && v_row_stride % 8 == 0 && grad_v_row_stride >= (int64_t)n_kv_heads * kD && softmax_scale > 0.f, PM_ERR_INVALID_ARG,
-             "pm_attn_varlen_bwd: bad sizes");
-  if (n_tokens == 0) return PM_OK;
-  const int64_t need = pm_attn_bwd_workspace_bytes(n_tokens, n_q_heads, n_kv_heads, head_dim);
-  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "pm_attn_varlen_bwd: workspace %lld < %lld", (long long)workspace_bytes,
-             (long long)need);
-  const int64_t n = n_tokens;
-  PM_REQUIRE(fits_buffer_range(n, (int64_t)n_q_heads * kD) && fits_buffer_range(n, v_row_stride), PM_ERR_UNSUPPORTED,
-             "pm_attn_varlen_bwd: q / k / v exceed the 2 GiB buffer-offset range");
+static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
+                         const float* lse, const int32_t* seq_start, int64_t q_row0, int64_t n_q, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                         float softmax_scale, void* grad_q, void* grad_k, void* grad_v, int64_t grad_v_row_stride, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(grad_out && q && k && v && out && lse && seq_start && grad_q && grad_k && grad_v, PM_ERR_INVALID_ARG, "%s: null pointer", who);
+  PM_REQUIRE(head_dim == kD, PM_ERR_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", who, head_dim);
+  PM_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, PM_ERR_INVALID_ARG, "%s: bad head counts", who);
+  PM_REQUIRE(n_q >= 0 && q_row0 >= 0 && v_row_stride % 8 == 0 && grad_v_row_stride >= (int64_t)n_kv_heads * kD && softmax_scale > 0.f, PM_ERR_INVALID_ARG,
+             "%s: bad sizes", who);
+  PM_REQUIRE(q_row0 % 128 == 0, PM_ERR_UNSUPPORTED, "%s: q_row0=%lld must be a multiple of 128", who, (long long)q_row0);
+  if (n_q == 0) return PM_OK;
+  const int64_t need = pm_attn_bwd_workspace_bytes(n_q, n_q_heads, n_kv_heads, head_dim);
+  PM_REQUIRE(workspace && workspace_bytes >= need, PM_ERR_WORKSPACE, "%s: workspace %lld < %lld", who, (long long)workspace_bytes, (long long)need);
+  const int64_t n = q_row0 + n_q;
+  PM_REQUIRE(n < (1ll << 31) - 256 && fits_buffer_range(n, (int64_t)n_q_heads * kD) && fits_buffer_range(n, v_row_stride), PM_ERR_UNSUPPORTED,
+             "%s: q / k / v exceed the 2 GiB buffer-offset range", who);
   hipStream_t st = as_stream(stream);
   float* ndelta = (float*)workspace;
-  float* nlse = ndelta + align256(n * n_q_heads * 4) / 4;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, lse, n,
+  float* nlse = ndelta + align256(n_q * n_q_heads * 4) / 4;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(n_q * n_q_heads, 16)), dim3(256), 0, st, (const bf16_t*)grad_out, (const bf16_t*)out, lse, n_q,
                      n_q_heads, 1.0f / softmax_scale, ndelta, nlse);
-  PM_CHECK_LAUNCH("pm_attn_varlen_bwd(delta)");
+  PM_CHECK_LAUNCH(who);
 
 #define PM_LAUNCH_DKDV(MINB_, FB_, QT_)                                                                                                           \
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q,     \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
-                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride)
+                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0)
   if (g_dkdv_var == 1) PM_LAUNCH_DKDV(2, 2, 64);
   else if (g_dkdv_var == 2) PM_LAUNCH_DKDV(2, 8, 64);
   else if (g_dkdv_var == 3) PM_LAUNCH_DKDV(3, 4, 32);
   else PM_LAUNCH_DKDV(2, 4, 64);
 #undef PM_LAUNCH_DKDV
-  PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dkdv)");
+  PM_CHECK_LAUNCH(who);
 
 #define PM_LAUNCH_DQ(KT_)                                                                                                                        \
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<2, KT_>), dim3((unsigned)(cdiv(n, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<2, KT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                      (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, softmax_scale,    \
-                     (bf16_t*)grad_q)
+                     (bf16_t*)grad_q, (int)q_row0)
   if (g_dq_var == 1) PM_LAUNCH_DQ(32);
   else PM_LAUNCH_DQ(64);
 #undef PM_LAUNCH_DQ
-  PM_CHECK_LAUNCH("pm_attn_varlen_bwd(dq)");
+  PM_CHECK_LAUNCH(who);
   return PM_OK;
+}
+
+extern "C" int pm_attn_varlen_bwd(const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
+                                  const float* lse, const int32_t* seq_start, int64_t n_tokens, int32_t n_q_heads, int32_t n_kv_heads,
+                                  int32_t head_dim, float softmax_scale, void* grad_q, void* grad_k, void* grad_v, int64_t grad_v_row_stride,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  return attn_bwd_impl("pm_attn_varlen_bwd", grad_out, q, k, v, v_row_stride, out, lse, seq_start, 0, n_tokens, n_q_heads, n_kv_heads, head_dim,
+                       softmax_scale, grad_q, grad_k, grad_v, grad_v_row_stride, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pm_attn_varlen_bwd_rows(const void* grad_out, const void* q, const void* k, const void* v, int64_t v_row_stride, const void* out,
+                                       const float* lse, const int32_t* seq_start, int64_t q_row0, int64_t n_q, int32_t n_q_heads, int32_t n_kv_heads,
+                                       int32_t head_dim, float softmax_scale, void* grad_q, void* grad_k, void* grad_v, int64_t grad_v_row_stride,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+  return attn_bwd_impl("pm_attn_varlen_bwd_rows", grad_out, q, k, v, v_row_stride, out, lse, seq_start, q_row0, n_q, n_q_heads, n_kv_heads, head_dim,
+                       softmax_scale, grad_q, grad_k, grad_v, grad_v_row_stride, workspace, workspace_bytes, stream);
 }

@@ -230,8 +230,11 @@ template <int MINB, int FB, int QT>
 __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
     const float* __restrict__ nlse, const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
-    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride) {
-  // nlse = -lse / scale, ndelta = -delta, both [hq][n] (attn_delta_kernel)
+    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride, int q_row0) {
+  // nlse = -lse / scale, ndelta = -delta, both [hq][nq] (attn_delta_kernel)
+  // Row window (context parallelism with gathered K / V, pm_attn_varlen_*_rows): k, v, seq_start, dk, dv hold rows [0, n) of the pass, the q-side
+  // arrays (q, dout, nlse, ndelta) only the rows [q_row0, n) this rank owns, addressed as row - q_row0; q_row0 is a multiple of 128, so no q
+  // tile straddles it.  q_row0 = 0 is the ordinary call.
   constexpr int NT = 256;
   constexpr int ROWS = 64;           // kv rows per workgroup (4 waves x 16)
   constexpr int PPW = QT / 16;       // 1 KiB DMA pieces per wave per operand tile
@@ -264,17 +267,19 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   }
   const int wg_last = (kv0 + ROWS - 1 < n - 1) ? kv0 + ROWS - 1 : n - 1;
   const float sc2 = scale * 1.44269504088896340736f;
+  const int nq = n - q_row0;
+  const int tile_lo = q_row0 > kv0 ? (q_row0 - kv0) / QT : 0;  // q tiles below the row window belong to other ranks
   if (t == 0) s_ntiles = 0;
   __syncthreads();
   {
     int mine = 0;
-    for (int c = t; kv0 + QT * c < n; c += NT)
+    for (int c = tile_lo + t; kv0 + QT * c < n; c += NT)
       if (seq_start[kv0 + QT * c] <= wg_last) mine = c + 1;
     if (mine) atomicMax(&s_ntiles, mine);
   }
   __syncthreads();
   const int ntiles = __builtin_amdgcn_readfirstlane(s_ntiles);
-  const int total_iters = ntiles * group;
+  const int total_iters = ntiles > tile_lo ? (ntiles - tile_lo) * group : 0;
 
   // execution order j = 0.. walks (q tile, head) pairs from the LAST q tile down (workgroups of one document stay in step on L2)
   struct Cursor {
@@ -287,11 +292,11 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     }
   };
   Cursor c_issue{ntiles - 1, group - 1}, c_cur = c_issue;
-  const int qbytes = n * hq * (kD * 2);  // host guarantees < 2 GiB
+  const int qbytes = nq * hq * (kD * 2);  // host guarantees < 2 GiB
   const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(q), 0, qbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t dorsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dout), 0, qbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nlse), 0, hq * n * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ndelta), 0, hq * n * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nlse), 0, hq * nq * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ndelta), 0, hq * nq * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(seq_start), 0, n * 4, 0x00020000);
   int voff[PPW];  // loop-invariant byte offset of this lane's chunk inside a q tile (source-side swizzle)
 #pragma unroll
@@ -302,9 +307,9 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   auto dma = [&](unsigned char* sm) {
     const int qi0 = kv0 + QT * c_issue.tile;
     const int qh = kvh * group + c_issue.head;
-    const int base = (qi0 * hq + qh) * (kD * 2);
+    const int base = ((qi0 - q_row0) * hq + qh) * (kD * 2);
     dma_pieces<PPW>(qrsrc, dorsrc, sm + w * PPW * 1024, TILE * 2, voff, voff, base, base);
-    const int roff = (qh * n + qi0 + lane) * 4;
+    const int roff = (qh * nq + qi0 - q_row0 + lane) * 4;
     unsigned char* rows = sm + 2 * TILE * 2;
     if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(lrsrc, (lds_void_ptr)rows, 4, roff, 0, 0, 0);
     else if (w == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void_ptr)(rows + 256), 4, roff, 0, 0, 0);
@@ -428,7 +433,8 @@ template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                   int64_t v_stride, const bf16_t* __restrict__ dout, const float* __restrict__ nlse,
                                                                   const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64,
-                                                                  int hq, int hkv, float scale, bf16_t* __restrict__ dq) {
+                                                                  int hq, int hkv, float scale, bf16_t* __restrict__ dq, int q_row0) {
+  // q_row0: see attn_bwd_dkdv_kernel — q, dout, nlse, ndelta, dq hold rows [q_row0, n) only
   __shared__ __attribute__((aligned(16))) unsigned char smA[kV5DqBufBytes<KT>];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kV5DqBufBytes<KT>];
   constexpr int TILE = KT * kD;      // elements of one [KT][128] tile
@@ -446,7 +452,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
   const int num_tiles = gridDim.x / hq;
   const int tile = num_tiles - 1 - b;
   const int qh = kvh * group + gi;
-  const int qt0 = tile * 128;
+  const int qt0 = q_row0 + tile * 128;
+  const int nq = n - q_row0;
   const int q0 = qt0 + w * 32;
   const bool active = q0 < n;
   u32x4 qf[2][4], dof[2][4];
@@ -459,12 +466,12 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
     const int row = qi[cb] < n ? qi[cb] : n - 1;
     hi[cb] = qi[cb] < n ? qi[cb] : -1;  // rows past the end see nothing
     lo[cb] = seq_start[row];
-    nL[cb] = nlse[(int64_t)qh * n + row];
-    nD[cb] = ndelta[(int64_t)qh * n + row];
+    nL[cb] = nlse[(int64_t)qh * nq + row - q_row0];
+    nD[cb] = ndelta[(int64_t)qh * nq + row - q_row0];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      qf[cb][kk] = ldg16(q + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
-      dof[cb][kk] = ldg16(dout + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
+      qf[cb][kk] = ldg16(q + ((int64_t)(row - q_row0) * hq + qh) * kD + kk * 32 + lq * 8);
+      dof[cb][kk] = ldg16(dout + ((int64_t)(row - q_row0) * hq + qh) * kD + kk * 32 + lq * 8);
     }
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) dqt[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     if (qi[cb] < n) {
-      bf16_t* op = dq + ((int64_t)qi[cb] * hq + qh) * kD + lq * 4;
+      bf16_t* op = dq + ((int64_t)(qi[cb] - q_row0) * hq + qh) * kD + lq * 4;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, dqt[cb][nb], scale);
     }
@@ -639,7 +646,9 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
 template <int MINW, int OPT = 0>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
-                                                               float scale, bf16_t* __restrict__ out, float* __restrict__ lse) {
+                                                               float scale, bf16_t* __restrict__ out, float* __restrict__ lse, int q_row0) {
+  // q_row0 (a multiple of 128; 0 = the ordinary call): q, out, lse hold rows [q_row0, n) only — addressed as row - q_row0 — while k, v, seq_start
+  // hold rows [0, n): one rank's share of a pass under context parallelism with gathered K / V (pm_attn_varlen_fwd_rows)
   __shared__ __attribute__((aligned(16))) unsigned char smA[kV5FwdBufBytes];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kV5FwdBufBytes];
   constexpr int PPW = 4;  // 1 KiB DMA pieces per wave per operand tile (64 rows x 256 B over 4 waves)
@@ -656,7 +665,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   const int num_tiles = gridDim.x / hq;
   const int tile = num_tiles - 1 - b;
   const int qh = kvh * group + gi;
-  const int qt0 = tile * 128;
+  const int qt0 = q_row0 + tile * 128;
+  const int nq = n - q_row0;
   const int q0 = qt0 + w * 32;
   const bool active = q0 < n;
 
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     m[cb] = -INFINITY;
     l[cb] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[cb][kk] = ldg16(q + ((int64_t)row * hq + qh) * kD + kk * 32 + lq * 8);
+    for (int kk = 0; kk < 4; ++kk) qf[cb][kk] = ldg16(q + ((int64_t)(row - q_row0) * hq + qh) * kD + kk * 32 + lq * 8);
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) ot[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -721,10 +731,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     const float lsum = xrow_sum(l[cb]);
     if (qi[cb] < n) {
       const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-      bf16_t* op = out + ((int64_t)qi[cb] * hq + qh) * kD + lq * 4;
+      bf16_t* op = out + ((int64_t)(qi[cb] - q_row0) * hq + qh) * kD + lq * 4;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, ot[cb][nb], inv);
-      if (lq == 0) lse[(int64_t)qh * n + qi[cb]] = m[cb] * 0.69314718055994530942f + logf(lsum);
+      if (lq == 0) lse[(int64_t)qh * nq + qi[cb] - q_row0] = m[cb] * 0.69314718055994530942f + logf(lsum);
     }
   }
 }

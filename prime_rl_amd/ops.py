@@ -458,6 +458,49 @@ def attn_varlen_bwd(grad_out: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tens
     return gq, gk, gv
 
 
+def attn_varlen_fwd_rows(q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, softmax_scale: float, q_row0: int) -> tuple[Tensor, Tensor]:
+    """The q rows [q_row0, q_row0 + n_q) of a pass against its K / V rows [0, q_row0 + n_q): q [n_q,Hq,128]; k, v hold at least q_row0 + n_q rows
+    (v may be row-strided), seq_start the document starts of those rows (pass-global indices).  Returns (out [n_q,Hq,128], lse [Hq,n_q])."""
+    lib = _lib.load()
+    _req(q, torch.bfloat16, "q"); _req(k, torch.bfloat16, "k"); _req(v, torch.bfloat16, "v", contiguous=False)
+    _req(seq_start, torch.int32, "seq_start")
+    nq, hq, d = q.shape
+    hkv = k.shape[1]
+    n = q_row0 + nq
+    if k.shape[0] < n or v.shape[0] < n or seq_start.numel() < n:
+        raise PrimeMI355XError(f"attn_varlen_fwd_rows: k / v / seq_start must hold the {n} rows up to the end of the q window")
+    if v.stride(2) != 1 or v.stride(1) != d:
+        raise PrimeMI355XError("v: heads must be contiguous within a row")
+    out = torch.empty_like(q)
+    lse = torch.empty((hq, nq), dtype=torch.float32, device=q.device)
+    check(lib.pm_attn_varlen_fwd_rows(_p(q), _p(k), _p(v), v.stride(0), _p(seq_start), q_row0, nq, hq, hkv, d, softmax_scale, _p(out), _p(lse), _stream()),
+          "pm_attn_varlen_fwd_rows")
+    return out, lse
+
+
+def attn_varlen_bwd_rows(grad_out: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor, seq_start: Tensor, softmax_scale: float,
+                         q_row0: int) -> tuple[Tensor, Tensor, Tensor]:
+    """Backward of attn_varlen_fwd_rows: (grad_q [n_q,...], grad_k, grad_v [q_row0 + n_q, Hkv, 128]) — grad_k / grad_v are this q window's
+    contribution to every kv row of the pass prefix (the caller sums them over the ranks that hold the other windows)."""
+    lib = _lib.load()
+    for t, nm in ((grad_out, "grad_out"), (q, "q"), (k, "k"), (out, "out")):
+        _req(t, torch.bfloat16, nm)
+    _req(v, torch.bfloat16, "v", contiguous=False)
+    nq, hq, d = q.shape
+    hkv = k.shape[1]
+    n = q_row0 + nq
+    if k.shape[0] < n or v.shape[0] < n or seq_start.numel() < n:
+        raise PrimeMI355XError(f"attn_varlen_bwd_rows: k / v / seq_start must hold the {n} rows up to the end of the q window")
+    gq = torch.empty_like(q)
+    gk = torch.empty((n, hkv, d), dtype=torch.bfloat16, device=q.device)
+    gv = torch.empty((n, hkv, d), dtype=torch.bfloat16, device=q.device)
+    wsb = lib.pm_attn_bwd_workspace_bytes(nq, hq, hkv, d)
+    ws = workspace(wsb, q.device, "attn_bwd")
+    check(lib.pm_attn_varlen_bwd_rows(_p(grad_out), _p(q), _p(k), _p(v), v.stride(0), _p(out), _p(lse), _p(seq_start), q_row0, nq, hq, hkv, d, softmax_scale,
+                                      _p(gq), _p(gk), _p(gv), gv.stride(0), _p(ws), ws.numel(), _stream()), "pm_attn_varlen_bwd_rows")
+    return gq, gk, gv
+
+
 def transpose_2d(src: Tensor, out: Tensor | None = None) -> Tensor:
     """out[c, r] = src[r, c] for a row-major bf16/f16 matrix (rows may be strided: `src.stride(1) == 1`)."""
     lib = _lib.load()

@@ -373,7 +373,7 @@ class GRPOEngine:
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
-                 shard_group: dist.ProcessGroup | None = None):
+                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses"):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -397,10 +397,17 @@ class GRPOEngine:
         # layers on 1/cp of its tokens and exchange heads <-> sequence around attention.  Gradients are partial sums over token shards,
         # so the ZeRO shard group (reduce-scatter / all-gather / norm all-reduce) is the dp x cp group; token counts and step statistics
         # are per pass, so they reduce over the dp group only.
+        # Two styles, the reference's `model.cp_style` (configs/trainer.py:98): "ulysses" = heads <-> sequence all-to-all around the unchanged
+        # kernel (every rank attends the full pass for 1/cp of the heads; balanced under the causal mask); "ring" = what the reference's
+        # ring_attn.py actually does (llama3-style): all-gather K / V over the cp group, every rank attends ITS q rows against the K / V prefix of
+        # the pass (pm_attn_varlen_*_rows), dK / dV reduce-scattered back — no head-count constraint, later ranks do more attention work.
         self.cp_group, self.cp_size = cp_group, cp_size
         self.cp_rank = dist.get_rank(cp_group) if cp_size > 1 else 0
+        if cp_style not in ("ulysses", "ring"):
+            raise PrimeMI355XError(f"cp_style must be 'ulysses' or 'ring', got {cp_style!r}")
+        self.cp_style = cp_style
         if cp_size > 1:
-            if dims.num_attention_heads % cp_size or (dims.num_key_value_heads % cp_size and cp_size % dims.num_key_value_heads):
+            if cp_style == "ulysses" and (dims.num_attention_heads % cp_size or (dims.num_key_value_heads % cp_size and cp_size % dims.num_key_value_heads)):
                 raise PrimeMI355XError(f"cp_size {cp_size} must divide the {dims.num_attention_heads} query heads and divide or be divided by the "
                                        f"{dims.num_key_value_heads} KV heads (ulysses_attn.py:27-31)")
             self.shard_group = shard_group
@@ -564,7 +571,7 @@ class GRPOEngine:
                 o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
                 attn_saved = None
             else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads)
-                o, attn_saved = self._ulysses_attn_fwd(q, k, v, seq_start, scale)
+                o, attn_saved = (self._ulysses_attn_fwd if self.cp_style == "ulysses" else self._gathered_kv_attn_fwd)(q, k, v, seq_start, scale)
                 lse = None
             attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
             h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
@@ -625,6 +632,33 @@ class GRPOEngine:
             dk, dv = ulysses.reduce_kv_replicas(dk, hkv), ulysses.reduce_kv_replicas(dv, hkv)
         dv_view.copy_(dv)
         return dq, dk
+
+    def _gathered_kv_attn_fwd(self, q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, scale: float):
+        """cp_style "ring": K / V of the whole pass gathered over the cp group; this rank's q rows against the prefix that precedes and contains them."""
+        cp, grp, n_loc = self.cp_size, self.cp_group, q.shape[0]
+        if n_loc % 128:
+            raise PrimeMI355XError(f"cp_style='ring': {n_loc} tokens per cp rank — the row-window attention kernels need a multiple of 128 "
+                                   "(pad the pass to cp x 128 tokens: data.pad_to_multiple_of)")
+        r1 = (self.cp_rank + 1) * n_loc
+        kf = ulysses.all_gather_tokens(k, cp, grp)[:r1]
+        vf = ulysses.all_gather_tokens(v.contiguous(), cp, grp)[:r1]
+        o, lse = ops.attn_varlen_fwd_rows(q, kf, vf, seq_start[:r1], scale, r1 - n_loc)
+        return o, (q, kf, vf, o, lse)
+
+    def _gathered_kv_attn_bwd(self, do: Tensor, saved, seq_start: Tensor, scale: float, dv_view: Tensor):
+        cp, grp = self.cp_size, self.cp_group
+        q, kf, vf, o, lse = saved
+        n_loc, r1 = q.shape[0], kf.shape[0]
+        dq, dk_part, dv_part = ops.attn_varlen_bwd_rows(do.contiguous(), q, kf, vf, o, lse, seq_start[:r1], scale, r1 - n_loc)
+        out = []
+        for part in (dk_part, dv_part):  # this rank's contribution to EVERY kv row of the prefix; rows after it get none (ring_attn.py:252-262)
+            full = part.new_zeros((cp * n_loc,) + tuple(part.shape[1:]))
+            full[:r1] = part
+            mine = part.new_empty((n_loc,) + tuple(part.shape[1:]))
+            dist.reduce_scatter_tensor(mine, full, op=dist.ReduceOp.SUM, group=grp)
+            out.append(mine)
+        dv_view.copy_(out[1])
+        return dq, out[0]
 
     # -- loss -------------------------------------------------------------------------------------------------------
     def loss(self, ctx: dict, scales: tuple[int, int, int]) -> dict:
@@ -707,7 +741,8 @@ class GRPOEngine:
             if self.cp_size == 1:
                 dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
             else:
-                dq, dk = self._ulysses_attn_bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
+                bwd = self._ulysses_attn_bwd if self.cp_style == "ulysses" else self._gathered_kv_attn_bwd
+                dq, dk = bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
             if d.qk_norm:
                 ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
                                     L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),

@@ -306,9 +306,6 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
         raise NotImplementedError("the flat-buffer engine is the dense path; MoE models (and model.ep > 1) run through setup_module_engine() "
                                   "(trainer/module_engine.py) on setup_model() / forward()")
     dims = resolve_model_dims(m)
-    if parallel_dims.cp_enabled and m.cp_style != "ulysses":
-        raise NotImplementedError("context parallelism on MI355X is Ulysses (all-to-all over the xGMI full mesh): set model.cp_style = 'ulysses'; "
-                                  "ring attention (models/layers/ring_attn.py) is not part of this engine")
     o = config.optim
     optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
     lc = config.loss
@@ -319,7 +316,7 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
                       kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
     engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
                         dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp,
-                        shard_group=parallel_dims.get_group("dp_cp"))
+                        shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style)
     sd = _local_safetensors(m.name)
     if sd is not None:
         engine.store.load_state_dict({k: v.to(device) for k, v in sd.items()})

@@ -142,6 +142,26 @@ def attn_varlen_bwd(grad_out, q, k, v, out, lse, seq_start, softmax_scale, grad_
     return gq.to(BF16), gk.to(BF16), gv.to(BF16)
 
 
+def attn_varlen_fwd_rows(q, k, v, seq_start, softmax_scale, q_row0):
+    """q rows [q_row0, q_row0 + n_q) of the pass against its K / V prefix: the full-prefix attention with zero queries in front, rows kept."""
+    n = q_row0 + q.shape[0]
+    qf = torch.zeros((n,) + tuple(q.shape[1:]))
+    qf[q_row0:] = q.float()
+    o = O.varlen_causal_attention(qf, k[:n].float(), v[:n].float(), _seq_lens(seq_start[:n]), softmax_scale)
+    return o[q_row0:].to(BF16), torch.zeros(q.shape[1], q.shape[0])
+
+
+@torch.enable_grad()
+def attn_varlen_bwd_rows(grad_out, q, k, v, out, lse, seq_start, softmax_scale, q_row0):
+    n = q_row0 + q.shape[0]
+    ql = q.float().requires_grad_(True)
+    kf, vf = k[:n].float().requires_grad_(True), v[:n].float().requires_grad_(True)
+    qf = torch.cat([torch.zeros((q_row0,) + tuple(q.shape[1:])), ql])
+    o = O.varlen_causal_attention(qf, kf, vf, _seq_lens(seq_start[:n]), softmax_scale)
+    gq, gk, gv = torch.autograd.grad(o[q_row0:], (ql, kf, vf), grad_out.float())
+    return gq.to(BF16), gk.to(BF16), gv.to(BF16)
+
+
 def swiglu_fwd(gate_up):
     i = gate_up.shape[1] // 2
     return (torch.nn.functional.silu(gate_up[:, :i].float()).to(BF16).float() * gate_up[:, i:].float()).to(BF16)

@@ -41,7 +41,7 @@ def _engine(dp_group=None, tied=False, **kw):
     return E, E.GRPOEngine(dims, device="cpu", optim=E.OptimConfig(lr=LR), seed=5, dp_group=dp_group, gemm_layouts=False, **kw)
 
 
-def _batches(E, dims, world, rank, step):
+def _batches(E, dims, world, rank, step, SEQ=SEQ):
     from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
 
     dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=MB_PER_RANK * world, generate_samples=True), seq_len=SEQ, dp_world_size=world, dp_rank=rank)
@@ -54,6 +54,10 @@ def _batches(E, dims, world, rank, step):
     return mbs
 
 
+def _seq(cp_style):
+    return 256 if cp_style == "ring" else SEQ  # the row-window attention needs 128-token multiples per cp rank
+
+
 def _passes(E, mbs, mode, rank):
     """"two": one pass per micro-batch (gradient accumulation, reduce-scatter only after the last one); "one": both micro-batches packed into a
     single pass on every rank (no earlier pass: the embedding bucket has no dense part); "ragged": rank 0 runs one pass, the others two."""
@@ -62,7 +66,7 @@ def _passes(E, mbs, mode, rank):
     return [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
 
 
-def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False):
+def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False, cp_style="ulysses"):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -78,11 +82,12 @@ def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False):
 
         pd = ParallelDims(dp_replicate=1, dp_shard=-1, cp=cp, pp=1, ep=1, world_size=world)
         assert pd.dp_size == dp and pd.dp_rank_of(rank) == rank // cp
-        E, eng = _engine(dp_group=pd.get_group("dp"), dp_size=pd.dp_size, cp_group=pd.get_group("cp"), cp_size=cp, shard_group=pd.get_group("dp_cp"))
+        E, eng = _engine(dp_group=pd.get_group("dp"), dp_size=pd.dp_size, cp_group=pd.get_group("cp"), cp_size=cp, shard_group=pd.get_group("dp_cp"),
+                         cp_style=cp_style)
         assert (eng.dp_size, eng.cp_size, eng.shard_size, eng.cp_rank, eng.dp_rank) == (dp, cp, world, rank % cp, rank // cp)
     rec = {"loss": [], "grad_norm": [], "shards": None}
     for step in range(STEPS):
-        mbs = _batches(E, eng.dims, dp, rank // cp, step)
+        mbs = _batches(E, eng.dims, dp, rank // cp, step, SEQ=_seq(cp_style))
         passes = _passes(E, mbs, mode, rank)
         out = eng.step(passes)
         # the embedding bucket went the split way: last pass's rows all-gathered to their owners, dense part (if any) reduce-scattered early
@@ -102,15 +107,17 @@ def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cp,mode,tied", [(2, 1, "two", False), (2, 2, "two", False), (4, 2, "two", False), (2, 1, "ragged", False),
-                                                 (2, 1, "one", False), (2, 1, "two", True)])
-def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode, tied):
+@pytest.mark.parametrize("world,cp,mode,tied,cp_style", [(2, 1, "two", False, "ulysses"), (2, 2, "two", False, "ulysses"), (4, 2, "two", False, "ulysses"),
+                                                          (2, 1, "ragged", False, "ulysses"), (2, 1, "one", False, "ulysses"), (2, 1, "two", True, "ulysses"),
+                                                          (2, 2, "two", False, "ring"), (4, 2, "one", False, "ring")])
+def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode, tied, cp_style):
     """(2, 1): ZeRO-2 data parallel.  (2, 2): one dp position, Ulysses context parallel over two ranks (heads <-> sequence all-to-all around
     attention, log-probs gathered for the full-pass loss, gradients reduce-scattered over dp x cp).  (4, 2): both at once.  The "ragged" / "one" /
-    tied cases walk the branches of the split embedding-bucket reduction (engine._plan_embed_split): ranks with different pass counts, no
+    cp_style "ring" = K / V gathered over the cp group, every rank attends its own q rows against the prefix (the reference's ring_attn.py), dK / dV
+    reduce-scattered.  The "ragged" / "one" / tied cases walk the branches of the split embedding-bucket reduction (engine._plan_embed_split): ranks with different pass counts, no
     dense part at all, and tied embeddings whose head gradient is the dense part."""
     dp = world // cp
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp, mode, tied), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp, mode, tied, cp_style), nprocs=world, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"r{k}.pt") for k in range(world)]
     # single process, same global batch (rank 0's micro-batches then rank 1's), one pass per rank-pass to keep the same accumulation units
     E, eng = _engine(tied=tied)
@@ -119,7 +126,7 @@ def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode,
     for step in range(STEPS):
         passes = []
         for k in range(dp):
-            mbs = _batches(E, eng.dims, dp, k, step)
+            mbs = _batches(E, eng.dims, dp, k, step, SEQ=_seq(cp_style))
             passes += [E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")]
         out = eng.step(passes)
         ref["loss"].append(sum(l.item() for l in out["loss"]))

@@ -556,6 +556,44 @@ def test_attention_forward_backward(ops, seq_lens, hq, hkv):
     assert torch.equal(gq, gq2) and torch.equal(gk, gk2) and torch.equal(gv, gv2), "backward must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("seq_lens,hq,hkv,cp", [([300, 212], 8, 2, 4), ([1024], 4, 1, 2), ([100, 700, 90, 134], 4, 4, 8), ([384], 2, 2, 3), ([130, 126], 2, 1, 2)])
+def test_attention_row_windows(ops, seq_lens, hq, hkv, cp):
+    """pm_attn_varlen_{fwd,bwd}_rows — context parallelism with gathered K / V (the reference's ring_fa3_varlen_func, ring_attn.py:99-280): every rank
+    runs its contiguous q window against the K / V prefix of the pass.  With windows on multiples of 128 the tiles are the full call's tiles:
+    out / lse / dq are the full call's rows BIT FOR BIT; dk / dv of the windows are partial sums whose total is the full call's dk / dv
+    (each partial rounded to bf16 once, like the reference's bf16 reduce-scatter of dk / dv)."""
+    n, d = sum(seq_lens), 128
+    q, k, v = (t.to(DEV) for t in _attn_case(n, seq_lens, hq, hkv, 5 * n))
+    scale = d**-0.5
+    cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    go = torch.randn(n, hq, d).to(torch.bfloat16).to(DEV)
+    out, lse = ops.attn_varlen_fwd(q, k, v, ss, scale)
+    gq, gk, gv = ops.attn_varlen_bwd(go, q, k, v, out, lse, ss, scale)
+    per = -(-n // cp)
+    per = (per + 127) // 128 * 128  # window starts on multiples of 128; the last window takes what is left (possibly nothing)
+    gk_sum, gv_sum = torch.zeros(n, hkv, d, device=DEV), torch.zeros(n, hkv, d, device=DEV)
+    for r in range(cp):
+        r0, r1 = min(r * per, n), min((r + 1) * per, n)
+        if r1 == r0:
+            continue
+        o_r, l_r = ops.attn_varlen_fwd_rows(q[r0:r1].contiguous(), k[:r1], v[:r1], ss[:r1], scale, r0)
+        assert torch.equal(o_r, out[r0:r1]) and torch.equal(l_r, lse[:, r0:r1]), (r, "forward rows differ from the full call")
+        gq_r, gk_r, gv_r = ops.attn_varlen_bwd_rows(go[r0:r1].contiguous(), q[r0:r1].contiguous(), k[:r1], v[:r1], o_r, l_r, ss[:r1], scale, r0)
+        assert torch.equal(gq_r, gq[r0:r1]), (r, "dq rows differ from the full call")
+        assert gk_r.shape == (r1, hkv, d) and bool(torch.isfinite(gk_r.float()).all()) and bool(torch.isfinite(gv_r.float()).all())
+        gk_sum[:r1] += gk_r.float()
+        gv_sum[:r1] += gv_r.float()
+        if r == 0:  # the first window sees only its own keys: its dk / dv ARE a full call on the prefix
+            o0, l0 = ops.attn_varlen_fwd(q[:r1].contiguous(), k[:r1].contiguous(), v[:r1].contiguous(), ss[:r1], scale)
+            g0 = ops.attn_varlen_bwd(go[:r1].contiguous(), q[:r1].contiguous(), k[:r1].contiguous(), v[:r1].contiguous(), o0, l0, ss[:r1], scale)
+            assert torch.equal(gk_r, g0[1]) and torch.equal(gv_r, g0[2])
+    _close(gk_sum, gk.float(), 2e-2, 3e-2, "sum of the windows' dk")
+    _close(gv_sum, gv.float(), 2e-2, 3e-2, "sum of the windows' dv")
+    with pytest.raises(Exception):
+        ops.attn_varlen_fwd_rows(q[64:128].contiguous(), k[:128], v[:128], ss[:128], scale, 64)  # window start not on a multiple of 128
+
+
 def test_attention_full_size_properties(ops):
     """BASELINE shape (8 x 2048-token rollouts packed in one 16 384-token row, 32 q / 8 kv heads, d = 128), where the CPU oracle would
     take minutes: size-independent properties instead.
