@@ -556,7 +556,9 @@ def test_attention_forward_backward(ops, seq_lens, hq, hkv):
     assert torch.equal(gq, gq2) and torch.equal(gk, gk2) and torch.equal(gv, gv2), "backward must be bitwise reproducible"
 
 
-@pytest.mark.parametrize("seq_lens,hq,hkv,cp", [([300, 212], 8, 2, 4), ([1024], 4, 1, 2), ([100, 700, 90, 134], 4, 4, 8), ([384], 2, 2, 3), ([130, 126], 2, 1, 2)])
+@pytest.mark.parametrize("seq_lens,hq,hkv,cp", [([300, 212], 8, 2, 4), ([1024], 4, 1, 2), ([100, 700, 90, 134], 4, 4, 8), ([384], 2, 2, 3), ([130, 126], 2, 1, 2),
+                                                # BASELINE.json configs[4]: one 32k-token multi-turn rollout, Qwen3-8B heads, context parallel over 8 ranks
+                                                ([32768], 32, 8, 8), ([20000, 12768], 32, 8, 8)])
 def test_attention_row_windows(ops, seq_lens, hq, hkv, cp):
     """pm_attn_varlen_{fwd,bwd}_rows — context parallelism with gathered K / V (the reference's ring_fa3_varlen_func, ring_attn.py:99-280): every rank
     runs its contiguous q window against the K / V prefix of the pass.  With windows on multiples of 128 the tiles are the full call's tiles:
