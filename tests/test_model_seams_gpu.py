@@ -164,3 +164,53 @@ def test_inject_prime_lm_head_into_a_stock_hf_model():
     out_f["logprobs"].sum().backward()
     g = fused.model.layers[0].mlp.down_proj.weight.grad
     assert g is not None and bool(torch.isfinite(g.float()).all()) and float(g.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen2", "qwen3"])
+def test_dense_families_match_hf_transformers_on_the_gpu(family):
+    """The reference's own model test (tests/unit/train/models/test_llama.py:43-127: HF class vs custom class, same weights, bf16 logits, atol 1.0)
+    for the three dense families on the HIP seams: `transformers` eager attention on the GPU against LlamaForCausalLM / Qwen2ForCausalLM /
+    Qwen3ForCausalLM of prime_rl_amd.trainer.models, one 200-token document, weights loaded from the HF state dict by name."""
+    import transformers
+
+    from prime_rl_amd.trainer.models.llama import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM
+    from prime_rl_amd.trainer.models.qwen3 import Qwen3Config, Qwen3ForCausalLM
+
+    common = dict(hidden_size=512, intermediate_size=768, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=1000,
+                  max_position_embeddings=512)
+    if family == "llama":
+        hf_cfg = transformers.LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, attention_bias=False, mlp_bias=False, tie_word_embeddings=False, **common)
+        hf_cls, cfg, cls = transformers.LlamaForCausalLM, LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, **common_mine(common)), LlamaForCausalLM
+    elif family == "qwen2":
+        hf_cfg = transformers.Qwen2Config(rms_norm_eps=1e-6, rope_theta=1_000_000.0, tie_word_embeddings=True, **common)
+        hf_cls, cfg, cls = transformers.Qwen2ForCausalLM, Qwen2Config(tie_word_embeddings=True, **common_mine(common)), Qwen2ForCausalLM
+    else:
+        hf_cfg = transformers.Qwen3Config(rms_norm_eps=1e-6, rope_theta=1_000_000.0, head_dim=128, attention_bias=False, tie_word_embeddings=False, **common)
+        hf_cls, cfg, cls = transformers.Qwen3ForCausalLM, Qwen3Config(**common_mine(common)), Qwen3ForCausalLM
+    hf_cfg._attn_implementation = "eager"
+    torch.manual_seed(7)
+    hf = hf_cls(hf_cfg)
+    with torch.no_grad():
+        for name, p in hf.named_parameters():
+            if name.endswith(".bias"):
+                p.normal_(0, 0.1)
+            elif "norm" in name:
+                p.copy_(1 + 0.1 * torch.randn_like(p))
+    hf = hf.to(DEV).to(torch.bfloat16).eval()
+    mine = cls(cfg).to(DEV).to(torch.bfloat16)
+    missing, unexpected = mine.load_state_dict(hf.state_dict(), strict=False)
+    assert not unexpected and all(k == "lm_head.weight" for k in missing), (missing, unexpected)
+    n = 200
+    ids = torch.randint(0, 1000, (1, n), device=DEV)
+    pos = torch.arange(n, device=DEV)[None]
+    with torch.no_grad():
+        want = hf(input_ids=ids, position_ids=pos).logits[0].float()
+        got = mine(input_ids=ids, position_ids=pos, seq_lens=torch.tensor([n], device=DEV))["logits"][0].float()
+    err = (got - want).abs()
+    # same bf16 weights, bf16 activations on both sides: a few logit ulps (logits are O(1)); the reference's own bound for this comparison is atol 1.0
+    assert float(err.max()) < 0.15 and float(err.mean()) < 0.02, (family, float(err.max()), float(err.mean()))
+    assert (got.argmax(-1) == want.argmax(-1)).float().mean() > 0.97
+
+
+def common_mine(common: dict) -> dict:
+    return {k: v for k, v in common.items() if k != "max_position_embeddings"} | {"head_dim": 128}
