@@ -10,7 +10,7 @@ classes (the `Field(description=...)`s say which):
   * accepted and inert BY DESIGN on 288 GB parts: model.{ac, ac_offloading, compile, optim_cpu_offload,
     fsdp_cpu_offload, reshard_after_forward, full_offload}, gc — the memory-saving machinery the MI355X engine does not need;
   * rejected with NotImplementedError by `validate_supported()` because they select subsystems outside SURVEY §8
-    (lora, quantization, vlm, ep > 1, non-AdamW optimizers, router replay, token export, nixl broadcast).
+    (lora, quantization, vlm, the fused Triton MoE kernel, non-AdamW optimizers, token export, nixl broadcast).
 
 The reference builds these classes on `pydantic_config.BaseConfig` (absent here); plain pydantic gives the same parsing rules.
 """
@@ -346,8 +346,6 @@ class TrainerConfig(BaseConfig):
             bad.append("model.moe_fused_kernel (the fused Triton MoE kernel; expert GEMMs here are the grouped MFMA kernels)")
         if self.optim.type != "adamw":
             bad.append(f"optim.type = {self.optim.type!r} (the fused on-GPU optimizer is AdamW)")
-        if self.enable_router_replay:
-            bad.append("enable_router_replay")
         if self.enable_token_export:
             bad.append("enable_token_export")
         if self.weight_broadcast is not None and self.weight_broadcast.type == "nixl":

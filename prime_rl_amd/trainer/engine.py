@@ -146,6 +146,7 @@ class PackedBatch:
     # bool [samples] | None: samples of micro-batches that shipped NO rl stream while another micro-batch of the pass did — the
     # reference runs the rl loss fn (and logs its metrics) for every sample of such a micro-batch (loss.py:367-371)
     rl_every_sample: Tensor | None = None
+    routed_experts: Tensor | None = None  # i32 [n, layers, top_k]: the inference engine's expert choices (router replay, train.py:349-360)
 
     @property
     def n_tokens(self) -> int:
@@ -201,12 +202,20 @@ def pack_micro_batches(micro_batches: list[dict], device: torch.device | str) ->
     def dev(t):
         return None if t is None else t.to(device, non_blocking=True)
 
+    routed = [mb.get("routed_experts") for mb in micro_batches]
+    if any(r is not None for r in routed) and not all(r is not None for r in routed):
+        raise ValueError("router replay: every micro-batch of a pass carries routed_experts, or none does")
+    routed = torch.cat([r.reshape((-1,) + tuple(r.shape[-2:])).to(torch.int32) for r in routed]) if routed[0] is not None else None
+    if routed is not None and routed.shape[0] != ids.numel():
+        raise ValueError(f"routed_experts rows ({routed.shape[0]}) != tokens ({ids.numel()})")
+
     return PackedBatch(
         input_ids=dev(ids), position_ids=dev(cat("position_ids", torch.int64)), labels=dev(labels), inv_temp=dev(1.0 / temps),
         advantages=dev(cat("advantages", torch.float32)), inference_logprobs=dev(cat("inference_logprobs", torch.float32)), loss_mask=dev(mask),
         cu_seqlens=dev(cu_seq), cu_samples=dev(cu_smp), sample_starts_mb=dev(torch.tensor(starts, dtype=torch.uint8)),
         n_micro_batches=len(micro_batches), ref_logprobs=dev(ref), rl_weights=dev(rl_w), ce_weights=dev(ce_w), ref_kl_weights=dev(rk_w),
         local_counts=(n_rl, n_ce, n_rk), rl_every_sample=dev(torch.tensor(every, dtype=torch.bool)) if (rl_w is not None and any(every)) else None,
+        routed_experts=dev(routed),
     )
 
 

@@ -289,7 +289,8 @@ def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.devic
     ep = parallel_dims.ep if parallel_dims.ep_enabled else 1
     return ModuleEngine(model, device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), dp_size=parallel_dims.dp_size,
                         ep_group=parallel_dims.get_group("ep") if ep > 1 else None, ep_size=ep,
-                        ep_replica_group=parallel_dims.get_group("ep_replica") if ep > 1 else None, name=config.model.name.split("/")[-1])
+                        ep_replica_group=parallel_dims.get_group("ep_replica") if ep > 1 else None, name=config.model.name.split("/")[-1],
+                        router_replay=bool(config.enable_router_replay))
 
 
 def uses_module_engine(config, parallel_dims: ParallelDims) -> bool:
@@ -306,6 +307,8 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
         raise NotImplementedError("the flat-buffer engine is the dense path; MoE models (and model.ep > 1) run through setup_module_engine() "
                                   "(trainer/module_engine.py) on setup_model() / forward()")
     dims = resolve_model_dims(m)
+    if config.enable_router_replay:
+        raise NotImplementedError("enable_router_replay: dense models have no router (MoE models take it through setup_module_engine)")
     o = config.optim
     optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
     lc = config.loss

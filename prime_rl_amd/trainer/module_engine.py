@@ -75,7 +75,7 @@ def _align(n: int, a: int = 128) -> int:
 
 class ModuleEngine:
     def __init__(self, model: nn.Module, device, optim: OptimConfig | None = None, loss: LossConfig | None = None, dp_group=None, dp_size: int = 1,
-                 ep_group=None, ep_size: int = 1, ep_replica_group=None, name: str = "module"):
+                 ep_group=None, ep_size: int = 1, ep_replica_group=None, name: str = "module", router_replay: bool = False):
         self.model, self.device = model, torch.device(device)
         self.optim, self.loss_cfg = optim or OptimConfig(), loss or LossConfig()
         self.dp_group, self.dp_size = dp_group, dp_size
@@ -85,6 +85,9 @@ class ModuleEngine:
         if dp_size > ep_size > 1 and ep_replica_group is None:
             raise PrimeMI355XError("ranks that hold the same experts in different ep groups need the `ep_replica` group to sum their gradients")
         self.dims = ModuleDims(model.config, name)
+        # `enable_router_replay` (train.py:349-360): the experts the inference engine picked are replayed instead of the trainer's own top-k;
+        # payloads that arrive while it is off are ignored, a missing payload while it is on is an error
+        self.router_replay = router_replay
         self.step_count = 0
         self.cp_size = 1
         # -- flat storage: replicated parameters first, expert parameters after them ---------------------------------------------------
@@ -167,8 +170,14 @@ class ModuleEngine:
     def forward_loss(self, b: PackedBatch, scales: tuple[int, int, int]) -> dict:
         n = b.n_tokens
         seq_lens = (b.cu_seqlens[1:] - b.cu_seqlens[:-1]).to(torch.int64)
+        kw = {}
+        if self.router_replay:
+            if b.routed_experts is None:
+                raise PrimeMI355XError("enable_router_replay needs routed_experts in the rollouts: set `enable_return_routed_experts=True` in the inference "
+                                       "config or pass `--enable-return-routed-experts` to the vLLM server (train.py:353-357)")
+            kw["routed_experts"] = b.routed_experts.unsqueeze(0)
         out = self.model(input_ids=b.input_ids.view(1, n), position_ids=b.position_ids.view(1, n), labels=b.labels.view(1, n),
-                         temperature=(1.0 / b.inv_temp).view(1, n), seq_lens=seq_lens)
+                         temperature=(1.0 / b.inv_temp).view(1, n), seq_lens=seq_lens, **kw)
         if not isinstance(out, dict) or "logprobs" not in out:
             raise PrimeMI355XError("the model must return log-probs and entropy (inject_prime_lm_head with the fused head; trainer/model.py:setup_model does)")
         logprobs = out["logprobs"].reshape(n).float()

@@ -11,6 +11,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import TypedDict
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -132,14 +133,18 @@ class DataLoader:
         def opt(v, dtype):
             return torch.tensor(v, dtype=dtype).unsqueeze(0) if v is not None else None
 
-        if mb.mm_kwargs or mb.routed_experts is not None:
-            raise NotImplementedError("multimodal / router-replay payloads are outside the dense GRPO path (SURVEY.md section 2 rows 12, 21)")
+        if mb.mm_kwargs:
+            raise NotImplementedError("multimodal payloads are outside the GRPO hot path (SURVEY.md section 2 row 12)")
+        routed = None
+        if mb.routed_experts is not None:  # router replay (data.py:197-208): raw bytes -> i32 [1, tokens, layers, top_k]
+            r = mb.routed_experts
+            routed = torch.from_numpy(np.frombuffer(r.data, dtype=np.dtype(r.dtype)).reshape(r.shape).astype(np.int32)).unsqueeze(0)
         return TensorMicroBatch(
             input_ids=torch.tensor(mb.input_ids, dtype=torch.long).unsqueeze(0), position_ids=torch.tensor(mb.position_ids, dtype=torch.long).unsqueeze(0),
             advantages=torch.tensor(mb.advantages, dtype=torch.float).unsqueeze(0),
             inference_logprobs=torch.tensor(mb.inference_logprobs, dtype=torch.float).unsqueeze(0), ref_logprobs=opt(mb.ref_logprobs, torch.float),
             loss_mask=torch.tensor(mb.loss_mask, dtype=torch.bool).unsqueeze(0), temperatures=torch.tensor(mb.temperatures, dtype=torch.float).unsqueeze(0),
             env_names=mb.env_names, sequence_lengths=mb.sequence_lengths, lora_num_tokens=torch.tensor([len(mb.input_ids)], dtype=torch.int32),
-            seq_lens=torch.tensor(mb.seq_lens, dtype=torch.long), mm_kwargs=None, mm_token_type_ids=None, routed_experts=None,
+            seq_lens=torch.tensor(mb.seq_lens, dtype=torch.long), mm_kwargs=None, mm_token_type_ids=None, routed_experts=routed,
             rl_weights=opt(mb.rl_weights, torch.float), ce_weights=opt(mb.ce_weights, torch.float), ref_kl_weights=opt(mb.ref_kl_weights, torch.float),
         )

@@ -48,7 +48,7 @@ def test_toml_tables_and_overrides(tmp_path):
 
 
 def test_out_of_scope_keys_are_refused_loudly():
-    for argv in (["--model.lora.rank", "8"], ["--model.moe-fused-kernel"], ["--optim.type", "muon"], ["--enable-router-replay"]):
+    for argv in (["--model.lora.rank", "8"], ["--model.moe-fused-kernel"], ["--optim.type", "muon"], ["--enable-token-export"]):
         with pytest.raises(NotImplementedError):
             parse_argv(argv).validate_supported()
 

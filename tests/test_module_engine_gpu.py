@@ -112,3 +112,82 @@ def test_train_loop_on_a_qwen3_moe_model(tmp_path, capsys):
                        num_experts_per_tok=2, moe_intermediate_size=128)
     want = 2 * (2 * 256 * 4 * 128 + 2 * 256 * 2 * 128) + 2 * (2 * 3 * 128 * 256 + 8 * 256) + 512 * 256
     assert ModuleDims(c).active_mm_params() == want
+
+
+def test_router_replay_through_rollout_files_and_train(tmp_path):
+    """`enable_router_replay` end to end (train.py:349-360): rollouts written by the orchestrator-side sender carry `routed_experts` (what vLLM returns
+    with --enable-return-routed-experts), travel the msgpack wire, are packed by prepare_batch, reach the MoE layers as forced expert indices.
+    Replaying the experts the SAME weights would pick gives the free run's numbers exactly; different experts give different numbers; a missing
+    payload with the flag on is an error; a payload with the flag off is ignored."""
+    import asyncio
+
+    import numpy as np
+
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.batch import build_bin_cost, prepare_batch
+    from prime_rl_amd.trainer.engine import pack_micro_batches
+    from prime_rl_amd.trainer.model import setup_module_engine
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims
+    from prime_rl_amd.trainer.rl.data import DataLoader
+    from prime_rl_amd.trainer.rl.train import train
+    from prime_rl_amd.transports.rollouts import FileSystemMicroBatchSender
+    from prime_rl_amd.transports.rollouts.types import RoutedExperts, TrainingSample
+
+    def cfg_for(out, replay, steps=1):
+        return TrainerConfig.model_validate(dict(model=dict(name="tiny-moe", seq_len=256, debug=dict(random_init=True)), max_steps=steps, output_dir=str(out),
+                                                 tokens_per_pass=1024, enable_router_replay=replay, optim=dict(lr=1e-3),
+                                                 rollout_transport=dict(type="filesystem")))
+
+    rng = np.random.default_rng(5)
+
+    def samples(routing_for=None):
+        out = []
+        r2 = np.random.default_rng(6)
+        for i, n in enumerate((200, 120, 256, 77)):
+            ids = r2.integers(0, 512, size=n).tolist()
+            routed = None
+            if routing_for is not None:
+                arr = routing_for(i, n)
+                routed = RoutedExperts(data=arr.astype("uint8").tobytes(), shape=[n, 2, 2], dtype="uint8")
+            out.append(TrainingSample(token_ids=ids, mask=[j >= 16 for j in range(n)], logprobs=(-5.0 - r2.random(n)).tolist(), temperatures=[1.0] * n,
+                                      env_name="math", advantages=r2.standard_normal(n).tolist(), routed_experts=routed))
+        return out
+
+    # --- the routing the model itself would choose for these samples: one free forward per sample through the same module engine
+    free_cfg = cfg_for(tmp_path / "probe", False)
+    eng = setup_module_engine(free_cfg, get_parallel_dims(free_cfg.model, 256, world_size=1), device=DEV)
+    own = {}
+    for i, s in enumerate(samples()):
+        (mb,), = prepare_batch([s], 256, 1, build_bin_cost(None), 1)
+        pb = pack_micro_batches([DataLoader._micro_batch_to_tensor(mb)], DEV)
+        recorded = []
+        hooks = [m.router.register_forward_hook(lambda mod, inp, out_: recorded.append(out_[1].clone())) for m in eng.model.moe_layers()]
+        with torch.no_grad():
+            eng.forward_loss(pb, (1, 1, 1))
+        for h in hooks:
+            h.remove()
+        own[i] = torch.stack(recorded, dim=1).cpu().numpy()  # [n, layers, top_k]
+    del eng
+    torch.cuda.empty_cache()
+
+    def run(name, routing_for, replay):
+        out = tmp_path / name
+        sender = FileSystemMicroBatchSender(out, data_world_size=1, current_step=1)
+        asyncio.run(sender.send(prepare_batch(samples(routing_for), 256, 1, build_bin_cost(None), 1)))
+        return train(cfg_for(out, replay))[0]
+
+    free = run("free", None, False)
+    same = run("same", lambda i, n: own[i][:n], True)
+    other = run("other", lambda i, n: (own[i][:n] + 1 + rng.integers(0, 3, size=own[i][:n].shape)) % 8, True)
+    ignored = run("ignored", lambda i, n: (own[i][:n] + 3) % 8, False)
+    for key in ("loss/mean", "entropy/all/mean", "mismatch_kl/all/mean", "optim/grad_norm"):
+        assert same[key] == free[key], (key, same[key], free[key])  # replaying the model's own choices changes nothing, bit for bit
+        assert ignored[key] == free[key], key  # payload present, flag off: not used
+    assert other["loss/mean"] != free["loss/mean"] and other["entropy/all/mean"] != free["entropy/all/mean"]
+    with pytest.raises(Exception, match="enable_router_replay needs routed_experts"):
+        run("missing", None, True)
+    dense = TrainerConfig.model_validate(dict(model=dict(name="tiny", seq_len=256, debug=dict(random_init=True)), enable_router_replay=True))
+    from prime_rl_amd.trainer.model import setup_engine
+
+    with pytest.raises(NotImplementedError, match="no router"):
+        setup_engine(dense, get_parallel_dims(dense.model, 256, world_size=1), device=DEV)
