@@ -346,6 +346,16 @@ int pm_adamw_step(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, 
                   void* param_bf16 /* nullable */, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */,
                   int32_t zero_grad, void* stream);
+/* The reference's other elementwise optimizers on the same flat shards (trainer/optim/__init__.py:74-95), same gradient scaling /
+ * clipping / bf16-shadow / zero_grad contract as pm_adamw_step.
+ * pm_sgd_step: torch.optim.SGD(lr, momentum, nesterov, weight_decay) — g += wd * p; buf = g at step 1, else momentum * buf + g;
+ * g = nesterov ? g + momentum * buf : buf; p -= lr * g.  momentum_buf may be NULL when momentum == 0.
+ * pm_sign_sgd_step: SignSGD (trainer/sign_sgd.py:34-51) — p -= lr * wd * p; p -= lr * sign(g).  No optimizer state. */
+int pm_sgd_step(float* master_f32, float* momentum_buf_f32 /* nullable */, float* grad_f32, void* param_bf16 /* nullable */, int64_t n,
+                float lr, float momentum, float weight_decay, int32_t nesterov, int64_t step, float grad_scale,
+                const float* clip_coef /* device, nullable=1 */, int32_t zero_grad, void* stream);
+int pm_sign_sgd_step(float* master_f32, float* grad_f32, void* param_bf16 /* nullable */, int64_t n, float lr, float weight_decay,
+                     float grad_scale, const float* clip_coef /* device, nullable=1 */, int32_t zero_grad, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * pm_comm_*: RCCL collectives over xGMI behind the C ABI (SURVEY.md section 8(b) minimum set).

@@ -106,6 +106,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_sumsq": (I, [P, I64, P, P, I64, P]),
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
+    "pm_sgd_step": (I, [P, P, P, P, I64, F, F, F, I32, I64, F, P, I32, P]),
+    "pm_sign_sgd_step": (I, [P, P, P, I64, F, F, F, P, I32, P]),
     "pm_comm_available": (c_int, []),
     "pm_comm_rccl_version": (c_int, []),
     "pm_comm_unique_id": (I, [P]),

@@ -344,8 +344,8 @@ class TrainerConfig(BaseConfig):
             bad.append("model.vlm (vision-language models)")
         if m.moe_fused_kernel:
             bad.append("model.moe_fused_kernel (the fused Triton MoE kernel; expert GEMMs here are the grouped MFMA kernels)")
-        if self.optim.type != "adamw":
-            bad.append(f"optim.type = {self.optim.type!r} (the fused on-GPU optimizer is AdamW)")
+        if self.optim.type not in ("adamw", "sgd", "sign_sgd"):
+            bad.append(f"optim.type = {self.optim.type!r} (the fused on-GPU optimizers are adamw, sgd and sign_sgd)")
         if self.enable_token_export:
             bad.append("enable_token_export")
         if self.weight_broadcast is not None and self.weight_broadcast.type == "nixl":

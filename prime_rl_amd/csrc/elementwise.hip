@@ -278,6 +278,68 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
+// SGD with momentum (torch.optim.SGD: L2 weight decay folded into the gradient, dampening 0, optional Nesterov — the reference's `SGD(...)`,
+// trainer/optim/__init__.py:74-81) and SignSGD (trainer/sign_sgd.py:34-51: decoupled decay, then p -= lr * sign(g); no state).  Same streaming
+// layout as adamw_kernel: f32 master (+ momentum buffer), f32 gradient scaled by grad_scale * clip, bf16 shadow written in the same pass.
+template <bool SIGN>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ buf, float* __restrict__ g, bf16_t* __restrict__ pb,
+                                                 int64_t n, float lr, float momentum, float wd, int nesterov, int first_step, float grad_scale,
+                                                 const float* __restrict__ clip_coef, int zero_grad) {
+  const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
+  auto one = [&](float P, float& B, float G) -> float {
+    float gr = G * gs;
+    if constexpr (SIGN) {
+      if (wd > 0.f) P = P + (-lr * wd) * P;
+      const float sg = gr > 0.f ? 1.0f : (gr < 0.f ? -1.0f : 0.0f);
+      return P + (-lr) * sg;
+    } else {
+      if (wd != 0.f) gr = gr + wd * P;
+      if (momentum != 0.f) {
+        B = first_step ? gr : momentum * B + gr;
+        gr = nesterov ? gr + momentum * B : B;
+      }
+      return P + (-lr) * gr;
+    }
+  };
+  const bool has_buf = !SIGN && momentum != 0.f;
+  const int64_t nvec = n >> 2;
+  f32x4v* pv = reinterpret_cast<f32x4v*>(p);
+  f32x4v* bv = reinterpret_cast<f32x4v*>(buf);
+  f32x4v* gv = reinterpret_cast<f32x4v*>(g);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    f32x4v P = __builtin_nontemporal_load(pv + i);
+    const f32x4v G = __builtin_nontemporal_load(gv + i);
+    f32x4v B = {0.f, 0.f, 0.f, 0.f};
+    if (has_buf && !first_step) B = __builtin_nontemporal_load(bv + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float b = B[k];
+      P[k] = one(P[k], b, G[k]);
+      B[k] = b;
+    }
+    __builtin_nontemporal_store(P, pv + i);
+    if (has_buf) __builtin_nontemporal_store(B, bv + i);
+    if (zero_grad) __builtin_nontemporal_store(f32x4v{0.f, 0.f, 0.f, 0.f}, gv + i);
+    if (pb) {
+      u32x2 o;
+      o.x = pack_bf16(P[0], P[1]);
+      o.y = pack_bf16(P[2], P[3]);
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(pb) + i);
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) {
+      float b = (has_buf && !first_step) ? buf[i] : 0.f;
+      const float pp = one(p[i], b, g[i]);
+      p[i] = pp;
+      if (has_buf) buf[i] = b;
+      if (zero_grad) g[i] = 0.f;
+      if (pb) pb[i] = f32_to_bf16(pp);
+    }
+  }
+}
+
 // ================================= 2-D transpose (16-bit elements) ============================
 // dst[c][r] = src[r][c].  One 64x64 tile per workgroup through LDS: 16-byte global loads along src rows, tile rows padded to 33
 // dwords so that the column gathers (8 x ds_read_u16 per 16-byte output vector) are bank-conflict free, 16-byte global stores
@@ -424,6 +486,33 @@ extern "C" int pm_clip_coef(const float* total_sumsq, float grad_scale, float ma
   PM_REQUIRE(total_sumsq && clip_coef, PM_ERR_INVALID_ARG, "pm_clip_coef: null pointer");
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, as_stream(stream), total_sumsq, grad_scale, max_norm, clip_coef, grad_norm_out);
   PM_CHECK_LAUNCH("pm_clip_coef");
+  return PM_OK;
+}
+
+extern "C" int pm_sgd_step(float* master, float* momentum_buf, float* grad, void* param_bf16, int64_t n, float lr, float momentum, float weight_decay,
+                           int32_t nesterov, int64_t step, float grad_scale, const float* clip_coef, int32_t zero_grad, void* stream) {
+  PM_REQUIRE(master && grad && n >= 0 && step >= 1 && momentum >= 0.f, PM_ERR_INVALID_ARG, "pm_sgd_step: bad args");
+  PM_REQUIRE(momentum == 0.f || momentum_buf, PM_ERR_INVALID_ARG, "pm_sgd_step: momentum %g needs a momentum buffer", (double)momentum);
+  PM_REQUIRE(!nesterov || momentum > 0.f, PM_ERR_INVALID_ARG, "pm_sgd_step: Nesterov momentum requires a momentum (torch.optim.SGD)");
+  PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(momentum_buf) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
+             PM_ERR_INVALID_ARG, "pm_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(sgd_kernel<false>, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, momentum_buf, grad, (bf16_t*)param_bf16, n,
+                     lr, momentum, weight_decay, (int)nesterov, (int)(step == 1), grad_scale, clip_coef, (int)zero_grad);
+  PM_CHECK_LAUNCH("pm_sgd_step");
+  return PM_OK;
+}
+
+extern "C" int pm_sign_sgd_step(float* master, float* grad, void* param_bf16, int64_t n, float lr, float weight_decay, float grad_scale,
+                                const float* clip_coef, int32_t zero_grad, void* stream) {
+  PM_REQUIRE(master && grad && n >= 0, PM_ERR_INVALID_ARG, "pm_sign_sgd_step: bad args");
+  PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0 && (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
+             PM_ERR_INVALID_ARG, "pm_sign_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(sgd_kernel<true>, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, (float*)nullptr, grad, (bf16_t*)param_bf16,
+                     n, lr, 0.f, weight_decay, 0, 0, grad_scale, clip_coef, (int)zero_grad);
+  PM_CHECK_LAUNCH("pm_sign_sgd_step");
   return PM_OK;
 }
 

@@ -764,3 +764,26 @@ def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None 
     dw2 = torch.empty((e, n - n1, k), dtype=torch.bfloat16, device=x.device) if n1 < n else None
     check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), _stream()), "pm_grouped_gemm_tn")
     return dw if n_first is None else (dw, dw2)
+
+
+def sgd_step(master: Tensor, momentum_buf: Tensor | None, grad: Tensor, param_bf16: Tensor | None, lr: float, momentum: float, weight_decay: float,
+             nesterov: bool, step: int, grad_scale: float = 1.0, clip: Tensor | None = None, zero_grad: bool = True) -> None:
+    """torch.optim.SGD(momentum, nesterov, L2 weight decay) on flat f32 buffers (pm_sgd_step)."""
+    lib = _lib.load()
+    for t, nm in ((master, "master"), (grad, "grad")) + (((momentum_buf, "momentum_buf"),) if momentum_buf is not None else ()):
+        _req(t, torch.float32, nm)
+    if param_bf16 is not None:
+        _req(param_bf16, torch.bfloat16, "param_bf16")
+    check(lib.pm_sgd_step(_p(master), _p(momentum_buf), _p(grad), _p(param_bf16), master.numel(), lr, momentum, weight_decay, 1 if nesterov else 0, step,
+                          grad_scale, _p(clip), 1 if zero_grad else 0, _stream()), "pm_sgd_step")
+
+
+def sign_sgd_step(master: Tensor, grad: Tensor, param_bf16: Tensor | None, lr: float, weight_decay: float, grad_scale: float = 1.0,
+                  clip: Tensor | None = None, zero_grad: bool = True) -> None:
+    """SignSGD (trainer/sign_sgd.py) on flat f32 buffers (pm_sign_sgd_step)."""
+    lib = _lib.load()
+    _req(master, torch.float32, "master"); _req(grad, torch.float32, "grad")
+    if param_bf16 is not None:
+        _req(param_bf16, torch.bfloat16, "param_bf16")
+    check(lib.pm_sign_sgd_step(_p(master), _p(grad), _p(param_bf16), master.numel(), lr, weight_decay, grad_scale, _p(clip), 1 if zero_grad else 0, _stream()),
+          "pm_sign_sgd_step")

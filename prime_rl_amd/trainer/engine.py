@@ -101,7 +101,8 @@ class ModelDims:
 
 @dataclass
 class OptimConfig:
-    """AdamWConfig defaults (packages/prime-rl-configs/src/prime_rl/configs/trainer.py:415-443)."""
+    """AdamWConfig defaults (packages/prime-rl-configs/src/prime_rl/configs/trainer.py:415-443); `type` "sgd" / "sign_sgd" select the reference's other
+    elementwise optimizers (SGDConfig :426-433: momentum 0.9, Nesterov; SignSGDConfig :459-460)."""
 
     lr: float = 1e-6
     weight_decay: float = 0.01
@@ -109,6 +110,9 @@ class OptimConfig:
     betas2: float = 0.999
     eps: float = 1e-8
     max_norm: float = 1.0
+    type: str = "adamw"
+    momentum: float = 0.9
+    nesterov: bool = True
 
 
 @dataclass
@@ -239,7 +243,7 @@ class ParamStore:
     `state_dict()` exposes HF-named views (q_proj.weight, k_proj.weight, ...) so checkpoints and the weight push keep the
     reference's names (trainer/models/qwen3/modeling_qwen3.py parameter names)."""
 
-    def __init__(self, dims: ModelDims, device, dp_rank: int = 0, dp_size: int = 1, force_collectives: bool = False):
+    def __init__(self, dims: ModelDims, device, dp_rank: int = 0, dp_size: int = 1, force_collectives: bool = False, optimizer: str = "adamw"):
         self.dims, self.device, self.dp_rank, self.dp_size = dims, torch.device(device), dp_rank, dp_size
         d = dims
         buckets: list[_Bucket] = []
@@ -281,8 +285,10 @@ class ParamStore:
         self.params = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
         self.main_grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.master = torch.empty(self.shard_total, dtype=torch.float32, device=self.device)
-        self.exp_avg = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
-        self.exp_avg_sq = torch.zeros(self.shard_total, dtype=torch.float32, device=self.device)
+        # optimizer state per parameter: AdamW two moments, SGD one momentum buffer (kept in exp_avg), SignSGD none
+        n_m, n_v = {"adamw": (self.shard_total, self.shard_total), "sgd": (self.shard_total, 0), "sign_sgd": (0, 0)}[optimizer]
+        self.exp_avg = torch.zeros(n_m, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n_v, dtype=torch.float32, device=self.device)
         # use_collectives: True whenever the reduce-scatter / all-gather path runs (dp > 1, or forced on one rank so the RCCL +
         # side-stream plumbing can be exercised on a single GPU: the collectives then degenerate to device copies)
         self.use_collectives = dp_size > 1 or force_collectives
@@ -430,7 +436,9 @@ class GRPOEngine:
             raise PrimeMI355XError("attention kernels are built for head_dim 128")
         if force_collectives and not dist.is_initialized():
             raise PrimeMI355XError("force_collectives needs an initialised process group (a world_size-1 nccl group is enough)")
-        self.store = ParamStore(dims, self.device, self.shard_rank, self.shard_size, force_collectives=force_collectives)
+        if self.optim.type not in ("adamw", "sgd", "sign_sgd"):
+            raise PrimeMI355XError(f"optim.type = {self.optim.type!r}: the fused on-GPU optimizers are adamw, sgd and sign_sgd")
+        self.store = ParamStore(dims, self.device, self.shard_rank, self.shard_size, force_collectives=force_collectives, optimizer=self.optim.type)
         self.use_collectives = self.store.use_collectives
         self.store.random_init(seed)
         self.inv_freq = ops.rope_inv_freq(dims.head_dim, dims.rope_theta, self.device)

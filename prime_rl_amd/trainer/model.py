@@ -271,6 +271,13 @@ def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, *, seq_le
     return cast_float_and_contiguous(PrimeLmOutput(logits=out.logits))
 
 
+def optim_from_config(o) -> OptimConfig:
+    """OptimizerConfig (adamw | sgd | sign_sgd: configs/trainer.py) -> the engine's OptimConfig; Muon is refused by validate_supported()."""
+    return OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=getattr(o, "betas1", 0.9), betas2=getattr(o, "betas2", 0.999), eps=getattr(o, "eps", 1e-8),
+                       max_norm=o.max_norm if o.max_norm is not None else 0.0, type=o.type, momentum=getattr(o, "momentum", 0.0),
+                       nesterov=getattr(o, "nesterov", False))
+
+
 def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.device | str = "cuda"):
     """TrainerConfig -> the nn.Module flavour of the trainer step (trainer/module_engine.py) on the model `setup_model` builds: the path of
     the MoE families and of `model.ep > 1` (BASELINE.json configs[3]: Qwen3-30B-A3B, expert parallel over the node)."""
@@ -283,7 +290,7 @@ def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.devic
     o, lc = config.optim, config.loss
     if lc.type == "custom":
         raise NotImplementedError("custom loss plugins: call prime_rl_amd.trainer.rl.loss.compute_loss on forward(model, ...) yourself")
-    optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
+    optim = optim_from_config(o)
     loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
                       kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
     ep = parallel_dims.ep if parallel_dims.ep_enabled else 1
@@ -310,7 +317,7 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     if config.enable_router_replay:
         raise NotImplementedError("enable_router_replay: dense models have no router (MoE models take it through setup_module_engine)")
     o = config.optim
-    optim = OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=o.betas1, betas2=o.betas2, eps=o.eps, max_norm=o.max_norm if o.max_norm is not None else 0.0)
+    optim = optim_from_config(o)
     lc = config.loss
     if lc.type == "custom":
         raise NotImplementedError("custom loss plugins run through prime_rl_amd.trainer.rl.loss.compute_loss (the per-sample LossFn contract) on the "

@@ -111,8 +111,9 @@ class ModuleEngine:
         dev = self.device
         self.params_bf16 = torch.zeros(self.total, dtype=torch.bfloat16, device=dev)
         self.master = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        n_m, n_v = {"adamw": (self.total, self.total), "sgd": (self.total, 0), "sign_sgd": (0, 0)}[self.optim.type]
+        self.exp_avg = torch.zeros(n_m, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n_v, dtype=torch.float32, device=dev)
         self.main_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self._grad_views: list[Tensor] = []
         with torch.no_grad():
@@ -229,8 +230,8 @@ class ModuleEngine:
         total = self._sumsq.sum().reshape(1)
         o = self.optim
         coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)
-        ops.adamw_step(self.master, self.exp_avg, self.exp_avg_sq, g, self.params_bf16, o.lr, o.betas1, o.betas2, o.eps, o.weight_decay, self.step_count,
-                       1.0, coef, zero_grad=True)
+        zero.apply_update(ops, o, self.master, self.exp_avg if self.exp_avg.numel() else None, self.exp_avg_sq if self.exp_avg_sq.numel() else None, g,
+                          self.params_bf16, self.step_count, coef, zero_grad=True)
         self._have_grad = False
         return norm
 

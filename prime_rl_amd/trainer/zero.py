@@ -37,6 +37,22 @@ def reduce_scatter_bucket(store, bucket, group, comm_stream=None) -> None:
         dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=group)
 
 
+def apply_update(kernels, optim, master, exp_avg, exp_avg_sq, grad, params_bf16, step: int, coef, zero_grad: bool) -> None:
+    """One fused optimizer launch on a flat f32 shard — `optim.type` selects the reference's optimizer (trainer/optim/__init__.py:74-95):
+    "adamw" (default), "sgd" (torch.optim.SGD with momentum / Nesterov; the momentum buffer lives in `exp_avg`), "sign_sgd" (stateless)."""
+    kind = getattr(optim, "type", "adamw")
+    if kind == "adamw":
+        kernels.adamw_step(master, exp_avg, exp_avg_sq, grad, params_bf16, optim.lr, optim.betas1, optim.betas2, optim.eps, optim.weight_decay, step, 1.0,
+                           coef, zero_grad=zero_grad)
+    elif kind == "sgd":
+        kernels.sgd_step(master, exp_avg if optim.momentum else None, grad, params_bf16, optim.lr, optim.momentum, optim.weight_decay, optim.nesterov, step,
+                         1.0, coef, zero_grad=zero_grad)
+    elif kind == "sign_sgd":
+        kernels.sign_sgd_step(master, grad, params_bf16, optim.lr, optim.weight_decay, 1.0, coef, zero_grad=zero_grad)
+    else:
+        raise ValueError(f"optim.type = {kind!r}: the fused on-GPU optimizers are adamw, sgd and sign_sgd (Muon stays with the reference)")
+
+
 def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=None, gather_events: dict | None = None, scratch: torch.Tensor | None = None):
     """Global-norm clip + AdamW on this rank's shard + in-place all-gather of the bf16 parameters.
     Returns the global gradient norm (1-element tensor)."""
@@ -52,13 +68,12 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
         dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=group)
     coef, norm = kernels.clip_coef(sumsq, 1.0, optim.max_norm if optim.max_norm else 0.0)
     if not collectives:
-        kernels.adamw_step(store.master, store.exp_avg, store.exp_avg_sq, store.grad_shard, store.params, optim.lr, optim.betas1, optim.betas2, optim.eps,
-                           optim.weight_decay, step, 1.0, coef, zero_grad=False)
+        apply_update(kernels, optim, store.master, store.exp_avg, store.exp_avg_sq, store.grad_shard, store.params, step, coef, zero_grad=False)
         return norm
     for b in store.buckets:
         full, local = store.shard_slices(b)
-        kernels.adamw_step(store.master[local], store.exp_avg[local], store.exp_avg_sq[local], store.grad_shard[local], store.params[full], optim.lr,
-                           optim.betas1, optim.betas2, optim.eps, optim.weight_decay, step, 1.0, coef, zero_grad=False)
+        apply_update(kernels, optim, store.master[local], store.exp_avg[local] if store.exp_avg.numel() else None,
+                     store.exp_avg_sq[local] if store.exp_avg_sq.numel() else None, store.grad_shard[local], store.params[full], step, coef, zero_grad=False)
         dst = store.params[b.offset:b.offset + b.size]
         if gpu and comm_stream is not None:
             ev = torch.cuda.Event()

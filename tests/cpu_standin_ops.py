@@ -343,3 +343,27 @@ def moe_ep_row_map(recv_counts, total_rows):
     tot = c.sum(0)
     offs = torch.cat([tot.new_zeros(1), tot.cumsum(0)]).to(torch.int32)
     return row_map.to(torch.int32), inv.to(torch.int32), offs
+
+
+def sgd_step(master, momentum_buf, grad, param_bf16, lr, momentum, weight_decay, nesterov, step, grad_scale=1.0, clip=None, zero_grad=True):
+    g = grad * grad_scale * (clip[0] if clip is not None else 1.0)
+    if weight_decay:
+        g = g + weight_decay * master
+    if momentum:
+        momentum_buf.copy_(g if step == 1 else momentum * momentum_buf + g)
+        g = g + momentum * momentum_buf if nesterov else momentum_buf
+    master.sub_(lr * g)
+    if param_bf16 is not None:
+        param_bf16.copy_(master.to(BF16))
+    if zero_grad:
+        grad.zero_()
+
+
+def sign_sgd_step(master, grad, param_bf16, lr, weight_decay, grad_scale=1.0, clip=None, zero_grad=True):
+    if weight_decay > 0:
+        master.add_(master, alpha=-lr * weight_decay)
+    master.add_(torch.sign(grad), alpha=-lr)
+    if param_bf16 is not None:
+        param_bf16.copy_(master.to(BF16))
+    if zero_grad:
+        grad.zero_()

@@ -414,3 +414,35 @@ def test_train_loop_fake_data_and_filesystem_broadcast(tmp_path, capsys):
     for step in (1, 2):  # keep=2: step_0 (startup policy) is already rotated out
         assert (tmp_path / "broadcasts" / f"step_{step}" / "STABLE").exists()
     assert len((tmp_path / "metrics.jsonl").read_text().strip().splitlines()) == 2
+
+
+@pytest.mark.parametrize("kind", ["sgd", "sign_sgd"])
+def test_engine_with_the_other_elementwise_optimizers(kind):
+    """optim.type = "sgd" / "sign_sgd" (configs/trainer.py; trainer/optim/__init__.py:74-95) through the engine: same gradients as the AdamW engine (the
+    optimizer does not touch forward / backward), parameters moved by exactly the optimizer's rule from those gradients, optimizer state sized to the rule
+    (one buffer / none), and the config path (`--optim.type sgd`) reaches it."""
+    from prime_rl_amd.configs.trainer import TrainerConfig
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+    from prime_rl_amd.trainer.model import optim_from_config
+
+    dims = ModelDims.tiny(layers=2, vocab=512)
+    lr = 1e-2
+    eng = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=lr, weight_decay=0.0, max_norm=0.0, type=kind, momentum=0.9, nesterov=True), seed=4)
+    assert eng.store.exp_avg_sq.numel() == 0 and eng.store.exp_avg.numel() == (eng.store.shard_total if kind == "sgd" else 0)
+    before = eng.store.master.clone()
+    batch = pack_micro_batches(_mbs(dims.vocab_size, 128, 4, True), DEV)
+    eng.step(batch)
+    eng.wait_params_ready()
+    g = eng.store.main_grad
+    delta = eng.store.master - before
+    if kind == "sgd":  # step 1 with Nesterov: buf = g, update = g + momentum * g
+        torch.testing.assert_close(delta, -lr * 1.9 * g, rtol=1e-4, atol=1.5e-7)  # atol: one f32 ulp of a norm weight (~1.0) in `master - before`
+    else:
+        torch.testing.assert_close(delta, -lr * torch.sign(g), rtol=0, atol=1.5e-7)
+    assert torch.equal(eng.store.params, eng.store.master.to(torch.bfloat16))
+    cfg = TrainerConfig.model_validate(dict(optim=dict(type=kind, lr=3e-4)))
+    cfg.validate_supported()
+    oc = optim_from_config(cfg.optim)
+    assert oc.type == kind and oc.lr == 3e-4 and (oc.momentum, oc.nesterov) == ((0.9, True) if kind == "sgd" else (0.0, False))
+    with pytest.raises(NotImplementedError):
+        TrainerConfig.model_validate(dict(optim=dict(type="muon"))).validate_supported()

@@ -722,6 +722,57 @@ def test_adamw_sumsq_clip(ops):
     assert torch.equal(mg, 2 * gb.float())
 
 
+@pytest.mark.parametrize("momentum,nesterov,wd", [(0.9, True, 0.01), (0.9, False, 0.0), (0.0, False, 0.01), (0.5, True, 0.0)])
+def test_sgd_step_matches_torch_sgd(ops, momentum, nesterov, wd):
+    """pm_sgd_step against torch.optim.SGD (what the reference builds for optim.type = "sgd", trainer/optim/__init__.py:74-81): four steps with a changing
+    gradient, clip coefficient applied to the gradient first, bf16 shadow = RNE of the master weights, gradient cleared."""
+    torch.manual_seed(1)
+    n = 70_001
+    pad = (-n) % 4
+    p0 = torch.randn(n)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p], lr=3e-3, momentum=momentum, nesterov=nesterov, weight_decay=wd)
+    master = torch.cat([p0, torch.zeros(pad)]).to(DEV)
+    buf = torch.zeros_like(master) if momentum else None
+    pb = torch.zeros(n + pad, dtype=torch.bfloat16, device=DEV)
+    coef = torch.tensor([0.37], device=DEV)
+    for step in range(1, 5):
+        g = torch.randn(n) * step
+        p.grad = g * 0.37
+        opt.step()
+        grad = torch.cat([g, torch.zeros(pad)]).to(DEV)
+        ops.sgd_step(master, buf, grad, pb, 3e-3, momentum, wd, nesterov, step, grad_scale=1.0, clip=coef, zero_grad=True)
+        assert not grad.any()
+    _close(master[:n], p.detach(), 2e-6, 1e-6, "SGD master weights")
+    assert torch.equal(pb, master.to(torch.bfloat16))
+    if momentum:
+        _close(buf[:n], opt.state[p]["momentum_buffer"], 2e-6, 1e-6, "momentum buffer")
+    with pytest.raises(Exception):
+        ops.sgd_step(master, None, grad, pb, 1e-3, 0.9, 0.0, True, 1)  # momentum without a buffer
+    with pytest.raises(Exception):
+        ops.sgd_step(master, None, grad, pb, 1e-3, 0.0, 0.0, True, 1)  # Nesterov needs a momentum (torch raises as well)
+
+
+def test_sign_sgd_step_matches_reference_formula(ops):
+    """pm_sign_sgd_step against SignSGD.step (trainer/sign_sgd.py:34-51): p.add_(p, alpha=-lr*wd); p.add_(sign(grad), alpha=-lr); zeros stay put."""
+    torch.manual_seed(2)
+    n = 50_002
+    pad = (-n) % 4
+    p = torch.randn(n)
+    master = torch.cat([p, torch.zeros(pad)]).to(DEV)
+    pb = torch.zeros(n + pad, dtype=torch.bfloat16, device=DEV)
+    for step in range(3):
+        g = torch.randn(n)
+        g[::7] = 0.0
+        p.add_(p, alpha=-2e-3 * 0.05)
+        p.add_(torch.sign(g), alpha=-2e-3)
+        grad = torch.cat([g, torch.zeros(pad)]).to(DEV)
+        ops.sign_sgd_step(master, grad, pb, 2e-3, 0.05, grad_scale=1.0, clip=torch.tensor([0.5], device=DEV), zero_grad=True)  # the clip cannot change a sign
+        assert not grad.any()
+    _close(master[:n], p, 1e-6, 1e-7, "SignSGD master weights")
+    assert torch.equal(pb, master.to(torch.bfloat16))
+
+
 # ================================================================================================ edge cases
 def test_edge_cases(ops):
     """Empty and degenerate inputs (the reference's tests cover empty components, singleton groups, length-1 documents)."""
