@@ -239,9 +239,15 @@ class ModuleEngine:
         passes = batch if isinstance(batch, list) else [batch]
         counts = tuple(sum(p.local_counts[k] for p in passes) for k in range(3))
         scales = self.global_scales(counts)
-        out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": []}
+        out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": [], "load_balance": []}
+        moe = bool(getattr(self.model.config, "num_experts", None))
         for p in passes:
             ctx = self.forward_loss(p, scales)
+            if moe:  # per-layer load violation and routing confidence of this pass, counters reset (train.py:531-535, model.py:561-592); the reference
+                # reads them per micro-batch — a pass is `tokens_per_pass // seq_len` micro-batches routed together
+                from .model import get_load_balance_stats
+
+                out["load_balance"].append(get_load_balance_stats(self.model))
             self.backward(ctx)
             out["loss"].append(ctx["loss"])
             out["entropy"].append(ctx["entropy"])

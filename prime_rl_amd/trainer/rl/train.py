@@ -163,6 +163,10 @@ def train(config: TrainerConfig) -> list[dict]:
             names = list(env_ids)
             collect_step_tensors(tensors, p, lp, en, out["sample_stats"][pi], out["sample_metrics"][pi], out["scales"], dims.vocab_size, config.loss.type,
                                  torch.tensor(sample_env), names, _lib.METRIC_KEYS, _lib.STAT)
+        for lb in out.get("load_balance", ()):  # MoE models (train.py:531-535): one value per MoE layer and pass
+            for name, v in lb.items():
+                if v is not None:
+                    tensors[name].append(v)
         keys, stat_dev = tensors.compute_stats_device()
         flat = torch.cat([stat_dev.reshape(-1), out["grad_norm"].reshape(1).float()]).cpu()  # ONE device-to-host copy per step
         torch.cuda.synchronize()
@@ -196,7 +200,8 @@ def train(config: TrainerConfig) -> list[dict]:
         if is_master:
             print(f"Step {step} | Time: {rec['time/step']:.2f}s | Loss: {rec['loss/mean']:.4f} | Entropy: {rec['entropy/all/mean']:.4f} | "
                   f"Mismatch KL: {rec['mismatch_kl/all/mean']:.4f} | Grad. Norm: {grad_norm:.4f} | LR: {engine.optim.lr:.2e} | "
-                  f"Throughput: {thr:.0f} tokens/s | MFU: {mfu:.1f}% | Peak Mem.: {peak:.1f} GiB", flush=True)
+                  f"Throughput: {thr:.0f} tokens/s | MFU: {mfu:.1f}% | Peak Mem.: {peak:.1f} GiB"
+                  + (f" | Max Vio {rec['max_vio/mean']:.4f}" if "max_vio/mean" in rec else ""), flush=True)  # train.py:644-645
             with open(metrics_path, "a") as f:
                 f.write(json.dumps(rec) + "\n")
         history.append(rec)

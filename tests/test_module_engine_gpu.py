@@ -100,6 +100,9 @@ def test_train_loop_on_a_qwen3_moe_model(tmp_path, capsys):
     for key in ("perf/throughput", "perf/mfu", "optim/lr", "optim/grad_norm", "loss/mean", "entropy/all/mean", "mismatch_kl/all/max", "is_masked/mean"):
         assert key in hist[0] and math.isfinite(hist[2][key]), key
     assert hist[0]["optim/grad_norm"] > 0 and hist[0]["perf/mfu"] > 0
+    # MoE load-balance statistics in the step record and on the console line (train.py:531-546, 644-645)
+    assert hist[0]["max_vio/mean"] >= 0 and 0 < hist[0]["routing_confidence/mean"] <= 1.0 + 1e-5 and "max_vio/max" in hist[0]
+    assert "| Max Vio " in capsys.readouterr().out
     assert any(abs(hist[0][k] - hist[2][k]) > 0 for k in ("loss/mean", "entropy/all/mean"))  # the parameters moved
     sd = load_file(str(tmp_path / "broadcasts" / "step_3" / "model.safetensors"))
     assert "model.layers.0.mlp.gate.weight" in sd and "model.layers.1.mlp.experts.7.down_proj.weight" in sd and "model.layers.0.mlp.experts.0.gate_proj.weight" in sd
