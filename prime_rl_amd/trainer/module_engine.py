@@ -129,7 +129,6 @@ class ModuleEngine:
                     p.data = self.master[off:off + n].view(p.shape)
                 self._grad_views.append(self.main_grad[off:off + n].view(p.shape))
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._have_grad = False
         self._param_readers: list = []
 
     # -- GRPOEngine-compatible surface used by train() and the weight broadcast -----------------------------------------------------
@@ -205,7 +204,6 @@ class ModuleEngine:
                 else:
                     gv.add_(p.grad)
                 p.grad = None
-        self._have_grad = True
 
     # -- optimizer ------------------------------------------------------------------------------------------------------------------
     def optimizer_step(self) -> Tensor:
@@ -232,7 +230,6 @@ class ModuleEngine:
         coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)
         zero.apply_update(ops, o, self.master, self.exp_avg if self.exp_avg.numel() else None, self.exp_avg_sq if self.exp_avg_sq.numel() else None, g,
                           self.params_bf16, self.step_count, coef, zero_grad=True)
-        self._have_grad = False
         return norm
 
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:
