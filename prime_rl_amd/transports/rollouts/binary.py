@@ -10,7 +10,8 @@ arrays (the `EncodedTensor` idea of types.py:4-10 applied to the token streams),
 
     sections (each 64-byte aligned, concatenated over the step's micro-batches in order):
       input_ids i32 [n] | position_ids i32 [n] | loss_mask u8 [n] | advantages f32 [n] | inference_logprobs f32 [n] |
-      temperatures f32 [n] | optional f32 [n]: ref_logprobs, rl_weights, ce_weights, ref_kl_weights
+      temperatures f32 [n] | optional f32 [n]: ref_logprobs, rl_weights, ce_weights, ref_kl_weights |
+      optional routed_experts [n, layers, top_k] in the sender's integer dtype (router replay; all micro-batches of the step or none)
     header: tokens per micro-batch, sample lengths (`sequence_lengths`) and document lengths (`seq_lens`) with per-micro-batch
       counts, the env-name table + one env id per SAMPLE (the per-token `env_names` list of the reference is constant within a
       sample), which optional sections are present.
@@ -54,9 +55,19 @@ def encode_step(mbs: list[MicroBatch]) -> bytes:
     if not mbs:
         raise ValueError("empty step")
     for mb in mbs:
-        if mb.mm_kwargs or mb.routed_experts is not None or mb.mm_token_type_ids is not None:
-            raise NotImplementedError("multimodal / router-replay payloads are outside the dense GRPO path")
+        if mb.mm_kwargs or mb.mm_token_type_ids is not None:
+            raise NotImplementedError("multimodal payloads are outside the GRPO hot path")
     counts = [len(mb.input_ids) for mb in mbs]
+    routed = None
+    if any(mb.routed_experts is not None for mb in mbs):  # router replay: raw [tokens, layers, top_k] blocks, concatenated like every other stream
+        if not all(mb.routed_experts is not None for mb in mbs):
+            raise ValueError("router replay: every micro-batch of a step carries routed_experts, or none does (one packed pass routes all of its tokens)")
+        r0 = mbs[0].routed_experts
+        for mb, n in zip(mbs, counts):
+            r = mb.routed_experts
+            if r.dtype != r0.dtype or list(r.shape[1:]) != list(r0.shape[1:]) or r.shape[0] != n:
+                raise ValueError(f"routed_experts: inconsistent payloads in one step ({r.shape} {r.dtype} vs {r0.shape} {r0.dtype}, {n} tokens)")
+        routed = dict(layers=int(r0.shape[1]), top_k=int(r0.shape[2]), dtype=str(np.dtype(r0.dtype)))
     env_table: dict[str, int] = {}
     sample_env: list[int] = []
     for mb in mbs:
@@ -72,6 +83,8 @@ def encode_step(mbs: list[MicroBatch]) -> bytes:
     header = dict(n_tokens=sum(counts), mb_tokens=counts, sample_lens=[s for mb in mbs for s in mb.sequence_lengths],
                   mb_samples=[len(mb.sequence_lengths) for mb in mbs], seq_lens=[s for mb in mbs for s in mb.seq_lens],
                   mb_seqs=[len(mb.seq_lens) for mb in mbs], env_names=list(env_table), sample_env=sample_env, optional=present)
+    if routed is not None:
+        header["routed"] = routed
     hbytes = msgpack.packb(header, use_bin_type=True)
     out = bytearray(MAGIC + struct.pack("<II", VERSION, len(hbytes)) + hbytes)
     out += b"\0" * _pad(len(out))
@@ -88,6 +101,8 @@ def encode_step(mbs: list[MicroBatch]) -> bytes:
             v = getattr(mb, name)
             parts.append(np.full(n, _FILL.get(name, 0.0), dtype=np.float32) if v is None else np.asarray(v, dtype=np.float32))
         section(np.concatenate(parts))
+    if routed is not None:
+        section(np.frombuffer(b"".join(bytes(mb.routed_experts.data) for mb in mbs), dtype=np.uint8))
     return bytes(out)
 
 
@@ -159,6 +174,10 @@ def _index(header: dict, payload: torch.Tensor) -> StepBlob:
         offsets[name] = (cur, n, np.dtype(dt))
         cur += n * np.dtype(dt).itemsize
         cur += _pad(cur)
+    if header.get("routed"):
+        r = header["routed"]
+        offsets["routed_experts"] = (cur, n * r["layers"] * r["top_k"], np.dtype(r["dtype"]))
+        cur += n * r["layers"] * r["top_k"] * np.dtype(r["dtype"]).itemsize
     if cur > payload.numel():
         raise ValueError("PMRB payload shorter than its header says")
     return StepBlob(header, payload, offsets)
@@ -169,6 +188,8 @@ def blob_to_tensor_micro_batches(blob: StepBlob) -> list[dict]:
     h = blob.header
     names = blob.env_names_per_token()
     out, t0, s0, d0 = [], 0, 0, 0
+    r = h.get("routed")
+    routed_all = blob.host_array("routed_experts").reshape(h["n_tokens"], r["layers"], r["top_k"]) if r else None
     for n, ns, nd in zip(h["mb_tokens"], h["mb_samples"], h["mb_seqs"]):
         def f(name, dtype):
             return torch.from_numpy(blob.host_array(name)[t0:t0 + n].copy()).to(dtype).unsqueeze(0)
@@ -181,7 +202,8 @@ def blob_to_tensor_micro_batches(blob: StepBlob) -> list[dict]:
                         loss_mask=f("loss_mask", torch.bool), temperatures=f("temperatures", torch.float), env_names=names[t0:t0 + n],
                         sequence_lengths=list(h["sample_lens"][s0:s0 + ns]), lora_num_tokens=torch.tensor([n], dtype=torch.int32),
                         seq_lens=torch.tensor(h["seq_lens"][d0:d0 + nd], dtype=torch.long), mm_kwargs=None, mm_token_type_ids=None,
-                        routed_experts=None, rl_weights=opt("rl_weights"), ce_weights=opt("ce_weights"), ref_kl_weights=opt("ref_kl_weights")))
+                        routed_experts=None if routed_all is None else torch.from_numpy(routed_all[t0:t0 + n].astype(np.int32)).unsqueeze(0),
+                        rl_weights=opt("rl_weights"), ce_weights=opt("ce_weights"), ref_kl_weights=opt("ref_kl_weights")))
         t0, s0, d0 = t0 + n, s0 + ns, d0 + nd
     return out
 
@@ -225,12 +247,19 @@ def blob_to_packed_batch(blob: StepBlob, device):
     def small(a):
         return torch.from_numpy(a).to(device, non_blocking=True)
 
+    routed = None
+    if h.get("routed"):
+        r = h["routed"]
+        off, cnt, dt = blob.offsets["routed_experts"]
+        tdt = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64}[dt.name]
+        routed = dev_payload[off:off + cnt * dt.itemsize].view(tdt).view(n, r["layers"], r["top_k"]).to(torch.int32)
+
     return PackedBatch(input_ids=ids, position_ids=sec("position_ids", torch.int32).to(torch.int64), labels=labels,
                        inv_temp=1.0 / sec("temperatures", torch.float32), advantages=sec("advantages", torch.float32),
                        inference_logprobs=sec("inference_logprobs", torch.float32), loss_mask=sec("loss_mask", torch.uint8).view(torch.bool),
                        cu_seqlens=small(cu_seq), cu_samples=small(cu_smp), sample_starts_mb=small(starts), n_micro_batches=len(h["mb_tokens"]),
                        ref_logprobs=opt("ref_logprobs"), rl_weights=opt("rl_weights"), ce_weights=opt("ce_weights"),
-                       ref_kl_weights=opt("ref_kl_weights"), local_counts=(n_rl, n_ce, n_rk))
+                       ref_kl_weights=opt("ref_kl_weights"), local_counts=(n_rl, n_ce, n_rk), routed_experts=routed)
 
 
 def step_file(output_dir: Path, step: int, rank: int) -> Path:

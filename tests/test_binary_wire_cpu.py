@@ -108,3 +108,32 @@ def test_binary_receiver_reads_ahead_in_order(tmp_path):
         assert len(mbs) == 2 and mbs[0]["env_names"] == grids[step][1][0].env_names
     th.join()
     assert loader.receiver.current_step == 3
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int16", "int32"])
+def test_binary_wire_carries_router_replay_payloads(dtype):
+    """`MicroBatch.routed_experts` (raw [tokens, layers, top_k] blocks) through the step blob: the packed batch and the per-micro-batch tensors equal
+    the msgpack path's, i32 on arrival whatever the sender's integer width; a step that mixes micro-batches with and without a payload is refused."""
+    import numpy as np
+
+    from prime_rl_amd.transports.rollouts.types import RoutedExperts
+
+    rng = random.Random(11)
+    nrng = np.random.default_rng(11)
+    mbs = [_mb(rng, rng.randint(1, 4), ["math", "code"]) for _ in range(3)]
+    for mb in mbs:
+        n = len(mb.input_ids)
+        arr = nrng.integers(0, 100, size=(n, 3, 4)).astype(dtype)
+        mb.routed_experts = RoutedExperts(data=arr.tobytes(), shape=[n, 3, 4], dtype=dtype)
+    ref_tensors = [DataLoader._micro_batch_to_tensor(mb) for mb in decode_micro_batches(encode_micro_batches(mbs))]
+    want = pack_micro_batches(ref_tensors, "cpu")
+    assert want.routed_experts.shape == (want.n_tokens, 3, 4) and want.routed_experts.dtype == torch.int32
+    blob = B.decode_step(B.encode_step(mbs))
+    got = B.blob_to_packed_batch(blob, "cpu")
+    _assert_packed_equal(got, want)
+    assert got.routed_experts.dtype == torch.int32 and torch.equal(got.routed_experts, want.routed_experts)
+    for g, r in zip(B.blob_to_tensor_micro_batches(blob), ref_tensors):
+        assert g["routed_experts"].dtype == torch.int32 and torch.equal(g["routed_experts"], r["routed_experts"])
+    mbs[1].routed_experts = None
+    with pytest.raises(ValueError, match="router replay"):
+        B.encode_step(mbs)
