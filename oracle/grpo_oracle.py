@@ -316,10 +316,31 @@ def rmsnorm(x, weight, eps: float):
     return weight * h.to(dt)
 
 
-def rope_cos_sin(position_ids, head_dim: int, theta: float, dtype):
-    """RotaryEmbedding.forward (trainer/models/layers/rotary_emb.py:60-73) with _compute_default_rope_parameters (:24)."""
+def rope_inv_freq(head_dim: int, theta: float, rope_scaling: dict | None = None):
+    """ROPE_INIT_FUNCTIONS of the reference's RotaryEmbedding (rotary_emb.py:41-57): "default" (:10-26), "linear" (inv_freq / factor) and "llama3"
+    (transformers `_compute_llama3_parameters`: long wavelengths / factor, a smooth band, short wavelengths untouched); attention_scaling is 1 for all."""
+    import math
+
     torch = _torch()
-    inv_freq = (1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))).to(position_ids.device)
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))
+    kind = (rope_scaling or {}).get("rope_type", (rope_scaling or {}).get("type", "default"))
+    if kind == "linear":
+        return inv_freq / float(rope_scaling["factor"])
+    if kind == "llama3":
+        f, lo, hi, old = (float(rope_scaling[k]) for k in ("factor", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings"))
+        wavelen = 2 * math.pi / inv_freq
+        base = torch.where(wavelen > old / lo, inv_freq / f, inv_freq)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        mid = ~(wavelen < old / hi) & ~(wavelen > old / lo)
+        return torch.where(mid, (1 - smooth) * base / f + smooth * base, base)
+    assert kind == "default", kind
+    return inv_freq
+
+
+def rope_cos_sin(position_ids, head_dim: int, theta: float, dtype, rope_scaling: dict | None = None):
+    """RotaryEmbedding.forward (trainer/models/layers/rotary_emb.py:60-73) with the config's ROPE_INIT_FUNCTIONS entry (rope_inv_freq above)."""
+    torch = _torch()
+    inv_freq = rope_inv_freq(head_dim, theta, rope_scaling).to(position_ids.device)
     freqs = position_ids.to(torch.float32)[:, None] * inv_freq[None, :]
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -376,6 +397,7 @@ class TinyQwen3Config:
     rope_theta: float = 1_000_000.0
     qk_norm: bool = True  # AttentionConfig.use_qk_norm (models/layers/attn.py:37): Qwen3 True, Llama / Qwen2 False
     attention_bias: bool = False  # AttentionConfig.attention_bias (attn.py:36,64-72): bias on q/k/v_proj — Qwen2 True
+    rope_scaling: dict | None = None  # HF rope_scaling of type "linear" / "llama3" (Llama-3.x checkpoints)
 
 
 def exact_mm(a, w, bias=None):
@@ -400,7 +422,7 @@ def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int
     mm = mm or (lambda a, w, b=None: torch.nn.functional.linear(a, w, b))
     hq, hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     x = params["model.embed_tokens.weight"][input_ids]
-    cos, sin = rope_cos_sin(position_ids, d, cfg.rope_theta, x.dtype)
+    cos, sin = rope_cos_sin(position_ids, d, cfg.rope_theta, x.dtype, getattr(cfg, "rope_scaling", None))
     n = x.shape[0]
     for i in range(cfg.num_hidden_layers):
         pre = f"model.layers.{i}."

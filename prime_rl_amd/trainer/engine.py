@@ -30,6 +30,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .. import _lib, ops
+from ..utils.rope import scaled_inv_freq
 from . import ulysses, zero
 from .._lib import LossParams, PrimeMI355XError
 
@@ -55,6 +56,7 @@ class ModelDims:
     name: str = "custom"
     qk_norm: bool = True
     attention_bias: bool = False
+    rope_scaling: dict | None = None  # HF `rope_scaling` / `rope_parameters` of type "linear" or "llama3" (utils/rope.py); None = default table
 
     @classmethod
     def qwen2_5_1_5b(cls) -> "ModelDims":  # public HF config of Qwen/Qwen2.5-1.5B(-Instruct) (BASELINE.json configs[1])
@@ -441,7 +443,7 @@ class GRPOEngine:
         self.store = ParamStore(dims, self.device, self.shard_rank, self.shard_size, force_collectives=force_collectives, optimizer=self.optim.type)
         self.use_collectives = self.store.use_collectives
         self.store.random_init(seed)
-        self.inv_freq = ops.rope_inv_freq(dims.head_dim, dims.rope_theta, self.device)
+        self.inv_freq = scaled_inv_freq(dims.head_dim, dims.rope_theta, dims.rope_scaling, self.device)  # == ops.rope_inv_freq without scaling
         self.lm_head_token_chunk = lm_head_token_chunk
         self.recompute_act = recompute_act
         self.step_count = 0

@@ -55,6 +55,15 @@ KNOWN_MODELS: dict[str, dict] = {
     "tiny-llama": dict(vocab_size=512, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                        qk_norm=False, rms_norm_eps=1e-5, rope_theta=500_000.0),
 }
+_LLAMA3 = dict(qk_norm=False, rms_norm_eps=1e-5, rope_theta=500_000.0,
+               rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192))
+KNOWN_MODELS["llama-3.1-8b"] = dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                                    num_key_value_heads=8, **_LLAMA3)
+KNOWN_MODELS["llama-3.2-3b"] = dict(vocab_size=128256, hidden_size=3072, intermediate_size=8192, num_hidden_layers=28, num_attention_heads=24,
+                                    num_key_value_heads=8, tie_word_embeddings=True,
+                                    **{**_LLAMA3, "rope_scaling": dict(_LLAMA3["rope_scaling"], factor=32.0)})
+for _k in ("llama-3.1-8b", "llama-3.2-3b"):
+    KNOWN_MODELS[_k + "-instruct"] = KNOWN_MODELS[_k]
 for _k in ("qwen2.5-1.5b", "qwen2.5-3b", "qwen2.5-7b"):
     KNOWN_MODELS[_k + "-instruct"] = KNOWN_MODELS[_k]
 # MoE families (models/qwen3_moe): the dense fields above plus the expert fields of configuration_qwen3_moe.py:150-205
@@ -101,10 +110,15 @@ def resolve_model_dims(config) -> ModelDims:
         family = hf.get("model_type")
         if family not in ("qwen3", "llama", "qwen2"):
             raise NotImplementedError(f"model_type {family!r}: the MI355X scoring forward is built for the dense Qwen3, Llama and Qwen2 decoders")
-        scaling = hf.get("rope_scaling") or (hf.get("rope_parameters") or {})
-        if scaling.get("rope_type", scaling.get("type", "default")) not in ("default", None):
-            raise NotImplementedError(f"rope_scaling {scaling.get('rope_type', scaling.get('type'))!r}: pm_rope_table builds the default table only "
-                                      "(inv_freq = theta^(-2i/d), rotary_emb.py:30-45)")
+        scaling = dict(hf.get("rope_scaling") or (hf.get("rope_parameters") or {}))
+        scaling.pop("rope_theta", None)
+        from ..utils.rope import SUPPORTED, rope_type_of
+
+        if rope_type_of(scaling) not in SUPPORTED:
+            raise NotImplementedError(f"rope_scaling {rope_type_of(scaling)!r}: pm_rope_table takes default, linear and llama3 frequencies (utils/rope.py); "
+                                      "yarn / longrope / dynamic rescale cos and sin or depend on the sequence length")
+        if rope_type_of(scaling) == "llama3":
+            scaling.setdefault("original_max_position_embeddings", hf.get("max_position_embeddings"))
         if hf.get("mlp_bias") or (family != "qwen2" and hf.get("attention_bias")):
             raise NotImplementedError("mlp_bias / o_proj bias are not on the MI355X path (q/k/v bias is: model_type qwen2)")
         fields = dict(vocab_size=hf["vocab_size"], hidden_size=hf["hidden_size"], intermediate_size=hf["intermediate_size"],
@@ -112,7 +126,8 @@ def resolve_model_dims(config) -> ModelDims:
                       num_key_value_heads=hf.get("num_key_value_heads", hf["num_attention_heads"]),
                       head_dim=hf.get("head_dim", hf["hidden_size"] // hf["num_attention_heads"]), rms_norm_eps=hf.get("rms_norm_eps", 1e-6),
                       rope_theta=hf.get("rope_theta", (hf.get("rope_parameters") or {}).get("rope_theta", 1_000_000.0)),
-                      tie_word_embeddings=hf.get("tie_word_embeddings", False), qk_norm=family == "qwen3", attention_bias=family == "qwen2")
+                      tie_word_embeddings=hf.get("tie_word_embeddings", False), qk_norm=family == "qwen3", attention_bias=family == "qwen2",
+                      rope_scaling=scaling if rope_type_of(scaling) != "default" else None)
         label = p.name
     else:
         key = name.split("/")[-1].lower()
@@ -201,7 +216,7 @@ def get_model(config, device: torch.device | str = "cuda", dtype: torch.dtype = 
     hf_cfg = cfg_cls(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size, num_hidden_layers=d.num_hidden_layers,
                      num_attention_heads=d.num_attention_heads, num_key_value_heads=d.num_key_value_heads, head_dim=d.head_dim,
                      rms_norm_eps=d.rms_norm_eps, rope_theta=d.rope_theta, tie_word_embeddings=d.tie_word_embeddings, use_qk_norm=d.qk_norm,
-                     attention_bias=d.attention_bias)
+                     attention_bias=d.attention_bias, rope_scaling=d.rope_scaling)
     with torch.device(device):
         model = model_cls(hf_cfg)
     return model.to(dtype)

@@ -9,14 +9,15 @@ import torch
 from torch import nn
 
 from .... import ops
+from ....utils.rope import scaled_inv_freq
 
 
 class RotaryEmbedding(nn.Module):
     inv_freq: torch.Tensor
 
-    def __init__(self, head_dim: int, rope_theta: float = 1_000_000.0, device=None):
+    def __init__(self, head_dim: int, rope_theta: float = 1_000_000.0, device=None, rope_scaling: dict | None = None):
         super().__init__()
-        inv_freq = 1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))  # rotary_emb.py:24
+        inv_freq = scaled_inv_freq(head_dim, rope_theta, rope_scaling)  # rotary_emb.py:24 + ROPE_INIT_FUNCTIONS["linear" | "llama3"]
         self.register_buffer("inv_freq", inv_freq.to(device) if device is not None else inv_freq, persistent=False)
         self.attention_scaling = 1.0
 

@@ -37,6 +37,7 @@ class Qwen3Config:
     attention_bias: bool = False
     tie_word_embeddings: bool = False
     _attn_implementation: str = "hip_varlen"
+    rope_scaling: dict | None = None  # "linear" / "llama3" scaling of the RoPE frequencies (utils/rope.py); None = default
     use_qk_norm: bool = True  # False: the Llama decoder block (models/llama/modeling_llama.py:52-62) / HF Qwen2 with attention_bias=True
 
 
@@ -82,7 +83,7 @@ class Qwen3Model(nn.Module):
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
         self.layers = nn.ModuleList([Qwen3DecoderLayer(config, i) for i in range(config.num_hidden_layers)])
         self.norm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))
-        self.rotary_emb = RotaryEmbedding(config.head_dim, config.rope_theta)
+        self.rotary_emb = RotaryEmbedding(config.head_dim, config.rope_theta, rope_scaling=getattr(config, "rope_scaling", None))
 
     def forward(self, input_ids=None, position_ids=None, inputs_embeds=None, *, seq_lens, seq_lens_are_pre_shard: bool = False):
         if (input_ids is None) ^ (inputs_embeds is not None):

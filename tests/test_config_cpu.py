@@ -116,12 +116,41 @@ def test_model_name_resolution(tmp_path):
         (tmp_path / "config.json").write_text(json.dumps(dict(model_type=family, **base)))
         d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
         assert (d.qk_norm, d.attention_bias) == want and d.head_dim == 128
-    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", rope_scaling=dict(rope_type="llama3", factor=8.0), **base)))
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", rope_scaling=dict(rope_type="yarn", factor=8.0), **base)))
     with pytest.raises(NotImplementedError, match="rope_scaling"):
         resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+    l3 = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", rope_scaling=l3, rope_theta=500000.0, max_position_embeddings=131072, **base)))
+    d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+    assert d.rope_scaling == l3 and d.rope_theta == 500000.0 and not d.qk_norm
+    d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="meta-llama/Llama-3.1-8B-Instruct"))).model)
+    assert d.rope_scaling["rope_type"] == "llama3" and d.num_params() == 8_030_261_248  # the published size of Llama-3.1-8B
     (tmp_path / "config.json").write_text(json.dumps(dict(model_type="llama", mlp_bias=True, **base)))
     with pytest.raises(NotImplementedError, match="mlp_bias"):
         resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
     (tmp_path / "config.json").write_text(json.dumps(dict(model_type="mistral", **base)))
     with pytest.raises(NotImplementedError, match="model_type"):
         resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name=str(tmp_path)))).model)
+
+
+def test_rope_frequency_scaling_equals_transformers():
+    """utils/rope.py against transformers' ROPE_INIT_FUNCTIONS (what the reference's RotaryEmbedding calls, rotary_emb.py:41-57): "llama3" with the
+    Llama-3.1 and 3.2 parameters and "linear", bit for bit; the default table; unsupported types refused."""
+    import torch
+    from transformers import LlamaConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+
+    from prime_rl_amd.utils.rope import scaled_inv_freq
+
+    for factor in (8.0, 32.0):
+        rs = dict(rope_type="llama3", factor=factor, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+        cfg = LlamaConfig(hidden_size=512, num_attention_heads=4, rope_theta=500000.0, rope_scaling=rs, max_position_embeddings=131072)
+        want, scale = ROPE_INIT_FUNCTIONS["llama3"](cfg, "cpu")
+        got = scaled_inv_freq(128, 500000.0, rs)
+        assert scale == 1.0 and torch.equal(got, want) and not torch.equal(got, scaled_inv_freq(128, 500000.0))
+    rs = dict(rope_type="linear", factor=4.0)
+    want, scale = ROPE_INIT_FUNCTIONS["linear"](LlamaConfig(hidden_size=512, num_attention_heads=4, rope_theta=10000.0, rope_scaling=rs), "cpu")
+    assert scale == 1.0 and torch.equal(scaled_inv_freq(128, 10000.0, rs), want)
+    assert torch.equal(scaled_inv_freq(128, 1e6), 1.0 / (1e6 ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128)))
+    with pytest.raises(NotImplementedError):
+        scaled_inv_freq(128, 1e6, dict(rope_type="yarn", factor=4.0))

@@ -39,7 +39,7 @@ def _oracle_cfg(dims):
     return O.TinyQwen3Config(hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=dims.num_hidden_layers,
                              num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=dims.head_dim,
                              vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta, qk_norm=dims.qk_norm,
-                             attention_bias=dims.attention_bias)
+                             attention_bias=dims.attention_bias, rope_scaling=dims.rope_scaling)
 
 
 def _parity_variant_mbs(vocab, seq_len, n_rollouts, prompt_len, seed=0):
@@ -198,7 +198,7 @@ def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=
     return engines, None
 
 
-@pytest.mark.parametrize("packed,family", [(False, "qwen3"), (True, "qwen3"), (True, "qwen2"), (False, "llama")])
+@pytest.mark.parametrize("packed,family", [(False, "qwen3"), (True, "qwen3"), (True, "qwen2"), (False, "llama"), (True, "llama3")])
 def test_engine_step_matches_oracle(packed, family):
     """Tiny model (H=256, V=512, 2 layers), 8 x 256 tokens: the loss gate, then gradients and the optimizer of the SHIPPED bf16
     engine against f32 autograd of the same model.  `family`: qwen3 = per-head q/k RMSNorm; qwen2 = q/k/v bias, no q/k norm (Qwen2.5 of
@@ -208,6 +208,9 @@ def test_engine_step_matches_oracle(packed, family):
     from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
 
     dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family == "qwen2")
+    if family == "llama3":  # Llama-3.x: scaled RoPE frequencies (utils/rope.py; original context shrunk so the 256-token test sees all three bands)
+        dims = dataclasses.replace(dims, rope_theta=500_000.0, rms_norm_eps=1e-5,
+                                   rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=64))
     seed_eng = GRPOEngine(dims, device=DEV, seed=0)
     # give the model non-trivial logits (std ~1)
     sd = {k: v.detach().cpu().clone() for k, v in seed_eng.store.state_dict().items()}

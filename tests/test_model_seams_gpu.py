@@ -166,7 +166,7 @@ def test_inject_prime_lm_head_into_a_stock_hf_model():
     assert g is not None and bool(torch.isfinite(g.float()).all()) and float(g.float().abs().sum()) > 0
 
 
-@pytest.mark.parametrize("family", ["llama", "qwen2", "qwen3"])
+@pytest.mark.parametrize("family", ["llama", "llama3", "qwen2", "qwen3"])
 def test_dense_families_match_hf_transformers_on_the_gpu(family):
     """The reference's own model test (tests/unit/train/models/test_llama.py:43-127: HF class vs custom class, same weights, bf16 logits, atol 1.0)
     for the three dense families on the HIP seams: `transformers` eager attention on the GPU against LlamaForCausalLM / Qwen2ForCausalLM /
@@ -178,9 +178,12 @@ def test_dense_families_match_hf_transformers_on_the_gpu(family):
 
     common = dict(hidden_size=512, intermediate_size=768, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=1000,
                   max_position_embeddings=512)
-    if family == "llama":
-        hf_cfg = transformers.LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, attention_bias=False, mlp_bias=False, tie_word_embeddings=False, **common)
-        hf_cls, cfg, cls = transformers.LlamaForCausalLM, LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, **common_mine(common)), LlamaForCausalLM
+    if family in ("llama", "llama3"):
+        scaling = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=64) if family == "llama3" else None
+        extra = dict(rope_scaling=scaling) if scaling else {}
+        hf_cfg = transformers.LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, attention_bias=False, mlp_bias=False, tie_word_embeddings=False, **common,
+                                          **extra)
+        hf_cls, cfg, cls = transformers.LlamaForCausalLM, LlamaConfig(rms_norm_eps=1e-5, rope_theta=500_000.0, rope_scaling=scaling, **common_mine(common)), LlamaForCausalLM
     elif family == "qwen2":
         hf_cfg = transformers.Qwen2Config(rms_norm_eps=1e-6, rope_theta=1_000_000.0, tie_word_embeddings=True, **common)
         hf_cls, cfg, cls = transformers.Qwen2ForCausalLM, Qwen2Config(tie_word_embeddings=True, **common_mine(common)), Qwen2ForCausalLM
