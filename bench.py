@@ -178,7 +178,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--micro-batches", type=int, default=8, help="2048-token micro-batches (= samples) per GPU per optimizer step")
     ap.add_argument("--seq-len", type=int, default=2048)
-    ap.add_argument("--model", default="qwen3-8b", choices=["qwen3-8b", "qwen3-0.6b", "qwen2.5-1.5b", "tiny"])
+    ap.add_argument("--model", default="qwen3-8b", choices=["qwen3-8b", "qwen3-0.6b", "qwen2.5-1.5b", "qwen2.5-0.5b", "tiny"])
     ap.add_argument("--tokens-per-pass", type=int, default=16384, help="micro-batches are concatenated into passes of at most this many tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
@@ -203,7 +203,8 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
 
-    dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "tiny": ModelDims.tiny}[args.model]()
+    dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "qwen2.5-0.5b": ModelDims.qwen2_5_0_5b,
+            "tiny": ModelDims.tiny}[args.model]()
     engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 

@@ -63,6 +63,10 @@ class ModelDims:
         return cls(151936, 1536, 8960, 28, 12, 2, 128, tie_word_embeddings=True, name="Qwen2.5-1.5B", qk_norm=False, attention_bias=True)
 
     @classmethod
+    def qwen2_5_0_5b(cls) -> "ModelDims":  # Qwen/Qwen2.5-0.5B(-Instruct): BASELINE.json configs[0]; 64-wide heads (run padded to 128)
+        return cls(151936, 896, 4864, 24, 14, 2, 64, tie_word_embeddings=True, name="Qwen2.5-0.5B", qk_norm=False, attention_bias=True)
+
+    @classmethod
     def qwen3_8b(cls) -> "ModelDims":  # public HF config
         return cls(151936, 4096, 12288, 36, 32, 8, 128, name="Qwen3-8B")
 
@@ -75,18 +79,30 @@ class ModelDims:
         return cls(vocab, 256, 512, layers, 4, 2, 128, name="tiny")
 
     @property
-    def q_dim(self) -> int:
-        return self.num_attention_heads * self.head_dim
+    def kernel_head_dim(self) -> int:
+        """Head width the attention / RoPE kernels run at.  They are built for 128-wide heads; a 64-wide head (Qwen2.5-0.5B of BASELINE.json
+        configs[0], Llama-3.2-1B) runs ZERO-PADDED to 128 — exact: its two rotary halves [0,32) / [32,64) sit at [0,32) / [64,96) of the padded head,
+        the other 64 positions hold zero weights (zero q, k, v columns and zero o_proj inputs contribute nothing and receive zero gradients)."""
+        return 128 if self.head_dim == 64 else self.head_dim
+
+    @property
+    def head_padded(self) -> bool:
+        return self.kernel_head_dim != self.head_dim
+
+    @property
+    def q_dim(self) -> int:  # width of the q block of the fused projection AS STORED (padded heads included)
+        return self.num_attention_heads * self.kernel_head_dim
 
     @property
     def kv_dim(self) -> int:
-        return self.num_key_value_heads * self.head_dim
+        return self.num_key_value_heads * self.kernel_head_dim
 
     def num_params(self) -> int:
         h, i, v = self.hidden_size, self.intermediate_size, self.vocab_size
-        per_layer = 2 * h + (self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h
+        q, kv = self.num_attention_heads * self.head_dim, self.num_key_value_heads * self.head_dim
+        per_layer = 2 * h + (q + 2 * kv) * h + h * q + 3 * i * h
         per_layer += 2 * self.head_dim if self.qk_norm else 0
-        per_layer += self.q_dim + 2 * self.kv_dim if self.attention_bias else 0
+        per_layer += q + 2 * kv if self.attention_bias else 0
         return v * h * (1 if self.tie_word_embeddings else 2) + self.num_hidden_layers * per_layer + h
 
     def flops_per_token(self, seq_len: int) -> int:
@@ -98,7 +114,8 @@ class ModelDims:
     def active_mm_params(self) -> int:
         """PerfCounter.get_active_mm_params (trainer/perf.py:120-175), dense case: q/k/v/o + gate/up/down per layer + LM head."""
         h, i = self.hidden_size, self.intermediate_size
-        return self.num_hidden_layers * ((self.q_dim + 2 * self.kv_dim) * h + h * self.q_dim + 3 * i * h) + self.vocab_size * h
+        q, kv = self.num_attention_heads * self.head_dim, self.num_key_value_heads * self.head_dim  # the model's own widths, not the padded storage
+        return self.num_hidden_layers * ((q + 2 * kv) * h + h * q + 3 * i * h) + self.vocab_size * h
 
 
 @dataclass
@@ -318,11 +335,43 @@ class ParamStore:
                 for s in range(0, flat.numel(), chunk):
                     e = min(s + chunk, flat.numel())
                     flat[s:e] = (torch.randn(e - s, device=self.device, generator=gen) * std).to(torch.bfloat16)
+        if self.dims.head_padded:  # the padding positions of every head hold zeros and stay zero (no gradient ever reaches them)
+            self.load_state_dict({k: v.clone() for k, v in self.state_dict().items()})
+            return
         self.sync_master_from_params()
+
+    # -- 64-wide heads stored zero-padded to the kernels' 128 (ModelDims.kernel_head_dim) --------------------------------------------
+    def _head_index(self, n_heads: int) -> Tensor:
+        """Positions of the model's own head dimensions inside the padded storage: rotary half 0 -> [0, d/2), half 1 -> [64, 64 + d/2) of every head."""
+        d, kd = self.dims.head_dim, self.dims.kernel_head_dim
+        one = torch.cat([torch.arange(d // 2), kd // 2 + torch.arange(d // 2)])
+        return (torch.arange(n_heads)[:, None] * kd + one[None, :]).reshape(-1).to(self.device)
+
+    def _pad_heads(self, t: Tensor, n_heads: int, dim: int) -> Tensor:
+        if not self.dims.head_padded:
+            return t
+        shape = list(t.shape)
+        shape[dim] = n_heads * self.dims.kernel_head_dim
+        out = torch.zeros(shape, dtype=t.dtype, device=self.device)
+        out.index_copy_(dim, self._head_index(n_heads), t.to(self.device))
+        return out
+
+    def _unpad_heads(self, t: Tensor, n_heads: int, dim: int) -> Tensor:
+        return t.index_select(dim, self._head_index(n_heads)) if self.dims.head_padded else t
 
     def load_state_dict(self, sd: dict[str, Tensor]) -> None:
         """HF-named tensors (q_proj/k_proj/v_proj, gate_proj/up_proj separate) -> fused flat storage."""
         d = self.dims
+        if d.head_padded:
+            sd = dict(sd)
+            for i in range(d.num_hidden_layers):
+                pre = f"model.layers.{i}.self_attn."
+                for nm, heads in (("q", d.num_attention_heads), ("k", d.num_key_value_heads), ("v", d.num_key_value_heads)):
+                    for kind in ("weight", "bias"):
+                        if pre + f"{nm}_proj.{kind}" in sd:
+                            sd[pre + f"{nm}_proj.{kind}"] = self._pad_heads(sd[pre + f"{nm}_proj.{kind}"], heads, 0)
+                if pre + "o_proj.weight" in sd:
+                    sd[pre + "o_proj.weight"] = self._pad_heads(sd[pre + "o_proj.weight"], d.num_attention_heads, 1)
         for i in range(d.num_hidden_layers):
             p = f"model.layers.{i}."
             sd = dict(sd)
@@ -343,9 +392,16 @@ class ParamStore:
         self.sync_master_from_params()
 
     def state_dict(self) -> dict[str, Tensor]:
-        """HF-named views of the bf16 parameters (no copies)."""
+        """HF-named views of the bf16 parameters (no copies; models with padded heads get de-padded copies of the attention projections)."""
+        return self._hf_named(self.w)
+
+    def grad_state_dict(self) -> dict[str, Tensor]:
+        """The f32 gradients under the same HF names."""
+        return self._hf_named(self.g)
+
+    def _hf_named(self, flat: dict[str, Tensor]) -> dict[str, Tensor]:
         d, out = self.dims, {}
-        for name, w in self.w.items():
+        for name, w in flat.items():
             if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
                 kind = name.rsplit(".", 1)[1]
                 base = name[: -len("qkv_proj." + kind)]
@@ -358,8 +414,14 @@ class ParamStore:
                 out[base + "up_proj.weight"] = w[d.intermediate_size:]
             else:
                 out[name] = w
+        if d.head_padded:
+            for name in list(out):
+                if ".self_attn." not in name or "norm" in name:
+                    continue
+                heads = d.num_attention_heads if (".q_proj." in name or ".o_proj." in name) else d.num_key_value_heads
+                out[name] = self._unpad_heads(out[name], heads, 1 if ".o_proj." in name else 0)
         if d.tie_word_embeddings:
-            out["lm_head.weight"] = self.w["model.embed_tokens.weight"]
+            out["lm_head.weight"] = flat["model.embed_tokens.weight"]
         return out
 
     def shard_slices(self, b: _Bucket) -> tuple[slice, slice]:
@@ -434,8 +496,10 @@ class GRPOEngine:
             self.shard_rank = dist.get_rank(shard_group)
         else:
             self.shard_group, self.shard_size, self.shard_rank = self.dp_group, self.dp_size, self.dp_rank
-        if dims.head_dim != 128:
-            raise PrimeMI355XError("attention kernels are built for head_dim 128")
+        if dims.kernel_head_dim != 128:
+            raise PrimeMI355XError(f"head_dim {dims.head_dim}: the attention kernels are built for 128-wide heads (64-wide heads run zero-padded to 128)")
+        if dims.head_padded and dims.qk_norm:
+            raise PrimeMI355XError("padded heads + per-head q/k RMSNorm: the norm would average over the padding (no such model family exists)")
         if force_collectives and not dist.is_initialized():
             raise PrimeMI355XError("force_collectives needs an initialised process group (a world_size-1 nccl group is enough)")
         if self.optim.type not in ("adamw", "sgd", "sign_sgd"):
@@ -444,6 +508,8 @@ class GRPOEngine:
         self.use_collectives = self.store.use_collectives
         self.store.random_init(seed)
         self.inv_freq = scaled_inv_freq(dims.head_dim, dims.rope_theta, dims.rope_scaling, self.device)  # == ops.rope_inv_freq without scaling
+        if dims.head_padded:  # frequencies of the padded positions: 0 (cos 1, sin 0 — they only ever rotate zeros)
+            self.inv_freq = torch.cat([self.inv_freq, torch.zeros(dims.kernel_head_dim // 2 - self.inv_freq.numel(), device=self.device)])
         self.lm_head_token_chunk = lm_head_token_chunk
         self.recompute_act = recompute_act
         self.step_count = 0
@@ -584,8 +650,8 @@ class GRPOEngine:
                 h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
             qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"], bias=w.get(p + "self_attn.qkv_proj.bias"))
             q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w.get(p + "self_attn.q_norm.weight"), w.get(p + "self_attn.k_norm.weight"), cos, sin,
-                                                 d.num_attention_heads, d.num_key_value_heads, d.head_dim, d.rms_norm_eps)
-            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+                                                 d.num_attention_heads, d.num_key_value_heads, d.kernel_head_dim, d.rms_norm_eps)
+            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             if cp == 1:
                 o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
                 attn_saved = None
@@ -751,12 +817,12 @@ class GRPOEngine:
             self._wgrad(dgu, L["h2"], g[p + "mlp.gate_up_proj.weight"], accumulate, k_contiguous_x=True)
             dx2 = ops.rmsnorm_bwd(dh2, L["x2"], w[p + "post_attention_layernorm.weight"], L["rstd2"],
                                   self._norm_grad(g[p + "post_attention_layernorm.weight"], accumulate), dresidual=dx)
-            do = self._dgrad(dx2, i, "self_attn.o_proj.weight").view(n, d.num_attention_heads, d.head_dim)
+            do = self._dgrad(dx2, i, "self_attn.o_proj.weight").view(n, d.num_attention_heads, d.kernel_head_dim)
             self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate)
             qkv = L["qkv"]
-            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             dqkv = torch.empty_like(qkv)
-            dv_view = dqkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.head_dim)
+            dv_view = dqkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             if self.cp_size == 1:
                 dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
             else:
@@ -766,10 +832,10 @@ class GRPOEngine:
                 ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
                                     L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),
                                     self._norm_grad(g[p + "self_attn.k_norm.weight"], accumulate), d.num_attention_heads, d.num_key_value_heads,
-                                    d.head_dim)
+                                    d.kernel_head_dim)
             else:
                 ops.qknorm_rope_bwd(dq, dk, None, None, None, ctx["cos"], ctx["sin"], None, dqkv, None, None, d.num_attention_heads,
-                                    d.num_key_value_heads, d.head_dim)
+                                    d.num_key_value_heads, d.kernel_head_dim)
             if d.attention_bias:  # grad_bias = column sums of the projection's output gradient
                 ops.column_sum(dqkv, self._norm_grad(g[p + "self_attn.qkv_proj.bias"], accumulate))
             dh1 = self._dgrad(dqkv, i, "self_attn.qkv_proj.weight")

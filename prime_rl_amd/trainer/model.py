@@ -44,6 +44,8 @@ KNOWN_MODELS: dict[str, dict] = {
                        tie_word_embeddings=True),
     "tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2),
     # Qwen2.5 (HF Qwen2: q/k/v bias, no q/k norm) — BASELINE.json configs[1] is Qwen2.5-1.5B-Instruct; only the head_dim-128 sizes run here
+    "qwen2.5-0.5b": dict(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=24, num_attention_heads=14, num_key_value_heads=2,
+                         head_dim=64, tie_word_embeddings=True, **_QWEN2),  # BASELINE.json configs[0]; 64-wide heads run zero-padded to 128 in the engine
     "qwen2.5-1.5b": dict(vocab_size=151936, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2,
                          tie_word_embeddings=True, **_QWEN2),
     "qwen2.5-3b": dict(vocab_size=151936, hidden_size=2048, intermediate_size=11008, num_hidden_layers=36, num_attention_heads=16, num_key_value_heads=2,
@@ -64,7 +66,11 @@ KNOWN_MODELS["llama-3.2-3b"] = dict(vocab_size=128256, hidden_size=3072, interme
                                     **{**_LLAMA3, "rope_scaling": dict(_LLAMA3["rope_scaling"], factor=32.0)})
 for _k in ("llama-3.1-8b", "llama-3.2-3b"):
     KNOWN_MODELS[_k + "-instruct"] = KNOWN_MODELS[_k]
-for _k in ("qwen2.5-1.5b", "qwen2.5-3b", "qwen2.5-7b"):
+KNOWN_MODELS["llama-3.2-1b"] = dict(vocab_size=128256, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32,
+                                    num_key_value_heads=8, head_dim=64, tie_word_embeddings=True,
+                                    **{**_LLAMA3, "rope_scaling": dict(_LLAMA3["rope_scaling"], factor=32.0)})
+KNOWN_MODELS["llama-3.2-1b-instruct"] = KNOWN_MODELS["llama-3.2-1b"]
+for _k in ("qwen2.5-0.5b", "qwen2.5-1.5b", "qwen2.5-3b", "qwen2.5-7b"):
     KNOWN_MODELS[_k + "-instruct"] = KNOWN_MODELS[_k]
 # MoE families (models/qwen3_moe): the dense fields above plus the expert fields of configuration_qwen3_moe.py:150-205
 KNOWN_MOE_MODELS: dict[str, dict] = {

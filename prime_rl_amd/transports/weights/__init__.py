@@ -95,6 +95,9 @@ class FileSystemWeightBroadcast(WeightBroadcast):
 def build_layout(store) -> list[dict]:
     """Manifest of the flat parameter buffer: one entry per bucket with HF-named (name, offset-in-bucket, shape) triples."""
     d = store.dims
+    if getattr(d, "head_padded", False):
+        raise NotImplementedError("the sharded push sends the flat buffers as they are stored; models whose 64-wide heads are stored zero-padded to 128 push "
+                                  "de-padded HF tensors with the reference protocol (PRIME_PUSH_PROTOCOL=reference) or the filesystem broadcast")
     out = []
     for b in store.buckets:
         entries = []

@@ -154,3 +154,35 @@ def test_rope_frequency_scaling_equals_transformers():
     assert torch.equal(scaled_inv_freq(128, 1e6), 1.0 / (1e6 ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128)))
     with pytest.raises(NotImplementedError):
         scaled_inv_freq(128, 1e6, dict(rope_type="yarn", factor=4.0))
+
+
+def test_64_wide_heads_are_stored_zero_padded_and_exposed_unpadded():
+    """Qwen2.5-0.5B (BASELINE.json configs[0]) and Llama-3.2-1B have 64-wide heads; the kernels are built for 128.  ParamStore keeps every head
+    zero-padded — rotary half 0 at [0, 32), half 1 at [64, 96) of the padded head — and speaks HF shapes at its boundary: load_state_dict pads,
+    state_dict / grad_state_dict de-pad, the parameter and flop counts are the model's own."""
+    import torch
+
+    from prime_rl_amd.trainer.engine import ModelDims, ParamStore
+    from prime_rl_amd.trainer.model import resolve_model_dims
+
+    d = resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="Qwen/Qwen2.5-0.5B-Instruct"))).model)
+    assert (d.head_dim, d.kernel_head_dim, d.head_padded, d.q_dim, d.kv_dim) == (64, 128, True, 14 * 128, 2 * 128)
+    assert d.num_params() == 494_032_768  # the published size of Qwen2.5-0.5B: padding is storage, not parameters
+    assert resolve_model_dims(TrainerConfig.model_validate(dict(model=dict(name="meta-llama/Llama-3.2-1B"))).model).num_params() == 1_235_814_400
+    assert not ModelDims.qwen3_8b().head_padded
+    dims = ModelDims(97, 128, 256, 2, 2, 1, 64, tie_word_embeddings=False, qk_norm=False, attention_bias=True, name="pad64")
+    st = ParamStore(dims, "cpu")
+    st.random_init(seed=3)
+    sd = {k: v.clone() for k, v in st.state_dict().items()}
+    assert sd["model.layers.1.self_attn.q_proj.weight"].shape == (128, 128) and sd["model.layers.1.self_attn.k_proj.bias"].shape == (64,)
+    assert sd["model.layers.0.self_attn.o_proj.weight"].shape == (128, 128) and all(float(v.abs().sum()) > 0 for v in sd.values())
+    qkv = st.w["model.layers.0.self_attn.qkv_proj.weight"].view(4, 128, 128)  # (2 q + 1 k + 1 v) heads x padded width x hidden
+    assert float(qkv[:, 32:64].abs().sum()) == 0 and float(qkv[:, 96:].abs().sum()) == 0 and float(qkv[:, :32].abs().sum()) > 0
+    assert torch.equal(qkv[0, 64:96], sd["model.layers.0.self_attn.q_proj.weight"][32:64])  # second rotary half of q head 0
+    o = st.w["model.layers.0.self_attn.o_proj.weight"].view(128, 2, 128)
+    assert float(o[:, :, 32:64].abs().sum()) == 0 and float(o[:, :, 96:].abs().sum()) == 0
+    st2 = ParamStore(dims, "cpu")
+    st2.load_state_dict(sd)
+    assert torch.equal(st2.params, st.params) and torch.equal(st2.master, st.master)
+    g = st.grad_state_dict()
+    assert set(g) == set(sd) and all(g[k].shape == sd[k].shape and g[k].dtype == torch.float32 for k in sd)

@@ -165,18 +165,7 @@ def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=
         loss_a.backward()
         eng, ctx = engines[check_grads_on]
         eng.backward(ctx, accumulate=False)
-        d = dims
-        gsd = {}
-        for name, gv in eng.store.g.items():
-            if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
-                kind = name.rsplit(".", 1)[1]
-                base = name[: -len("qkv_proj." + kind)]
-                gsd[base + "q_proj." + kind], gsd[base + "k_proj." + kind], gsd[base + "v_proj." + kind] = gv[: d.q_dim], gv[d.q_dim: d.q_dim + d.kv_dim], gv[d.q_dim + d.kv_dim:]
-            elif name.endswith("gate_up_proj.weight"):
-                base = name[: -len("gate_up_proj.weight")]
-                gsd[base + "gate_proj.weight"], gsd[base + "up_proj.weight"] = gv[: d.intermediate_size], gv[d.intermediate_size:]
-            else:
-                gsd[name] = gv
+        gsd = eng.store.grad_state_dict()  # HF names: fused q|k|v and gate|up split, padded heads de-padded
         worst = 1.0
         for name, p in params_a.items():
             if dims.tie_word_embeddings and name == "lm_head.weight":
@@ -198,7 +187,8 @@ def _engine_vs_f32_oracle(dims, sd, mbs, oracle_device, seq_len, check_grads_on=
     return engines, None
 
 
-@pytest.mark.parametrize("packed,family", [(False, "qwen3"), (True, "qwen3"), (True, "qwen2"), (False, "llama"), (True, "llama3")])
+@pytest.mark.parametrize("packed,family", [(False, "qwen3"), (True, "qwen3"), (True, "qwen2"), (False, "llama"), (True, "llama3"),
+                                           (True, "qwen2_hd64"), (False, "llama_hd64")])
 def test_engine_step_matches_oracle(packed, family):
     """Tiny model (H=256, V=512, 2 layers), 8 x 256 tokens: the loss gate, then gradients and the optimizer of the SHIPPED bf16
     engine against f32 autograd of the same model.  `family`: qwen3 = per-head q/k RMSNorm; qwen2 = q/k/v bias, no q/k norm (Qwen2.5 of
@@ -207,7 +197,10 @@ def test_engine_step_matches_oracle(packed, family):
 
     from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
 
-    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family == "qwen2")
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), qk_norm=family == "qwen3", attention_bias=family.startswith("qwen2"))
+    if family.endswith("_hd64"):  # 64-wide heads (Qwen2.5-0.5B of BASELINE configs[0], Llama-3.2-1B): stored and run zero-padded to the kernels' 128
+        dims = dataclasses.replace(dims, head_dim=64, num_attention_heads=4, num_key_value_heads=2)
+        assert dims.head_padded and dims.q_dim == 512
     if family == "llama3":  # Llama-3.x: scaled RoPE frequencies (utils/rope.py; original context shrunk so the 256-token test sees all three bands)
         dims = dataclasses.replace(dims, rope_theta=500_000.0, rms_norm_eps=1e-5,
                                    rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=64))
@@ -223,7 +216,9 @@ def test_engine_step_matches_oracle(packed, family):
             sd[k] = (1 + 0.1 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
         elif k.endswith(".bias"):
             sd[k] = (0.1 * torch.randn(sd[k].shape, generator=g)).to(torch.bfloat16)
-    assert any(k.endswith("q_proj.bias") for k in sd) == (family == "qwen2") and any(k.endswith("q_norm.weight") for k in sd) == (family == "qwen3")
+    assert any(k.endswith("q_proj.bias") for k in sd) == family.startswith("qwen2") and any(k.endswith("q_norm.weight") for k in sd) == (family == "qwen3")
+    if dims.head_padded:
+        assert sd["model.layers.0.self_attn.q_proj.weight"].shape == (256, 256) and sd["model.layers.0.self_attn.o_proj.weight"].shape == (256, 256)
     if packed:  # FakeDataLoader's packed-document micro-batches (data.py:87-130) with a masked prefix and mixed temperatures
         mbs = _mbs(dims.vocab_size, 256, 8, True)
     else:
