@@ -227,8 +227,8 @@ class RCCLWeightBroadcast(WeightBroadcast):
         save_dir = get_step_path(get_broadcast_dir(self.output_dir), step)
         if self.rank == 0:
             save_dir.mkdir(parents=True, exist_ok=True)
-            if flat:
-                (save_dir / "LAYOUT.json").write_text(json.dumps(build_layout(store)))
+            if flat and (self.protocol == "sharded" or not getattr(store.dims, "head_padded", False)):
+                (save_dir / "LAYOUT.json").write_text(json.dumps(build_layout(store)))  # refuses padded-head storage: those models push by name
             self._notify_orchestrator(save_dir)
             sync_wait_for_path(save_dir / NCCL_READY_MARKER, interval=0.05, timeout=self.ready_timeout)
         # every trainer rank waits for the inference pool before enqueuing collectives (nccl.py:203-211)
