@@ -355,10 +355,11 @@ def apply_rope(x, cos, sin):
     return (x * cos[:, None, :]) + (rot * sin[:, None, :])
 
 
-def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float):
+def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float, window: int | None = None):
     """flash_attn_varlen_func(q,k,v,cu,cu,max,max,causal=True) semantics at FlashAttention._compute_attention
     (trainer/models/layers/attn.py:94-110): per-document causal softmax attention with GQA, f32 math.
-    q [N,Hq,D], k/v [N,Hkv,D] -> [N,Hq,D] f32."""
+    q [N,Hq,D], k/v [N,Hkv,D] -> [N,Hq,D] f32.  `window` = the optional sliding window (attn.py:97-99: `window_size=(sliding_window - 1, 0)`):
+    query i sees keys i - window + 1 .. i of its document."""
     torch = _torch()
     n, hq, d = q.shape
     hkv = k.shape[1]
@@ -371,6 +372,8 @@ def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float):
         vs = v[off:off + ln].to(torch.float32).repeat_interleave(g, dim=1)
         s = torch.einsum("ihd,jhd->hij", qs, ks) * scale
         causal = torch.ones(ln, ln, dtype=torch.bool, device=q.device).tril()
+        if window is not None:
+            causal &= torch.ones(ln, ln, dtype=torch.bool, device=q.device).triu(-(window - 1))
         s = s.masked_fill(~causal, float("-inf"))
         p = torch.softmax(s, dim=-1)
         out[off:off + ln] = torch.einsum("hij,jhd->ihd", p, vs)

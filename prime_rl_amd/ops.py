@@ -414,6 +414,17 @@ def seq_start_from_cu(cu_seqlens: Tensor, n_tokens: int) -> Tensor:
     return out
 
 
+def seq_start_with_window(seq_start: Tensor, window: int) -> Tensor:
+    """First visible key per query row under a sliding window of `window` keys (the reference passes `window_size=(sliding_window - 1, 0)` to
+    flash-attn, models/layers/attn.py:94-100): max(document start, row - window + 1).  The attention kernels only ever read `seq_start[row]` as
+    "lowest visible key of this row" (monotone in the row), so the windowed mask needs no kernel of its own — hand them this array instead."""
+    _req(seq_start, torch.int32, "seq_start")
+    if window < 1:
+        raise PrimeMI355XError(f"sliding window must be >= 1, got {window}")
+    rows = torch.arange(seq_start.numel(), dtype=torch.int32, device=seq_start.device)
+    return torch.maximum(seq_start, rows - (window - 1)).contiguous()
+
+
 def attn_varlen_fwd(q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, softmax_scale: float) -> tuple[Tensor, Tensor]:
     """q [N,Hq,128], k [N,Hkv,128] contiguous; v [N,Hkv,128] may be a row-strided view (e.g. the v slice of qkv)."""
     lib = _lib.load()

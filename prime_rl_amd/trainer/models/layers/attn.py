@@ -87,9 +87,13 @@ class _VarlenAttnFn(torch.autograd.Function):
         return gq, gk, gv, None, None
 
 
-def varlen_causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, scale: float) -> torch.Tensor:
-    """flash_attn_varlen_func(q, k, v, cu, cu, max, max, causal=True) equivalent on packed [N, heads, 128] bf16 tensors."""
+def varlen_causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, scale: float,
+                            sliding_window: int | None = None) -> torch.Tensor:
+    """flash_attn_varlen_func(q, k, v, cu, cu, max, max, causal=True[, window_size=(sliding_window - 1, 0)]) equivalent on packed
+    [N, heads, 128] bf16 tensors (attn.py:94-110).  The window only raises each row's first visible key: same kernels."""
     seq_start = ops.seq_start_from_cu(cu_seqlens.to(torch.int32).contiguous(), q.shape[0])
+    if sliding_window is not None:
+        seq_start = ops.seq_start_with_window(seq_start, sliding_window)
     return _VarlenAttnFn.apply(q.contiguous(), k.contiguous(), v, seq_start, scale)
 
 
@@ -128,7 +132,7 @@ class HipVarlenAttention(nn.Module):
         else:
             q, k = _RopeFn.apply(qkv, cos, sin, self.hq, self.hkv, self.head_dim)
         v = qkv[:, (self.hq + self.hkv) * self.head_dim:].view(n, self.hkv, self.head_dim)
-        out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling)
+        out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling, sliding_window=getattr(self, "sliding_window", None))  # attn.py:97-99
         return self.o_proj(out.view(n, self.hq * self.head_dim)).unsqueeze(0), None
 
 

@@ -596,6 +596,35 @@ def test_attention_row_windows(ops, seq_lens, hq, hkv, cp):
         ops.attn_varlen_fwd_rows(q[64:128].contiguous(), k[:128], v[:128], ss[:128], scale, 64)  # window start not on a multiple of 128
 
 
+@pytest.mark.parametrize("seq_lens,hq,hkv,window", [([300, 212], 4, 2, 64), ([1024], 4, 1, 100), ([64, 1, 100, 37, 98], 8, 2, 7), ([700], 2, 2, 1), ([200], 2, 1, 4096)])
+def test_attention_sliding_window(ops, seq_lens, hq, hkv, window):
+    """The optional sliding window of the reference's attention (attn.py:97-99) with the SAME kernels: `seq_start_with_window` raises each row's first
+    visible key to row - window + 1; forward, lse-free check of the output and all three gradients against the windowed oracle; a window longer than
+    every document is the plain causal call bit for bit."""
+    n, d = sum(seq_lens), 128
+    q, k, v = _attn_case(n, seq_lens, hq, hkv, 3 * n + window)
+    scale = d**-0.5
+    cu = torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    lo = ops.seq_start_with_window(ss, window)
+    out, lse = ops.attn_varlen_fwd(q.to(DEV), k.to(DEV), v.to(DEV), lo, scale)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    want = O.varlen_causal_attention(qf, kf, vf, seq_lens, scale, window=window)
+    _close(out, want, 1e-2, 1e-2, "windowed attention forward")
+    go = torch.randn(n, hq, d).to(torch.bfloat16)
+    (want * go.float()).sum().backward()
+    gq, gk, gv = ops.attn_varlen_bwd(go.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV), out, lse, lo, scale)
+    _close(gq, qf.grad, 2e-2, 3e-2, "windowed dq")
+    _close(gk, kf.grad, 2e-2, 3e-2, "windowed dk")
+    _close(gv, vf.grad, 2e-2, 3e-2, "windowed dv")
+    if window >= max(seq_lens):
+        plain, plain_lse = ops.attn_varlen_fwd(q.to(DEV), k.to(DEV), v.to(DEV), ss, scale)
+        assert torch.equal(lo, ss) and torch.equal(out, plain) and torch.equal(lse, plain_lse)
+    if window == 1:  # every query sees only itself: the output is its own value row
+        g = hq // hkv
+        assert torch.equal(out.cpu(), v.repeat_interleave(g, dim=1))
+
+
 def test_attention_full_size_properties(ops):
     """BASELINE shape (8 x 2048-token rollouts packed in one 16 384-token row, 32 q / 8 kv heads, d = 128), where the CPU oracle would
     take minutes: size-independent properties instead.
