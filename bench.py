@@ -194,9 +194,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run (one rank per GPU)")
+    # PM_BENCH_DRYRUN_SHARED_GPU=1: rehearsal of the N > 1 launch on a ONE-GPU box — every rank uses device 0 and the group runs over gloo (RCCL refuses
+    # two ranks on one device).  Same script, same engine, same barriers / reductions / extras; the line it prints carries config.diagnostic and is
+    # not a measurement (tests/test_multirank_one_gpu.py runs it).
+    dryrun = os.environ.get("PM_BENCH_DRYRUN_SHARED_GPU") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and dryrun:
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" IS RCCL on ROCm
     elif args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -369,6 +377,8 @@ def main() -> None:
             }
         if args.force_collectives and world == 1:
             result["config"]["diagnostic"] = "force_collectives: world_size-1 RCCL reduce-scatter/all-gather on the comm stream (not the headline run)"
+        if dryrun:
+            result["config"]["diagnostic"] = f"PM_BENCH_DRYRUN_SHARED_GPU: {world} ranks share ONE GPU over gloo — a rehearsal of the launch path, not a measurement"
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -190,3 +190,30 @@ def test_expert_parallel_module_engine_on_one_gpu(world):
     """The MoE trainer step under expert parallelism with the real router / sort / grouped-GEMM kernels and the all-to-all dispatch between processes
     that share the GPU: ep = 2 (world 4: two ep groups, expert gradients summed over `ep_replica`), against the engine that holds every expert."""
     mp.start_processes(_moe_worker, args=(world, _free_port(), ""), nprocs=world, join=True, start_method="spawn")
+
+
+def test_bench_script_multi_rank_launch_rehearsal(tmp_path):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`) with PM_BENCH_DRYRUN_SHARED_GPU=1: both ranks share the GPU over gloo, everything else is the script as it runs on a node — warm-up,
+    barrier-bracketed timed region, max-over-ranks, the extras (2-micro-batch line, the sharded weight push between the ranks), ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PM_BENCH_DRYRUN_SHARED_GPU="1", PM_BENCH_EXTRA_TIMEOUT="240")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny", "--seq-len", "256", "--tokens-per-pass", "512",
+           "--micro-batches", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["value"] == pytest.approx(4 * 2 * 2 / (rec["ms_per_step"] * 2 / 1e3), rel=1e-3)  # whole-job samples / max-over-ranks time
+    assert "rehearsal" in rec["config"]["diagnostic"] and rec["roofline"]["frac"] > 0 and rec.get("cpu_baseline") is None
+    extra = rec["config"]["extra"]
+    assert "samples_per_s" in extra["mb2"] and extra["weight_push"]["bytes_sent_per_rank"] > 0, extra
+    assert "RCCL group up: world=2" in out.stderr or "world=2" in out.stderr
