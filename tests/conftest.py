@@ -18,6 +18,15 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    # multi-process tests (gloo / RCCL rendezvous, spawned workers) must FAIL rather than hang a whole run if a rank never shows up
+    try:
+        import pytest_timeout  # noqa: F401
+
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(900))
+    except ImportError:  # pragma: no cover
+        pass
     try:
         import torch
 
