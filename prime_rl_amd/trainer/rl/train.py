@@ -78,13 +78,21 @@ def train(config: TrainerConfig) -> list[dict]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = int(os.environ.get("WORLD_SIZE", "1"))
+    # PRIME_TRAINER_SHARED_GPU=1: rehearsal of a multi-rank launch on a ONE-GPU box — every rank uses device 0 and the trainer group runs over gloo
+    # (RCCL refuses two ranks on one device); same loop, same engines, same collectives (tests/test_multirank_one_gpu.py)
+    shared_gpu = os.environ.get("PRIME_TRAINER_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.set_float32_matmul_precision(config.matmul_precision)  # train.py:117-120
     wbc = config.weight_broadcast
     trainer_world = launched
     if launched > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=device, timeout=timedelta(seconds=config.dist_timeout_seconds))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo", timeout=timedelta(seconds=config.dist_timeout_seconds))
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, timeout=timedelta(seconds=config.dist_timeout_seconds))
     is_master = rank == 0
     # the torchrun world holds trainer ranks only; the inference GPUs are reached through a SEPARATE raw RCCL communicator bootstrapped at
     # weight_broadcast.host:port (below), as in the reference (transports/weights/nccl.py:128-136) — ZeRO shards can never span them
