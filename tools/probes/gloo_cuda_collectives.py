@@ -1,7 +1,6 @@
 """Probe: which collectives does the gloo backend run on CUDA tensors when two ranks share one GPU?  (Used to decide whether the multi-rank engine path
 can be exercised with the real HIP kernels on a one-GPU box.)"""
 import os
-import sys
 
 import torch
 import torch.distributed as dist

@@ -1,6 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, '.')
-from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
+from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, pack_micro_batches
 from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
 dev = torch.device('cuda', 0)
 dims = ModelDims.qwen3_8b()
