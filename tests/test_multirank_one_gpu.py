@@ -219,7 +219,8 @@ def test_bench_script_multi_rank_launch_rehearsal(tmp_path):
     assert "RCCL group up: world=2" in out.stderr or "world=2" in out.stderr
 
 
-@pytest.mark.parametrize("model,extra", [("tiny", []), ("tiny-moe", ["--model.ep", "2"])])
+@pytest.mark.parametrize("model,extra", [("tiny", []), ("tiny-moe", ["--model.ep", "2"]), ("tiny", ["--model.cp", "2", "--model.cp-style", "ring"]),
+                                         ("tiny", ["--model.cp", "2", "--model.cp-style", "ulysses"])])
 def test_train_cli_two_ranks_on_one_gpu(tmp_path, model, extra):
     """`torchrun --nproc-per-node 2 -m prime_rl_amd.trainer.rl.train @ rl.toml …` (the reference's launch grammar) with PRIME_TRAINER_SHARED_GPU=1: the
     whole train loop at world 2 — dense model: ZeRO-2 over dp = 2; MoE model: expert parallel over the two ranks — data-parallel FakeDataLoader shards,
@@ -243,7 +244,7 @@ def test_train_cli_two_ranks_on_one_gpu(tmp_path, model, extra):
     recs = [json.loads(ln) for ln in (tmp_path / "metrics.jsonl").read_text().strip().splitlines()]
     assert len(recs) == 2 and all(math.isfinite(r[k]) for r in recs for k in ("loss/mean", "entropy/all/mean", "optim/grad_norm", "perf/throughput"))
     assert "Step 2 |" in out.stdout
-    # 8 micro-batches of 128 tokens per step over the two ranks: the throughput counts the whole job
+    # the throughput counts the whole job (with cp = 2 both ranks work on the same micro-batches: one dp position)
     assert recs[0]["perf/throughput_per_gpu"] == pytest.approx(recs[0]["perf/throughput"] / 2, rel=1e-6)
     sd = load_file(str(tmp_path / "broadcasts" / "step_2" / "model.safetensors"))
     if model == "tiny-moe":
