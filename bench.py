@@ -183,6 +183,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: at N=1 run the RCCL reduce-scatter/all-gather + comm-stream path on a world_size-1 group (not the headline run)")
+    ap.add_argument("--recompute", default="none", choices=["none", "layer"],
+                    help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements reported under config.extra (2 micro-batches/GPU line, weight push)")
     args = ap.parse_args()
 
@@ -213,7 +215,8 @@ def main() -> None:
 
     dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "qwen2.5-0.5b": ModelDims.qwen2_5_0_5b,
             "tiny": ModelDims.tiny}[args.model]()
-    engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1)
+    engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1,
+                        recompute=args.recompute)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 
     per_pass = max(args.tokens_per_pass // args.seq_len, 1)
@@ -288,7 +291,8 @@ def main() -> None:
                     traffic = None
         flops_per_sample = dims.flops_per_token(args.seq_len) * args.seq_len
         result = {
-            "metric": "GRPO trainer samples/sec (Qwen3-8B, 2k-token rollouts)" if args.model == "qwen3-8b" else f"GRPO trainer samples/sec ({dims.name})",
+            "metric": "GRPO trainer samples/sec (Qwen3-8B, 2k-token rollouts)" if (args.model == "qwen3-8b" and args.seq_len == 2048)
+            else f"GRPO trainer samples/sec ({dims.name}, {args.seq_len}-token rollouts)",
             "value": round(value, 4),
             "unit": "samples/s",
             "n_gpus": world,
@@ -377,6 +381,8 @@ def main() -> None:
             }
         if args.force_collectives and world == 1:
             result["config"]["diagnostic"] = "force_collectives: world_size-1 RCCL reduce-scatter/all-gather on the comm stream (not the headline run)"
+        if args.recompute != "none":
+            result["config"]["recompute"] = args.recompute + " (one extra forward per layer in backward; not the headline configuration)"
         if dryrun:
             result["config"]["diagnostic"] = f"PM_BENCH_DRYRUN_SHARED_GPU: {world} ranks share ONE GPU over gloo — a rehearsal of the launch path, not a measurement"
     if dist.is_initialized():

@@ -452,7 +452,7 @@ class GRPOEngine:
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
-                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses"):
+                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -512,6 +512,13 @@ class GRPOEngine:
             self.inv_freq = torch.cat([self.inv_freq, torch.zeros(dims.kernel_head_dim // 2 - self.inv_freq.numel(), device=self.device)])
         self.lm_head_token_chunk = lm_head_token_chunk
         self.recompute_act = recompute_act
+        # "layer": block-level activation recomputation (the reference's default `model.ac`, trainer/model.py:1188-1194): forward keeps each decoder
+        # layer's INPUT only (8 KB per token and layer instead of ~130 KB), backward re-runs the layer's forward first.  One extra forward of compute;
+        # bit-identical gradients (every kernel on the path is deterministic and the stored input is the already-rounded residual sum).  Off by
+        # default: 288 GB holds the activations of 16k-token passes; a 32k-token pass on one GPU needs it.
+        self.recompute = recompute or os.environ.get("PM_RECOMPUTE", "none")
+        if self.recompute not in ("none", "layer"):
+            raise PrimeMI355XError(f"recompute must be 'none' or 'layer', got {self.recompute!r}")
         self.step_count = 0
         # a dedicated stream for the collectives — on the GPU; the CPU flavour (tests/test_engine_gloo_cpu.py: the SAME engine code over gloo with
         # stand-in kernels) issues them synchronously
@@ -642,30 +649,9 @@ class GRPOEngine:
         scale = d.head_dim**-0.5
         pending = None  # mlp output whose residual add is fused into the next RMSNorm
         for i in range(d.num_hidden_layers):
-            p = f"model.layers.{i}."
             self._wait_gather(f"layer{i}")
-            if pending is None:
-                h1, rstd1, _ = ops.rmsnorm_fwd(x, w[p + "input_layernorm.weight"], d.rms_norm_eps)
-            else:
-                h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
-            qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"], bias=w.get(p + "self_attn.qkv_proj.bias"))
-            q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w.get(p + "self_attn.q_norm.weight"), w.get(p + "self_attn.k_norm.weight"), cos, sin,
-                                                 d.num_attention_heads, d.num_key_value_heads, d.kernel_head_dim, d.rms_norm_eps)
-            v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
-            if cp == 1:
-                o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
-                attn_saved = None
-            else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads)
-                o, attn_saved = (self._ulysses_attn_fwd if self.cp_style == "ulysses" else self._gathered_kv_attn_fwd)(q, k, v, seq_start, scale)
-                lse = None
-            attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
-            h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
-            gu = self._fwd_mm(h2, w[p + "mlp.gate_up_proj.weight"])
-            act = ops.swiglu_fwd(gu)
-            pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
-            ctx["layers"].append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2,
-                                      gu=gu, act=None if self.recompute_act else act, attn_saved=attn_saved))
-            x = x2
+            L, x, pending = self._layer_forward(i, x, pending, cos, sin, seq_start, scale, n)
+            ctx["layers"].append({"x": L["x"], "recompute": True} if self.recompute == "layer" else L)
         self._wait_gather("head")
         hf, rstd_f, x_last = ops.rmsnorm_fwd(pending, w["model.norm.weight"], d.rms_norm_eps, residual=x)
         ctx.update(x_last=x_last, rstd_f=rstd_f, hf=hf)
@@ -697,6 +683,34 @@ class GRPOEngine:
             entropy = ulysses.all_gather_tokens(entropy, cp, self.cp_group)
         ctx.update(logits_chunks=chunks, logprobs=logprobs, entropy=entropy, logz=logz)
         return ctx
+
+    def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int):
+        """One decoder layer: (saved activations, residual stream after attention, mlp output whose residual add the NEXT norm fuses).  `pending` = the
+        previous layer's mlp output (None for layer 0 and when re-running a layer from its saved, already-summed input)."""
+        d, w = self.dims, self.store.w
+        p = f"model.layers.{i}."
+        if pending is None:
+            h1, rstd1, _ = ops.rmsnorm_fwd(x, w[p + "input_layernorm.weight"], d.rms_norm_eps)
+        else:
+            h1, rstd1, x = ops.rmsnorm_fwd(pending, w[p + "input_layernorm.weight"], d.rms_norm_eps, residual=x)
+        qkv = self._fwd_mm(h1, w[p + "self_attn.qkv_proj.weight"], bias=w.get(p + "self_attn.qkv_proj.bias"))
+        q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w.get(p + "self_attn.q_norm.weight"), w.get(p + "self_attn.k_norm.weight"), cos, sin,
+                                             d.num_attention_heads, d.num_key_value_heads, d.kernel_head_dim, d.rms_norm_eps)
+        v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
+        if self.cp_size == 1:
+            o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+            attn_saved = None
+        else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads); "ring": gathered K / V
+            o, attn_saved = (self._ulysses_attn_fwd if self.cp_style == "ulysses" else self._gathered_kv_attn_fwd)(q, k, v, seq_start, scale)
+            lse = None
+        attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
+        h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
+        gu = self._fwd_mm(h2, w[p + "mlp.gate_up_proj.weight"])
+        act = ops.swiglu_fwd(gu)
+        pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
+        saved = dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2, gu=gu,
+                     act=None if self.recompute_act else act, attn_saved=attn_saved)
+        return saved, x2, pending
 
     def _ulysses_attn_fwd(self, q: Tensor, k: Tensor, v: Tensor, seq_start: Tensor, scale: float):
         cp, grp, hkv = self.cp_size, self.cp_group, self.dims.num_key_value_heads
@@ -808,6 +822,8 @@ class GRPOEngine:
         for i in reversed(range(d.num_hidden_layers)):
             p = f"model.layers.{i}."
             L = ctx["layers"][i]
+            if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input
+                L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n)
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
             dact = self._dgrad(dx, i, "mlp.down_proj.weight")
             self._wgrad(dx, act, g[p + "mlp.down_proj.weight"], accumulate, k_contiguous_x=True)

@@ -444,3 +444,23 @@ def test_engine_with_the_other_elementwise_optimizers(kind):
     assert oc.type == kind and oc.lr == 3e-4 and (oc.momentum, oc.nesterov) == ((0.9, True) if kind == "sgd" else (0.0, False))
     with pytest.raises(NotImplementedError):
         TrainerConfig.model_validate(dict(optim=dict(type="muon"))).validate_supported()
+
+
+def test_block_level_recompute_gives_bit_identical_gradients():
+    """`recompute="layer"` (the reference's default `model.ac`): forward keeps each layer's input only, backward re-runs the layer's forward — every kernel on
+    the path is deterministic and the stored input is the already-rounded residual sum, so loss, gradients and the optimizer step are the plain engine's bit
+    for bit, over accumulated passes too."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=3, vocab=512)
+    plain = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), seed=7)
+    rec = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), seed=7, recompute="layer")
+    for step in range(2):
+        mbs = _mbs(dims.vocab_size, 192, 4, True, seed_shift=step)
+        passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+        a, b = plain.step(passes), rec.step(passes)
+        plain.wait_params_ready(); rec.wait_params_ready()
+        assert all(torch.equal(x, y) for x, y in zip(a["loss"], b["loss"])) and torch.equal(a["grad_norm"], b["grad_norm"])
+        assert torch.equal(plain.store.main_grad, rec.store.main_grad) and torch.equal(plain.store.params, rec.store.params)
+    ctx = rec.forward(passes[0])
+    assert all(set(L) == {"x", "recompute"} for L in ctx["layers"])  # nothing but the layer inputs is kept
