@@ -144,6 +144,9 @@ class LossConfig:
     adv_tau: float = 1.0
     kl_tau: float = 1e-3
     ipo_threshold: float = 0.1
+    # type "custom": a LossFn plugin (loss.py:13-45, selected by import_path + kwargs, configs/trainer.py:522-532) evaluated per sample under autograd
+    # on the engine's log-probs (trainer/rl/loss.py: plugin_loss_over_pass); everything else of the step stays the engine's
+    custom_fn: object = None
 
 
 @dataclass
@@ -763,6 +766,12 @@ class GRPOEngine:
     def loss(self, ctx: dict, scales: tuple[int, int, int]) -> dict:
         b: PackedBatch = ctx["batch"]
         c = self.loss_cfg
+        if c.type == "custom":
+            from .rl.loss import plugin_loss_over_pass
+
+            loss, grad, per_mb, metrics = plugin_loss_over_pass(ctx["logprobs"], b, scales, c.custom_fn, self.dims.vocab_size)
+            ctx.update(loss=loss, grad_logprobs=grad, sample_stats=None, sample_metrics=dict(loss_per_micro_batch=per_mb, metrics=metrics))
+            return ctx
         params = LossParams(loss_type=_lib.PM_LOSS_IPO if c.type == "ipo" else _lib.PM_LOSS_DEFAULT, dppo_mask_low=c.dppo_mask_low,
                             dppo_mask_high=c.dppo_mask_high, adv_tau=c.adv_tau, kl_tau=c.kl_tau, ipo_threshold=c.ipo_threshold,
                             rl_scale=float(max(scales[0], 1)), ce_scale=float(max(scales[1], 1)), ref_kl_scale=float(max(scales[2], 1)), shift=1,

@@ -292,6 +292,17 @@ def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, *, seq_le
     return cast_float_and_contiguous(PrimeLmOutput(logits=out.logits))
 
 
+def loss_from_config(lc) -> LossConfig:
+    """LossConfig union (default | ipo | custom: configs/trainer.py:494-532) -> the engines' LossConfig; a custom plugin is imported here
+    (`import_path`, called with `kwargs`: setup_rl_loss_fn, loss.py:262-282)."""
+    if lc.type == "custom":
+        from .rl.loss import setup_rl_loss_fn
+
+        return LossConfig(type="custom", custom_fn=setup_rl_loss_fn(lc))
+    return LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
+                      kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
+
+
 def optim_from_config(o) -> OptimConfig:
     """OptimizerConfig (adamw | sgd | sign_sgd: configs/trainer.py) -> the engine's OptimConfig; Muon is refused by validate_supported()."""
     return OptimConfig(lr=o.lr, weight_decay=o.weight_decay, betas1=getattr(o, "betas1", 0.9), betas2=getattr(o, "betas2", 0.999), eps=getattr(o, "eps", 1e-8),
@@ -309,11 +320,8 @@ def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.devic
         raise NotImplementedError("context parallelism runs in the flat-buffer engine (dense models); MoE models take model.cp = 1")
     model = setup_model(config.model, parallel_dims)
     o, lc = config.optim, config.loss
-    if lc.type == "custom":
-        raise NotImplementedError("custom loss plugins: call prime_rl_amd.trainer.rl.loss.compute_loss on forward(model, ...) yourself")
     optim = optim_from_config(o)
-    loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
-                      kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
+    loss = loss_from_config(lc)
     ep = parallel_dims.ep if parallel_dims.ep_enabled else 1
     return ModuleEngine(model, device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), dp_size=parallel_dims.dp_size,
                         ep_group=parallel_dims.get_group("ep") if ep > 1 else None, ep_size=ep,
@@ -339,12 +347,7 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
         raise NotImplementedError("enable_router_replay: dense models have no router (MoE models take it through setup_module_engine)")
     o = config.optim
     optim = optim_from_config(o)
-    lc = config.loss
-    if lc.type == "custom":
-        raise NotImplementedError("custom loss plugins run through prime_rl_amd.trainer.rl.loss.compute_loss (the per-sample LossFn contract) on the "
-                                  "autograd model from setup_model(); the flat-buffer engine fuses the built-in default / ipo losses")
-    loss = LossConfig(type=lc.type, dppo_mask_low=getattr(lc, "dppo_mask_low", 0.2), dppo_mask_high=getattr(lc, "dppo_mask_high", 0.2), adv_tau=lc.adv_tau,
-                      kl_tau=lc.kl_tau, ipo_threshold=getattr(lc, "ipo_threshold", 0.1))
+    loss = loss_from_config(config.loss)
     engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
                         dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp,
                         shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style)

@@ -183,6 +183,12 @@ class ModuleEngine:
         logprobs = out["logprobs"].reshape(n).float()
         entropy = out["entropy"].reshape(n).float().detach()
         c = self.loss_cfg
+        if c.type == "custom":  # LossFn plugin: per-sample Python under autograd on the detached log-probs (trainer/rl/loss.py)
+            from .rl.loss import plugin_loss_over_pass
+
+            loss, grad, per_mb, metrics = plugin_loss_over_pass(logprobs, b, scales, c.custom_fn, self.dims.vocab_size)
+            return dict(loss=loss, grad_logprobs=grad, sample_stats=None, sample_metrics=dict(loss_per_micro_batch=per_mb, metrics=metrics),
+                        logprobs=logprobs, entropy=entropy)
         params = LossParams(loss_type=_lib.PM_LOSS_IPO if c.type == "ipo" else _lib.PM_LOSS_DEFAULT, dppo_mask_low=c.dppo_mask_low,
                             dppo_mask_high=c.dppo_mask_high, adv_tau=c.adv_tau, kl_tau=c.kl_tau, ipo_threshold=c.ipo_threshold,
                             rl_scale=float(max(scales[0], 1)), ce_scale=float(max(scales[1], 1)), ref_kl_scale=float(max(scales[2], 1)), shift=1,

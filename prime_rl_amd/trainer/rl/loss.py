@@ -11,6 +11,7 @@ function keeps the reference's per-sample plugin loop (loss.py:345-392).  All fu
 from __future__ import annotations
 
 import importlib
+import math
 from dataclasses import dataclass, field
 from typing import Any, Callable
 
@@ -313,3 +314,42 @@ def _compute_loss_plugin(trainer_logprobs, inference_logprobs, ref_logprobs, adv
     scaled = rl_loss / rl_scale + ce_loss / ce_scale + ref_kl_loss / ref_kl_scale
     agg = {k: (torch.stack(v) if v[0].dim() == 0 else torch.cat(v)) for k, v in all_metrics.items()}
     return scaled, agg
+
+
+def plugin_loss_over_pass(logprobs: Tensor, packed, scales: tuple[int, int, int], rl_loss_fn: LossFn, vocab_size: int):
+    """A custom loss plugin (`[trainer.loss] type = "custom"`, loss.py:262-282) over one packed pass of the engines: the reference's micro-batch body
+    (train.py:450-480) — shift_tensor_right with log(1/V) at the head of every micro-batch, per-sample split, `compute_loss` with the plugin as the rl
+    component — run under autograd on the engine's (detached) log-probs, so that d loss / d log-prob comes back as a plain tensor the engines feed into
+    their own backward.  Returns (total scaled loss, grad w.r.t. the UNSHIFTED log-probs, per-micro-batch losses [n_mb], {metric: [per-micro-batch tensors]})."""
+    n = logprobs.numel()
+    lp = logprobs.detach().float().clone().requires_grad_(True)
+    starts = packed.sample_starts_mb.tolist()
+    cu = packed.cu_samples.tolist()
+    pad = lp.new_full((1,), math.log(1.0 / vocab_size))
+    mb_bounds = [cu[i] for i, s in enumerate(starts) if s] + [n]
+    sample_of_mb: list[list[tuple[int, int]]] = []
+    for i, s in enumerate(starts):
+        if s:
+            sample_of_mb.append([])
+        sample_of_mb[-1].append((cu[i], cu[i + 1]))
+
+    def opt(t):
+        return None if t is None else t
+
+    total = lp.sum() * 0.0
+    per_mb, metrics = [], {}
+    for (m0, m1), samples in zip(zip(mb_bounds[:-1], mb_bounds[1:]), sample_of_mb):
+        shifted = torch.cat([pad, lp[m0:m1 - 1]])  # shift_tensor_right within the micro-batch (loss.py:76-91)
+
+        def cut(t):
+            return None if t is None else [t[a:b] for a, b in samples]
+
+        loss, met = compute_loss([shifted[a - m0:b - m0] for a, b in samples], cut(packed.inference_logprobs), cut(opt(packed.ref_logprobs)),
+                                 cut(packed.advantages), cut(packed.loss_mask), cut(opt(packed.rl_weights)), cut(opt(packed.ce_weights)),
+                                 cut(opt(packed.ref_kl_weights)), rl_loss_fn=rl_loss_fn, rl_scale=scales[0], ce_scale=scales[1], ref_kl_scale=scales[2])
+        total = total + loss
+        per_mb.append(loss.detach().reshape(()))
+        for k, v in met.items():
+            metrics.setdefault(k, []).append(v.detach().reshape(-1))
+    total.backward()
+    return total.detach().reshape(1), lp.grad, torch.stack(per_mb), metrics
