@@ -93,3 +93,52 @@ def test_zero2_two_ranks_match_single_process(tmp_path):
     for i in range(len(r[0]["shard"])):
         (f0, l0), (f1, l1) = r[0]["shard"][i], r[1]["shard"][i]
         assert f0.stop == f1.start and (f0.stop - f0.start) == (f1.stop - f1.start) == (l0.stop - l0.start)
+
+
+def _worker_other_optimizers(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tests.cpu_standin_ops as standin
+    from prime_rl_amd.trainer import zero
+    from prime_rl_amd.trainer.engine import ModelDims, OptimConfig, ParamStore
+
+    res = {}
+    for kind in ("sgd", "sign_sgd"):
+        store = ParamStore(ModelDims.tiny(layers=1, vocab=320), "cpu", dp_rank=rank, dp_size=world, optimizer=kind)
+        assert store.exp_avg_sq.numel() == 0 and store.exp_avg.numel() == (store.shard_total if kind == "sgd" else 0)
+        store.random_init(seed=0)
+        init = store.master.clone()
+        optim = OptimConfig(lr=1e-2, weight_decay=0.0, max_norm=0.0, type=kind, momentum=0.9, nesterov=True)
+        grads = []
+        for step in (1, 2):
+            g = torch.Generator().manual_seed(10 * step + rank)
+            store.main_grad.copy_(torch.randn(store.total, generator=g) * 0.01)
+            grads.append(store.main_grad.clone())
+            for b in reversed(store.buckets):
+                zero.reduce_scatter_bucket(store, b, None, None)
+            zero.sharded_optimizer_step(store, optim, step, None, standin)
+        res[kind] = dict(init=init, grads=grads, master=store.master.clone(), params=store.params.clone(), slices=[store.shard_slices(b) for b in store.buckets])
+    torch.save(res, os.path.join(out_dir, f"opt{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_with_sgd_and_sign_sgd(tmp_path):
+    """`optim.type = "sgd" | "sign_sgd"` under ZeRO-2 at world 2 (zero.apply_update on shard slices, momentum buffer sharded like the master weights, no
+    second moment allocated): every rank's master shard after two steps is the single-process rule applied to the summed gradients."""
+    world = 2
+    mp.start_processes(_worker_other_optimizers, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(tmp_path / f"opt{i}.pt", weights_only=False) for i in range(world)]
+    for kind in ("sgd", "sign_sgd"):
+        assert torch.equal(r[0][kind]["params"], r[1][kind]["params"])
+        g1 = r[0][kind]["grads"][0] + r[1][kind]["grads"][0]
+        g2 = r[0][kind]["grads"][1] + r[1][kind]["grads"][1]
+        for rank in range(world):
+            for full, local in r[rank][kind]["slices"]:
+                p0 = r[rank][kind]["init"][local]
+                a, b = g1[full], g2[full]
+                if kind == "sgd":  # Nesterov, momentum 0.9: buf1 = g1, step1 = g1 + 0.9 g1; buf2 = 0.9 g1 + g2, step2 = g2 + 0.9 buf2
+                    want = p0 - 1e-2 * (1.9 * a) - 1e-2 * (b + 0.9 * (0.9 * a + b))
+                else:
+                    want = p0 - 1e-2 * torch.sign(a) - 1e-2 * torch.sign(b)
+                torch.testing.assert_close(r[rank][kind]["master"][local], want, rtol=1e-5, atol=1e-7)
