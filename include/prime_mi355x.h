@@ -460,6 +460,21 @@ int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* o
                        int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Dense bf16 GEMM of the scoring model (csrc/gemm.hip): OUT[M, N] = sum_K X[M, K] * W[N, K] (+ bias[N]), f32 accumulation on the MFMA units,
+ * bf16 or f32 result.  Replaces every `F.linear` / autograd matmul the reference hands to cuBLAS:
+ *   forward  (trainer/models/layers/mlp.py:27-29, attn.py:60-84, lm_head.py:118-148)   x [M, K], w [N, K]          x_kmajor = 0, w_kmajor = 0
+ *   dgrad    dx = dy @ w            dy [M, K = out], w stored [K = out, N = in]                                   x_kmajor = 0, w_kmajor = 1
+ *   wgrad    dw[out][in] = sum_tok dy[tok][out] x[tok][in]: X = dy stored [K = tok, M = out], W = x stored [K = tok, N = in],
+ *            f32 output with `accumulate` (gradient accumulation in f32, configs/trainer.py:233-237)              x_kmajor = 1, w_kmajor = 1
+ * "kmajor" = the operand is stored [K, rows] (its M / N coordinate is the contiguous one).  ld* are row strides in elements; rows 16-byte
+ * aligned.  K % 128 == 0 unless both operands are K-major (pm_gemm_supported).  `bias` (bf16 [N], nullable) is added before the rounding. */
+int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmajor, int32_t w_kmajor);
+int pm_gemm_bf16(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
+                 int32_t out_dtype /* PM_DTYPE_BF16 | PM_DTYPE_F32 */, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n,
+                 int64_t k, void* stream);
+int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced fragment reads */
+
+/* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
  * C[16,16] = A[16,32] @ B[32,16]^T-free form: c = sum_k a[i][k]*b[j][k]  (both operands K-contiguous, bf16). */
 int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);

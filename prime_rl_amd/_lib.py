@@ -139,6 +139,9 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
     "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
+    "pm_gemm_supported": (I, [I64, I64, I64, I32, I32]),
+    "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P]),
+    "pm_gemm_debug_set_variant": (I, [I32]),
 }
 
 

@@ -798,3 +798,61 @@ def sign_sgd_step(master: Tensor, grad: Tensor, param_bf16: Tensor | None, lr: f
         _req(param_bf16, torch.bfloat16, "param_bf16")
     check(lib.pm_sign_sgd_step(_p(master), _p(grad), _p(param_bf16), master.numel(), lr, weight_decay, grad_scale, _p(clip), 1 if zero_grad else 0, _stream()),
           "pm_sign_sgd_step")
+
+
+# ------------------------------------------------------------------------------------------------ dense MFMA GEMM (csrc/gemm.hip)
+def _gemm_operand(t: Tensor, name: str) -> tuple[int, bool, int, int]:
+    """(row stride in elements, stored K-major?, rows, k) of a 2-D bf16 operand given as the LOGICAL [rows, K] matrix: unit stride along K =
+    K-contiguous storage; unit stride along the rows (a `.t()` view of a [K, rows] tensor) = K-major storage."""
+    _req(t, torch.bfloat16, name, contiguous=False)
+    if t.dim() != 2:
+        raise PrimeMI355XError(f"{name}: expected a 2-D operand, got {tuple(t.shape)}")
+    rows, k = t.shape
+    if t.stride(1) == 1:
+        return t.stride(0), False, rows, k
+    if t.stride(0) == 1:
+        return t.stride(1), True, rows, k
+    raise PrimeMI355XError(f"{name}: one of the two axes must have unit stride, got strides {t.stride()}")
+
+
+def gemm_supported(x: Tensor, w: Tensor) -> bool:
+    """Can `gemm(x, w)` run on the hand-written MFMA core (shape / layout / alignment)?"""
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+        return False
+    try:
+        ldx, xk, m, k = _gemm_operand(x, "x")
+        ldw, wk, n, _ = _gemm_operand(w, "w")
+    except PrimeMI355XError:
+        return False
+    if ldx % 8 or ldw % 8 or x.data_ptr() % 16 or w.data_ptr() % 16:
+        return False
+    return bool(_lib.load().pm_gemm_supported(m, n, k, int(xk), int(wk)))
+
+
+def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16, bias: Tensor | None = None, accumulate: bool = False) -> Tensor:
+    """out[M, N] (+)= x[M, K] @ w[N, K]^T (+ bias) on the MFMA core — F.linear's product for any of the three layouts the trainer step has:
+    forward `gemm(x, W)`, dgrad `gemm(dy, W.t())` (W.t() = the [in, out] view of the stored [out, in] weight), wgrad
+    `gemm(dy.t(), x.t(), out=grad, out_dtype=f32, accumulate=...)`.  Operands are passed as LOGICAL [rows, K] matrices; their strides say how
+    they are stored (no copies are made)."""
+    lib = _lib.load()
+    ldx, xk, m, k = _gemm_operand(x, "x")
+    ldw, wk, n, k2 = _gemm_operand(w, "w")
+    if k != k2:
+        raise PrimeMI355XError(f"gemm: contraction mismatch {tuple(x.shape)} vs {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+    else:
+        _req(out, None, "out", contiguous=False)
+        if out.dtype not in _DT or tuple(out.shape) != (m, n) or out.stride(1) != 1:
+            raise PrimeMI355XError(f"gemm: out must be [{m}, {n}] f32 | bf16 with unit stride along N, got {tuple(out.shape)} {out.dtype} {out.stride()}")
+    if bias is not None:
+        _req(bias, torch.bfloat16, "bias")
+        if bias.numel() != n:
+            raise PrimeMI355XError("gemm: bias length != N")
+    check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
+          "pm_gemm_bf16")
+    return out
+
+
+def gemm_set_variant(v: int) -> None:
+    check(_lib.load().pm_gemm_debug_set_variant(v), "pm_gemm_debug_set_variant")

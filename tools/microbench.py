@@ -167,6 +167,57 @@ def bench_gemm(out):
         torch.cuda.empty_cache()
 
 
+def bench_gemm_core(out, t=16384, variants=(1, 3, 0, 2), rounds=3):
+    """The hand-written MFMA GEMM core (csrc/gemm.hip) against the library call it replaces, per Qwen3-8B projection and layout, interleaved in one
+    process (boxes differ by a few %).  Random operands (guide §5.4 rule 25: zero-filled operands clock ~15 % higher)."""
+    shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
+    if os.environ.get("PM_GEMM_HEAD", "1") == "1":
+        shapes["head"] = (151936, 4096)
+    for name, (o, i) in shapes.items():
+        x = torch.randn(t, i, device=DEV).to(torch.bfloat16)
+        dy = torch.randn(t, o, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
+        wt = w.t().contiguous()
+        y, dx = torch.empty(t, o, dtype=torch.bfloat16, device=DEV), torch.empty(t, i, dtype=torch.bfloat16, device=DEV)
+        g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
+        fl = 2.0 * t * o * i
+        cases = {
+            "fwd": (lambda: torch.mm(x, w.t(), out=y), lambda: ops.gemm(x, w, out=y)),
+            "dgrad": (lambda: torch.mm(dy, wt.t(), out=dx), lambda: ops.gemm(dy, w.t(), out=dx)),
+            "wgrad": (lambda: torch.mm(dy.t(), x, out_dtype=torch.float32, out=g), lambda: ops.gemm(dy.t(), x.t(), out=g)),
+        }
+        for cname, (lib_fn, own_fn) in cases.items():
+            # correctness on the spot (sampled rows: the f32 reference of the head shape would be 10 GB)
+            own_fn()
+            idx = torch.randint(0, t if cname != "wgrad" else o, (64,), device=DEV)
+            if cname == "fwd":
+                ref, got = x[idx].float() @ w.float().t(), y[idx].float()
+            elif cname == "dgrad":
+                ref, got = dy[idx].float() @ w.float(), dx[idx].float()
+            else:
+                ref, got = dy[:, idx].float().t() @ x.float(), g[idx]
+            rel = ((got - ref).abs().max() / (ref.abs().max() + 1e-9)).item()
+            res = {"lib": []}
+            for v in variants:
+                res[f"v{v}"] = []
+            for _ in range(rounds):
+                med, _ = timeit(lib_fn, iters=5, warmup=1)
+                res["lib"].append(med)
+                for v in variants:
+                    ops.gemm_set_variant(v)
+                    med, _ = timeit(own_fn, iters=5, warmup=1)
+                    res[f"v{v}"].append(med)
+            ops.gemm_set_variant(1)
+            rec = dict(kernel=f"gemm_core {name} {cname} t={t}", max_rel_err=rel)
+            for key, ts in res.items():
+                ts.sort()
+                rec[key + "_ms"] = ts[len(ts) // 2] * 1e3
+                rec[key + "_TF"] = fl / ts[len(ts) // 2] / 1e12
+            out.append(rec)
+        del x, dy, w, wt, y, dx, g
+        torch.cuda.empty_cache()
+
+
 def bench_lmhead(out, n=16384, h=4096, v=151936):
     """J1 (fused MFMA LM head) against the library path it can replace: hipBLASLt GEMM -> bf16 logits in HBM -> K1."""
     hidden = torch.randn(n, h, device=DEV).to(torch.bfloat16)
@@ -370,6 +421,20 @@ def main():
         bench_lmhead(out, n=4096)
     if which == "gemm":
         bench_gemm(out)
+    if which == "gemmprobe":  # a few launches of each layout of the MFMA GEMM core at the gate|up shape (for tools/pmc.sh)
+        t, o, i = 16384, 24576, 4096
+        x = torch.randn(t, i, device=DEV).to(torch.bfloat16)
+        dy = torch.randn(t, o, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
+        g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
+        ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "1")))
+        for _ in range(4):
+            ops.gemm(x, w)
+            ops.gemm(dy, w.t())
+            ops.gemm(dy.t(), x.t(), out=g)
+        torch.cuda.synchronize()
+    if which == "gemmcore":
+        bench_gemm_core(out, t=int(sys.argv[2]) if len(sys.argv) > 2 else 16384)
     if which in ("k1", "all"):
         bench_k1(out)
     if which == "k1step":
