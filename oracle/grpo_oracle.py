@@ -367,16 +367,23 @@ def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float, window: 
     out = torch.zeros((n, hq, d), dtype=torch.float32, device=q.device)
     off = 0
     for ln in seq_lens:
-        qs = q[off:off + ln].to(torch.float32)
-        ks = k[off:off + ln].to(torch.float32).repeat_interleave(g, dim=1)
-        vs = v[off:off + ln].to(torch.float32).repeat_interleave(g, dim=1)
-        s = torch.einsum("ihd,jhd->hij", qs, ks) * scale
         causal = torch.ones(ln, ln, dtype=torch.bool, device=q.device).tril()
         if window is not None:
             causal &= torch.ones(ln, ln, dtype=torch.bool, device=q.device).triu(-(window - 1))
-        s = s.masked_fill(~causal, float("-inf"))
-        p = torch.softmax(s, dim=-1)
-        out[off:off + ln] = torch.einsum("hij,jhd->ihd", p, vs)
+        # heads are independent: long documents (the 32k-token rollouts of BASELINE.json configs[4]) are processed a few heads at a time so that
+        # the [heads, ln, ln] f32 score block stays below ~8 GB; the arithmetic per head is the same either way
+        hc = max(1, min(hq, int(8e9 // max(4 * ln * ln, 1))))
+        hc = max(g, hc // g * g) if hc >= g else hc  # whole KV groups when possible (keeps the einsum shapes of the short-document path)
+        for h0 in range(0, hq, hc):
+            h1 = min(h0 + hc, hq)
+            qs = q[off:off + ln, h0:h1].to(torch.float32)
+            kv_idx = torch.arange(h0, h1, device=q.device) // g
+            ks = k[off:off + ln].to(torch.float32)[:, kv_idx]
+            vs = v[off:off + ln].to(torch.float32)[:, kv_idx]
+            s = torch.einsum("ihd,jhd->hij", qs, ks) * scale
+            s = s.masked_fill(~causal, float("-inf"))
+            p = torch.softmax(s, dim=-1)
+            out[off:off + ln, h0:h1] = torch.einsum("hij,jhd->ihd", p, vs)
         off += ln
     return out
 

@@ -35,6 +35,7 @@
 //   * blockIdx -> tile: block b runs on XCD b % 8; the 32 tiles an XCD runs concurrently form an 8 (X) x 4 (W) patch that walks K in step,
 //     so 12 row panels feed 32 tiles through one L2, and the 8 XCDs work on patches that share their W panels.
 #include "common.cuh"
+#include <algorithm>
 
 namespace pm {
 namespace gm {
@@ -450,19 +451,34 @@ extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const 
   PM_REQUIRE(ldx >= (x_kmajor ? m : k) && ldw >= (w_kmajor ? n : k) && ldo >= n, PM_ERR_INVALID_ARG, "pm_gemm_bf16: leading dimension too small");
   PM_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, PM_ERR_INVALID_ARG,
              "pm_gemm_bf16: rows must start 16-byte aligned (ldx, ldw multiples of 8; ldo of 4; 16-byte aligned bases)");
-  // 32-bit byte offsets inside a tile's buffer descriptor
-  const int64_t span_x = x_kmajor ? k * ldx * 2 : 256 * ldx * 2, span_w = w_kmajor ? k * ldw * 2 : 256 * ldw * 2;
-  PM_REQUIRE(span_x < (1ll << 31) && span_w < (1ll << 31) && m < (1ll << 31) && n < (1ll << 31), PM_ERR_UNSUPPORTED, "pm_gemm_bf16: sizes beyond int32 offsets");
+  // 32-bit byte offsets inside a tile's buffer descriptor: a K-contiguous operand spans 256 rows, a K-major operand all K rows of the tensor.  When
+  // a K-major span does not fit (the LM-head weight gradient: 16384 tokens x 151936 columns of dlogits = 5 GB), the contraction is cut into K-chunks
+  // that accumulate into the f32 output.
+  const int64_t kLimit = (1ll << 31) - 4096;
+  PM_REQUIRE((x_kmajor || 256 * ldx * 2 < kLimit) && (w_kmajor || 256 * ldw * 2 < kLimit) && m < (1ll << 31) && n < (1ll << 31), PM_ERR_UNSUPPORTED,
+             "pm_gemm_bf16: sizes beyond int32 offsets");
+  int64_t k_chunk = k;
+  if (x_kmajor && k * ldx * 2 >= kLimit) k_chunk = std::min(k_chunk, kLimit / (ldx * 2) / 128 * 128);
+  if (w_kmajor && k * ldw * 2 >= kLimit) k_chunk = std::min(k_chunk, kLimit / (ldw * 2) / 128 * 128);
+  PM_REQUIRE(k_chunk >= 128, PM_ERR_UNSUPPORTED, "pm_gemm_bf16: a K-major operand with rows beyond 8M elements");
+  PM_REQUIRE(k_chunk == k || (out_dtype == PM_DTYPE_F32 && x_kmajor && w_kmajor && !bias), PM_ERR_UNSUPPORTED,
+             "pm_gemm_bf16: a K-major operand beyond 2 GB needs the f32-accumulating wgrad form");
   gm::Params p;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = out; p.bias = (const bf16_t*)bias;
+  p.out = out; p.bias = (const bf16_t*)bias;
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
-  p.m = (int)m; p.n = (int)n; p.k = (int)k;
+  p.m = (int)m; p.n = (int)n;
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
-  p.out_f32 = out_dtype == PM_DTYPE_F32; p.accumulate = accumulate ? 1 : 0;
+  p.out_f32 = out_dtype == PM_DTYPE_F32;
   hipStream_t st = as_stream(stream);
-  if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
-  else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
-  else gm::launch<true, true>(p, st);
+  for (int64_t k0 = 0; k0 < k; k0 += k_chunk) {
+    p.x = (const bf16_t*)x + (x_kmajor ? k0 * ldx : k0);
+    p.w = (const bf16_t*)w + (w_kmajor ? k0 * ldw : k0);
+    p.k = (int)std::min(k_chunk, k - k0);
+    p.accumulate = (accumulate || k0 > 0) ? 1 : 0;
+    if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
+    else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
+    else gm::launch<true, true>(p, st);
+  }
   PM_CHECK_LAUNCH("gemm_kernel");
   return PM_OK;
 }

@@ -539,6 +539,18 @@ class GRPOEngine:
         self._wgrad_direct = self._probe_wgrad_direct()
         # keep GEMM-friendly operand layouts (K-contiguous weight copies for dgrad, transposed MLP inputs for wgrad); PM_GEMM_LAYOUTS=0 is the A/B switch
         self.gemm_layouts = gemm_layouts and os.environ.get("PM_GEMM_LAYOUTS", "1") != "0" and not self.gemm_f32
+        # Which of the step's GEMM classes run on the hand-written MFMA core (csrc/gemm.hip, ops.gemm) instead of the library: a subset of
+        # {"fwd", "dgrad", "wgrad"} ("all" / "none" accepted).  Default = what measured faster on the MI355X (profiles/r03_gemm.md): the weight
+        # gradients — the core reads dy and x in their native token-major layout (no transposed activations) and accumulates straight into the f32
+        # gradient buffer, 15-20 % faster than the library on the o / gate|up / down products; forward and dgrad stay on hipBLASLt (1.5 vs 1.3 PFLOP/s).
+        sel = os.environ.get("PM_GEMM_OWN", "wgrad")
+        self.gemm_own = {"all": {"fwd", "dgrad", "wgrad"}, "none": set()}.get(sel, set(filter(None, sel.split(","))))
+        if self.gemm_own - {"fwd", "dgrad", "wgrad"}:
+            raise PrimeMI355XError(f"PM_GEMM_OWN: unknown GEMM class in {sel!r} (fwd, dgrad, wgrad, all, none)")
+        if self.gemm_f32 or self.device.type != "cuda":
+            self.gemm_own = set()
+        if "dgrad" in self.gemm_own:  # the core reads the stored [out, in] weight K-major: no [in, out] copies
+            self.gemm_layouts = False
         self._wt: dict[str, Tensor] = {}
         self._wt_version: dict[int, int] = {}
         if self.gemm_layouts:  # allocated up front (one slab) so the caching allocator sees the same request stream from the first step on
@@ -586,6 +598,8 @@ class GRPOEngine:
             if bias is not None:
                 y += bias.float()
             return y if out_f32 else y.to(torch.bfloat16)
+        if "fwd" in self.gemm_own and ops.gemm_supported(x, w):
+            return ops.gemm(x, w, out_dtype=torch.float32 if out_f32 else torch.bfloat16, bias=bias)
         if bias is not None:
             return torch.addmm(bias, x, w.t())
         return torch.mm(x, w.t(), out_dtype=torch.float32) if out_f32 else torch.mm(x, w.t())
@@ -602,6 +616,10 @@ class GRPOEngine:
                 gview.add_(prod)
             else:
                 gview.copy_(prod)
+            return
+        if "wgrad" in self.gemm_own and ops.gemm_supported(dy.t(), x.t()):
+            # dw[out, in] (+)= sum_tok dy[tok, out] x[tok, in]: both operands K-major (tokens are their rows), f32 accumulate in the epilogue
+            ops.gemm(dy.t(), x.t(), out=gview, accumulate=accumulate)
             return
         if self._wgrad_direct:
             xop = ops.transpose_2d(x).t() if (k_contiguous_x and self.gemm_layouts) else x
@@ -624,6 +642,8 @@ class GRPOEngine:
         name = f"model.layers.{layer}.{suffix}"
         if self.gemm_f32:
             return torch.mm(dy.float(), self.store.w[name].float()).to(torch.bfloat16)
+        if "dgrad" in self.gemm_own and ops.gemm_supported(dy, self.store.w[name].t()):
+            return ops.gemm(dy, self.store.w[name].t())  # the [out, in] weight read K-major
         if not self.gemm_layouts:
             return torch.mm(dy, self.store.w[name])
         if self._wt_version.get(layer) != self.store.version:
@@ -793,7 +813,7 @@ class GRPOEngine:
         hf = ctx["hf"]
         dhf = torch.empty_like(hf)
         acc_head = accumulate
-        head_t = "head" in self._wt  # K-contiguous [H, V] copy of the head weight for the dgrad GEMM (same reasoning as _dgrad)
+        head_t = "head" in self._wt and "dgrad" not in self.gemm_own  # K-contiguous [H, V] copy of the head weight for the library's dgrad GEMM (same reasoning as _dgrad)
         if head_t and self._wt_version.get("head") != self.store.version:
             ops.transpose_2d(wh, out=self._wt["head"])
             self._wt_version["head"] = self.store.version
@@ -811,6 +831,8 @@ class GRPOEngine:
                 dl = ops.logprob_bwd(logits, labels[s:e], inv_temp[s:e], ctx["logz"][s:e], grad_lp[s:e], out=logits)
             if self.gemm_f32:
                 dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
+            elif "dgrad" in self.gemm_own and ops.gemm_supported(dl, wh.t()):
+                ops.gemm(dl, wh.t(), out=dhf[s:e])
             elif head_t:
                 torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
             else:

@@ -367,3 +367,20 @@ def sign_sgd_step(master, grad, param_bf16, lr, weight_decay, grad_scale=1.0, cl
         param_bf16.copy_(master.to(BF16))
     if zero_grad:
         grad.zero_()
+
+
+def gemm_supported(x, w):
+    return False  # the CPU stand-in engine keeps the library (torch) GEMM calls
+
+
+def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    if out is None:
+        return y.to(out_dtype)
+    if accumulate:
+        out.add_(y.to(out.dtype))
+    else:
+        out.copy_(y)
+    return out

@@ -213,7 +213,7 @@ def bench_gemm_core(out, t=16384, variants=(1, 3, 0, 2), rounds=3):
                 ts.sort()
                 rec[key + "_ms"] = ts[len(ts) // 2] * 1e3
                 rec[key + "_TF"] = fl / ts[len(ts) // 2] / 1e12
-            out.append(rec)
+            print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
         del x, dy, w, wt, y, dx, g
         torch.cuda.empty_cache()
 
@@ -428,10 +428,15 @@ def main():
         w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
         g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
         ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "1")))
+        wt = w.t().contiguous()
         for _ in range(4):
             ops.gemm(x, w)
             ops.gemm(dy, w.t())
             ops.gemm(dy.t(), x.t(), out=g)
+            if os.environ.get("PM_PROBE_LIB", "1") == "1":  # the library kernels next to ours, for the same counters
+                torch.mm(x, w.t())
+                torch.mm(dy, wt.t())
+                torch.mm(dy.t(), x, out_dtype=torch.float32, out=g)
         torch.cuda.synchronize()
     if which == "gemmcore":
         bench_gemm_core(out, t=int(sys.argv[2]) if len(sys.argv) > 2 else 16384)
