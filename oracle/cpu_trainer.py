@@ -35,7 +35,8 @@ def default_loss_torch(lp, li, adv, mask, cfg: O.LossConfig):
     return (-pg + cfg.kl_tau * kl).sum()
 
 
-def step_logprobs_and_loss(params: dict, cfg, micro_batches: list[dict], loss_cfg: O.LossConfig, rl_scale: int, mm=None, f32_logits: bool = False):
+def step_logprobs_and_loss(params: dict, cfg, micro_batches: list[dict], loss_cfg: O.LossConfig, rl_scale: int, mm=None, f32_logits: bool = False,
+                           attn_p_bf16: bool = False):
     """Forward + log-probs + loss of a list of TensorMicroBatch dicts; returns (loss, [logprobs per mb], [entropy per mb]).
     Device-agnostic (runs where the tensors live).  `mm` = the GEMM hook of O.qwen3_forward; `f32_logits` keeps the head GEMM's
     output in f32 instead of rounding it to the activation dtype first (the reference rounds: lm_head.py:133 / :23-34)."""
@@ -44,7 +45,7 @@ def step_logprobs_and_loss(params: dict, cfg, micro_batches: list[dict], loss_cf
     for mb in micro_batches:
         ids = mb["input_ids"][0]
         labels = torch.cat([ids[1:], ids.new_zeros(1)])
-        h = O.qwen3_forward(params, cfg, ids, mb["position_ids"][0], [int(x) for x in mb["seq_lens"]], mm=mm)
+        h = O.qwen3_forward(params, cfg, ids, mb["position_ids"][0], [int(x) for x in mb["seq_lens"]], mm=mm, attn_p_bf16=attn_p_bf16)
         if f32_logits:
             logits = (h.float() @ params["lm_head.weight"].float().T) / mb["temperatures"][0][:, None]
         else:

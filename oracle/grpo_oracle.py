@@ -355,11 +355,14 @@ def apply_rope(x, cos, sin):
     return (x * cos[:, None, :]) + (rot * sin[:, None, :])
 
 
-def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float, window: int | None = None):
+def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float, window: int | None = None, p_bf16: bool = False):
     """flash_attn_varlen_func(q,k,v,cu,cu,max,max,causal=True) semantics at FlashAttention._compute_attention
     (trainer/models/layers/attn.py:94-110): per-document causal softmax attention with GQA, f32 math.
     q [N,Hq,D], k/v [N,Hkv,D] -> [N,Hq,D] f32.  `window` = the optional sliding window (attn.py:97-99: `window_size=(sliding_window - 1, 0)`):
-    query i sees keys i - window + 1 .. i of its document."""
+    query i sees keys i - window + 1 .. i of its document.
+    `p_bf16`: model the ONE rounding point inside the flash-attention kernels the f32 restatement does not have (flash-attn 2.8.3, the reference's
+    pinned dependency): the unnormalised probabilities exp(s - rowmax) are cast to the input dtype for the P.V matrix product
+    (f32 accumulation) and the row sum stays f32.  Not bit-identical to the kernel (its running row max moves block by block); same rounding statistics."""
     torch = _torch()
     n, hq, d = q.shape
     hkv = k.shape[1]
@@ -382,8 +385,14 @@ def varlen_causal_attention(q, k, v, seq_lens: list[int], scale: float, window: 
             vs = v[off:off + ln].to(torch.float32)[:, kv_idx]
             s = torch.einsum("ihd,jhd->hij", qs, ks) * scale
             s = s.masked_fill(~causal, float("-inf"))
-            p = torch.softmax(s, dim=-1)
-            out[off:off + ln, h0:h1] = torch.einsum("hij,jhd->ihd", p, vs)
+            if p_bf16:
+                e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+                den = e.sum(dim=-1)
+                o = torch.einsum("hij,jhd->ihd", e.to(torch.bfloat16).to(torch.float32), vs)
+                out[off:off + ln, h0:h1] = o / den.transpose(0, 1)[:, :, None]
+            else:
+                p = torch.softmax(s, dim=-1)
+                out[off:off + ln, h0:h1] = torch.einsum("hij,jhd->ihd", p, vs)
         off += ln
     return out
 
@@ -419,7 +428,7 @@ def exact_mm(a, w, bias=None):
     return (y if bias is None else y + bias.to(torch.float32)).to(a.dtype)
 
 
-def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int], mm=None):
+def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int], mm=None, attn_p_bf16: bool = False):
     """Qwen3Model.forward + Qwen3DecoderLayer.forward (trainer/models/qwen3/modeling_qwen3.py:65-85,155-196) with
     FlashAttention.attn_projections (trainer/models/layers/attn.py:123-160).  `params` uses HF names
     (model.layers.{i}.self_attn.q_proj.weight, ...); returns the final-norm hidden states [N, H] in the params' dtype.
@@ -448,7 +457,7 @@ def qwen3_forward(params: dict, cfg, input_ids, position_ids, seq_lens: list[int
             q = rmsnorm(q, params[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
             k = rmsnorm(k, params[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
-        a = varlen_causal_attention(q, k, v, seq_lens, d**-0.5).to(x.dtype).reshape(n, hq * d)
+        a = varlen_causal_attention(q, k, v, seq_lens, d**-0.5, p_bf16=attn_p_bf16).to(x.dtype).reshape(n, hq * d)
         x = res + mm(a, params[pre + "self_attn.o_proj.weight"])
         res = x
         h = rmsnorm(x, params[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)

@@ -48,9 +48,16 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr int kTile = 256;            // output tile edge (both ways)
 constexpr int kBK = 64;               // contraction per K-tile
 constexpr int kSlot = 128 * 128;      // one half-tile slot: 128 rows x 64 bf16
-constexpr int kSmem = 8 * kSlot;      // 128 KiB
+constexpr int kRing = 8 * kSlot;      // 128 KiB: the staging ring (two K-tiles)
+constexpr int kSmem = kRing + 8 * 4096;  // + a 4 KiB epilogue block per wave = all 160 KiB of the CU
 
 enum { SLOT_W0 = 0, SLOT_W1 = 1, SLOT_X0 = 2, SLOT_X1 = 3 };
+// Ring layout: the four W slots (two buffers x two halves) fill the first 64 KiB, the four X slots the second, so that ONE per-lane address register
+// per k-step reaches every slot of its operand through the 16-bit immediate offset of the LDS read.
+__host__ __device__ constexpr int slot_in_window(int buf, int slot) { return (buf * 2 + (slot & 1)) * kSlot; }            // offset inside the operand's 64 KiB window
+__host__ __device__ constexpr int slot_offset(int buf, int slot) { return (slot >= SLOT_X0 ? 4 * kSlot : 0) + slot_in_window(buf, slot); }
+
+static int g_variant = 7;  // bit 0 s_setprio, bit 1 balanced reads, bit 2 persistent grid, bits 3-4 timing ablations (pm_gemm_debug_set_variant)
 
 struct Params {
   const bf16_t* x;    // M-side operand: [M, K] (K-contiguous) or [K, M] (K-major), row stride ldx (elements)
@@ -60,6 +67,7 @@ struct Params {
   int64_t ldx, ldw, ldo;
   int m, n, k;
   int tiles_m, tiles_n;
+  int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
   int accumulate;     // f32 out only: out += product
 };
@@ -68,7 +76,7 @@ __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-// blockIdx.x -> (tile_m, tile_n); false for the padding blocks of the last patch round
+// virtual block id -> (tile_m, tile_n); false for the padding ids of the last patch round
 __device__ __forceinline__ bool tile_of_block(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int xcd = b & 7, s = b >> 3;
   const int patch = (s >> 5) * 8 + xcd, within = s & 31;
@@ -96,19 +104,26 @@ static inline int grid_blocks(int tiles_m, int tiles_n) {
 //   K-major operand: [64 k][128 rows] bf16, 256-byte LDS rows, chunk c (8 operand rows) of k-row q at chunk c ^ ((q & 3) << 2); a fragment is
 //     TWO ds_read_b64_tr_b16 per lane (k-rows 16 kk + 8 hi + {0..3}, then {4..7}): the 16 lanes of a transpose group read a 4 (k) x 16 (rows)
 //     block, and the four k-rows of a half-wave land in four different 64-byte quads of the bank row (conflict-free by construction).
+//
+// The LOAD SEGMENT of a phase is on the critical path of the ping-pong (it runs beside the partner's 256-cycle MFMA segment and every instruction
+// of it costs ~5 cycles of issue; measured: two extra scalar branches per phase = -4 %), so it is kept to the minimum: fragment reads with
+// precomputed per-lane addresses + immediate offsets (inline asm, so that hipcc can neither re-materialise the addresses with VALU adds nor guard
+// the reads with `vmcnt(0)` against the LDS-DMA in flight), one counted wait, ONE m0 write for the two DMA pieces (the second piece uses the
+// instruction offset, which moves the LDS and the memory address together, on a source offset pre-decremented by the same 1 KiB), one scalar add.
 struct Wave {
   f32x16 acc[2][2][2];  // [i: W half][a: 32-row fragment][j: X half]
   u32x4 wf[2][2][4];    // W fragments [i][a][kk]      (K-contiguous operand)
   u32x4 xf[2][4];       // X fragments [j][kk]
   u32x2 wlo[2][2][4], whi[2][2][4];  // K-major operand: the two transpose-read halves of a fragment (k 0..3 | 4..7 of the lane's 8)
   u32x2 xlo[2][4], xhi[2][4];
-  unsigned aw[2][2], ax[2];          // K-major operand: per-lane LDS byte address of the fragment read for (kk = 0, slot 0 of buffer BUF) [BUF][a]
-  __amdgpu_buffer_rsrc_t wr, xr;
-  int vw[2], vx[2];     // per-lane byte offsets of this wave's two DMA pieces (half-tile 0; half-tile 1 adds wstep / xstep)
-  int wstep, xstep;     // byte distance between the two halves of an operand tile (128 rows, or 128 columns of a K-major operand)
+  __amdgpu_buffer_rsrc_t wr, xr;     // buffer descriptors of the operand panels being STAGED: the current output tile's, and from the third phase of its
+                                     // last K-tile pair on the next tile's (persistent tile stream)
+  int vw[2], vx[2];     // per-lane byte offsets of this wave's two DMA pieces (half-tile 0); the second one minus the 1 KiB instruction offset
+  int off[4];           // wave-uniform running source offsets per slot kind (K-tile advance + half-tile step), see stage()
   int wk, xk;           // byte distance between consecutive K-tiles
+  int wstep, xstep;     // byte distance between the two halves of an operand tile (128 rows, or 128 columns of a K-major operand)
   int piece_lds;        // wave-uniform: byte offset of this wave's first piece inside a slot
-  int rd_w[4], rd_x[4]; // per-lane LDS byte offsets of the fragment reads per kk (inside a slot; W fragment a adds a constant)
+  unsigned aw[4], ax[4];  // per-lane LDS byte addresses of the fragment reads (slot 0 of the operand's window): K-contiguous [kk]; K-major [a] (W), [0] (X)
 };
 
 __device__ __forceinline__ unsigned char* lds_base() {
@@ -116,80 +131,93 @@ __device__ __forceinline__ unsigned char* lds_base() {
   return smem;
 }
 
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_ptr;
-
+// stage one half-tile (this wave's 2 KiB of it) of slot kind SLOT into buffer BUF from the source offset `s.off[SLOT]`, then advance that offset by
+// one K-tile.
 template <int SLOT, int BUF>
-__device__ __forceinline__ void stage(const Wave& s, unsigned char* smem, int ktile) {
-  constexpr int slot_off = (BUF * 4 + SLOT) * kSlot;
+__device__ __forceinline__ void stage(Wave& s, unsigned char* smem) {
+  constexpr int slot_off = slot_offset(BUF, SLOT);
   constexpr bool is_w = SLOT == SLOT_W0 || SLOT == SLOT_W1;
-  constexpr int half = (SLOT == SLOT_W1 || SLOT == SLOT_X1) ? 1 : 0;
-  const int soff = ktile * (is_w ? s.wk : s.xk) + half * (is_w ? s.wstep : s.xstep);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    unsigned char* dst = smem + slot_off + s.piece_lds + q * 1024;
-    if (is_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(s.wr, (lds_void_ptr)dst, 16, s.vw[q], soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(s.xr, (lds_void_ptr)dst, 16, s.vx[q], soff, 0, 0);
-  }
+  const __amdgpu_buffer_rsrc_t rsrc = is_w ? s.wr : s.xr;
+  unsigned char* dst = smem + slot_off + s.piece_lds;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[0] : s.vx[0], s.off[SLOT], 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[1] : s.vx[1], s.off[SLOT], 1024, 0);
+  s.off[SLOT] += is_w ? s.wk : s.xk;
+}
+// source offsets of K-tile 0 (slot kinds of buffer 0: W0 X0 X1 W1 of K-tile 0; the loop then alternates buffers, so every kind advances one K-tile
+// per use)
+__device__ __forceinline__ void reset_offsets(Wave& s) {
+  s.off[SLOT_W0] = 0;
+  s.off[SLOT_W1] = s.wstep;
+  s.off[SLOT_X0] = 0;
+  s.off[SLOT_X1] = s.xstep;
 }
 
-// K-major fragments are read with INLINE-ASM transpose reads: hipcc guards `__builtin_amdgcn_ds_read_tr16_b64` against every LDS-DMA in flight
-// with `s_waitcnt vmcnt(0)` (it cannot tell the ring slots apart), which would drain the whole prefetch in every phase.  The compiler does not
-// track asm results on lgkmcnt, so the consumer side is explicit: `s_waitcnt lgkmcnt(0)` after the barrier, then `tie()` — an empty asm that
-// takes the registers in and out — so that nothing that uses them can be scheduled above the wait.
+// Fragment reads are INLINE ASM: (a) hipcc guards `__builtin_amdgcn_ds_read_tr16_b64` against every LDS-DMA in flight with `s_waitcnt vmcnt(0)` (it
+// cannot tell the ring slots apart), which would drain the whole prefetch in every phase; (b) it re-materialises plain-load addresses with one VALU
+// add per read once registers are tight.  The compiler does not track asm results on lgkmcnt, so the consumer side is explicit: `s_waitcnt
+// lgkmcnt(0)` after the barrier, then `tie()` — an empty asm that takes the registers in and out — so that nothing that uses them can be scheduled
+// above the wait.
 template <int IMM>
 __device__ __forceinline__ u32x2 tr_read(unsigned addr) {
   u32x2 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
   return v;
 }
+template <int IMM>
+__device__ __forceinline__ u32x4 b128_read(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
 __device__ __forceinline__ void tie(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f, u32x2& g, u32x2& h) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
 }
+__device__ __forceinline__ void tie(u32x4& a, u32x4& b, u32x4& c, u32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) { return u32x4{lo.x, lo.y, hi.x, hi.y}; }
 
 template <int I, int BUF, bool KM>
-__device__ __forceinline__ void read_w(Wave& s, const unsigned char* smem) {
-  constexpr int slot = I ? SLOT_W1 : SLOT_W0;
+__device__ __forceinline__ void read_w(Wave& s) {
+  constexpr int slot = slot_in_window(BUF, I ? SLOT_W1 : SLOT_W0);  // an immediate
   if constexpr (!KM) {
-    constexpr int slot_off = (BUF * 4 + slot) * kSlot;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) s.wf[I][a][kk] = *reinterpret_cast<const u32x4*>(smem + slot_off + a * 32 * 128 + s.rd_w[kk]);
+#define PM_RDW(A, KK) s.wf[I][A][KK] = b128_read<slot + A * 32 * 128>(s.aw[KK]);
+    PM_RDW(0, 0) PM_RDW(0, 1) PM_RDW(0, 2) PM_RDW(0, 3) PM_RDW(1, 0) PM_RDW(1, 1) PM_RDW(1, 2) PM_RDW(1, 3)
+#undef PM_RDW
   } else {
-    // k-rows 16 kk + {0..3} then {4..7}: 4 KiB per kk, 1 KiB between the two reads; slot offsets inside the 64 KiB of buffer BUF as immediates
-#define PM_TRW(A, KK)                                                                 \
-    s.wlo[I][A][KK] = tr_read<slot * kSlot + KK * 4096>(s.aw[BUF][A]);                \
-    s.whi[I][A][KK] = tr_read<slot * kSlot + KK * 4096 + 1024>(s.aw[BUF][A]);
+    // k-rows 16 kk + {0..3} then {4..7}: 4 KiB per kk, 1 KiB between the two reads
+#define PM_TRW(A, KK)                                               \
+    s.wlo[I][A][KK] = tr_read<slot + KK * 4096>(s.aw[A]);        \
+    s.whi[I][A][KK] = tr_read<slot + KK * 4096 + 1024>(s.aw[A]);
     PM_TRW(0, 0) PM_TRW(0, 1) PM_TRW(0, 2) PM_TRW(0, 3) PM_TRW(1, 0) PM_TRW(1, 1) PM_TRW(1, 2) PM_TRW(1, 3)
 #undef PM_TRW
   }
 }
 template <int J, int BUF, bool KM>
-__device__ __forceinline__ void read_x(Wave& s, const unsigned char* smem) {
-  constexpr int slot = J ? SLOT_X1 : SLOT_X0;
+__device__ __forceinline__ void read_x(Wave& s) {
+  constexpr int slot = slot_in_window(BUF, J ? SLOT_X1 : SLOT_X0);
   if constexpr (!KM) {
-    constexpr int slot_off = (BUF * 4 + slot) * kSlot;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) s.xf[J][kk] = *reinterpret_cast<const u32x4*>(smem + slot_off + s.rd_x[kk]);
+#define PM_RDX(KK) s.xf[J][KK] = b128_read<slot>(s.ax[KK]);
+    PM_RDX(0) PM_RDX(1) PM_RDX(2) PM_RDX(3)
+#undef PM_RDX
   } else {
-#define PM_TRX(KK)                                                              \
-    s.xlo[J][KK] = tr_read<slot * kSlot + KK * 4096>(s.ax[BUF]);                \
-    s.xhi[J][KK] = tr_read<slot * kSlot + KK * 4096 + 1024>(s.ax[BUF]);
+#define PM_TRX(KK)                                            \
+    s.xlo[J][KK] = tr_read<slot + KK * 4096>(s.ax[0]);     \
+    s.xhi[J][KK] = tr_read<slot + KK * 4096 + 1024>(s.ax[0]);
     PM_TRX(0) PM_TRX(1) PM_TRX(2) PM_TRX(3)
 #undef PM_TRX
   }
 }
-template <int I>
+template <int I, bool KM>
 __device__ __forceinline__ void tie_w(Wave& s) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-    tie(s.wlo[I][a][0], s.whi[I][a][0], s.wlo[I][a][1], s.whi[I][a][1], s.wlo[I][a][2], s.whi[I][a][2], s.wlo[I][a][3], s.whi[I][a][3]);
+  for (int a = 0; a < 2; ++a) {
+    if constexpr (KM) tie(s.wlo[I][a][0], s.whi[I][a][0], s.wlo[I][a][1], s.whi[I][a][1], s.wlo[I][a][2], s.whi[I][a][2], s.wlo[I][a][3], s.whi[I][a][3]);
+    else tie(s.wf[I][a][0], s.wf[I][a][1], s.wf[I][a][2], s.wf[I][a][3]);
+  }
 }
-template <int J>
+template <int J, bool KM>
 __device__ __forceinline__ void tie_x(Wave& s) {
-  tie(s.xlo[J][0], s.xhi[J][0], s.xlo[J][1], s.xhi[J][1], s.xlo[J][2], s.xhi[J][2], s.xlo[J][3], s.xhi[J][3]);
+  if constexpr (KM) tie(s.xlo[J][0], s.xhi[J][0], s.xlo[J][1], s.xhi[J][1], s.xlo[J][2], s.xhi[J][2], s.xlo[J][3], s.xhi[J][3]);
+  else tie(s.xf[J][0], s.xf[J][1], s.xf[J][2], s.xf[J][3]);
 }
 template <int I, int J, bool XK, bool WK>
 __device__ __forceinline__ void quadrant(Wave& s) {
@@ -203,44 +231,49 @@ __device__ __forceinline__ void quadrant(Wave& s) {
     }
 }
 
-// One phase.  P = phase inside the K-tile (0..3), BUF = parity of the K-tile.  `more1` / `more2`: K-tiles t+1 / t+2 exist (wave-uniform).
+// One phase.  P = phase inside the K-tile (0..3), BUF = parity of the K-tile.  Phases 1-2 stage the OTHER buffer's X1 / W1 half-tiles (K-tile + 1),
+// phases 3-4 THIS buffer's W0 / X0 (K-tile + 2) — unconditionally, from whatever panels `s.wr / s.xr / s.off[]` currently describe: the stream of
+// K-tiles runs across output-tile boundaries (the last K-tile pair of a tile stages the first six half-tiles of the next one, its "prologue"; after
+// the workgroup's last tile it re-stages that tile's first K-tiles, which nobody reads), so that the phase body has no branch and ONE copy.
 // V bit 0: s_setprio(1) around the MFMA cluster.  V bit 1: balanced reads (W0 of the NEXT K-tile is read in phase 4 instead of phase 1).
+// V bits 3 / 4: TIMING ABLATIONS (wrong results): no LDS-DMA inside the loop / no fragment reads.
 template <int P, int BUF, int V, bool XK, bool WK>
-__device__ __forceinline__ void phase(Wave& s, unsigned char* smem, int t, bool more1, bool more2) {
-  constexpr bool kBalanced = (V & 2) != 0;
+__device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
+  constexpr bool kBalanced = (V & 2) != 0, kNoDma = (V & 8) != 0, kNoReads = (V & 16) != 0;
   // ---- load segment
-  if (P == 0) {
-    if (!kBalanced) read_w<0, BUF, WK>(s, smem);
-    read_x<0, BUF, XK>(s, smem);
-  } else if (P == 1) {
-    read_x<1, BUF, XK>(s, smem);
-  } else if (P == 2) {
-    read_w<1, BUF, WK>(s, smem);
-  } else if (kBalanced) {
-    if (more1) read_w<0, BUF ^ 1, WK>(s, smem);
+  if (!kNoReads) {
+    if (P == 0) {
+      if (!kBalanced) read_w<0, BUF, WK>(s);
+      read_x<0, BUF, XK>(s);
+    } else if (P == 1) {
+      read_x<1, BUF, XK>(s);
+    } else if (P == 2) {
+      read_w<1, BUF, WK>(s);
+    } else if (kBalanced) {
+      read_w<0, BUF ^ 1, WK>(s);
+    }
   }
-  const bool issue = (P < 2) ? more1 : more2;
-  if (issue) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (P == 0) stage<SLOT_X1, BUF ^ 1>(s, smem, t + 1);
-    else if (P == 1) stage<SLOT_W1, BUF ^ 1>(s, smem, t + 1);
-    else if (P == 2) stage<SLOT_W0, BUF>(s, smem, t + 2);
-    else stage<SLOT_X0, BUF>(s, smem, t + 2);
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (!kNoDma) {
+    if (P == 0) stage<SLOT_X1, BUF ^ 1>(s, smem);
+    else if (P == 1) stage<SLOT_W1, BUF ^ 1>(s, smem);
+    else if (P == 2) stage<SLOT_W0, BUF>(s, smem);
+    else stage<SLOT_X0, BUF>(s, smem);
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // asm transpose reads of this phase: their registers become usable only here
-  if (P == 0) {
-    if (WK) tie_w<0>(s);  // also in balanced mode: the prologue read of K-tile 0
-    if (XK) tie_x<0>(s);
-  } else if (P == 1) {
-    if (XK) tie_x<1>(s);
-  } else if (P == 2) {
-    if (WK) tie_w<1>(s);
-  } else if (kBalanced) {
-    if (WK) tie_w<0>(s);
+  // the asm reads of this phase: their registers become usable only here
+  if (!kNoReads) {
+    if (P == 0) {
+      tie_w<0, WK>(s);  // also in balanced mode: the prologue read of the first K-tile
+      tie_x<0, XK>(s);
+    } else if (P == 1) {
+      tie_x<1, XK>(s);
+    } else if (P == 2) {
+      tie_w<1, WK>(s);
+    } else if (kBalanced) {
+      tie_w<0, WK>(s);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- compute segment
@@ -253,171 +286,264 @@ __device__ __forceinline__ void phase(Wave& s, unsigned char* smem, int t, bool 
   __builtin_amdgcn_s_barrier();
 }
 
-// per-lane DMA source offsets + fragment read offsets of one operand.  `rows_valid`: operand rows (M or N coordinate) left from the tile's first
-// row; `wsel`: this wave's first row inside a half (64 wv for W, 32 wt for X).
+// buffer descriptor of one operand panel of an output tile.  K-contiguous [rows, K]: based at the tile's first row, rows past the tensor's end are
+// out of range -> zeros.  K-major [K, rows]: based at column row0 and ending with the tensor, so k-rows past K read as zeros.
 template <bool KM>
-__device__ __forceinline__ void setup_operand(const bf16_t* base, int64_t ld, int64_t row0, int64_t rows_total, int k, int wave, int lane, int wsel,
-                                              __amdgpu_buffer_rsrc_t& rsrc, int (&voff)[2], int& half_step, int& k_step, int (&rd)[4]) {
-  const int l31 = lane & 31, hi = lane >> 5;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int64_t ld, int64_t row0, int64_t rows_total, int k) {
   if (!KM) {
     const int64_t rows = rows_total - row0 < kTile ? rows_total - row0 : kTile;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0 * ld), 0, (int)(((rows - 1) * ld + k) * 2), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0 * ld), 0, (int)(((rows - 1) * ld + k) * 2), 0x00020000);
+  }
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0), 0, (int)((((int64_t)k - 1) * ld + (rows_total - row0)) * 2), 0x00020000);
+}
+
+// per-lane DMA source offsets + fragment read addresses of one operand (tile independent).  `wsel`: this wave's first row inside a half (64 wv for
+// W, 32 wt for X); `lds0`: LDS byte address of the ring.
+template <bool KM>
+__device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, int wsel, unsigned lds0, int (&voff)[2], int& half_step, int& k_step, unsigned (&rd)[4]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (!KM) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int rho = (wave * 2 + q) * 8 + (lane >> 3);  // slot row of this lane's 16 bytes (piece = 8 rows x 128 bytes)
-      voff[q] = (int)(rho * ld * 2) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4);
+      voff[q] = (int)(rho * ld * 2) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4) - q * 1024;
     }
     half_step = (int)(128 * ld * 2);
     k_step = kBK * 2;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) rd[kk] = (wsel + l31) * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+    for (int kk = 0; kk < 4; ++kk) rd[kk] = lds0 + (wsel + l31) * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
   } else {
-    // [K, rows] tensor: the descriptor starts at column row0 and ends with the tensor, so k-rows past K read as zeros
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0), 0, (int)((((int64_t)k - 1) * ld + (rows_total - row0)) * 2), 0x00020000);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int krow = (wave * 2 + q) * 4 + (lane >> 4);  // piece = 4 k-rows x 256 bytes
-      voff[q] = (int)(krow * ld * 2) + (((lane & 15) ^ ((krow & 3) << 2)) << 4);
+      voff[q] = (int)(krow * ld * 2) + (((lane & 15) ^ ((krow & 3) << 2)) << 4) - q * 1024;
     }
     half_step = 128 * 2;
     k_step = (int)(kBK * ld * 2);
     const int lam = lane & 15, grp = (lane >> 4) & 1;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int krow = kk * 16 + hi * 8 + (lam >> 2);
-      const int chunk = ((wsel + grp * 16) >> 3) + ((lam & 3) >> 1);
-      rd[kk] = krow * 256 + ((chunk ^ ((krow & 3) << 2)) << 4) + (lam & 1) * 8;
-    }
+    const int krow = hi * 8 + (lam >> 2);  // kk = 0; kk adds 16 k-rows = 4 KiB (an immediate)
+    const int chunk = ((wsel + grp * 16) >> 3) + ((lam & 3) >> 1);
+    const unsigned a0 = krow * 256 + ((chunk ^ ((krow & 3) << 2)) << 4) + (lam & 1) * 8;
+    rd[0] = lds0 + a0;
+    rd[1] = lds0 + (a0 ^ 64);  // W fragment a = 1: 32 operand rows further = chunk bit 2 — an XOR, because the swizzle flips that bit
+    rd[2] = rd[3] = 0;
   }
+}
+
+// next valid output tile of this workgroup at or after virtual block id v (stride = gridDim.x, a multiple of 8, so v % 8 — the XCD — never changes)
+__device__ __forceinline__ bool next_tile(const Params& p, int& v, int& tm, int& tn) {
+  for (; v < p.n_blocks; v += gridDim.x)
+    if (tile_of_block(v, p.tiles_m, p.tiles_n, tm, tn)) return true;
+  return false;
 }
 
 template <int V, bool XK, bool WK>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   unsigned char* smem = lds_base();
-  int tm, tn;
-  if (!tile_of_block(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;
+  int v = blockIdx.x, tm, tn;
+  if (!next_tile(p, v, tm, tn)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = wave >> 2, wt = wave & 3;  // wv: which 64 W rows of a half (also the ping-pong group), wt: which 32 X rows of a half
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int m0 = tm * kTile, n0 = tn * kTile;
 
   Wave s;
-  setup_operand<WK>(p.w, p.ldw, n0, p.n, p.k, wave, lane, wv * 64, s.wr, s.vw, s.wstep, s.wk, s.rd_w);
-  setup_operand<XK>(p.x, p.ldx, m0, p.m, p.k, wave, lane, wt * 32, s.xr, s.vx, s.xstep, s.xk, s.rd_x);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  setup_operand<WK>(p.ldw, wave, lane, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
+  setup_operand<XK>(p.ldx, wave, lane, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);  // the X window is the second 64 KiB of the ring
+  s.wr = panel_rsrc<WK>(p.w, p.ldw, (int64_t)tn * kTile, p.n, p.k);
+  s.xr = panel_rsrc<XK>(p.x, p.ldx, (int64_t)tm * kTile, p.m, p.k);
   s.piece_lds = wave * 2048;
-  {
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      s.aw[b][0] = lds0 + b * 4 * kSlot + s.rd_w[0];
-      s.aw[b][1] = lds0 + b * 4 * kSlot + (s.rd_w[0] ^ 64);  // fragment a = 1: chunk bit 2 (an XOR: the swizzle flips that bit)
-      s.ax[b] = lds0 + b * 4 * kSlot + s.rd_x[0];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s.acc[i][a][j][r] = 0.f;
-
-  const int nk = ((p.k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
-  // ---- prologue: the issue order continues into the loop's (X1, W1, W0, X0) rotation
-  stage<SLOT_W0, 0>(s, smem, 0);
-  stage<SLOT_X0, 0>(s, smem, 0);
-  stage<SLOT_X1, 0>(s, smem, 0);
-  stage<SLOT_W1, 0>(s, smem, 0);
-  stage<SLOT_W0, 1>(s, smem, 1);
-  stage<SLOT_X0, 1>(s, smem, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // W0(0) and X0(0) of this wave have landed
-  __builtin_amdgcn_s_barrier();
-  if ((V & 2) != 0) {  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1 like the later ones, which are read in phase 4 of the previous K-tile)
-    read_w<0, 0, WK>(s, smem);
-  }
-  if (wv == 1) __builtin_amdgcn_s_barrier();    // the second wave group runs one barrier behind the first
-
-  for (int t = 0; t < nk; t += 2) {
-    const bool m2 = t + 2 < nk, m3 = t + 3 < nk;
-    phase<0, 0, V, XK, WK>(s, smem, t, true, m2);
-    phase<1, 0, V, XK, WK>(s, smem, t, true, m2);
-    phase<2, 0, V, XK, WK>(s, smem, t, true, m2);
-    phase<3, 0, V, XK, WK>(s, smem, t, true, m2);
-    phase<0, 1, V, XK, WK>(s, smem, t + 1, m2, m3);
-    phase<1, 1, V, XK, WK>(s, smem, t + 1, m2, m3);
-    phase<2, 1, V, XK, WK>(s, smem, t + 1, m2, m3);
-    phase<3, 1, V, XK, WK>(s, smem, t + 1, m2, m3);
-  }
-  if (wv == 0) __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + j * 128 + wt * 32 + l31;
-    if (m >= p.m) continue;
+  if (V & 16) {  // timing ablation: fragments are never read; give them defined (non-zero) contents
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = n0 + i * 128 + wv * 64 + a * 32 + g * 8 + hi * 4;
-          if (nb >= p.n) continue;
-          float v[4];
+        for (int kk = 0; kk < 4; ++kk) {
+          s.wf[i][a][kk] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          s.xf[i][kk] = u32x4{0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u};
+          s.wlo[i][a][kk] = s.whi[i][a][kk] = s.xlo[i][kk] = s.xhi[i][kk] = u32x2{0x3f803f80u, 0x3f803f80u + lane};
+        }
+  }
+  const int nk = ((p.k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
+  // ---- prologue of the FIRST tile: the issue order continues into the loop's (X1, W1, W0, X0) rotation
+  reset_offsets(s);
+  stage<SLOT_W0, 0>(s, smem);
+  stage<SLOT_X0, 0>(s, smem);
+  stage<SLOT_X1, 0>(s, smem);
+  stage<SLOT_W1, 0>(s, smem);
+  stage<SLOT_W0, 1>(s, smem);
+  stage<SLOT_X0, 1>(s, smem);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // W0(0) and X0(0) of this wave have landed
+  __builtin_amdgcn_s_barrier();
+  if ((V & 2) != 0 && !(V & 16)) read_w<0, 0, WK>(s);  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1), later ones in phase 4 of the previous K-tile
+  if (wv == 1) __builtin_amdgcn_s_barrier();           // the second wave group runs one barrier behind the first
+
+  for (;;) {  // ---- the workgroup's output tiles
+    const int m0 = tm * kTile, n0 = tn * kTile;
+    {
+      // Re-derive the per-lane DMA offsets / read addresses from an OPAQUE copy of the lane id at the top of every tile: otherwise they stay live across
+      // the epilogue (the register-hungriest part), get spilled, and every DMA in the K loop waits for a scratch reload with `vmcnt(1)`.
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      setup_operand<WK>(p.ldw, wave, lane_o, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
+      setup_operand<XK>(p.ldx, wave, lane_o, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);
+    }
+    int v_n = v + gridDim.x, tm_n = tm, tn_n = tn;
+    const bool has_next = next_tile(p, v_n, tm_n, tn_n);
+    if (!has_next) {
+      tm_n = tm;  // after the last tile the stream re-stages this tile's first K-tiles (never read; drained before the kernel ends)
+      tn_n = tn;
+    }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = s.acc[i][a][j][g * 4 + r];
-          const bool full = nb + 3 < p.n;
-          if (p.bias) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (full || nb + r < p.n) v[r] += bf16_to_f32(p.bias[nb + r]);
-          }
-          if (p.out_f32) {
-            float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nb;
-            if (full) {
-              f32x4 o = {v[0], v[1], v[2], v[3]};
-              if (p.accumulate) {
-                const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
-                o += old;
-              }
-              *reinterpret_cast<f32x4*>(dst) = o;
-            } else {
-              for (int r = 0; r < 4; ++r)
-                if (nb + r < p.n) dst[r] = p.accumulate ? dst[r] + v[r] : v[r];
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s.acc[i][a][j][r] = 0.f;
+
+    for (int t = 0; t < nk; t += 2) {  // two K-tiles per iteration: t in buffer 0, t + 1 in buffer 1
+      phase<0, 0, V, XK, WK>(s, smem);
+      phase<1, 0, V, XK, WK>(s, smem);
+      if (t + 2 >= nk) {  // the last pair of this output tile: every half-tile staged from here on belongs to the next one
+        s.wr = panel_rsrc<WK>(p.w, p.ldw, (int64_t)tn_n * kTile, p.n, p.k);
+        s.xr = panel_rsrc<XK>(p.x, p.ldx, (int64_t)tm_n * kTile, p.m, p.k);
+        reset_offsets(s);
+      }
+      phase<2, 0, V, XK, WK>(s, smem);
+      phase<3, 0, V, XK, WK>(s, smem);
+      phase<0, 1, V, XK, WK>(s, smem);
+      phase<1, 1, V, XK, WK>(s, smem);
+      phase<2, 1, V, XK, WK>(s, smem);
+      phase<3, 1, V, XK, WK>(s, smem);
+    }
+
+    // ---- epilogue.  A lane of the C fragment owns ONE output row and 4 x 4 scattered columns: stored directly, one wave instruction would touch
+    // 32 different rows with 8 / 16 bytes each, and the CU drains such stores at ~8 B/clk.  So each wave transposes through a private 4 KiB LDS block
+    // ([32 rows][128 bytes], 16-byte chunk c of row r at c ^ (r & 7)): fragment registers in by ds_write_b64 / b128, full rows out by ds_read_b128,
+    // and every global store instruction writes 8 complete 128-byte row segments.  LDS operations of one wave execute in order: no barrier.
+    {
+      int lane_e = lane;  // opaque per tile: keeps the epilogue's dozens of per-lane addresses from being hoisted out of the tile loop and spilled across the K loop
+      asm volatile("" : "+v"(lane_e));
+      const int l31 = lane_e & 31, hi = lane_e >> 5;
+      unsigned char* stg = smem + kRing + wave * 4096;
+      const int srow = lane_e >> 3, schunk = lane_e & 7;
+      const bool wide = p.out_f32 ? (p.n % 4 == 0) : (p.n % 8 == 0 && p.ldo % 8 == 0);
+      if (wide) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ncol0 = n0 + i * 128 + wv * 64;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int mrow0 = m0 + j * 128 + wt * 32;
+            if (p.bias) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int nb = ncol0 + a * 32 + g * 8 + hi * 4 + r;
+                    if (nb < p.n) s.acc[i][a][j][g * 4 + r] += bf16_to_f32(p.bias[nb]);
+                  }
             }
-          } else {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (int64_t)m * p.ldo + nb;
-            if (full) {
-              *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16_hw(v[0], v[1]), pack_bf16_hw(v[2], v[3])};
+            if (!p.out_f32) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const f32x16& c = s.acc[i][a][j];
+                  const u32x2 pk = {pack_bf16_hw(c[g * 4], c[g * 4 + 1]), pack_bf16_hw(c[g * 4 + 2], c[g * 4 + 3])};
+                  *reinterpret_cast<u32x2*>(stg + l31 * 128 + (((a * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+                }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int ml = q * 8 + srow;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
+                const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
+                if (m < p.m && nn < p.n) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (int64_t)m * p.ldo + nn) = val;
+              }
             } else {
-              for (int r = 0; r < 4; ++r)
-                if (nb + r < p.n) dst[r] = f32_to_bf16(v[r]);
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const f32x16& c = s.acc[i][a][j];
+                  *reinterpret_cast<f32x4*>(stg + l31 * 128 + (((g * 2 + hi) ^ (l31 & 7)) << 4)) = f32x4{c[g * 4], c[g * 4 + 1], c[g * 4 + 2], c[g * 4 + 3]};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int ml = q * 8 + srow;
+                  f32x4 val = *reinterpret_cast<const f32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
+                  const int m = mrow0 + ml, nn = ncol0 + a * 32 + schunk * 4;
+                  if (m < p.m && nn < p.n) {
+                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nn;
+                    if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = val;
+                  }
+                }
+              }
             }
           }
         }
-  }
+      } else {  // ragged column counts: the direct form
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int m = m0 + j * 128 + wt * 32 + l31;
+          if (m >= p.m) continue;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + i * 128 + wv * 64 + a * 32 + g * 8 + hi * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  if (nb + r >= p.n) continue;
+                  float val = s.acc[i][a][j][g * 4 + r];
+                  if (p.bias) val += bf16_to_f32(p.bias[nb + r]);
+                  if (p.out_f32) {
+                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nb + r;
+                    *dst = p.accumulate ? *dst + val : val;
+                  } else {
+                    reinterpret_cast<bf16_t*>(p.out)[(int64_t)m * p.ldo + nb + r] = f32_to_bf16(val);
+                  }
+                }
+              }
+        }
+      }
+    }
+    if (!has_next) break;
+    v = v_n; tm = tm_n; tn = tn_n;
+  }  // tiles
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
+  if (wv == 0) __builtin_amdgcn_s_barrier();
 }
 
-static int g_variant = 1;
+template <int V, bool XK, bool WK>
+static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<V, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<V, XK, WK>), grid, dim3(512), kSmem, st, p);
+}
 
 template <bool XK, bool WK>
 static void launch(const Params& p, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<0, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<1, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<2, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<3, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_done = true;
-  }
-  const dim3 grid(grid_blocks(p.tiles_m, p.tiles_n)), block(512);
-  switch (g_variant & 3) {
-    case 0: hipLaunchKernelGGL((gemm_kernel<0, XK, WK>), grid, block, kSmem, st, p); break;
-    case 1: hipLaunchKernelGGL((gemm_kernel<1, XK, WK>), grid, block, kSmem, st, p); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<2, XK, WK>), grid, block, kSmem, st, p); break;
-    default: hipLaunchKernelGGL((gemm_kernel<3, XK, WK>), grid, block, kSmem, st, p); break;
-  }
+  // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
+  // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
+  const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
+  const int v = g_variant & ~4;
+  if (v == 0) launch_v<0, XK, WK>(p, st, grid);
+  else if (v == 3) launch_v<3, XK, WK>(p, st, grid);
+  else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
+  else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16, false, false>(p, st, grid);
+  else if (!XK && !WK && v == (1 | 8 | 16)) launch_v<1 | 8 | 16, false, false>(p, st, grid);
+  else launch_v<1, XK, WK>(p, st, grid);
 }
 
 }  // namespace gm
@@ -435,8 +561,8 @@ extern "C" int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmaj
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   if (x_kmajor && !w_kmajor) return 0;  // no caller has that pair
   if (!(x_kmajor && w_kmajor) && k % 128 != 0) return 0;
-  if (x_kmajor && m % 8 != 0) return 0;  // 16-byte chunks along the rows of a K-major operand
-  if (w_kmajor && n % 8 != 0) return 0;
+  if (x_kmajor && (m % 8 != 0 || m < 128)) return 0;  // 16-byte chunks along the rows of a K-major operand; its row stride (>= rows) covers the 1 KiB piece offset
+  if (w_kmajor && (n % 8 != 0 || n < 128)) return 0;
   return 1;
 }
 
@@ -460,7 +586,7 @@ extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const 
   int64_t k_chunk = k;
   if (x_kmajor && k * ldx * 2 >= kLimit) k_chunk = std::min(k_chunk, kLimit / (ldx * 2) / 128 * 128);
   if (w_kmajor && k * ldw * 2 >= kLimit) k_chunk = std::min(k_chunk, kLimit / (ldw * 2) / 128 * 128);
-  PM_REQUIRE(k_chunk >= 128, PM_ERR_UNSUPPORTED, "pm_gemm_bf16: a K-major operand with rows beyond 8M elements");
+  PM_REQUIRE(k_chunk >= 128 || k_chunk == k, PM_ERR_UNSUPPORTED, "pm_gemm_bf16: a K-major operand with rows beyond 8M elements");
   PM_REQUIRE(k_chunk == k || (out_dtype == PM_DTYPE_F32 && x_kmajor && w_kmajor && !bias), PM_ERR_UNSUPPORTED,
              "pm_gemm_bf16: a K-major operand beyond 2 GB needs the f32-accumulating wgrad form");
   gm::Params p;
@@ -468,6 +594,7 @@ extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const 
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
   p.m = (int)m; p.n = (int)n;
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
+  p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
   hipStream_t st = as_stream(stream);
   for (int64_t k0 = 0; k0 < k; k0 += k_chunk) {

@@ -27,7 +27,7 @@ def _check(out, ref, k, bf16_out):
     assert err <= tol, f"max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (300, 520, 384), (1000, 256, 1024), (77, 1000, 128)])
 def test_gemm_forward_layout(m, n, k, variant):
     ops.gemm_set_variant(variant)
@@ -37,7 +37,7 @@ def test_gemm_forward_layout(m, n, k, variant):
         _check(ops.gemm(x, w), ref, k, True)
         _check(ops.gemm(x, w, out_dtype=torch.float32), ref, k, False)
     finally:
-        ops.gemm_set_variant(1)
+        ops.gemm_set_variant(7)
 
 
 def test_gemm_bias_and_strided_operands():
@@ -53,7 +53,7 @@ def test_gemm_bias_and_strided_operands():
     assert torch.count_nonzero(out[:, :n]) == 0
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 7])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 384, 256), (300, 520, 640), (77, 1024, 128)])
 def test_gemm_dgrad_layout(m, n, k, variant):
     """dx[m, in] = dy[m, out] @ W[out, in]: the weight is read K-major (no transposed copy)."""
@@ -63,10 +63,10 @@ def test_gemm_dgrad_layout(m, n, k, variant):
         ref = dy.float() @ w.float()
         _check(ops.gemm(dy, w.t()), ref, k, True)
     finally:
-        ops.gemm_set_variant(1)
+        ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 7])
 @pytest.mark.parametrize("tokens,n_out,n_in", [(128, 256, 256), (1024, 512, 384), (1000, 264, 520), (77, 256, 128), (4096, 256, 256)])
 def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
     """dw[out, in] (+)= dy[tok, out]^T @ x[tok, in], f32, any token count (rows past the last token read as zeros)."""
@@ -80,16 +80,16 @@ def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
         ops.gemm(dy.t(), x.t(), out=g, accumulate=True)
         _check(g, 2 * ref, tokens, False)
     finally:
-        ops.gemm_set_variant(1)
+        ops.gemm_set_variant(7)
 
 
 def test_gemm_is_deterministic_and_matches_itself_across_variants():
     x, w = _rand(512, 512, 1.0, 10), _rand(512, 512, 0.05, 11)
     outs = []
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 3, 5, 7):
         ops.gemm_set_variant(v)
         outs.append(ops.gemm(x, w, out_dtype=torch.float32))
-    ops.gemm_set_variant(1)
+    ops.gemm_set_variant(7)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])  # same summation order in every schedule variant
     assert torch.equal(ops.gemm(x, w, out_dtype=torch.float32), outs[1])
@@ -103,3 +103,22 @@ def test_gemm_identity_with_asymmetric_operand():
     assert torch.equal(ops.gemm(eye, w, out_dtype=torch.float32), w.float().t().contiguous())
     wk = w[:256].t().contiguous()  # stored [K, N]: the K-major path
     assert torch.equal(ops.gemm(eye, wk.t(), out_dtype=torch.float32), w[:256].float().t().contiguous())
+
+
+@pytest.mark.parametrize("variant", [1, 7])
+def test_gemm_many_tiles_per_workgroup(variant):
+    """More output tiles than CUs: the persistent form (variant bit 2) walks several tiles per workgroup, staging the next tile's first K-tiles under
+    the current tile's last ones; results must equal the one-workgroup-per-tile form bit for bit."""
+    ops.gemm_set_variant(variant)
+    try:
+        m, n, k = 2048 + 77, 10240, 256  # 9 x 40 = 360 tiles
+        x, w = _rand(m, k, 1.0, 21), _rand(n, k, 0.05, 22)
+        out = ops.gemm(x, w)
+        ref = x.float() @ w.float().t()
+        _check(out, ref, k, True)
+        dy, xx = _rand(1000, 4096, 1.0, 23), _rand(1000, 5120, 1.0, 24)  # wgrad: 16 x 20 = 320 tiles, ragged token count
+        g = torch.zeros(4096, 5120, dtype=torch.float32, device=DEV)
+        ops.gemm(dy.t(), xx.t(), out=g)
+        _check(g, dy.float().t() @ xx.float(), 1000, False)
+    finally:
+        ops.gemm_set_variant(7)

@@ -167,7 +167,7 @@ def bench_gemm(out):
         torch.cuda.empty_cache()
 
 
-def bench_gemm_core(out, t=16384, variants=(1, 3, 0, 2), rounds=3):
+def bench_gemm_core(out, t=16384, variants=(7, 3, 1), rounds=3):
     """The hand-written MFMA GEMM core (csrc/gemm.hip) against the library call it replaces, per Qwen3-8B projection and layout, interleaved in one
     process (boxes differ by a few %).  Random operands (guide §5.4 rule 25: zero-filled operands clock ~15 % higher)."""
     shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
@@ -207,7 +207,7 @@ def bench_gemm_core(out, t=16384, variants=(1, 3, 0, 2), rounds=3):
                     ops.gemm_set_variant(v)
                     med, _ = timeit(own_fn, iters=5, warmup=1)
                     res[f"v{v}"].append(med)
-            ops.gemm_set_variant(1)
+            ops.gemm_set_variant(7)
             rec = dict(kernel=f"gemm_core {name} {cname} t={t}", max_rel_err=rel)
             for key, ts in res.items():
                 ts.sort()
@@ -427,8 +427,24 @@ def main():
         dy = torch.randn(t, o, device=DEV).to(torch.bfloat16)
         w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
         g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
-        ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "1")))
+        ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "5")))
         wt = w.t().contiguous()
+        if os.environ.get("PM_PROBE_ZERO") == "1":  # DVFS check (guide: zero-filled operands clock ~15-19 % higher)
+            x.zero_(); dy.zero_(); w.zero_(); wt.zero_()
+        if os.environ.get("PM_PROBE_TIME") == "1":
+            def own_v(v):
+                def f():
+                    ops.gemm_set_variant(v)
+                    ops.gemm(x, w)
+                    ops.gemm_set_variant(7)
+                return f
+            cases = [("own fwd", lambda: ops.gemm(x, w)), ("lib fwd", lambda: torch.mm(x, w.t())), ("own wgrad", lambda: ops.gemm(dy.t(), x.t(), out=g)),
+                     ("lib wgrad", lambda: torch.mm(dy.t(), x, out_dtype=torch.float32, out=g))]
+            cases += [(f"own fwd variant {v} ({d})", own_v(v)) for v, d in ((1, "one WG per tile"), (4, "no setprio"), (7, "balanced reads"), (13, "ABLATION no DMA"), (21, "ABLATION no reads"), (29, "ABLATION no DMA, no reads"))]
+            for label, fn in cases:
+                med, best = timeit(fn, iters=10, warmup=2)
+                print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
+            return
         for _ in range(4):
             ops.gemm(x, w)
             ops.gemm(dy, w.t())
