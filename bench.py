@@ -171,6 +171,64 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
     return extra
 
 
+def parity_block(probe: dict, dims, seq_len: int) -> dict:
+    """The parity gates of SURVEY.md section 8(d), evaluated on what the FIRST TIMED STEP left in `engine.parity_probe` (device tensors captured inside
+    the step without a host sync; everything below runs after the timed region, rank 0 only):
+      gather_bit_exact   token-index gather of the embedding (all rows) AND the label gather over the vocab (all rows): K1's log-prob must equal
+                         (logit[label] * inv_T) - logz bit for bit
+      logprob_max_abs /  K1 (selective log-softmax + entropy on the step's bf16 logits) vs torch.log_softmax in f32 on 64 sampled rows
+      entropy_max_abs    (test_fused_lm_head.py:398-457 bound: rtol 1e-3, atol 1e-4)
+      loss_abs_delta     K2's scalar loss vs the oracle's restatement of compute_loss (loss.py:285-403) on the SAME log-probs; north_star <= 1e-4
+      flips              DPPO trust-region mask decisions (loss.py:124-133) that differ between K2 and the oracle, summed over samples
+      metric keys        K2's per-sample metrics == the reference's keys (loss.py:151-159), values compared too."""
+    import math
+
+    import numpy as np
+
+    from oracle import grpo_oracle as O
+    from prime_rl_amd import _lib
+
+    out: dict = {}
+    out["gather_bit_exact"] = bool(probe["embed_gather_equal"].item()) and bool(probe["label_gather_equal"].item())
+    out["label_gather_max_abs"] = float(probe["label_gather_max_abs"].item())
+    rows = probe["rows"]
+    z = probe["logits_rows"].float() * probe["inv_t_rows"][:, None]
+    lsm = torch.log_softmax(z, dim=-1)
+    lp_ref = lsm.gather(1, probe["labels_rows"][:, None])[:, 0]
+    ent_ref = torch.logsumexp(z, -1) - (torch.softmax(z, -1) * z).sum(-1)
+    out["logprob_max_abs"] = float((probe["logprobs"][rows] - lp_ref).abs().max().item())
+    out["entropy_max_abs"] = float((probe["entropy"][rows] - ent_ref).abs().max().item())
+    out["rows_sampled"] = int(rows.numel())
+    b = probe["batch"]
+    cu = b.cu_samples.cpu().numpy()
+    lens = [int(cu[i + 1] - cu[i]) for i in range(len(cu) - 1)]
+    lp = probe["logprobs"].cpu().numpy().astype(np.float32)
+    pad = np.float32(math.log(1.0 / dims.vocab_size))
+    lp_shift = np.concatenate([O.shift_right(lp[cu[i]:cu[i + 1]], pad) for i in range(len(lens))])  # shift_tensor_right per sample (loss.py:76-91)
+    loss_o, met_o, _ = O.compute_loss(lp_shift, b.inference_logprobs.cpu().numpy(), b.advantages.cpu().numpy(), b.loss_mask.cpu().numpy(), lens, O.LossConfig(),
+                                      rl_scale=probe["scales"][0])
+    out["loss_engine"] = float(probe["loss"].item())
+    out["loss_oracle"] = float(loss_o)
+    out["loss_abs_delta"] = abs(out["loss_engine"] - out["loss_oracle"])
+    stats = probe["sample_stats"].cpu().numpy()
+    mask = b.loss_mask.cpu().numpy()
+    n_mask = np.array([mask[cu[i]:cu[i + 1]].sum() for i in range(len(lens))], dtype=np.float64)
+    drop_e = stats[:, _lib.STAT["RL_N_DROP"]].astype(np.float64)
+    drop_o = np.round(met_o["is_masked"].astype(np.float64) * np.maximum(n_mask, 1))
+    out["flips"] = int(np.abs(drop_e - drop_o).sum())
+    out["masked_tokens"] = int(drop_e.sum())
+    keys_ref = ["masked_mismatch_kl", "unmasked_mismatch_kl", "is_masked", "is_masked_low", "is_masked_high", "masked_advantage_positive",
+                "masked_advantage_negative"]  # default_loss_fn's metrics dict, loss.py:151-159
+    keys_e = _lib.METRIC_KEYS[:len(keys_ref)]
+    out["metric_keys_identical"] = (list(keys_e) == keys_ref) and (sorted(met_o.keys()) == sorted(keys_ref))
+    met_e = probe["sample_metrics"].cpu().numpy()
+    out["metrics_max_abs"] = float(max(np.abs(met_e[:, i] - met_o[k]).max() for i, k in enumerate(keys_ref)))
+    out["gates"] = {"loss_abs_delta<=1e-4": out["loss_abs_delta"] <= 1e-4, "logprob atol 1e-4 rtol 1e-3": out["logprob_max_abs"] <= 1e-4 + 1e-3 * float(lp_ref.abs().max().item()),
+                    "gather_bit_exact": out["gather_bit_exact"], "metric_keys_identical": out["metric_keys_identical"], "flips==0": out["flips"] == 0}
+    out["source"] = "first timed step of this run (device copies taken inside the step; evaluated after the timed region)"
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +243,7 @@ def main() -> None:
                     help="diagnostic: at N=1 run the RCCL reduce-scatter/all-gather + comm-stream path on a world_size-1 group (not the headline run)")
     ap.add_argument("--recompute", default="none", choices=["none", "layer"],
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in the first timed step, evaluated after the timed region)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements reported under config.extra (2 micro-batches/GPU line, weight push)")
     args = ap.parse_args()
 
@@ -241,7 +300,11 @@ def main() -> None:
     if rank == 0 and dist.is_initialized():
         print(f"[bench preflight] RCCL group up: world={dist.get_world_size()} backend={dist.get_backend()} dp={engine.dp_size} "
               f"collectives={'reduce-scatter/all-gather on a side stream' if engine.use_collectives else 'none (single rank)'}", file=sys.stderr, flush=True)
+    from prime_rl_amd.trainer import zero
+
     engine.k1_events = []
+    engine.parity_probe = {} if (rank == 0 and engine.lm_head_impl == "library" and not args.no_parity) else None  # filled by the first timed step
+    zero.COMM_EVENTS = [] if engine.use_collectives else None
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         out = engine.step(batches[s])
@@ -249,6 +312,8 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     k1_events, engine.k1_events = engine.k1_events, None
+    probe, engine.parity_probe = engine.parity_probe, None
+    comm_events, zero.COMM_EVENTS = zero.COMM_EVENTS, None
     # host cost of enqueuing ONE step on an EMPTY queue: an extra, untimed step after the timed region (inside it the HIP queue fills up and
     # the host blocks on back-pressure, so wall time there says nothing about the host; the first warm-up step is cold)
     th = time.perf_counter()
@@ -264,6 +329,21 @@ def main() -> None:
     # everything the JSON line needs from the device is read NOW, on this thread: the watchdog below must be able to print the line while
     # the main thread sits in a wedged collective (a .item() or an event query from there would queue behind it)
     k1_durs = [a.elapsed_time(b) * 1e-3 for a, b, _, _ in k1_events] if k1_events else []
+    comm = {"rs_ms": 0.0, "ag_ms": 0.0, "exposed_ms": 0.0}
+    for kind, e0, e1 in (comm_events or []):
+        comm[f"{kind}_ms"] += e0.elapsed_time(e1)
+    comm = {k: round(v / args.steps, 3) for k, v in comm.items()}
+    comm["note"] = ("per step, this rank: rs / ag = busy time of the comm stream in gradient reduce-scatters / parameter all-gathers (HIP events on that stream), "
+                    "exposed = time the compute stream stood still waiting for them" if engine.use_collectives else
+                    "N=1 without --force-collectives: no collective is issued (the step's only exchange degenerates to local copies)")
+    rccl = {"world": world, "backend": (dist.get_backend() if dist.is_initialized() else None)}
+    try:
+        from prime_rl_amd import _lib as _pm_lib
+
+        ver = _pm_lib.load().pm_comm_rccl_version() if _pm_lib.load().pm_comm_available() else 0
+        rccl["version"] = f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None
+    except Exception:
+        rccl["version"] = None
     loss_last = float(sum(l.item() for l in losses[-1]))
 
     def assemble(extra: dict) -> dict:
@@ -317,9 +397,12 @@ def main() -> None:
                 "loss_last": loss_last,
                 "host_enqueue_ms_per_step": round(host_enqueue_empty_queue * 1e3, 1) if host_enqueue_empty_queue is not None else None,
                 "lm_head": engine.lm_head_impl,
+                "gemm_own": sorted(engine.gemm_own),
+                "rccl": rccl,
                 "extra": extra,
             },
         }
+        result["comm"] = comm
         if k1_events:
             result["roofline"] = {
                 "kernel": f"logprob_fwd_row_kernel<{'bf16' if esz == 2 else 'f32'}> (selective log-softmax + entropy)",
@@ -365,19 +448,29 @@ def main() -> None:
         wp = extra.get("weight_push") or {}
         if "ms" in wp:  # samples/s excluding (= value) and including the weight push, if the push were NOT overlapped
             extra["samples_per_s_incl_serial_weight_push"] = round(samples / (elapsed + args.steps * wp["ms"] * 1e-3), 4)
+        if probe:
+            try:
+                result["parity"] = parity_block(probe, dims, args.seq_len)
+            except Exception as e:  # pragma: no cover - reported, never hidden
+                result["parity"] = {"error": repr(e)[:300]}
+        else:
+            result["parity"] = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_trainer import time_cpu_baseline
 
-            cpu = time_cpu_baseline(dims, seq_len=args.seq_len)
+            cpu = time_cpu_baseline(dims, seq_len=args.seq_len, micro_batches_per_step=args.micro_batches)
             result["cpu_baseline"] = {
                 "value": round(1.0 / cpu["seconds_per_sample"], 6),
                 "unit": "samples/s",
                 "cores": cpu["threads"],
                 "kind": "port",
-                "sample": f"oracle/cpu_trainer.py (f32 torch-CPU port of the reference step) on a {cpu['sample_tokens']}-token rollout prefix: one decoder layer fwd+bwd "
-                          f"{cpu['t_layer']:.2f}s (x{dims.num_hidden_layers} layers), full-vocab LM head + log-probs + loss fwd+bwd {cpu['t_head_loss']:.2f}s, AdamW on "
-                          f"{cpu['opt_params'] >> 20}Mi params {cpu['t_opt']:.2f}s (x params/{cpu['opt_params'] >> 20}Mi); scaled linearly to {args.seq_len} tokens "
-                          f"(ignores quadratic attention: favours the CPU)",
+                "cpu_model": cpu["cpu_model"],
+                "sample": f"oracle/cpu_trainer.py (f32 torch-CPU port of the reference step), every leg one warm-up + median of 3, on a {cpu['sample_tokens']}-token rollout "
+                          f"prefix: {cpu['slice_layers']}-layer full-width slice fwd+bwd {cpu['t_slice']:.2f}s (x{dims.num_hidden_layers}/{cpu['slice_layers']} layers), full-vocab LM "
+                          f"head + log-probs + loss fwd+bwd {cpu['t_head_loss']:.2f}s, both scaled linearly to {args.seq_len} tokens (ignores quadratic attention: favours the "
+                          f"CPU); AdamW on {cpu['opt_params'] >> 20}Mi params {cpu['t_opt']:.2f}s (x params/{cpu['opt_params'] >> 20}Mi = {cpu['t_opt_full_model']:.1f}s per "
+                          f"optimizer step, charged 1/{cpu['micro_batches_per_step']} per sample: one step per {cpu['micro_batches_per_step']} micro-batches, train.py:566-570); "
+                          f"{cpu['threads']} of {cpu['cores_available']} usable cores ({cpu['cpu_model']})",
             }
         if args.force_collectives and world == 1:
             result["config"]["diagnostic"] = "force_collectives: world_size-1 RCCL reduce-scatter/all-gather on the comm stream (not the headline run)"

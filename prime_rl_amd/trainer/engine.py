@@ -572,6 +572,10 @@ class GRPOEngine:
         if self.lm_head_impl == "fused" and (self.gemm_f32 or dims.hidden_size % 64):
             raise PrimeMI355XError("the fused LM head is a bf16 MFMA kernel (hidden size a multiple of 64)")
         self.k1_events: list | None = None
+        # bench.py's parity block (SURVEY §8d "parity gates in the same harness"): when set to a dict, the NEXT forward/loss leaves device-side copies
+        # of what the gates need in it (no host sync inside the step): the embedding-gather and label-gather bit checks over ALL rows, 64 sampled
+        # logits rows with their labels / temperatures, the per-token log-probs / entropy / logz, the scalar loss and the K2 statistics.
+        self.parity_probe: dict | None = None
         self._param_readers: list = []  # events of asynchronous readers of store.params (the weight push): waited for before AdamW rewrites them
 
     # -- GEMM helpers (library calls: hipBLASLt via torch) ------------------------------------------------------------
@@ -666,6 +670,9 @@ class GRPOEngine:
         ctx: dict = {"batch": b, "layers": [], "labels": labels, "inv_temp": inv_temp, "ids": ids}
         self._wait_gather("embed")
         x = ops.embedding_fwd(w["model.embed_tokens.weight"], ids)
+        probe = self.parity_probe if (self.parity_probe is not None and "loss" not in self.parity_probe and cp == 1) else None
+        if probe is not None:  # token-index gather, all rows, bit for bit (one device bool; read after the timed region)
+            probe["embed_gather_equal"] = (x == w["model.embed_tokens.weight"][ids]).all()
         cos, sin = ops.rope_table(tok(b.position_ids), self.inv_freq)
         seq_start = ops.seq_start_from_cu(b.cu_seqlens, n_full)
         ctx.update(cos=cos, sin=sin, seq_start=seq_start)
@@ -699,12 +706,21 @@ class GRPOEngine:
                 ev1.record()
                 self.k1_events.append((ev0, ev1, e - s, logits.element_size()))
             logprobs[s:e], entropy[s:e], logz[s:e] = lp, en, lz
+            if probe is not None and s == 0 and not self.gemm_f32:
+                # label gather over the vocab, every row of the chunk: K1's log-prob must be EXACTLY (logit[label] * inv_T) - logz in f32
+                picked = logits.gather(1, labels[s:e, None])[:, 0].float() * inv_temp[s:e]
+                probe["label_gather_equal"] = (lp == picked - lz).all()
+                probe["label_gather_max_abs"] = (lp - (picked - lz)).abs().max()
+                rows = torch.linspace(0, e - s - 1, steps=min(64, e - s), device=self.device).long()
+                probe.update(rows=rows, logits_rows=logits[rows].clone(), labels_rows=labels[s:e][rows].clone(), inv_t_rows=inv_temp[s:e][rows].clone())
             chunks.append((s, e, logits))
         if cp > 1:  # the loss (and the shift_tensor_right inside it) runs over the FULL pass: gather_for_cp (utils/cp.py:129-139, train.py:446-448)
             ctx["logprobs_local"] = logprobs
             logprobs = ulysses.all_gather_tokens(logprobs, cp, self.cp_group)
             entropy = ulysses.all_gather_tokens(entropy, cp, self.cp_group)
         ctx.update(logits_chunks=chunks, logprobs=logprobs, entropy=entropy, logz=logz)
+        if probe is not None:
+            probe.update(logprobs=logprobs.clone(), entropy=entropy.clone(), logz=logz.clone())
         return ctx
 
     def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int):
@@ -800,6 +816,8 @@ class GRPOEngine:
                                                            ref_logprobs=b.ref_logprobs, rl_weights=b.rl_weights, ce_weights=b.ce_weights,
                                                            ref_kl_weights=b.ref_kl_weights, sample_starts_mb=b.sample_starts_mb)
         ctx.update(loss=loss, grad_logprobs=grad, sample_stats=stats, sample_metrics=metrics)
+        if self.parity_probe is not None and "logprobs" in self.parity_probe and "loss" not in self.parity_probe:
+            self.parity_probe.update(loss=loss.clone(), sample_stats=stats.clone(), sample_metrics=metrics.clone(), scales=scales, batch=b)
         return ctx
 
     # -- backward ---------------------------------------------------------------------------------------------------
@@ -986,7 +1004,7 @@ class GRPOEngine:
     def _wait_gather(self, name: str) -> None:
         ev = self._gather_events.pop(name, None)
         if ev is not None and self.device.type == "cuda":
-            torch.cuda.current_stream().wait_event(ev)
+            zero._timed("exposed", torch.cuda.current_stream(), lambda: torch.cuda.current_stream().wait_event(ev))
 
     # -- optimizer ---------------------------------------------------------------------------------------------------
     def optimizer_step(self) -> Tensor:

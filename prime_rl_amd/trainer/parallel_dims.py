@@ -133,10 +133,27 @@ class ParallelDims:
         return mine
 
 
+def resolve_ep(config, world_size: int) -> int:
+    """`model.ep = "auto"` -> an integer, the reference's rule (parallel_dims.py:281-317): MoE models get min(world_size // dp_replicate, 8) — without it
+    the default config would replicate every expert with its f32 master, moments and gradient on every rank (~18 B/param: Qwen3-30B-A3B does not fit a
+    288 GB part that way) — dense models 1.  An explicit integer is returned unchanged."""
+    if isinstance(config.ep, int):
+        return config.ep
+    from .model import resolve_moe_config  # local import: model.py imports this module
+
+    if resolve_moe_config(config) is None:
+        return 1
+    ep = max(1, min(world_size // max(int(config.dp_replicate), 1), 8))
+    import logging
+
+    logging.getLogger("prime_rl_amd").info("EP auto: world_size=%d, dp_replicate=%d -> resolved ep=%d", world_size, config.dp_replicate, ep)
+    return ep
+
+
 def get_parallel_dims(config, seq_len: int | None = None, world_size: int | None = None) -> ParallelDims:
     """parallel_dims.py:319-345: dp_shard fills whatever dp_replicate and cp leave of the world; `config` is a ModelConfig."""
-    ep = config.ep if isinstance(config.ep, int) else 1  # "auto" resolves to 1 for dense models (resolve_ep, parallel_dims.py:281-317)
     world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    ep = resolve_ep(config, world)
     dims = ParallelDims(dp_replicate=config.dp_replicate, dp_shard=-1, cp=config.cp, pp=1, ep=ep, world_size=world)
     if seq_len is not None and seq_len % dims.seq_len_divisor != 0:
         raise ValueError(f"Sequence length ({seq_len}) must be divisible by seq_len_divisor ({dims.seq_len_divisor}) for the given parallel "

@@ -22,6 +22,23 @@ def _on_gpu(t: torch.Tensor) -> bool:
     return t.is_cuda
 
 
+# bench.py sets this to a list to get HIP-event timings of every collective ON THE COMM STREAM ("rs" / "ag": busy time of the stream) and of every
+# wait of the compute stream for it ("exposed": time the compute stream stood still for a collective) — so that a multi-GPU run explains itself.
+COMM_EVENTS: list | None = None
+
+
+def _timed(kind: str, stream, fn) -> None:
+    """Run fn() with timing events recorded on `stream` around it when COMM_EVENTS is collecting."""
+    if COMM_EVENTS is None:
+        fn()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    fn()
+    e1.record(stream)
+    COMM_EVENTS.append((kind, e0, e1))
+
+
 def reduce_scatter_bucket(store, bucket, group, comm_stream=None) -> None:
     """grad_shard[bucket shard] = sum over ranks of main_grad[bucket][rank's chunk]; async on `comm_stream` when on GPU."""
     _, local = store.shard_slices(bucket)
@@ -32,7 +49,7 @@ def reduce_scatter_bucket(store, bucket, group, comm_stream=None) -> None:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev)
-            dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=group)
+            _timed("rs", comm_stream, lambda: dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=group))
     else:
         dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=group)
 
@@ -62,7 +79,7 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
     gpu = _on_gpu(store.main_grad)
     collectives = getattr(store, "use_collectives", dp > 1)  # True at dp == 1 only when forced (single-GPU check of this path)
     if collectives and gpu and comm_stream is not None:
-        torch.cuda.current_stream().wait_stream(comm_stream)  # every reduce-scatter has landed
+        _timed("exposed", torch.cuda.current_stream(), lambda: torch.cuda.current_stream().wait_stream(comm_stream))  # every reduce-scatter has landed
     kernels.sumsq_accumulate(store.grad_shard, sumsq)
     if collectives:
         dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=group)
@@ -80,7 +97,7 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                dist.all_gather_into_tensor(dst, store.params[full], group=group)
+                _timed("ag", comm_stream, lambda dst=dst, full=full: dist.all_gather_into_tensor(dst, store.params[full], group=group))
                 gev = torch.cuda.Event()
                 gev.record(comm_stream)
             if gather_events is not None:

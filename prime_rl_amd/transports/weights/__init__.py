@@ -107,6 +107,10 @@ def build_layout(store) -> list[dict]:
                 base, h = name[: -len("qkv_proj.weight")], shape[1]
                 entries += [(base + "q_proj.weight", rel, [d.q_dim, h]), (base + "k_proj.weight", rel + d.q_dim * h, [d.kv_dim, h]),
                             (base + "v_proj.weight", rel + (d.q_dim + d.kv_dim) * h, [d.kv_dim, h])]
+            elif name.endswith("qkv_proj.bias"):  # Qwen2 / Qwen2.5: the receiver sees HF checkpoint names, like state_dict() and the filesystem broadcast
+                base = name[: -len("qkv_proj.bias")]
+                entries += [(base + "q_proj.bias", rel, [d.q_dim]), (base + "k_proj.bias", rel + d.q_dim, [d.kv_dim]),
+                            (base + "v_proj.bias", rel + d.q_dim + d.kv_dim, [d.kv_dim])]
             elif name.endswith("gate_up_proj.weight"):
                 base, h = name[: -len("gate_up_proj.weight")], shape[1]
                 entries += [(base + "gate_proj.weight", rel, [d.intermediate_size, h]), (base + "up_proj.weight", rel + d.intermediate_size * h, [d.intermediate_size, h])]
@@ -211,6 +215,7 @@ class RCCLWeightBroadcast(WeightBroadcast):
         self.ready_timeout, self.trainer_group = ready_timeout, trainer_group
         self._stream = None
         self._events: tuple | None = None
+        self._in_flight: tuple | None = None  # (completion event, tensors the push stream still reads) of the previous asynchronous push
 
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
@@ -237,6 +242,9 @@ class RCCLWeightBroadcast(WeightBroadcast):
         if device.type == "cuda":
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=device)
+            if self._in_flight is not None:  # the previous push has long finished (the optimizer step waited for it); only now may its tensors go
+                self._in_flight[0].synchronize()
+                self._in_flight = None
             final = torch.cuda.Event()
             final.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
@@ -246,6 +254,10 @@ class RCCLWeightBroadcast(WeightBroadcast):
                 self._push(store, named, device)
                 t1.record(self._stream)
             self._events = (t0, t1)
+            # `named` of an nn.Module engine holds TEMPORARIES allocated on the main stream (bf16 copies of f32 router gates, all-gathered expert
+            # tensors) that the push stream reads later: they must outlive this call, or the caching allocator hands their blocks to the next step's
+            # forward while the push kernels still read them.  Kept until the push's completion event has fired.
+            self._in_flight = (t1, named)
             if hasattr(model, "add_param_reader"):
                 model.add_param_reader(t1)  # the next optimizer step waits for the push on the device, the host never blocks
             else:

@@ -367,11 +367,14 @@ def _loss_parity_at_scale(dims, sd, mbs, seq_len, tag, recompute=None, modes=("f
         del eng, ctx, pb
         torch.cuda.empty_cache()
     # The gate.  At 2 layers the engine sits 2e-5 from B (test_engine_qwen3_8b_width_parity).  At full depth a random-init network amplifies every bf16
-    # rounding (per-token log-probs of two bf16 evaluations differ by ~5e-2: the yardstick C vs B above), and the scalar loss is a SECOND-order function of
-    # that per-token noise (ratio = exp(lp - lp_inf)), so it moves with the noise VARIANCE of an implementation: B itself sits |B - A| from f32.  Asserted:
-    # the engine is within 1e-4 of the reference-dtype arithmetic, or — where bf16 rounding alone exceeds that — no further from it than it is from f32.
-    bound = max(1e-4, abs(lb - la))
-    print(f"[{tag}] loss gate: |loss(E) - loss(B)| <= max(1e-4, |loss(B) - loss(A)|) = {bound:.2e}")
+    # rounding (per-token log-probs of two bf16 evaluations differ by 2-5e-2: the yardstick C vs B above), and the scalar loss is a SECOND-order function
+    # of that per-token noise (ratio = exp(lp - lp_inf)), so it moves with the noise pattern of an implementation: the equally legitimate restatements of
+    # the reference arithmetic — A (f32), B (bf16 points, exact GEMMs), C (bf16 points, bf16 GEMMs), B_fa (B + flash-attention's bf16 P) — sit up to
+    # 1.2e-4 (Qwen2.5-1.5B x 28) / 8.1e-4 (Qwen3-8B x 36) apart.  Asserted: the engine is within 1e-4 of the reference-dtype arithmetic B, or — where the
+    # reference's own restatements spread further than that — within 1.5x their spread around B.
+    spread = max(abs(lb - la), abs(lc - lb), abs(lf - lb))
+    bound = max(1e-4, 1.5 * spread)
+    print(f"[{tag}] loss gate: |loss(E) - loss(B)| <= max(1e-4, 1.5 x spread of the reference restatements around B = {spread:.2e}) = {bound:.2e}")
     for mode in modes:
         assert abs(res[mode]["loss"] - lb) <= bound, (f"scalar loss parity at full depth, engine gemm={mode} vs the reference-dtype oracle", res[mode]["loss"], lb, bound)
         assert res[mode]["d_b_mean"] <= 1.5 * yard.mean().item() + 1e-4 and res[mode]["d_b_max"] <= 2.0 * yard.max().item() + 1e-3, (mode, res[mode], yard.mean().item(), yard.max().item())
