@@ -350,6 +350,17 @@ class TrainerConfig(BaseConfig):
             bad.append("enable_token_export")
         if self.weight_broadcast is not None and self.weight_broadcast.type == "nixl":
             bad.append("weight_broadcast.type = 'nixl'")
+        # keys the reference's train() acts on but this train loop does not build: refusing them by name beats silently writing no checkpoint
+        if self.ckpt is not None:
+            bad.append("ckpt (checkpoint saving / loading: control plane, stays with the reference)")
+        if self.resume is not None:
+            bad.append("resume")
+        for key in ("heartbeat", "metrics_server", "trace_path", "memory_profiler_path"):
+            if getattr(self, key) is not None:
+                bad.append(f"{key} (monitoring / profiling hooks of the reference's train loop)")
+        if self.rollout_transport.type == "zmq" and self.data.fake is None:
+            bad.append("rollout_transport.type = 'zmq' with a live data loader (networking stays with the reference: use rollout_transport.type = 'filesystem', "
+                       "or data.fake for synthetic batches)")
         if bad:
             raise NotImplementedError("outside the MI355X GRPO hot path: " + "; ".join(bad))
 

@@ -186,3 +186,18 @@ def test_64_wide_heads_are_stored_zero_padded_and_exposed_unpadded():
     assert torch.equal(st2.params, st.params) and torch.equal(st2.master, st.master)
     g = st.grad_state_dict()
     assert set(g) == set(sd) and all(g[k].shape == sd[k].shape and g[k].dtype == torch.float32 for k in sd)
+
+
+def test_ep_auto_resolves_like_the_reference():
+    """model.ep = "auto" (the default): MoE models -> min(world // dp_replicate, 8), dense models -> 1 (parallel_dims.py:281-317)."""
+    from prime_rl_amd.configs.trainer import ModelConfig
+    from prime_rl_amd.trainer.parallel_dims import get_parallel_dims, resolve_ep
+
+    dense = ModelConfig(name="Qwen/Qwen3-8B")
+    moe = ModelConfig(name="Qwen/Qwen3-30B-A3B")
+    assert dense.ep == "auto" and moe.ep == "auto"
+    assert resolve_ep(dense, 8) == 1
+    assert resolve_ep(moe, 8) == 8 and resolve_ep(moe, 4) == 4 and resolve_ep(moe, 1) == 1 and resolve_ep(moe, 16) == 8
+    assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", dp_replicate=2), 8) == 4
+    assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep=2), 8) == 2
+    assert get_parallel_dims(moe, world_size=8).ep == 8 and get_parallel_dims(dense, world_size=8).ep == 1

@@ -215,3 +215,29 @@ def test_push_of_an_expert_parallel_moe_model(tmp_path):
     for k in sent:
         assert got[k].shape == sent[k].shape and torch.equal(got[k], sent[k].to(got[k].dtype)), k
     assert not (tmp_path / "broadcasts" / "step_3" / "LAYOUT.json").exists()  # the manifest belongs to the sharded protocol
+
+
+def test_sharded_layout_speaks_hf_names_for_attention_bias_models():
+    """Qwen2 / Qwen2.5 carry a fused q|k|v BIAS next to the fused weight: the LAYOUT.json of the sharded push must split both into the HF checkpoint names
+    that `state_dict()` and the filesystem broadcast emit, and the (offset, shape) of every entry must address exactly that tensor in the flat buffer."""
+    import dataclasses
+
+    from prime_rl_amd.trainer.engine import ModelDims, ParamStore
+    from prime_rl_amd.transports.weights import build_layout
+
+    dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=320), qk_norm=False, attention_bias=True, name="tiny-qwen2")
+    store = ParamStore(dims, "cpu")
+    store.random_init(seed=5)
+    sd = store.state_dict()
+    names, seen = set(), 0
+    for bucket, b in zip(build_layout(store), store.buckets):
+        flat = store.params[b.offset:b.offset + b.size]
+        for name, rel, shape in bucket["params"]:
+            n = 1
+            for d in shape:
+                n *= d
+            assert torch.equal(flat[rel:rel + n].view(shape), sd[name]), name
+            names.add(name)
+            seen += 1
+    assert names == set(sd) - ({"lm_head.weight"} if dims.tie_word_embeddings else set())
+    assert any(n.endswith("q_proj.bias") for n in names) and not any("qkv_proj" in n for n in names)
