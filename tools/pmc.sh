@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.environ["OUT"] + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if os.environ["MATCH"] not in k:
+        if not any(m in k for m in os.environ["MATCH"].split("|")):  # "a|b": any of the substrings
             continue
         acc[k[:110]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
