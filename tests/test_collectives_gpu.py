@@ -115,6 +115,79 @@ def test_rccl_weight_push_trainer_side_on_device(rccl_world1, tmp_path):
             assert torch.equal(view, sd[name])
 
 
+class _Loopback:
+    """A world-1 raw RCCL communicator presented as the 1 trainer + 1 inference push world: every peer is this rank.  RCCL refuses two ranks on one
+    device, but a send and the matching receive of ONE rank posted inside one ncclGroup are a legal pair — the bytes travel device -> device through
+    RCCL's own copy kernel, which is as much of the a25 data path as a one-GPU box can exercise."""
+
+    def __init__(self, comm):
+        self.comm, self.rank, self.size = comm, 0, 2
+
+    def send(self, t, peer):
+        self.comm.send(t, 0)
+
+    def recv(self, t, peer):
+        self.comm.recv(t, 0)
+
+    def group_start(self):
+        self.comm.group_start()  # ncclGroupStart / End nest: only the outermost End launches
+
+    def group_end(self):
+        self.comm.group_end()
+
+
+def test_rccl_weight_push_moves_real_bytes_device_to_device(tmp_path):
+    """a25 with DATA on the GPU (the other on-device push test runs with an empty inference pool): the sharded push protocol end to end on one
+    device — trainer side `push_sharded` and inference side `receive_sharded` of the SAME process posted inside one RCCL group on a world-1 raw
+    communicator, so every bucket of the flat bf16 parameter buffer crosses RCCL (ncclSend / ncclRecv self pair) and must come out bit for bit under
+    its HF name.  Also times a 256 MiB self pair (informational: an on-device copy rate, not an xGMI number)."""
+    import socket
+    import time
+
+    from prime_rl_amd._lib import PrimeMI355XError
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims
+    from prime_rl_amd.transports import weights as W
+
+    dims = ModelDims.tiny(layers=2, vocab=512)
+    eng = GRPOEngine(dims, device=DEV, seed=13)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    raw = W.init_push_communicator("127.0.0.1", port, 0, 1, 0, DEV, timeout=60)
+    loop = _Loopback(raw)
+    layout = W.build_layout(eng.store)
+    try:
+        loop.group_start()
+        W.push_sharded(loop, eng.store, 0, 1, 1)
+        received = list(W.receive_sharded(loop, layout, 1, torch.device(DEV)))  # views of the receive buffers: filled when the outer group ends
+        loop.group_end()
+        torch.cuda.synchronize()
+    except PrimeMI355XError as e:  # pragma: no cover - an RCCL build that refuses self pairs: say so instead of passing silently
+        raw.close()
+        pytest.skip(f"RCCL refused a self send / recv pair on one device: {e} (a25 on-device bytes stay blocked on a one-GPU box)")
+    sd = eng.store.state_dict()
+    assert {n for n, _ in received} == set(sd)
+    n_bytes = 0
+    for name, t in received:
+        assert torch.equal(t, sd[name]), name
+        n_bytes += t.numel() * t.element_size()
+    assert n_bytes > 0
+    a = torch.randint(0, 2 ** 15, (128 * 1024 * 1024,), dtype=torch.int16, device=DEV).view(torch.bfloat16)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        raw.group_start()
+        raw.send(a, 0)
+        raw.recv(b, 0)
+        raw.group_end()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    print(f"[a25 self pair] {n_bytes} parameter bytes bit-exact through RCCL on one device; 256 MiB self pair {dt * 1e3:.2f} ms = {a.numel() * 2 / dt / 1e9:.0f} GB/s")
+    raw.close()
+
+
 def test_train_loop_with_nccl_weight_broadcast_from_the_config_path(tmp_path):
     """`[weight_broadcast] type = "nccl"` through train(config) (this path used to raise KeyError): train() bootstraps the raw
     RCCL push communicator from host:port, pushes the startup policy v0 and one policy per step except the last (train.py:582-587), the
