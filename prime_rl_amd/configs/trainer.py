@@ -358,11 +358,16 @@ class TrainerConfig(BaseConfig):
         for key in ("heartbeat", "metrics_server", "trace_path", "memory_profiler_path"):
             if getattr(self, key) is not None:
                 bad.append(f"{key} (monitoring / profiling hooks of the reference's train loop)")
-        if self.rollout_transport.type == "zmq" and self.data.fake is None:
-            bad.append("rollout_transport.type = 'zmq' with a live data loader (networking stays with the reference: use rollout_transport.type = 'filesystem', "
-                       "or data.fake for synthetic batches)")
         if bad:
             raise NotImplementedError("outside the MI355X GRPO hot path: " + "; ".join(bad))
+
+    def validate_for_train_loop(self) -> None:
+        """What only `train(config)` needs, checked BEFORE the engine is built: the default rollout transport of the reference (ZMQ) is networking and
+        stays with the reference — a live data loader reads the filesystem transport here."""
+        self.validate_supported()
+        if self.rollout_transport.type == "zmq" and self.data.fake is None:
+            raise NotImplementedError("outside the MI355X GRPO hot path: rollout_transport.type = 'zmq' with a live data loader (networking stays with the "
+                                      "reference: use rollout_transport.type = 'filesystem', or data.fake for synthetic batches)")
 
 
 # -- loading -------------------------------------------------------------------------------------------------------------------

@@ -74,7 +74,7 @@ def setup_scheduler(config: TrainerConfig):
 def train(config: TrainerConfig) -> list[dict]:
     """`prime_rl.trainer.rl.train.train(config)` (train.py:75) for the dense data-parallel path: one process per GPU under torchrun
     (RANK / LOCAL_RANK / WORLD_SIZE), every rank a trainer rank."""
-    config.validate_supported()
+    config.validate_for_train_loop()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = int(os.environ.get("WORLD_SIZE", "1"))
