@@ -72,8 +72,11 @@ struct Params {
   int accumulate;     // f32 out only: out += product
 };
 
-__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+// v_mfma_f32_16x16x32_bf16, not 32x32x16: the chip is POWER-limited on dense GEMMs and the 16x16x32 form moves less register data per MAC (its
+// accumulator tile is half as large per unit of work): tools/probes/mfma_power_probe.hip sustains 1.83-1.92 PFLOP/s with it on random operands against
+// 1.69-1.70 for 32x32x16 (zero-filled operands: 2.41-2.45 vs 2.48-2.49 — the bigger shape only wins where power is not the limit).
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 // virtual block id -> (tile_m, tile_n); false for the padding ids of the last patch round
@@ -96,14 +99,15 @@ static inline int grid_blocks(int tiles_m, int tiles_n) {
 // Everything a wave carries through the K loop.  After inlining the struct is scalar-replaced (all indices are compile-time).
 //
 // Half-tile slots.  W^i = tile rows [128 i, 128 i + 128) of the N-side operand, X^j = rows [128 j, 128 j + 128) of the M-side operand; wave
-// (wv, wt) owns W rows 128 i + 64 wv + [0, 64) and X rows 128 j + 32 wt + [0, 32) of every half, i.e. the output elements
-//   OUT[m0 + 128 j + 32 wt + l31][n0 + 128 i + 64 wv + 32 a + 8 (r >> 2) + 4 hi + (r & 3)]  =  acc[i][a][j][r].
+// (wv, wt) owns W rows 128 i + 64 wv + [0, 64) and X rows 128 j + 32 wt + [0, 32) of every half, i.e. with lr = lane & 15, lq = lane >> 4 the output elements
+//   OUT[m0 + 128 j + 32 wt + 16 g + lr][n0 + 128 i + 64 wv + 16 f + 4 lq + r]  =  acc[i][f][j][g][r]        (f = 0..3, g = 0..1, r = 0..3).
 // LDS image of a slot:
-//   K-contiguous operand: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); a fragment (32 rows x 16 k)
-//     is ONE ds_read_b128 per lane: row l31, chunk 2 kk + hi.
-//   K-major operand: [64 k][128 rows] bf16, 256-byte LDS rows, chunk c (8 operand rows) of k-row q at chunk c ^ ((q & 3) << 2); a fragment is
-//     TWO ds_read_b64_tr_b16 per lane (k-rows 16 kk + 8 hi + {0..3}, then {4..7}): the 16 lanes of a transpose group read a 4 (k) x 16 (rows)
-//     block, and the four k-rows of a half-wave land in four different 64-byte quads of the bank row (conflict-free by construction).
+//   K-contiguous operand: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); a fragment (16 rows x 32 k) is
+//     ONE ds_read_b128 per lane: row lr, chunk 4 kk + lq — conflict-free against the real lane groups of ds_read_b128 ({0-3,12-15,20-27} reads rows
+//     0-3, 12-15 at chunk c and rows 4-11 at chunk c + 1: the eight XOR values {0,1,6,7} and {2,3,4,5}^1 are distinct).
+//   K-major operand: [64 k][128 rows] bf16, 256-byte LDS rows, chunk c (8 operand rows) of k-row q at chunk c ^ ((q & 3) << 2 | ((q >> 3) & 1) << 1); a
+//     fragment is TWO ds_read_b64_tr_b16 per lane (k-rows 32 kk + 8 lq + {0..3}, then {4..7}): the 16 lanes of a transpose group read a 4 (k) x 16
+//     (rows) block, and the 8 k-rows x 32 bytes a half-wave touches land on 16 different 16-byte slots of the bank row.
 //
 // The LOAD SEGMENT of a phase is on the critical path of the ping-pong (it runs beside the partner's 256-cycle MFMA segment and every instruction
 // of it costs ~5 cycles of issue; measured: two extra scalar branches per phase = -4 %), so it is kept to the minimum: fragment reads with
@@ -111,11 +115,11 @@ static inline int grid_blocks(int tiles_m, int tiles_n) {
 // the reads with `vmcnt(0)` against the LDS-DMA in flight), one counted wait, ONE m0 write for the two DMA pieces (the second piece uses the
 // instruction offset, which moves the LDS and the memory address together, on a source offset pre-decremented by the same 1 KiB), one scalar add.
 struct Wave {
-  f32x16 acc[2][2][2];  // [i: W half][a: 32-row fragment][j: X half]
-  u32x4 wf[2][2][4];    // W fragments [i][a][kk]      (K-contiguous operand)
-  u32x4 xf[2][4];       // X fragments [j][kk]
-  u32x2 wlo[2][2][4], whi[2][2][4];  // K-major operand: the two transpose-read halves of a fragment (k 0..3 | 4..7 of the lane's 8)
-  u32x2 xlo[2][4], xhi[2][4];
+  f32x4 acc[2][4][2][2];  // [i: W half][f: 16-row W fragment][j: X half][g: 16-row X fragment]
+  u32x4 wf[2][4][2];      // W fragments [i][f][kk]     (K-contiguous operand; kk = 32-deep k-step)
+  u32x4 xf[2][2][2];      // X fragments [j][g][kk]
+  u32x2 wlo[2][4][2], whi[2][4][2];  // K-major operand: the two transpose-read halves of a fragment (k 0..3 | 4..7 of the lane's 8)
+  u32x2 xlo[2][2][2], xhi[2][2][2];
   __amdgpu_buffer_rsrc_t wr, xr;     // buffer descriptors of the operand panels being STAGED: the current output tile's, and from the third phase of its
                                      // last K-tile pair on the next tile's (persistent tile stream)
   int vw[2], vx[2];     // per-lane byte offsets of this wave's two DMA pieces (half-tile 0); the second one minus the 1 KiB instruction offset
@@ -123,7 +127,8 @@ struct Wave {
   int wk, xk;           // byte distance between consecutive K-tiles
   int wstep, xstep;     // byte distance between the two halves of an operand tile (128 rows, or 128 columns of a K-major operand)
   int piece_lds;        // wave-uniform: byte offset of this wave's first piece inside a slot
-  unsigned aw[4], ax[4];  // per-lane LDS byte addresses of the fragment reads (slot 0 of the operand's window): K-contiguous [kk]; K-major [a] (W), [0] (X)
+  unsigned aw[4], ax[4];  // per-lane LDS byte addresses of the fragment reads (slot 0 of the operand's window): K-contiguous [kk] (fragment = immediate);
+                          // K-major [f] (W) / [g] (X) (k-step = immediate; a fragment is an XOR on the address because the swizzle flips its chunk bits)
 };
 
 __device__ __forceinline__ unsigned char* lds_base() {
@@ -179,15 +184,15 @@ template <int I, int BUF, bool KM>
 __device__ __forceinline__ void read_w(Wave& s) {
   constexpr int slot = slot_in_window(BUF, I ? SLOT_W1 : SLOT_W0);  // an immediate
   if constexpr (!KM) {
-#define PM_RDW(A, KK) s.wf[I][A][KK] = b128_read<slot + A * 32 * 128>(s.aw[KK]);
-    PM_RDW(0, 0) PM_RDW(0, 1) PM_RDW(0, 2) PM_RDW(0, 3) PM_RDW(1, 0) PM_RDW(1, 1) PM_RDW(1, 2) PM_RDW(1, 3)
+#define PM_RDW(F, KK) s.wf[I][F][KK] = b128_read<slot + F * 16 * 128>(s.aw[KK]);
+    PM_RDW(0, 0) PM_RDW(1, 0) PM_RDW(2, 0) PM_RDW(3, 0) PM_RDW(0, 1) PM_RDW(1, 1) PM_RDW(2, 1) PM_RDW(3, 1)
 #undef PM_RDW
   } else {
-    // k-rows 16 kk + {0..3} then {4..7}: 4 KiB per kk, 1 KiB between the two reads
-#define PM_TRW(A, KK)                                               \
-    s.wlo[I][A][KK] = tr_read<slot + KK * 4096>(s.aw[A]);        \
-    s.whi[I][A][KK] = tr_read<slot + KK * 4096 + 1024>(s.aw[A]);
-    PM_TRW(0, 0) PM_TRW(0, 1) PM_TRW(0, 2) PM_TRW(0, 3) PM_TRW(1, 0) PM_TRW(1, 1) PM_TRW(1, 2) PM_TRW(1, 3)
+    // k-rows 32 kk + 8 lq + {0..3} then {4..7}: 8 KiB per kk, 1 KiB between the two reads
+#define PM_TRW(F, KK)                                               \
+    s.wlo[I][F][KK] = tr_read<slot + KK * 8192>(s.aw[F]);            \
+    s.whi[I][F][KK] = tr_read<slot + KK * 8192 + 1024>(s.aw[F]);
+    PM_TRW(0, 0) PM_TRW(1, 0) PM_TRW(2, 0) PM_TRW(3, 0) PM_TRW(0, 1) PM_TRW(1, 1) PM_TRW(2, 1) PM_TRW(3, 1)
 #undef PM_TRW
   }
 }
@@ -195,40 +200,42 @@ template <int J, int BUF, bool KM>
 __device__ __forceinline__ void read_x(Wave& s) {
   constexpr int slot = slot_in_window(BUF, J ? SLOT_X1 : SLOT_X0);
   if constexpr (!KM) {
-#define PM_RDX(KK) s.xf[J][KK] = b128_read<slot>(s.ax[KK]);
-    PM_RDX(0) PM_RDX(1) PM_RDX(2) PM_RDX(3)
+#define PM_RDX(G, KK) s.xf[J][G][KK] = b128_read<slot + G * 16 * 128>(s.ax[KK]);
+    PM_RDX(0, 0) PM_RDX(1, 0) PM_RDX(0, 1) PM_RDX(1, 1)
 #undef PM_RDX
   } else {
-#define PM_TRX(KK)                                            \
-    s.xlo[J][KK] = tr_read<slot + KK * 4096>(s.ax[0]);     \
-    s.xhi[J][KK] = tr_read<slot + KK * 4096 + 1024>(s.ax[0]);
-    PM_TRX(0) PM_TRX(1) PM_TRX(2) PM_TRX(3)
+#define PM_TRX(G, KK)                                            \
+    s.xlo[J][G][KK] = tr_read<slot + KK * 8192>(s.ax[G]);          \
+    s.xhi[J][G][KK] = tr_read<slot + KK * 8192 + 1024>(s.ax[G]);
+    PM_TRX(0, 0) PM_TRX(1, 0) PM_TRX(0, 1) PM_TRX(1, 1)
 #undef PM_TRX
   }
 }
 template <int I, bool KM>
 __device__ __forceinline__ void tie_w(Wave& s) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    if constexpr (KM) tie(s.wlo[I][a][0], s.whi[I][a][0], s.wlo[I][a][1], s.whi[I][a][1], s.wlo[I][a][2], s.whi[I][a][2], s.wlo[I][a][3], s.whi[I][a][3]);
-    else tie(s.wf[I][a][0], s.wf[I][a][1], s.wf[I][a][2], s.wf[I][a][3]);
+  for (int kk = 0; kk < 2; ++kk) {
+    if constexpr (KM) tie(s.wlo[I][0][kk], s.whi[I][0][kk], s.wlo[I][1][kk], s.whi[I][1][kk], s.wlo[I][2][kk], s.whi[I][2][kk], s.wlo[I][3][kk], s.whi[I][3][kk]);
+    else tie(s.wf[I][0][kk], s.wf[I][1][kk], s.wf[I][2][kk], s.wf[I][3][kk]);
   }
 }
 template <int J, bool KM>
 __device__ __forceinline__ void tie_x(Wave& s) {
-  if constexpr (KM) tie(s.xlo[J][0], s.xhi[J][0], s.xlo[J][1], s.xhi[J][1], s.xlo[J][2], s.xhi[J][2], s.xlo[J][3], s.xhi[J][3]);
-  else tie(s.xf[J][0], s.xf[J][1], s.xf[J][2], s.xf[J][3]);
+  if constexpr (KM) tie(s.xlo[J][0][0], s.xhi[J][0][0], s.xlo[J][1][0], s.xhi[J][1][0], s.xlo[J][0][1], s.xhi[J][0][1], s.xlo[J][1][1], s.xhi[J][1][1]);
+  else tie(s.xf[J][0][0], s.xf[J][1][0], s.xf[J][0][1], s.xf[J][1][1]);
 }
 template <int I, int J, bool XK, bool WK>
-__device__ __forceinline__ void quadrant(Wave& s) {
+__device__ __forceinline__ void quadrant(Wave& s) {  // 64 W rows x 32 X rows x 64 k: 16 MFMAs on 8 independent accumulators per k-step
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
+  for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const u32x4 wfrag = WK ? join(s.wlo[I][a][kk], s.whi[I][a][kk]) : s.wf[I][a][kk];
-      const u32x4 xfrag = XK ? join(s.xlo[J][kk], s.xhi[J][kk]) : s.xf[J][kk];
-      s.acc[I][a][J] = mfma32(wfrag, xfrag, s.acc[I][a][J]);
-    }
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const u32x4 wfrag = WK ? join(s.wlo[I][f][kk], s.whi[I][f][kk]) : s.wf[I][f][kk];
+        const u32x4 xfrag = XK ? join(s.xlo[J][g][kk], s.xhi[J][g][kk]) : s.xf[J][g][kk];
+        s.acc[I][f][J][g] = mfma16(wfrag, xfrag, s.acc[I][f][J][g]);
+      }
 }
 
 // One phase.  P = phase inside the K-tile (0..3), BUF = parity of the K-tile.  Phases 1-2 stage the OTHER buffer's X1 / W1 half-tiles (K-tile + 1),
@@ -298,10 +305,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base,
 }
 
 // per-lane DMA source offsets + fragment read addresses of one operand (tile independent).  `wsel`: this wave's first row inside a half (64 wv for
-// W, 32 wt for X); `lds0`: LDS byte address of the ring.
+// W, 32 wt for X); `lds0`: LDS byte address of the operand's window of the ring.
 template <bool KM>
 __device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, int wsel, unsigned lds0, int (&voff)[2], int& half_step, int& k_step, unsigned (&rd)[4]) {
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int lr = lane & 15, lq = lane >> 4;
   if (!KM) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -310,23 +317,25 @@ __device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, in
     }
     half_step = (int)(128 * ld * 2);
     k_step = kBK * 2;
+    // fragment f of the wave starts 16 rows further: (row >> 1) & 7 does not change, so f is an immediate; the k-step flips chunk bit 2: a second register
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) rd[kk] = lds0 + (wsel + l31) * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+    for (int kk = 0; kk < 2; ++kk) rd[kk] = lds0 + (wsel + lr) * 128 + (((kk * 4 + lq) ^ ((lr >> 1) & 7)) << 4);
+    rd[2] = rd[3] = 0;
   } else {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int krow = (wave * 2 + q) * 4 + (lane >> 4);  // piece = 4 k-rows x 256 bytes
-      voff[q] = (int)(krow * ld * 2) + (((lane & 15) ^ ((krow & 3) << 2)) << 4) - q * 1024;
+      voff[q] = (int)(krow * ld * 2) + (((lane & 15) ^ (((krow & 3) << 2) | (((krow >> 3) & 1) << 1))) << 4) - q * 1024;
     }
     half_step = 128 * 2;
     k_step = (int)(kBK * ld * 2);
-    const int lam = lane & 15, grp = (lane >> 4) & 1;
-    const int krow = hi * 8 + (lam >> 2);  // kk = 0; kk adds 16 k-rows = 4 KiB (an immediate)
-    const int chunk = ((wsel + grp * 16) >> 3) + ((lam & 3) >> 1);
-    const unsigned a0 = krow * 256 + ((chunk ^ ((krow & 3) << 2)) << 4) + (lam & 1) * 8;
-    rd[0] = lds0 + a0;
-    rd[1] = lds0 + (a0 ^ 64);  // W fragment a = 1: 32 operand rows further = chunk bit 2 — an XOR, because the swizzle flips that bit
-    rd[2] = rd[3] = 0;
+    const int krow = lq * 8 + (lr >> 2);  // kk = 0; kk adds 32 k-rows = 8 KiB, the second transpose read 4 k-rows = 1 KiB (immediates; neither changes the swizzle)
+    const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {  // 16 operand rows per fragment = 2 chunks
+      const int chunk = (wsel >> 3) + f * 2 + ((lr & 3) >> 1);
+      rd[f] = lds0 + krow * 256 + ((chunk ^ swz) << 4) + (lr & 1) * 8;
+    }
   }
 }
 
@@ -356,12 +365,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          s.wf[i][a][kk] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-          s.xf[i][kk] = u32x4{0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u};
-          s.wlo[i][a][kk] = s.whi[i][a][kk] = s.xlo[i][kk] = s.xhi[i][kk] = u32x2{0x3f803f80u, 0x3f803f80u + lane};
+        for (int kk = 0; kk < 2; ++kk) {
+          s.wf[i][f][kk] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          s.xf[i][f & 1][kk] = u32x4{0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u};
+          s.wlo[i][f][kk] = s.whi[i][f][kk] = s.xlo[i][f & 1][kk] = s.xhi[i][f & 1][kk] = u32x2{0x3f803f80u, 0x3f803f80u + lane};
         }
   }
   const int nk = ((p.k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
@@ -397,11 +406,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s.acc[i][a][j][r] = 0.f;
+          for (int g = 0; g < 2; ++g) s.acc[i][f][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < nk; t += 2) {  // two K-tiles per iteration: t in buffer 0, t + 1 in buffer 1
       phase<0, 0, V, XK, WK>(s, smem);
@@ -419,14 +428,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       phase<3, 1, V, XK, WK>(s, smem);
     }
 
-    // ---- epilogue.  A lane of the C fragment owns ONE output row and 4 x 4 scattered columns: stored directly, one wave instruction would touch
-    // 32 different rows with 8 / 16 bytes each, and the CU drains such stores at ~8 B/clk.  So each wave transposes through a private 4 KiB LDS block
-    // ([32 rows][128 bytes], 16-byte chunk c of row r at c ^ (r & 7)): fragment registers in by ds_write_b64 / b128, full rows out by ds_read_b128,
-    // and every global store instruction writes 8 complete 128-byte row segments.  LDS operations of one wave execute in order: no barrier.
+    // ---- epilogue.  A lane of a C fragment owns ONE output row (lr) and 4 consecutive columns of every 16-column block: stored directly, one wave
+    // instruction would touch 16 different rows with 8 / 16 bytes each, and the CU drains such stores at ~8 B/clk.  So each wave transposes through a
+    // private 4 KiB LDS block ([32 rows][128 bytes], 16-byte chunk c of row r at c ^ (r & 7)): fragment registers in by ds_write_b64 / b128, full rows
+    // out by ds_read_b128, and every global store instruction writes 8 complete 128-byte row segments.  LDS operations of one wave execute in order:
+    // no barrier.
     {
       int lane_e = lane;  // opaque per tile: keeps the epilogue's dozens of per-lane addresses from being hoisted out of the tile loop and spilled across the K loop
       asm volatile("" : "+v"(lane_e));
-      const int l31 = lane_e & 31, hi = lane_e >> 5;
+      const int lr = lane_e & 15, lq = lane_e >> 4;
       unsigned char* stg = smem + kRing + wave * 4096;
       const int srow = lane_e >> 3, schunk = lane_e & 7;
       const bool wide = p.out_f32 ? (p.n % 4 == 0) : (p.n % 8 == 0 && p.ldo % 8 == 0);
@@ -439,23 +449,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
             const int mrow0 = m0 + j * 128 + wt * 32;
             if (p.bias) {
 #pragma unroll
-              for (int a = 0; a < 2; ++a)
+              for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    const int nb = ncol0 + a * 32 + g * 8 + hi * 4 + r;
-                    if (nb < p.n) s.acc[i][a][j][g * 4 + r] += bf16_to_f32(p.bias[nb]);
-                  }
+                for (int r = 0; r < 4; ++r) {
+                  const int nb = ncol0 + f * 16 + lq * 4 + r;
+                  const float bv = nb < p.n ? bf16_to_f32(p.bias[nb]) : 0.f;
+                  s.acc[i][f][j][0][r] += bv;
+                  s.acc[i][f][j][1][r] += bv;
+                }
             }
-            if (!p.out_f32) {
+            if (!p.out_f32) {  // block = [32 rows: g, lr][64 columns: f, lq, r] bf16
 #pragma unroll
-              for (int a = 0; a < 2; ++a)
+              for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const f32x16& c = s.acc[i][a][j];
-                  const u32x2 pk = {pack_bf16_hw(c[g * 4], c[g * 4 + 1]), pack_bf16_hw(c[g * 4 + 2], c[g * 4 + 3])};
-                  *reinterpret_cast<u32x2*>(stg + l31 * 128 + (((a * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+                for (int g = 0; g < 2; ++g) {
+                  const f32x4& c = s.acc[i][f][j][g];
+                  const int ml = g * 16 + lr;
+                  *reinterpret_cast<u32x2*>(stg + ml * 128 + (((f * 2 + (lq >> 1)) ^ (ml & 7)) << 4) + (lq & 1) * 8) = u32x2{pack_bf16_hw(c[0], c[1]), pack_bf16_hw(c[2], c[3])};
                 }
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -464,14 +474,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                 const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
                 if (m < p.m && nn < p.n) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (int64_t)m * p.ldo + nn) = val;
               }
-            } else {
+            } else {  // two blocks of [32 rows][32 columns: f & 1, lq, r] f32
 #pragma unroll
               for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const f32x16& c = s.acc[i][a][j];
-                  *reinterpret_cast<f32x4*>(stg + l31 * 128 + (((g * 2 + hi) ^ (l31 & 7)) << 4)) = f32x4{c[g * 4], c[g * 4 + 1], c[g * 4 + 2], c[g * 4 + 3]};
-                }
+                for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+                  for (int g = 0; g < 2; ++g) {
+                    const int ml = g * 16 + lr;
+                    *reinterpret_cast<f32x4*>(stg + ml * 128 + (((fl * 4 + lq) ^ (ml & 7)) << 4)) = s.acc[i][a * 2 + fl][j][g];
+                  }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int ml = q * 8 + srow;
@@ -489,30 +501,29 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         }
       } else {  // ragged column counts: the direct form
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int m = m0 + j * 128 + wt * 32 + l31;
-          if (m >= p.m) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int g = 0; g < 2; ++g) {
+            const int m = m0 + j * 128 + wt * 32 + g * 16 + lr;
+            if (m >= p.m) continue;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + i * 128 + wv * 64 + a * 32 + g * 8 + hi * 4;
+              for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  if (nb + r >= p.n) continue;
-                  float val = s.acc[i][a][j][g * 4 + r];
-                  if (p.bias) val += bf16_to_f32(p.bias[nb + r]);
+                  const int nb = n0 + i * 128 + wv * 64 + f * 16 + lq * 4 + r;
+                  if (nb >= p.n) continue;
+                  float val = s.acc[i][f][j][g][r];
+                  if (p.bias) val += bf16_to_f32(p.bias[nb]);
                   if (p.out_f32) {
-                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nb + r;
+                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nb;
                     *dst = p.accumulate ? *dst + val : val;
                   } else {
-                    reinterpret_cast<bf16_t*>(p.out)[(int64_t)m * p.ldo + nb + r] = f32_to_bf16(val);
+                    reinterpret_cast<bf16_t*>(p.out)[(int64_t)m * p.ldo + nb] = f32_to_bf16(val);
                   }
                 }
-              }
-        }
+          }
       }
     }
     if (!has_next) break;
