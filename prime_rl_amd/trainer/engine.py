@@ -551,6 +551,11 @@ class GRPOEngine:
             self.gemm_own = set()
         if "dgrad" in self.gemm_own:  # the core reads the stored [out, in] weight K-major: no [in, out] copies
             self.gemm_layouts = False
+        if self.gemm_own:
+            # Schedule of the own core: one PERSISTENT workgroup per CU walking its tiles (+0-2 %) when this rank's GPU runs nothing beside the step; one
+            # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
+            # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
+            ops.gemm_set_variant(3 if self.use_collectives else 7)
         self._wt: dict[str, Tensor] = {}
         self._wt_version: dict[int, int] = {}
         if self.gemm_layouts:  # allocated up front (one slab) so the caching allocator sees the same request stream from the first step on
