@@ -70,6 +70,12 @@ struct Params {
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
   int accumulate;     // f32 out only: out += product
+  // grouped products over expert-sorted rows (MODE 1-3 of gemm_kernel; see the tile sources below)
+  const int32_t* offsets;  // [n_experts + 1] on the device: rows of expert e = [offsets[e], offsets[e + 1])
+  const bf16_t* w2;        // second weight set (the experts' up projection next to the gate projection), or null
+  void* out2;              // second output (MODE 3: its weight gradient)
+  int n_experts;
+  int n_first;             // columns / contraction rows served by the first weight set
 };
 
 // v_mfma_f32_16x16x32_bf16, not 32x32x16: the chip is POWER-limited on dense GEMMs and the 16x16x32 form moves less register data per MAC (its
@@ -293,15 +299,176 @@ __device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
   __builtin_amdgcn_s_barrier();
 }
 
-// buffer descriptor of one operand panel of an output tile.  K-contiguous [rows, K]: based at the tile's first row, rows past the tensor's end are
-// out of range -> zeros.  K-major [K, rows]: based at column row0 and ending with the tensor, so k-rows past K read as zeros.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Tile sources.  A workgroup walks virtual ids v = blockIdx.x, + gridDim.x, ...; a source turns (v, part) into one unit of the K-tile stream:
+// operand panels, contraction length, output block.  A unit is a whole output tile, or one PART of an accumulation chain (`first` / `last`: zero the
+// accumulators before / run the epilogue after) — how the grouped row gradient contracts over two weight sets without a descriptor switch inside
+// the K loop.  Everything in a Tile is wave-uniform.
+struct Tile {
+  const bf16_t *xb, *wb;   // panel bases: first row (K-contiguous) or first column (K-major) of the tile's panel
+  int64_t x_rows, w_rows;  // rows / columns of the operand tensor left from the base (range checks: what lies beyond reads as zero / is never stored)
+  int k;                   // contraction length (rows past it read as zeros for K-major operands)
+  unsigned char* out;      // output block origin (element (0, 0) of the tile)
+  int64_t ldo;
+  int m_valid, n_valid;    // rows / columns of the block that exist
+  int nk;                  // K-tiles: even, >= 2
+  bool first, last;
+};
 template <bool KM>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int64_t ld, int64_t row0, int64_t rows_total, int k) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int64_t ld, int64_t rows_left, int k) {
+  // K-contiguous [rows, K]: rows past the tensor's (or the group's) end are out of range -> zeros.  K-major [K, rows]: the descriptor ends with the
+  // last k-row, so k-rows past K read as zeros.
+  // Every input is wave-uniform, but the compiler cannot always prove it (the grouped sources go through cross-lane scans): a descriptor it believes
+  // divergent lives in VGPRs and EVERY DMA becomes a waterfall loop.  readfirstlane pins the three words to scalar registers.
+  const uint64_t addr = reinterpret_cast<uint64_t>(base);
+  const uint64_t addr_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)addr);
+  int bytes;
   if (!KM) {
-    const int64_t rows = rows_total - row0 < kTile ? rows_total - row0 : kTile;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0 * ld), 0, (int)(((rows - 1) * ld + k) * 2), 0x00020000);
+    const int64_t rows = rows_left < kTile ? rows_left : kTile;
+    bytes = rows > 0 ? (int)(((rows - 1) * ld + k) * 2) : 0;
+  } else {
+    bytes = k > 0 ? (int)((((int64_t)k - 1) * ld + rows_left) * 2) : 0;
   }
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + row0), 0, (int)((((int64_t)k - 1) * ld + (rows_total - row0)) * 2), 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(addr_u), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ int k_tiles(int k) {
+  const int nk = ((k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
+  return nk < 2 ? 2 : nk;
+}
+
+// ROWS-row tile `t` of the expert-sorted rows -> (expert, first row, end of the expert's rows); false past the last tile.  Every wave runs the same
+// prefix scan over ceil(rows_e / 256) (a row tile never straddles two experts).
+__device__ __forceinline__ bool locate_row_tile(const int32_t* __restrict__ offsets, int n_experts, int t, int lane, int& expert, int& row0, int& row_end) {
+  int base = 0;
+  for (int e0 = 0; e0 < n_experts; e0 += 64) {
+    const int e = e0 + lane;
+    int lo = 0, hi = 0;
+    if (e < n_experts) {
+      lo = offsets[e];
+      hi = offsets[e + 1];
+    }
+    const int tiles = (hi - lo + kTile - 1) / kTile;
+    int incl = tiles;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const unsigned long long hit = __ballot(base + incl > t);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      const int first_tile = base + __shfl(incl, src, 64) - __shfl(tiles, src, 64);
+      expert = __builtin_amdgcn_readfirstlane(e0 + src);
+      row0 = __builtin_amdgcn_readfirstlane(__shfl(lo, src, 64) + (t - first_tile) * kTile);
+      row_end = __builtin_amdgcn_readfirstlane(__shfl(hi, src, 64));
+      return true;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  return false;
+}
+
+// MODE 0: the dense product.  1: grouped forward  y[m] = x[m] . [w | w2][e(m)]^T      (x, w K-contiguous; column tiles >= n_first come from w2)
+// 2: grouped row gradient  dx[m] = dy[m, :n_first] . w[e] + dy[m, n_first:] . w2[e]   (dy K-contiguous, weights K-major; two chained parts)
+// 3: grouped weight gradient  dw[e] = dy[rows of e]^T . x[rows of e]                  (both K-major; K = the expert's row count; rows < n_first -> out, else out2)
+template <int MODE>
+__device__ __forceinline__ constexpr int parts_of() { return MODE == 2 ? 2 : 1; }
+
+template <int MODE, bool XK, bool WK>
+__device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, Tile& t) {
+  t.first = t.last = true;
+  if (MODE == 0) {
+    int tm, tn;
+    if (!tile_of_block(v, p.tiles_m, p.tiles_n, tm, tn)) return false;
+    const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
+    t.xb = p.x + (XK ? m0 : m0 * p.ldx);
+    t.wb = p.w + (WK ? n0 : n0 * p.ldw);
+    t.x_rows = p.m - m0;
+    t.w_rows = p.n - n0;
+    t.k = p.k;
+    t.out = reinterpret_cast<unsigned char*>(p.out) + (m0 * p.ldo + n0) * (p.out_f32 ? 4 : 2);
+    t.ldo = p.ldo;
+    t.m_valid = (int)(p.m - m0 < kTile ? p.m - m0 : kTile);
+    t.n_valid = (int)(p.n - n0 < kTile ? p.n - n0 : kTile);
+    t.nk = k_tiles(p.k);
+    return true;
+  }
+  // grouped: block v runs on XCD v % 8; the `ncol` column tiles of one row tile (MODE 1, 2) / the tiles of one expert (MODE 3) are consecutive ids of ONE
+  // XCD, so the rows they share leave HBM once
+  const int xcd = v & 7, q = v >> 3;
+  if (MODE == 1 || MODE == 2) {
+    const int ncol = p.tiles_n;
+    const int rt = (q / ncol) * 8 + xcd, ct = q % ncol;
+    int e, row0, row_end;
+    if (!locate_row_tile(p.offsets, p.n_experts, rt, lane, e, row0, row_end)) return false;
+    const int c0 = ct * kTile;
+    t.m_valid = row_end - row0 < kTile ? row_end - row0 : kTile;
+    t.ldo = p.ldo;
+    t.out = reinterpret_cast<unsigned char*>(p.out) + ((int64_t)row0 * p.ldo + c0) * 2;
+    if (MODE == 1) {  // x [M, K], w [E, n_first, K], w2 [E, N - n_first, K]
+      const bool second = c0 >= p.n_first;
+      const int wn = second ? p.n - p.n_first : p.n_first, nw0 = second ? c0 - p.n_first : c0;
+      t.xb = p.x + (int64_t)row0 * p.ldx;
+      t.x_rows = row_end - row0;
+      t.wb = (second ? p.w2 : p.w) + ((int64_t)e * wn + nw0) * p.ldw;
+      t.w_rows = wn - nw0;
+      t.k = p.k;
+      t.n_valid = wn - nw0 < kTile ? wn - nw0 : kTile;
+      t.nk = k_tiles(p.k);
+    } else {          // dy [M, n_dim = K], w [E, n_first, k_out = N] read K-major, then w2 [E, K - n_first, N]
+      const int na = p.n_first, nb = p.k - p.n_first;
+      const bool second = part == 1;
+      const int kk = second ? nb : na;
+      t.xb = p.x + (int64_t)row0 * p.ldx + (second ? na : 0);
+      t.x_rows = row_end - row0;
+      t.wb = (second ? p.w2 + (int64_t)e * nb * p.ldw : p.w + (int64_t)e * na * p.ldw) + c0;
+      t.w_rows = p.n - c0;
+      t.k = kk;
+      t.n_valid = p.n - c0 < kTile ? p.n - c0 : kTile;
+      t.nk = k_tiles(kk);
+      t.first = !second;
+      t.last = second || nb == 0;
+      if (second && nb == 0) return false;  // a single weight set: no second part
+    }
+    return true;
+  }
+  // MODE 3: per expert (n_dim / 256) x (k_dim / 256) tiles; X = dy [M, n_dim] K-major (M-side = n), W = x [M, k_dim] K-major (N-side = k)
+  const int per = p.tiles_m * p.tiles_n;
+  const int e = (q / per) * 8 + xcd, tile = q % per;
+  if (e >= p.n_experts) return false;
+  const int lo = p.offsets[e], hi = p.offsets[e + 1];
+  const int tmn = tile / p.tiles_n, tk = tile % p.tiles_n;
+  const int n0 = tmn * kTile, k0 = tk * kTile;
+  t.xb = p.x + (int64_t)lo * p.ldx + n0;
+  t.x_rows = p.m - n0;
+  t.wb = p.w + (int64_t)lo * p.ldw + k0;
+  t.w_rows = p.n - k0;
+  t.k = hi - lo;
+  const bool second = n0 >= p.n_first;
+  const int on = second ? p.m - p.n_first : p.n_first, on0 = second ? n0 - p.n_first : n0;
+  t.out = reinterpret_cast<unsigned char*>(second ? p.out2 : p.out) + (((int64_t)e * on + on0) * p.ldo + k0) * 2;
+  t.ldo = p.ldo;
+  t.m_valid = on - on0 < kTile ? on - on0 : kTile;
+  t.n_valid = p.n - k0 < kTile ? p.n - k0 : kTile;
+  t.nk = k_tiles(hi - lo);
+  return true;
+}
+
+// the next unit of this workgroup's stream at or after (v, part); false when the stream is exhausted
+template <int MODE, bool XK, bool WK>
+__device__ __forceinline__ bool next_unit(const Params& p, int& v, int& part, int lane, Tile& t) {
+  for (; v < p.n_blocks;) {
+    if (tile_at<MODE, XK, WK>(p, v, part, lane, t)) return true;
+    part = 0;
+    v += gridDim.x;
+  }
+  return false;
+}
+__device__ __forceinline__ void advance_unit(int& v, int& part, int parts) {
+  if (++part >= parts) {
+    part = 0;
+    v += gridDim.x;
+  }
 }
 
 // per-lane DMA source offsets + fragment read addresses of one operand (tile independent).  `wsel`: this wave's first row inside a half (64 wv for
@@ -339,27 +506,21 @@ __device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, in
   }
 }
 
-// next valid output tile of this workgroup at or after virtual block id v (stride = gridDim.x, a multiple of 8, so v % 8 — the XCD — never changes)
-__device__ __forceinline__ bool next_tile(const Params& p, int& v, int& tm, int& tn) {
-  for (; v < p.n_blocks; v += gridDim.x)
-    if (tile_of_block(v, p.tiles_m, p.tiles_n, tm, tn)) return true;
-  return false;
-}
-
-template <int V, bool XK, bool WK>
+template <int V, bool XK, bool WK, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   unsigned char* smem = lds_base();
-  int v = blockIdx.x, tm, tn;
-  if (!next_tile(p, v, tm, tn)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = wave >> 2, wt = wave & 3;  // wv: which 64 W rows of a half (also the ping-pong group), wt: which 32 X rows of a half
+  int v = blockIdx.x, part = 0;
+  Tile cur;
+  if (!next_unit<MODE, XK, WK>(p, v, part, lane, cur)) return;
 
   Wave s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   setup_operand<WK>(p.ldw, wave, lane, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
   setup_operand<XK>(p.ldx, wave, lane, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);  // the X window is the second 64 KiB of the ring
-  s.wr = panel_rsrc<WK>(p.w, p.ldw, (int64_t)tn * kTile, p.n, p.k);
-  s.xr = panel_rsrc<XK>(p.x, p.ldx, (int64_t)tm * kTile, p.m, p.k);
+  s.wr = panel_rsrc<WK>(cur.wb, p.ldw, cur.w_rows, cur.k);
+  s.xr = panel_rsrc<XK>(cur.xb, p.ldx, cur.x_rows, cur.k);
   s.piece_lds = wave * 2048;
   if (V & 16) {  // timing ablation: fragments are never read; give them defined (non-zero) contents
 #pragma unroll
@@ -373,8 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
           s.wlo[i][f][kk] = s.whi[i][f][kk] = s.xlo[i][f & 1][kk] = s.xhi[i][f & 1][kk] = u32x2{0x3f803f80u, 0x3f803f80u + lane};
         }
   }
-  const int nk = ((p.k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
-  // ---- prologue of the FIRST tile: the issue order continues into the loop's (X1, W1, W0, X0) rotation
+  // ---- prologue of the FIRST unit: the issue order continues into the loop's (X1, W1, W0, X0) rotation
   reset_offsets(s);
   stage<SLOT_W0, 0>(s, smem);
   stage<SLOT_X0, 0>(s, smem);
@@ -387,37 +547,42 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   if ((V & 2) != 0 && !(V & 16)) read_w<0, 0, WK>(s);  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1), later ones in phase 4 of the previous K-tile
   if (wv == 1) __builtin_amdgcn_s_barrier();           // the second wave group runs one barrier behind the first
 
-  for (;;) {  // ---- the workgroup's output tiles
-    const int m0 = tm * kTile, n0 = tn * kTile;
+  for (;;) {  // ---- the workgroup's stream of units (output tiles, or parts of an accumulation chain)
     {
-      // Re-derive the per-lane DMA offsets / read addresses from an OPAQUE copy of the lane id at the top of every tile: otherwise they stay live across
+      // Re-derive the per-lane DMA offsets / read addresses from an OPAQUE copy of the lane id at the top of every unit: otherwise they stay live across
       // the epilogue (the register-hungriest part), get spilled, and every DMA in the K loop waits for a scratch reload with `vmcnt(1)`.
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       setup_operand<WK>(p.ldw, wave, lane_o, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
       setup_operand<XK>(p.ldx, wave, lane_o, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);
     }
-    int v_n = v + gridDim.x, tm_n = tm, tn_n = tn;
-    const bool has_next = next_tile(p, v_n, tm_n, tn_n);
-    if (!has_next) {
-      tm_n = tm;  // after the last tile the stream re-stages this tile's first K-tiles (never read; drained before the kernel ends)
-      tn_n = tn;
+    // Only what the epilogue needs of `cur` stays live across the K loop; the NEXT unit is looked up at the point where the staging switches to it,
+    // its two descriptors are built and the rest is dropped again (it is looked up once more as `cur` at the top of its own turn): scalar registers
+    // are the scarce resource of this kernel (spilled SGPRs land in VGPR lanes and push the vector allocation over 256).
+    int v_n = v, part_n = part;
+    bool has_next = false;
+    if (cur.first) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) s.acc[i][f][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 2; ++g) s.acc[i][f][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    const int nk = cur.nk;
     for (int t = 0; t < nk; t += 2) {  // two K-tiles per iteration: t in buffer 0, t + 1 in buffer 1
       phase<0, 0, V, XK, WK>(s, smem);
       phase<1, 0, V, XK, WK>(s, smem);
-      if (t + 2 >= nk) {  // the last pair of this output tile: every half-tile staged from here on belongs to the next one
-        s.wr = panel_rsrc<WK>(p.w, p.ldw, (int64_t)tn_n * kTile, p.n, p.k);
-        s.xr = panel_rsrc<XK>(p.x, p.ldx, (int64_t)tm_n * kTile, p.m, p.k);
+      if (t + 2 >= nk) {  // the last pair of this unit: every half-tile staged from here on belongs to the next one
+        advance_unit(v_n, part_n, parts_of<MODE>());
+        Tile nxt;
+        has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+        if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
+          s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+          s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
+        }
         reset_offsets(s);
       }
       phase<2, 0, V, XK, WK>(s, smem);
@@ -427,38 +592,40 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       phase<2, 1, V, XK, WK>(s, smem);
       phase<3, 1, V, XK, WK>(s, smem);
     }
-
+    if (cur.last) {
     // ---- epilogue.  A lane of a C fragment owns ONE output row (lr) and 4 consecutive columns of every 16-column block: stored directly, one wave
     // instruction would touch 16 different rows with 8 / 16 bytes each, and the CU drains such stores at ~8 B/clk.  So each wave transposes through a
     // private 4 KiB LDS block ([32 rows][128 bytes], 16-byte chunk c of row r at c ^ (r & 7)): fragment registers in by ds_write_b64 / b128, full rows
     // out by ds_read_b128, and every global store instruction writes 8 complete 128-byte row segments.  LDS operations of one wave execute in order:
-    // no barrier.
+    // no barrier.  Coordinates are relative to the output block of the tile (cur.out, cur.m_valid x cur.n_valid).
     {
       int lane_e = lane;  // opaque per tile: keeps the epilogue's dozens of per-lane addresses from being hoisted out of the tile loop and spilled across the K loop
       asm volatile("" : "+v"(lane_e));
       const int lr = lane_e & 15, lq = lane_e >> 4;
       unsigned char* stg = smem + kRing + wave * 4096;
       const int srow = lane_e >> 3, schunk = lane_e & 7;
-      const bool wide = p.out_f32 ? (p.n % 4 == 0) : (p.n % 8 == 0 && p.ldo % 8 == 0);
+      const bool f32o = MODE == 0 && p.out_f32;
+      const bool wide = f32o ? (p.n % 4 == 0) : (p.n % 8 == 0 && cur.ldo % 8 == 0);
+      const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
       if (wide) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int ncol0 = n0 + i * 128 + wv * 64;
+          const int ncol0 = i * 128 + wv * 64;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int mrow0 = m0 + j * 128 + wt * 32;
-            if (p.bias) {
+            const int mrow0 = j * 128 + wt * 32;
+            if (bias) {
 #pragma unroll
               for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int nb = ncol0 + f * 16 + lq * 4 + r;
-                  const float bv = nb < p.n ? bf16_to_f32(p.bias[nb]) : 0.f;
+                  const float bv = nb < cur.n_valid ? bf16_to_f32(bias[nb]) : 0.f;
                   s.acc[i][f][j][0][r] += bv;
                   s.acc[i][f][j][1][r] += bv;
                 }
             }
-            if (!p.out_f32) {  // block = [32 rows: g, lr][64 columns: f, lq, r] bf16
+            if (!f32o) {  // block = [32 rows: g, lr][64 columns: f, lq, r] bf16
 #pragma unroll
               for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -472,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                 const int ml = q * 8 + srow;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
                 const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
-                if (m < p.m && nn < p.n) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (int64_t)m * p.ldo + nn) = val;
+                if (m < cur.m_valid && nn < cur.n_valid) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn) = val;
               }
             } else {  // two blocks of [32 rows][32 columns: f & 1, lq, r] f32
 #pragma unroll
@@ -489,8 +656,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                   const int ml = q * 8 + srow;
                   f32x4 val = *reinterpret_cast<const f32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
                   const int m = mrow0 + ml, nn = ncol0 + a * 32 + schunk * 4;
-                  if (m < p.m && nn < p.n) {
-                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nn;
+                  if (m < cur.m_valid && nn < cur.n_valid) {
+                    float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
                     if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = val;
                   }
@@ -504,43 +671,46 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
-            const int m = m0 + j * 128 + wt * 32 + g * 16 + lr;
-            if (m >= p.m) continue;
+            const int m = j * 128 + wt * 32 + g * 16 + lr;
+            if (m >= cur.m_valid) continue;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const int nb = n0 + i * 128 + wv * 64 + f * 16 + lq * 4 + r;
-                  if (nb >= p.n) continue;
+                  const int nb = i * 128 + wv * 64 + f * 16 + lq * 4 + r;
+                  if (nb >= cur.n_valid) continue;
                   float val = s.acc[i][f][j][g][r];
-                  if (p.bias) val += bf16_to_f32(p.bias[nb]);
-                  if (p.out_f32) {
-                    float* dst = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + nb;
+                  if (bias) val += bf16_to_f32(bias[nb]);
+                  if (f32o) {
+                    float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nb;
                     *dst = p.accumulate ? *dst + val : val;
                   } else {
-                    reinterpret_cast<bf16_t*>(p.out)[(int64_t)m * p.ldo + nb] = f32_to_bf16(val);
+                    reinterpret_cast<bf16_t*>(cur.out)[(int64_t)m * cur.ldo + nb] = f32_to_bf16(val);
                   }
                 }
           }
       }
     }
+    }  // cur.last
     if (!has_next) break;
-    v = v_n; tm = tm_n; tn = tn_n;
-  }  // tiles
+    v = v_n;
+    part = part_n;
+    tile_at<MODE, XK, WK>(p, v, part, lane, cur);
+  }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
   if (wv == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <int V, bool XK, bool WK>
+template <int V, bool XK, bool WK, int MODE = 0>
 static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<V, XK, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<V, XK, WK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<V, XK, WK>), grid, dim3(512), kSmem, st, p);
+  hipLaunchKernelGGL((gemm_kernel<V, XK, WK, MODE>), grid, dim3(512), kSmem, st, p);
 }
 
 template <bool XK, bool WK>
@@ -550,11 +720,70 @@ static void launch(const Params& p, hipStream_t st) {
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
   const int v = g_variant & ~4;
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
-  else if (v == 3) launch_v<3, XK, WK>(p, st, grid);
+  else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
   else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16, false, false>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8 | 16)) launch_v<1 | 8 | 16, false, false>(p, st, grid);
-  else launch_v<1, XK, WK>(p, st, grid);
+  else launch_v<3, XK, WK>(p, st, grid);
+}
+// grouped products: always the balanced + setprio schedule; persistent unless the debug variant clears bit 2
+template <bool XK, bool WK, int MODE>
+static void launch_grouped(const Params& p, hipStream_t st) {
+  const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
+  launch_v<3, XK, WK, MODE>(p, st, grid);
+}
+
+// ---- grouped products on the same core (called by the pm_grouped_gemm_* entry points in grouped_gemm.hip) ----------------------------------------
+static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int64_t n_first) {
+  p.bias = nullptr;
+  p.out_f32 = 0;
+  p.accumulate = 0;
+  p.offsets = offsets;
+  p.n_experts = n_experts;
+  p.n_first = (int)n_first;
+  p.w2 = nullptr;
+  p.out2 = nullptr;
+}
+bool grouped_shapes_ok(int64_t n_first, int64_t n, int64_t k_or_second) { return n_first % 256 == 0 && n % 256 == 0 && k_or_second % 128 == 0; }
+
+// y[m] = x[m] . [w | w2][e(m)]^T : x [M, K], w [E, n_first, K], w2 [E, N - n_first, K] -> y [M, N]
+int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_out,
+               int64_t k_dim, bf16_t* y, hipStream_t st) {
+  Params p;
+  grouped_common(p, offsets, n_experts, n_first);
+  p.x = x; p.w = w; p.w2 = w2; p.out = y;
+  p.ldx = k_dim; p.ldw = k_dim; p.ldo = n_out;
+  p.m = (int)n_rows; p.n = (int)n_out; p.k = (int)k_dim;
+  p.tiles_m = 0; p.tiles_n = (int)(n_out / kTile);
+  p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
+  launch_grouped<false, false, 1>(p, st);
+  return PM_OK;
+}
+// dx[m] = dy[m, :n_first] . w[e] + dy[m, n_first:] . w2[e] : dy [M, n_dim], w [E, n_first, k_out], w2 [E, n_dim - n_first, k_out] -> dx [M, k_out]
+int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
+               int64_t k_out, bf16_t* dx, hipStream_t st) {
+  Params p;
+  grouped_common(p, offsets, n_experts, n_first);
+  p.x = dy; p.w = w; p.w2 = w2; p.out = dx;
+  p.ldx = n_dim; p.ldw = k_out; p.ldo = k_out;
+  p.m = (int)n_rows; p.n = (int)k_out; p.k = (int)n_dim;
+  p.tiles_m = 0; p.tiles_n = (int)(k_out / kTile);
+  p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
+  launch_grouped<false, true, 2>(p, st);
+  return PM_OK;
+}
+// dw[e] = dy[rows of e]^T . x[rows of e] : dy [M, n_dim], x [M, k_dim] -> dw [E, n_first, k_dim], dw2 [E, n_dim - n_first, k_dim]
+int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, bf16_t* dw, bf16_t* dw2,
+               hipStream_t st) {
+  Params p;
+  grouped_common(p, offsets, n_experts, n_first);
+  p.x = dy; p.w = x; p.out = dw; p.out2 = dw2;
+  p.ldx = n_dim; p.ldw = k_dim; p.ldo = k_dim;
+  p.m = (int)n_dim; p.n = (int)k_dim; p.k = 0;
+  p.tiles_m = (int)(n_dim / kTile); p.tiles_n = (int)(k_dim / kTile);
+  p.n_blocks = (int)(cdiv(n_experts, 8) * 8 * p.tiles_m * p.tiles_n);
+  launch_grouped<true, true, 3>(p, st);
+  return PM_OK;
 }
 
 }  // namespace gm
@@ -601,6 +830,7 @@ extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const 
   PM_REQUIRE(k_chunk == k || (out_dtype == PM_DTYPE_F32 && x_kmajor && w_kmajor && !bias), PM_ERR_UNSUPPORTED,
              "pm_gemm_bf16: a K-major operand beyond 2 GB needs the f32-accumulating wgrad form");
   gm::Params p;
+  p.offsets = nullptr; p.w2 = nullptr; p.out2 = nullptr; p.n_experts = 0; p.n_first = 0;
   p.out = out; p.bias = (const bf16_t*)bias;
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
   p.m = (int)m; p.n = (int)n;

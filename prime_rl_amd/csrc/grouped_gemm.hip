@@ -607,7 +607,21 @@ __global__ __launch_bounds__(512, 1) void grouped_tn_big_kernel(const bf16_t* __
 
 using namespace pm;
 
-static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = 256 x 256 tiles where the shape allows, 1 = 128 x 128 tiles everywhere
+// Round 3: the three products run on the ping-pong core of gemm.hip (a problem list in its persistent tile stream: gm::grouped_nt / nn / tn) whenever the
+// shape is made of whole 256-wide tiles; the kernels of this file remain for the other shapes (and as the A/B reference).
+namespace pm {
+namespace gm {
+bool grouped_shapes_ok(int64_t n_first, int64_t n, int64_t k_or_second);
+int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_out,
+               int64_t k_dim, bf16_t* y, hipStream_t st);
+int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
+               int64_t k_out, bf16_t* dx, hipStream_t st);
+int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, bf16_t* dw, bf16_t* dw2,
+               hipStream_t st);
+}  // namespace gm
+}  // namespace pm
+
+static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = the gemm.hip core where the shape allows, 2 = this file's 256 x 256 kernels, 1 = 128 x 128 tiles everywhere
 extern "C" int pm_grouped_gemm_debug_set_variant(int32_t value) {
   g_nt_variant = value;
   return PM_OK;
@@ -625,6 +639,11 @@ extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const 
   PM_REQUIRE(gg_shapes_ok(n_rows, n_out, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nt: n_out=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_out, (long long)k_dim);
   if (n_rows == 0) return PM_OK;
+  if (g_nt_variant == 0 && gm::grouped_shapes_ok(n_first, n_out, k_dim) && (n_out - n_first) % 256 == 0) {
+    gm::grouped_nt((const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_out, k_dim, (bf16_t*)y_bf16, as_stream(stream));
+    PM_CHECK_LAUNCH("pm_grouped_gemm_nt");
+    return PM_OK;
+  }
   if (g_nt_variant != 1 && n_first % 256 == 0 && n_out % 256 == 0) {
     const dim3 gridb((unsigned)(cdiv(cdiv(n_rows, 256) + n_experts, 8) * 8 * (n_out / 256)));
     hipLaunchKernelGGL(gg::grouped_nt_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16,
@@ -647,6 +666,11 @@ extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_out), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_nn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_out);
   if (n_rows == 0) return PM_OK;
+  if (g_nt_variant == 0 && k_out % 256 == 0 && n_first % 128 == 0 && (n_dim - n_first) % 128 == 0) {
+    gm::grouped_nn((const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_dim, k_out, (bf16_t*)dx_bf16, as_stream(stream));
+    PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
+    return PM_OK;
+  }
   if (g_nt_variant != 1 && k_out % 256 == 0) {
     const dim3 gridb((unsigned)(cdiv(cdiv(n_rows, 256) + n_experts, 8) * 8 * (k_out / 256)));
     hipLaunchKernelGGL(gg::grouped_nn_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16,
@@ -668,6 +692,11 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: n_first must be a multiple of 128 in (0, n_dim]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
+  if (g_nt_variant == 0 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
+    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, (bf16_t*)dw_bf16, (bf16_t*)dw2_bf16, as_stream(stream));
+    PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
+    return PM_OK;
+  }
   if (g_nt_variant != 1 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
     const dim3 gridb((unsigned)((n_dim / 256) * (k_dim / 256)), (unsigned)n_experts);
     hipLaunchKernelGGL(gg::grouped_tn_big_kernel, gridb, dim3(512), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, (int)n_first,

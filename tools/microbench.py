@@ -324,7 +324,7 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
                     max_abs_diff_vs_loop=err))
     from prime_rl_amd import _lib as _l
 
-    for variant, label in ((1, "128 x 128 tiles"), (0, "256 x 256 tiles")):
+    for variant, label in ((1, "128 x 128 tiles"), (2, "256 x 256 tiles, round-2 kernel"), (0, "256 x 256 tiles, ping-pong core")):
         _l.load().pm_grouped_gemm_debug_set_variant(variant)
         ts = []
         for _ in range(3):
@@ -334,7 +334,7 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
         out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}] ({label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
     _l.load().pm_grouped_gemm_debug_set_variant(0)
     hmid = ops.grouped_gemm_nt(y, w1, offsets)
-    for variant, label in ((1, "128 x 128 tiles"), (0, "256 x 256 tiles")):
+    for variant, label in ((1, "128 x 128 tiles"), (2, "256 x 256 tiles, round-2 kernel"), (0, "256 x 256 tiles, ping-pong core")):
         _l.load().pm_grouped_gemm_debug_set_variant(variant)
         med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
         out.append(dict(kernel=f"pm_grouped_gemm_nn (row gradient of the same; {label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
