@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 #include "attention_kernels.cuh"
+#include "attention_fwd_pp.cuh"
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
@@ -113,7 +114,7 @@ using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   if (kernel == 0) {
-    if (value > 3) return PM_ERR_INVALID_ARG;
+    if (value > 3 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
     g_fwd_var = value;
     return PM_OK;
   }
@@ -166,6 +167,38 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
   hipLaunchKernelGGL((attn_fwd_kernel<2, OPT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse,  \
                      (int)q_row0)
+  if (g_fwd_var >= 64) {
+    const int group = n_q_heads / n_kv_heads;
+    const int by_rows = (group & 1) ? 1 : 0;
+    const unsigned grid = by_rows ? (unsigned)(cdiv(n_q, 256) * n_q_heads) : (unsigned)(cdiv(n_q, 128) * n_kv_heads * (group / 2));
+#define PM_LAUNCH_PP(OPT_)                                                                                                                             \
+  case OPT_: {                                                                                                                                         \
+    static bool attr_done = false;                                                                                                                     \
+    if (!attr_done) {                                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<OPT_>, hipFuncAttributeMaxDynamicSharedMemorySize, kPPSmem);                           \
+      attr_done = true;                                                                                                                                \
+    }                                                                                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<OPT_>), dim3(grid), dim3(512), kPPSmem, as_stream(stream), (const bf16_t*)q, (const bf16_t*)k,             \
+                       (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse, (int)q_row0, by_rows);   \
+  } break
+    switch (g_fwd_var - 64) {
+      PM_LAUNCH_PP(0);
+      PM_LAUNCH_PP(1);
+      PM_LAUNCH_PP(32);
+      PM_LAUNCH_PP(33);
+      PM_LAUNCH_PP(36);
+      PM_LAUNCH_PP(40);
+      PM_LAUNCH_PP(44);
+      PM_LAUNCH_PP(48);
+      PM_LAUNCH_PP(96);
+      PM_LAUNCH_PP(112);
+      PM_LAUNCH_PP(124);
+      default: PM_REQUIRE(false, PM_ERR_INVALID_ARG, "%s: ping-pong forward variant %d is not built", who, g_fwd_var - 64);
+    }
+#undef PM_LAUNCH_PP
+    PM_CHECK_LAUNCH(who);
+    return PM_OK;
+  }
   switch (g_fwd_var < 0 ? kFwdDefaultOpt : g_fwd_var) {
     case 0: PM_LAUNCH_FWD(0); break;
     case 1: PM_LAUNCH_FWD(1); break;

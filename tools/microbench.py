@@ -406,7 +406,31 @@ def main():
     if which == "moestep":
         bench_moe_step(out, layers=int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     if which == "attnfwd":
-        bench_attn_variants(out, 0, [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3, 0, 1, 2])
+        docs = int(sys.argv[3]) if len(sys.argv) > 3 else 8  # 16 384 tokens as `docs` equal documents
+        bench_attn_variants(out, 0, [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3, 0, 1, 2], seqs=(16384 // docs,) * docs)
+    if which == "attnprobe":  # phase timers of the ping-pong forward kernel (variants 64 + 32 + ablation bits): cycles per kv tile of block 0's waves
+        from prime_rl_amd import _lib
+
+        lib = _lib.load()
+        n, hq, hkv, d = 16384, 32, 8, 128
+        docs = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+        q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+        k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+        v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+        cu = torch.tensor([0] + [n // docs * (i + 1) for i in range(docs)], dtype=torch.int32, device=DEV)
+        ss = ops.seq_start_from_cu(cu, n)
+        for var in [int(x) for x in sys.argv[2].split(",")]:
+            lib.pm_attn_debug_set_variant(0, var)
+            for _ in range(3):
+                o, lse = ops.attn_varlen_fwd(q, k, v, ss, d**-0.5)
+            torch.cuda.synchronize()
+            for g in range(2):
+                for wl in range(4):
+                    r = lse[g, n - 128 + wl * 32:n - 128 + wl * 32 + 7].tolist()
+                    it = max(r[6], 1)
+                    out.append(dict(variant=var, wave=g * 4 + wl, tiles=int(it), L=round(r[0] / it), C1=round(r[1] / it), V=round(r[2] / it), C2=round(r[3] / it),
+                                    per_tile=round(r[4] / it), total_cyc=int(r[4]), realtime_ticks=int(r[5])))
+        lib.pm_attn_debug_set_variant(0, -1)
     if which == "attnbwd":
         bench_attn_variants(out, 1, [int(x) for x in sys.argv[2].split(",")])
     if which == "attndq":
