@@ -337,6 +337,10 @@ int pm_grad_accumulate(float* main_grad_f32, const void* grad_bf16, int64_t n, v
 int64_t pm_sumsq_workspace_bytes(int64_t n);
 int pm_sumsq(const float* x, int64_t n, float* out_sumsq /* device scalar, accumulated into */,
              void* workspace, int64_t workspace_bytes, void* stream);
+/* The same for `n_segments` (offset, length) pairs of a flat buffer, one partial per segment (segments <= 1 Mi elements each; int64 pairs on the device),
+ * and the deterministic last stage: out[0] += sum(partials). */
+int pm_sumsq_segments(const float* base, const int64_t* segments /* [n_segments][2] */, int32_t n_segments, float* partials, void* stream);
+int pm_sum_partials(const float* partials, int64_t n, float* out /* device scalar, accumulated into */, void* stream);
 /* clip_coef[0] = min(1, max_norm/(sqrt(total_sumsq*grad_scale^2)+1e-6)); grad_norm_out[0] = sqrt(total_sumsq)*grad_scale
  * (torch clip_grad_norm_ semantics, trainer/utils.py:88-98). */
 int pm_clip_coef(const float* total_sumsq, float grad_scale, float max_norm, float* clip_coef, float* grad_norm_out, void* stream);
@@ -472,6 +476,13 @@ int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmajor, int32_t
 int pm_gemm_bf16(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                  int32_t out_dtype /* PM_DTYPE_BF16 | PM_DTYPE_F32 */, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n,
                  int64_t k, void* stream);
+/* The weight-gradient form with the gradient-norm pass fused into its epilogue (the reference clips the GLOBAL gradient norm before the optimizer step,
+ * trainer/rl/train.py:557-570 `clip_grad_norm_`; here every wave adds up the squares of the FINAL f32 values it stores and writes the sum to
+ * tile_sumsq[tile * 8 + wave] — pm_gemm_sumsq_slots(m, n) floats, deterministic, slots of tiles that do not exist are left untouched).  Summing the
+ * slots (pm_sum_partials) gives sum(out^2) without reading the 4-byte-per-parameter gradient again. */
+int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n);
+int pm_gemm_bf16_sumsq(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, float* out_f32, int64_t ldo,
+                       int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream);
 int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced fragment reads */
 
 /* --------------------------------------------------------------------------------------------

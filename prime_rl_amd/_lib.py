@@ -104,6 +104,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grad_accumulate": (I, [P, P, I64, P]),
     "pm_sumsq_workspace_bytes": (I64, [I64]),
     "pm_sumsq": (I, [P, I64, P, P, I64, P]),
+    "pm_sumsq_segments": (I, [P, P, I32, P, P]),
+    "pm_sum_partials": (I, [P, I64, P, P]),
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
     "pm_sgd_step": (I, [P, P, P, P, I64, F, F, F, I32, I64, F, P, I32, P]),
@@ -141,6 +143,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
     "pm_gemm_supported": (I, [I64, I64, I64, I32, I32]),
     "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P]),
+    "pm_gemm_sumsq_slots": (I64, [I64, I64]),
+    "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, P]),
     "pm_gemm_debug_set_variant": (I, [I32]),
 }
 

@@ -210,6 +210,24 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
   if (threadIdx.x == 0) out[0] += tot;
 }
 
+// One workgroup per segment (offset, length) of a flat f32 buffer: the small tensors between the GEMM weights of a bucket (norm weights, biases), whose
+// squared norm the weight-gradient epilogues do not cover (pm_gemm_bf16_sumsq).  Callers split anything large into segments of <= 1 Mi elements.
+__global__ __launch_bounds__(256) void sumsq_segments_kernel(const float* __restrict__ base, const int64_t* __restrict__ segs, float* __restrict__ partials) {
+  __shared__ float smem[4];
+  const int64_t off = segs[2 * blockIdx.x], len = segs[2 * blockIdx.x + 1];
+  const float* x = base + off;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t i = threadIdx.x;
+  for (; i + 256 < len; i += 512) {
+    const float a = x[i], b = x[i + 256];
+    s0 = fmaf(a, a, s0);
+    s1 = fmaf(b, b, s1);
+  }
+  if (i < len) s0 = fmaf(x[i], x[i], s0);
+  const float tot = block_sum<4>(s0 + s1, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 __global__ void clip_coef_kernel(const float* __restrict__ total_sumsq, float grad_scale, float max_norm, float* __restrict__ coef,
                                  float* __restrict__ norm_out) {
   const float norm = sqrtf(total_sumsq[0]) * grad_scale;
@@ -479,6 +497,23 @@ extern "C" int pm_sumsq(const float* x, int64_t n, float* out_sumsq, void* works
   PM_CHECK_LAUNCH("pm_sumsq");
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, out_sumsq);
   PM_CHECK_LAUNCH("pm_sumsq(final)");
+  return PM_OK;
+}
+
+extern "C" int pm_sumsq_segments(const float* base, const int64_t* segments, int32_t n_segments, float* partials, void* stream) {
+  if (n_segments == 0) return PM_OK;
+  PM_REQUIRE(base && segments && partials && n_segments > 0, PM_ERR_INVALID_ARG, "pm_sumsq_segments: bad args");
+  hipLaunchKernelGGL(sumsq_segments_kernel, dim3((unsigned)n_segments), dim3(256), 0, as_stream(stream), base, segments, partials);
+  PM_CHECK_LAUNCH("pm_sumsq_segments");
+  return PM_OK;
+}
+
+// out[0] += sum(partials) in a fixed order (one workgroup): the last stage of the fused gradient norm
+extern "C" int pm_sum_partials(const float* partials, int64_t n, float* out, void* stream) {
+  PM_REQUIRE(partials && out && n >= 0 && n < (1ll << 31), PM_ERR_INVALID_ARG, "pm_sum_partials: bad args");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, (int)n, out);
+  PM_CHECK_LAUNCH("pm_sum_partials");
   return PM_OK;
 }
 

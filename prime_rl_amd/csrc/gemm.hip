@@ -70,6 +70,7 @@ struct Params {
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
   int accumulate;     // f32 out only: out += product
+  float* sumsq;       // f32 out only, optional: [n_blocks][8] — every wave writes the sum of squares of the FINAL values it stored for tile v to [v][wave]
   // grouped products over expert-sorted rows (MODE 1-3 of gemm_kernel; see the tile sources below)
   const int32_t* offsets;  // [n_experts + 1] on the device: rows of expert e = [offsets[e], offsets[e + 1])
   const bf16_t* w2;        // second weight set (the experts' up projection next to the gate projection), or null
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       int lane_e = lane;  // opaque per tile: keeps the epilogue's dozens of per-lane addresses from being hoisted out of the tile loop and spilled across the K loop
       asm volatile("" : "+v"(lane_e));
       const int lr = lane_e & 15, lq = lane_e >> 4;
+      float ss = 0.f;  // squared norm of what this lane stores (p.sumsq: the gradient-norm pass fused into the weight-gradient epilogue)
       unsigned char* stg = smem + kRing + wave * 4096;
       const int srow = lane_e >> 3, schunk = lane_e & 7;
       const bool f32o = MODE == 0 && p.out_f32;
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                     float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
                     if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = val;
+                    if (MODE == 0 && p.sumsq) ss = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], ss))));
                   }
                 }
               }
@@ -685,12 +688,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                   if (bias) val += bf16_to_f32(bias[nb]);
                   if (f32o) {
                     float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nb;
-                    *dst = p.accumulate ? *dst + val : val;
+                    if (p.accumulate) val += *dst;
+                    *dst = val;
+                    if (MODE == 0 && p.sumsq) ss = fmaf(val, val, ss);
                   } else {
                     reinterpret_cast<bf16_t*>(cur.out)[(int64_t)m * cur.ldo + nb] = f32_to_bf16(val);
                   }
                 }
           }
+      }
+      if (MODE == 0 && p.sumsq) {  // wave-uniform
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane_e == 0) p.sumsq[(int64_t)v * 8 + wave] = ss;
       }
     }
     }  // cur.last
@@ -738,6 +748,7 @@ static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int
   p.bias = nullptr;
   p.out_f32 = 0;
   p.accumulate = 0;
+  p.sumsq = nullptr;
   p.offsets = offsets;
   p.n_experts = n_experts;
   p.n_first = (int)n_first;
@@ -806,8 +817,27 @@ extern "C" int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmaj
   return 1;
 }
 
+extern "C" int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  return (int64_t)gm::grid_blocks((int)cdiv(m, gm::kTile), (int)cdiv(n, gm::kTile)) * 8;
+}
+
+static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
+                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* stream);
+
 extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                             int32_t out_dtype, const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, void* stream) {
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, nullptr, stream);
+}
+
+extern "C" int pm_gemm_bf16_sumsq(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, float* out, int64_t ldo,
+                                  int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream) {
+  PM_REQUIRE(tile_sumsq && tile_sumsq_len >= pm_gemm_sumsq_slots(m, n), PM_ERR_WORKSPACE, "pm_gemm_bf16_sumsq: tile_sumsq needs pm_gemm_sumsq_slots(m, n) floats");
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, PM_DTYPE_F32, nullptr, accumulate, m, n, k, tile_sumsq, stream);
+}
+
+static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
+                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* stream) {
   if (m == 0 || n == 0) return PM_OK;
   PM_REQUIRE(x && w && out, PM_ERR_INVALID_ARG, "pm_gemm_bf16: null pointer");
   PM_REQUIRE(pm_gemm_supported(m, n, k, x_kmajor, w_kmajor), PM_ERR_UNSUPPORTED,
@@ -843,6 +873,7 @@ extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const 
     p.w = (const bf16_t*)w + (w_kmajor ? k0 * ldw : k0);
     p.k = (int)std::min(k_chunk, k - k0);
     p.accumulate = (accumulate || k0 > 0) ? 1 : 0;
+    p.sumsq = k0 + k_chunk >= k ? tile_sumsq : nullptr;  // only the last K-chunk stores final values
     if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
     else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
     else gm::launch<true, true>(p, st);

@@ -829,11 +829,13 @@ def gemm_supported(x: Tensor, w: Tensor) -> bool:
     return bool(_lib.load().pm_gemm_supported(m, n, k, int(xk), int(wk)))
 
 
-def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16, bias: Tensor | None = None, accumulate: bool = False) -> Tensor:
+def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16, bias: Tensor | None = None, accumulate: bool = False,
+         tile_sumsq: Tensor | None = None) -> Tensor:
     """out[M, N] (+)= x[M, K] @ w[N, K]^T (+ bias) on the MFMA core — F.linear's product for any of the three layouts the trainer step has:
     forward `gemm(x, W)`, dgrad `gemm(dy, W.t())` (W.t() = the [in, out] view of the stored [out, in] weight), wgrad
     `gemm(dy.t(), x.t(), out=grad, out_dtype=f32, accumulate=...)`.  Operands are passed as LOGICAL [rows, K] matrices; their strides say how
-    they are stored (no copies are made)."""
+    they are stored (no copies are made).  `tile_sumsq` (f32, >= gemm_sumsq_slots(M, N) elements; f32 `out` only): every wave also writes the
+    sum of squares of the final values it stored — the gradient-norm pass fused into the weight-gradient epilogue (sum the slots with sum_partials)."""
     lib = _lib.load()
     ldx, xk, m, k = _gemm_operand(x, "x")
     ldw, wk, n, k2 = _gemm_operand(w, "w")
@@ -849,9 +851,34 @@ def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype
         _req(bias, torch.bfloat16, "bias")
         if bias.numel() != n:
             raise PrimeMI355XError("gemm: bias length != N")
+    if tile_sumsq is not None:
+        _req(tile_sumsq, torch.float32, "tile_sumsq")
+        if out.dtype != torch.float32 or bias is not None:
+            raise PrimeMI355XError("gemm: tile_sumsq needs an f32 output and no bias")
+        check(lib.pm_gemm_bf16_sumsq(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), int(accumulate), m, n, k, _p(tile_sumsq),
+                                     tile_sumsq.numel(), _stream()), "pm_gemm_bf16_sumsq")
+        return out
     check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
           "pm_gemm_bf16")
     return out
+
+
+def gemm_sumsq_slots(m: int, n: int) -> int:
+    return int(_lib.load().pm_gemm_sumsq_slots(m, n))
+
+
+def sumsq_segments(base: Tensor, segments: Tensor, partials: Tensor) -> None:
+    """partials[i] = sum(base[off_i : off_i + len_i]^2) for the int64 [n, 2] (offset, length) rows of `segments` (on the device)."""
+    _req(base, torch.float32, "base"); _req(partials, torch.float32, "partials"); _req(segments, torch.int64, "segments")
+    if segments.dim() != 2 or segments.shape[1] != 2 or partials.numel() < segments.shape[0]:
+        raise PrimeMI355XError("sumsq_segments: segments must be [n, 2] and partials hold n floats")
+    check(_lib.load().pm_sumsq_segments(_p(base), _p(segments), segments.shape[0], _p(partials), _stream()), "pm_sumsq_segments")
+
+
+def sum_partials(partials: Tensor, out_scalar: Tensor) -> None:
+    """out_scalar[0] += sum(partials), in a fixed order."""
+    _req(partials, torch.float32, "partials"); _req(out_scalar, torch.float32, "out")
+    check(_lib.load().pm_sum_partials(_p(partials), partials.numel(), _p(out_scalar), _stream()), "pm_sum_partials")
 
 
 def gemm_set_variant(v: int) -> None:

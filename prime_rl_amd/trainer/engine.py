@@ -556,6 +556,13 @@ class GRPOEngine:
             # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
             # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
             ops.gemm_set_variant(3 if self.use_collectives else 7)
+        # The gradient-norm pass fused into the weight-gradient epilogues (ops.gemm(tile_sumsq=...)): on the LAST backward pass of a step every wgrad GEMM
+        # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
+        # (norm weights, biases, the embedding) instead of re-reading the whole 4-byte-per-parameter buffer (5.3 ms per Qwen3-8B step).  Only without
+        # collectives: under ZeRO-2 the norm is taken over the REDUCED shard.  PM_FUSED_SUMSQ=0 is the A/B switch.
+        self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and os.environ.get("PM_FUSED_SUMSQ", "1") != "0"
+        self._fs_plan: dict | None = None
+        self._fs_covered: set[str] = set()
         self._wt: dict[str, Tensor] = {}
         self._wt_version: dict[int, int] = {}
         if self.gemm_layouts:  # allocated up front (one slab) so the caching allocator sees the same request stream from the first step on
@@ -613,7 +620,7 @@ class GRPOEngine:
             return torch.addmm(bias, x, w.t())
         return torch.mm(x, w.t(), out_dtype=torch.float32) if out_f32 else torch.mm(x, w.t())
 
-    def _wgrad(self, dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool, k_contiguous_x: bool = False) -> None:
+    def _wgrad(self, dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool, k_contiguous_x: bool = False, final_name: str | None = None) -> None:
         """gview[out,in] (+)= dy[n,out]^T @ x[n,in] with f32 accumulation.
 
         `k_contiguous_x`: first re-lay x as [in, n] (pm_transpose_2d) so the library GEMM reads it along the reduction dimension —
@@ -628,7 +635,11 @@ class GRPOEngine:
             return
         if "wgrad" in self.gemm_own and ops.gemm_supported(dy.t(), x.t()):
             # dw[out, in] (+)= sum_tok dy[tok, out] x[tok, in]: both operands K-major (tokens are their rows), f32 accumulate in the epilogue
-            ops.gemm(dy.t(), x.t(), out=gview, accumulate=accumulate)
+            # `final_name`: this call writes the FINAL gradient of that parameter for the step -> its squared norm comes out of the epilogue
+            slot = self._fs_slot(final_name) if (final_name is not None and self.fused_sumsq) else None
+            ops.gemm(dy.t(), x.t(), out=gview, accumulate=accumulate, tile_sumsq=slot)
+            if slot is not None:
+                self._fs_covered.add(final_name)
             return
         if self._wgrad_direct:
             xop = ops.transpose_2d(x).t() if (k_contiguous_x and self.gemm_layouts) else x
@@ -641,6 +652,60 @@ class GRPOEngine:
             if not accumulate:
                 gview.zero_()
             ops.grad_accumulate(gview.view(-1), tmp.view(-1))
+
+    _FS_SEGMENT = 1 << 20  # elements per workgroup of pm_sumsq_segments
+
+    def _fs_build(self) -> dict:
+        """Slots of the per-tile partials of every GEMM weight, and the (offset, length) segments of everything else in the flat gradient buffer."""
+        d, st = self.dims, self.store
+        slots: dict[str, tuple[int, int]] = {}
+        cursor = 0
+        rest: list[tuple[int, int]] = []
+        for b in st.buckets:
+            for pname, off, shape in b.params:
+                is_matrix = len(shape) == 2 and pname != "model.embed_tokens.weight" and not (pname == "lm_head.weight" and d.tie_word_embeddings)
+                if is_matrix:
+                    n = ops.gemm_sumsq_slots(shape[0], shape[1])
+                    slots[pname] = (cursor, n)
+                    cursor += n
+                else:
+                    rest.append((off, math.prod(shape)))
+        big = [(o, ln) for o, ln in rest if ln >= 4 * self._FS_SEGMENT]  # the embedding: the streaming two-stage kernel (pm_sumsq) on its range
+        segs = [(o + c, min(self._FS_SEGMENT, ln - c)) for o, ln in rest if ln < 4 * self._FS_SEGMENT for c in range(0, ln, self._FS_SEGMENT)]
+        return {
+            "slots": slots,
+            "big": big,
+            "tiles": torch.zeros(max(cursor, 1), dtype=torch.float32, device=self.device),  # slots of tiles that do not exist stay zero forever
+            "segments": torch.tensor(segs, dtype=torch.int64, device=self.device).reshape(-1, 2),
+            "seg_partials": torch.zeros(max(len(segs), 1), dtype=torch.float32, device=self.device),
+        }
+
+    def _fs_slot(self, name: str) -> Tensor | None:
+        if self._fs_plan is None:
+            self._fs_plan = self._fs_build()
+        ent = self._fs_plan["slots"].get(name)
+        if ent is None:
+            return None
+        return self._fs_plan["tiles"][ent[0]:ent[0] + ent[1]]
+
+    def _fs_norm(self, out_scalar: Tensor) -> None:
+        """out_scalar[0] += sum(main_grad^2), from the epilogue partials + the segments the GEMMs do not cover (+ any matrix whose last wgrad
+        call did not run on the own core this step: re-read like before)."""
+        plan = self._fs_plan if self._fs_plan is not None else self._fs_build()
+        self._fs_plan = plan
+        missing = [nm for nm in plan["slots"] if nm not in self._fs_covered]
+        if missing:  # e.g. a shape the own core does not take: zero its slots and read that gradient the old way
+            for nm in missing:
+                o, n = plan["slots"][nm]
+                plan["tiles"][o:o + n].zero_()
+                ops.sumsq_accumulate(self.store.g[nm].view(-1), out_scalar)
+        ops.sum_partials(plan["tiles"], out_scalar)
+        for o, ln in plan["big"]:
+            ops.sumsq_accumulate(self.store.main_grad[o:o + ln], out_scalar)
+        if plan["segments"].shape[0]:
+            ops.sumsq_segments(self.store.main_grad, plan["segments"], plan["seg_partials"])
+            ops.sum_partials(plan["seg_partials"][:plan["segments"].shape[0]], out_scalar)
+        self._fs_covered.clear()
 
     _DGRAD_MATRICES = ("self_attn.qkv_proj.weight", "self_attn.o_proj.weight", "mlp.gate_up_proj.weight", "mlp.down_proj.weight")
 
@@ -847,7 +912,7 @@ class GRPOEngine:
                 todo += [(s0, min(s0 + fused_chunk, e), None) for s0 in range(s, e, fused_chunk)]
             else:
                 todo.append((s, e, logits))
-        for s, e, logits in todo:
+        for ci, (s, e, logits) in enumerate(todo):
             if logits is None:
                 dl = ops.lmhead_logprob_bwd(hf[s:e], wh, labels[s:e], inv_temp[s:e], ctx["logz"][s:e], grad_lp[s:e])
             else:
@@ -860,7 +925,8 @@ class GRPOEngine:
                 torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
             else:
                 torch.mm(dl, wh, out=dhf[s:e])
-            self._wgrad(dl, hf[s:e], gh, acc_head, k_contiguous_x=True)
+            self._wgrad(dl, hf[s:e], gh, acc_head, k_contiguous_x=True,
+                        final_name="lm_head.weight" if (last_pass and ci == len(todo) - 1 and not d.tie_word_embeddings) else None)
             acc_head = True
         ctx["logits_chunks"] = None
         # tied embeddings: the embedding backward below must accumulate on top of the head gradient
@@ -880,15 +946,17 @@ class GRPOEngine:
                 L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n)
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
             dact = self._dgrad(dx, i, "mlp.down_proj.weight")
-            self._wgrad(dx, act, g[p + "mlp.down_proj.weight"], accumulate, k_contiguous_x=True)
+            self._wgrad(dx, act, g[p + "mlp.down_proj.weight"], accumulate, k_contiguous_x=True,
+                        final_name=p + "mlp.down_proj.weight" if last_pass else None)
             del act
             dgu = ops.swiglu_bwd(dact, L["gu"])
             dh2 = self._dgrad(dgu, i, "mlp.gate_up_proj.weight")
-            self._wgrad(dgu, L["h2"], g[p + "mlp.gate_up_proj.weight"], accumulate, k_contiguous_x=True)
+            self._wgrad(dgu, L["h2"], g[p + "mlp.gate_up_proj.weight"], accumulate, k_contiguous_x=True,
+                        final_name=p + "mlp.gate_up_proj.weight" if last_pass else None)
             dx2 = ops.rmsnorm_bwd(dh2, L["x2"], w[p + "post_attention_layernorm.weight"], L["rstd2"],
                                   self._norm_grad(g[p + "post_attention_layernorm.weight"], accumulate), dresidual=dx)
             do = self._dgrad(dx2, i, "self_attn.o_proj.weight").view(n, d.num_attention_heads, d.kernel_head_dim)
-            self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate)
+            self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate, final_name=p + "self_attn.o_proj.weight" if last_pass else None)
             qkv = L["qkv"]
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             dqkv = torch.empty_like(qkv)
@@ -909,7 +977,7 @@ class GRPOEngine:
             if d.attention_bias:  # grad_bias = column sums of the projection's output gradient
                 ops.column_sum(dqkv, self._norm_grad(g[p + "self_attn.qkv_proj.bias"], accumulate))
             dh1 = self._dgrad(dqkv, i, "self_attn.qkv_proj.weight")
-            self._wgrad(dqkv, L["h1"], g[p + "self_attn.qkv_proj.weight"], accumulate)
+            self._wgrad(dqkv, L["h1"], g[p + "self_attn.qkv_proj.weight"], accumulate, final_name=p + "self_attn.qkv_proj.weight" if last_pass else None)
             dx = ops.rmsnorm_bwd(dh1, L["x"], w[p + "input_layernorm.weight"], L["rstd1"],
                                  self._norm_grad(g[p + "input_layernorm.weight"], accumulate), dresidual=dx2)
             ctx["layers"][i] = None
@@ -1027,7 +1095,8 @@ class GRPOEngine:
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(ev)
         self._param_readers.clear()
-        return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq)
+        return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq,
+                                           local_sumsq=self._fs_norm if self.fused_sumsq else None)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:

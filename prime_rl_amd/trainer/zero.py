@@ -70,8 +70,10 @@ def apply_update(kernels, optim, master, exp_avg, exp_avg_sq, grad, params_bf16,
         raise ValueError(f"optim.type = {kind!r}: the fused on-GPU optimizers are adamw, sgd and sign_sgd (Muon stays with the reference)")
 
 
-def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=None, gather_events: dict | None = None, scratch: torch.Tensor | None = None):
+def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=None, gather_events: dict | None = None, scratch: torch.Tensor | None = None,
+                           local_sumsq=None):
     """Global-norm clip + AdamW on this rank's shard + in-place all-gather of the bf16 parameters.
+    `local_sumsq(out)`: optional replacement of the norm pass over the local gradient (single-rank engines only).
     Returns the global gradient norm (1-element tensor)."""
     dp = store.dp_size
     sumsq = scratch if scratch is not None else torch.zeros(1, dtype=torch.float32, device=store.main_grad.device)
@@ -80,7 +82,10 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
     collectives = getattr(store, "use_collectives", dp > 1)  # True at dp == 1 only when forced (single-GPU check of this path)
     if collectives and gpu and comm_stream is not None:
         _timed("exposed", torch.cuda.current_stream(), lambda: torch.cuda.current_stream().wait_stream(comm_stream))  # every reduce-scatter has landed
-    kernels.sumsq_accumulate(store.grad_shard, sumsq)
+    if local_sumsq is not None and not collectives:  # the engine already holds the pieces of the norm (weight-gradient epilogue partials): no re-read
+        local_sumsq(sumsq)
+    else:
+        kernels.sumsq_accumulate(store.grad_shard, sumsq)
     if collectives:
         dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=group)
     coef, norm = kernels.clip_coef(sumsq, 1.0, optim.max_norm if optim.max_norm else 0.0)

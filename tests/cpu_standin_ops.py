@@ -373,7 +373,20 @@ def gemm_supported(x, w):
     return False  # the CPU stand-in engine keeps the library (torch) GEMM calls
 
 
-def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False):
+def gemm_sumsq_slots(m, n):
+    return ((m + 255) // 256) * ((n + 255) // 256) * 8
+
+
+def sumsq_segments(base, segments, partials):
+    for i, (o, ln) in enumerate(segments.tolist()):
+        partials[i] = base[o:o + ln].float().pow(2).sum()
+
+
+def sum_partials(partials, out_scalar):
+    out_scalar += partials.sum()
+
+
+def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False, tile_sumsq=None):
     y = x.float() @ w.float().t()
     if bias is not None:
         y = y + bias.float()
@@ -383,4 +396,7 @@ def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False):
         out.add_(y.to(out.dtype))
     else:
         out.copy_(y)
+    if tile_sumsq is not None:  # the stand-in keeps the whole sum in slot 0
+        tile_sumsq.zero_()
+        tile_sumsq[0] = out.float().pow(2).sum()
     return out

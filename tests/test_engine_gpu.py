@@ -501,6 +501,32 @@ def test_engine_two_passes_equal_one_pass():
     assert rel < 2e-2, rel
 
 
+def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
+    """PM_FUSED_SUMSQ (default): the squared gradient norm is assembled from the weight-gradient epilogues' per-tile partials + the small tensors in
+    between; it must agree with the streaming pass over the whole gradient buffer, over one and over two accumulation passes, and the optimizer
+    steps must follow each other (clip coefficient = f(norm))."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=1024)
+    mbs = _mbs(dims.vocab_size, 256, 4, True)
+    passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+    norms, params = {}, {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PM_FUSED_SUMSQ", fused)
+        eng = GRPOEngine(dims, device=DEV, seed=5, optim=OptimConfig(lr=1e-3, max_norm=0.05))
+        assert eng.fused_sumsq == (fused == "1" and "wgrad" in eng.gemm_own)
+        out = [eng.step(passes), eng.step(passes[0])]
+        norms[fused] = [float(o["grad_norm"]) for o in out]
+        params[fused] = eng.store.params.clone()
+        if fused == "1":
+            assert not eng._fs_covered  # consumed by the optimizer
+            assert eng._fs_plan is not None and len(eng._fs_plan["slots"]) == 4 * dims.num_hidden_layers + (0 if dims.tie_word_embeddings else 1)
+    for a, b in zip(norms["1"], norms["0"]):
+        assert abs(a - b) <= 2e-6 * abs(b), (a, b)
+    assert torch.allclose(params["1"].float(), params["0"].float(), rtol=0, atol=2e-3)
+    assert (params["1"] != params["0"]).float().mean().item() < 0.01  # an ulp of the clip coefficient may flip a few bf16 roundings
+
+
 def test_gemm_layout_copies_track_parameter_updates():
     """The K-contiguous weight copies used by dgrad (and the transposed MLP inputs used by wgrad) change only the operand layout:
     gradients equal the plain-layout engine's up to GEMM summation order, also AFTER optimizer steps moved the weights (a stale

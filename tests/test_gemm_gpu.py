@@ -83,6 +83,47 @@ def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
         ops.gemm_set_variant(7)
 
 
+@pytest.mark.parametrize("variant", [3, 7])
+@pytest.mark.parametrize("tokens,n_out,n_in", [(256, 256, 256), (1024, 768, 512), (1000, 264, 520), (2048, 4096, 1024)])
+def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
+    """The gradient-norm pass fused into the weight-gradient epilogue: the per-(tile, wave) partials add up to sum(dw^2) of the FINAL values (also
+    after an accumulating call), bit-identically from run to run; slots of tiles that do not exist are not written."""
+    ops.gemm_set_variant(variant)
+    try:
+        dy, x = _rand(tokens, n_out, 1.0, 12), _rand(tokens, n_in, 1.0, 13)
+        g = torch.empty((n_out, n_in), dtype=torch.float32, device=DEV)
+        slots = torch.full((ops.gemm_sumsq_slots(n_out, n_in),), -1.0, dtype=torch.float32, device=DEV)
+        ops.gemm(dy.t(), x.t(), out=g, accumulate=False, tile_sumsq=slots)
+        written = slots[slots >= 0]
+        want = g.double().pow(2).sum().item()
+        assert abs(written.double().sum().item() - want) <= 1e-5 * want
+        assert written.numel() == 8 * ((n_out + 255) // 256) * ((n_in + 255) // 256)
+        ref = dy.float().t() @ x.float()
+        _check(g, ref, tokens, False)  # the values themselves are unchanged by the extra output
+        first = slots.clone()
+        ops.gemm(dy.t(), x.t(), out=g, accumulate=False, tile_sumsq=slots)
+        assert torch.equal(first, slots)
+        ops.gemm(dy.t(), x.t(), out=g, accumulate=True, tile_sumsq=slots)  # g = 2 ref: the partials follow the stored values, not the product
+        want2 = g.double().pow(2).sum().item()
+        assert abs(slots[slots >= 0].double().sum().item() - want2) <= 1e-5 * want2
+        total = torch.zeros(1, dtype=torch.float32, device=DEV)
+        slots.clamp_(min=0)
+        ops.sum_partials(slots, total)
+        assert abs(total.item() - want2) <= 1e-5 * want2
+    finally:
+        ops.gemm_set_variant(7)
+
+
+def test_sumsq_segments():
+    base = torch.randn(300_000, device=DEV)
+    segs = torch.tensor([[0, 4096], [4224, 128], [8192, 1], [10_000, 250_001], [299_999, 1]], dtype=torch.int64, device=DEV)
+    part = torch.zeros(5, dtype=torch.float32, device=DEV)
+    ops.sumsq_segments(base, segs, part)
+    for i, (o, n) in enumerate(segs.tolist()):
+        want = base[o:o + n].double().pow(2).sum().item()
+        assert abs(part[i].item() - want) <= 1e-5 * max(want, 1e-6), (i, part[i].item(), want)
+
+
 def test_gemm_is_deterministic_and_matches_itself_across_variants():
     x, w = _rand(512, 512, 1.0, 10), _rand(512, 512, 0.05, 11)
     outs = []
