@@ -135,6 +135,34 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
                                     "mean_launch_ms": round(ms, 3)}
     except Exception as e:  # pragma: no cover
         extra["j1_roofline"] = {"error": repr(e)[:300]}
+    # -- the own MFMA GEMM core stand-alone: the weight gradient of gate|up at this step's token count (the largest own kernel of the step) --------------
+    try:
+        from prime_rl_amd import ops
+
+        if rank == 0 and "wgrad" in getattr(engine, "gemm_own", ()):
+            n = min(args.tokens_per_pass, args.micro_batches * args.seq_len)
+            dy = torch.randn(n, 2 * dims.intermediate_size, device=device).to(torch.bfloat16)
+            xin = torch.randn(n, dims.hidden_size, device=device).to(torch.bfloat16)
+            gbuf = torch.empty(2 * dims.intermediate_size, dims.hidden_size, dtype=torch.float32, device=device)
+            ops.gemm(dy.t(), xin.t(), out=gbuf)
+            evs = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm(dy.t(), xin.t(), out=gbuf, accumulate=True)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+            flop = 2.0 * n * 2 * dims.intermediate_size * dims.hidden_size
+            extra["gemm_roofline"] = {"kernel": "gemm_kernel<3, K-major, K-major> (pm_gemm_bf16: gate|up weight gradient, bf16 x bf16 -> f32 accumulate, random operands)",
+                                      "bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                      "frac": round(flop / (ms * 1e-3) / MFMA_BF16_PEAK, 4), "traffic": None, "flops_per_launch": flop, "tokens_per_launch": n,
+                                      "median_launch_ms": round(ms, 3),
+                                      "note": "the step's 145 weight-gradient GEMMs run on this kernel (27 % of the step); PMC: profiles/r03_gemm.md (MFMA busy 87.6 %)"}
+            del dy, xin, gbuf
+    except Exception as e:  # pragma: no cover
+        extra["gemm_roofline"] = {"error": repr(e)[:300]}
     # -- one MoE layer of config 4 (Qwen3-30B-A3B shapes), forward + backward, on the row-f4 kernels -----------------------------------------
     try:
         from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
@@ -162,7 +190,7 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
         flop = 3 * 3 * 2.0 * n * k * hidden_dim * inter  # three expert GEMMs, forward + two gradients each
         extra["moe_layer"] = {"shape": f"{n} tokens, {e} experts top-{k}, hidden {hidden_dim}, expert intermediate {inter} (Qwen3-30B-A3B layer), forward + backward",
                               "ms": round(ms, 3), "expert_gemm_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1),
-                              "note": "router, stable sort, gather, grouped MFMA GEMMs (pm_grouped_gemm_nt/nn/tn), combine; per-kernel numbers in profiles/r02_moe.md"}
+                              "note": "router, stable sort, gather, grouped MFMA GEMMs (pm_grouped_gemm_nt/nn/tn on the gemm.hip core), combine; per-kernel numbers in profiles/r02_moe.md, r03_gemm.md"}
         del layer, x, gy
     except Exception as ex:  # pragma: no cover
         extra["moe_layer"] = {"error": repr(ex)[:300]}

@@ -528,11 +528,15 @@ def transpose_2d(src: Tensor, out: Tensor | None = None) -> Tensor:
     return out
 
 
-def swiglu_fwd(gate_up: Tensor) -> Tensor:
+def swiglu_fwd(gate_up: Tensor, out: Tensor | None = None) -> Tensor:
     lib = _lib.load()
     _req(gate_up, torch.bfloat16, "gate_up")
     n, two_i = gate_up.shape
-    act = torch.empty((n, two_i // 2), dtype=torch.bfloat16, device=gate_up.device)
+    if out is not None:
+        _req(out, torch.bfloat16, "out")
+        if tuple(out.shape) != (n, two_i // 2):
+            raise PrimeMI355XError(f"swiglu_fwd: out must be [{n}, {two_i // 2}]")
+    act = out if out is not None else torch.empty((n, two_i // 2), dtype=torch.bfloat16, device=gate_up.device)
     check(lib.pm_swiglu_fwd(_p(gate_up), n, two_i // 2, _p(act), _stream()), "pm_swiglu_fwd")
     return act
 

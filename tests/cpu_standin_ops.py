@@ -162,9 +162,13 @@ def attn_varlen_bwd_rows(grad_out, q, k, v, out, lse, seq_start, softmax_scale, 
     return gq.to(BF16), gk.to(BF16), gv.to(BF16)
 
 
-def swiglu_fwd(gate_up):
+def swiglu_fwd(gate_up, out=None):
     i = gate_up.shape[1] // 2
-    return (torch.nn.functional.silu(gate_up[:, :i].float()).to(BF16).float() * gate_up[:, i:].float()).to(BF16)
+    act = (torch.nn.functional.silu(gate_up[:, :i].float()).to(BF16).float() * gate_up[:, i:].float()).to(BF16)
+    if out is not None:
+        out.copy_(act)
+        return out
+    return act
 
 
 @torch.enable_grad()  # also callable from inside an autograd.Function.backward (grad mode is off there)
