@@ -462,6 +462,11 @@ int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_b
                        int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream);
 int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
                        int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, void* stream);
+/* The same with the gradient written (accumulate = 0) or accumulated (1) in f32 straight into a main-gradient buffer [E, n_first, K] / [E, N - n_first, K]
+ * (gradient accumulation in f32: configs/trainer.py:233-237; the reference's autograd adds bf16 `.grad`s that FSDP then reduces in f32).  n_first, N, K
+ * multiples of 256. */
+int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
+                           int64_t k_dim, float* dw_f32, float* dw2_f32 /* nullable */, int32_t accumulate, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Dense bf16 GEMM of the scoring model (csrc/gemm.hip): OUT[M, N] = sum_K X[M, K] * W[N, K] (+ bias[N]), f32 accumulation on the MFMA units,

@@ -447,7 +447,7 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
   t.k = hi - lo;
   const bool second = n0 >= p.n_first;
   const int on = second ? p.m - p.n_first : p.n_first, on0 = second ? n0 - p.n_first : n0;
-  t.out = reinterpret_cast<unsigned char*>(second ? p.out2 : p.out) + (((int64_t)e * on + on0) * p.ldo + k0) * 2;
+  t.out = reinterpret_cast<unsigned char*>(second ? p.out2 : p.out) + (((int64_t)e * on + on0) * p.ldo + k0) * (p.out_f32 ? 4 : 2);
   t.ldo = p.ldo;
   t.m_valid = on - on0 < kTile ? on - on0 : kTile;
   t.n_valid = p.n - k0 < kTile ? p.n - k0 : kTile;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       float ss = 0.f;  // squared norm of what this lane stores (p.sumsq: the gradient-norm pass fused into the weight-gradient epilogue)
       unsigned char* stg = smem + kRing + wave * 4096;
       const int srow = lane_e >> 3, schunk = lane_e & 7;
-      const bool f32o = MODE == 0 && p.out_f32;
+      const bool f32o = (MODE == 0 || MODE == 3) && p.out_f32;  // f32 results: the dense product and the grouped weight gradient (accumulated in f32)
       const bool wide = f32o ? (p.n % 4 == 0) : (p.n % 8 == 0 && cur.ldo % 8 == 0);
       const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
       if (wide) {
@@ -784,10 +784,12 @@ int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_
   return PM_OK;
 }
 // dw[e] = dy[rows of e]^T . x[rows of e] : dy [M, n_dim], x [M, k_dim] -> dw [E, n_first, k_dim], dw2 [E, n_dim - n_first, k_dim]
-int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, bf16_t* dw, bf16_t* dw2,
-               hipStream_t st) {
+int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
+               int out_f32, int accumulate, hipStream_t st) {
   Params p;
   grouped_common(p, offsets, n_experts, n_first);
+  p.out_f32 = out_f32;
+  p.accumulate = out_f32 ? accumulate : 0;
   p.x = dy; p.w = x; p.out = dw; p.out2 = dw2;
   p.ldx = n_dim; p.ldw = k_dim; p.ldo = k_dim;
   p.m = (int)n_dim; p.n = (int)k_dim; p.k = 0;

@@ -616,8 +616,8 @@ int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t
                int64_t k_dim, bf16_t* y, hipStream_t st);
 int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
                int64_t k_out, bf16_t* dx, hipStream_t st);
-int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, bf16_t* dw, bf16_t* dw2,
-               hipStream_t st);
+int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
+               int out_f32, int accumulate, hipStream_t st);
 }  // namespace gm
 }  // namespace pm
 
@@ -693,7 +693,7 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
   if (g_nt_variant == 0 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
-    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, (bf16_t*)dw_bf16, (bf16_t*)dw2_bf16, as_stream(stream));
+    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_bf16, dw2_bf16, 0, 0, as_stream(stream));
     PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
     return PM_OK;
   }
@@ -710,3 +710,18 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
   PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
   return PM_OK;
 }
+
+// The weight gradient written (or accumulated) in f32 straight into a main-gradient buffer — what the dense engine's wgrad GEMMs do (pm_gemm_bf16 with an
+// f32 output): no bf16 gradient tensor, no separate bf16 -> f32 accumulation pass over the expert parameters.  Runs on the gemm.hip core only.
+extern "C" int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first,
+                                      int64_t n_dim, int64_t k_dim, float* dw_f32, float* dw2_f32, int32_t accumulate, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32: bad sizes");
+  PM_REQUIRE(offsets && dw_f32 && (n_rows == 0 || (dy_bf16 && x_bf16)) && (n_first == n_dim || dw2_f32), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32: null pointer");
+  PM_REQUIRE(n_first > 0 && n_first <= n_dim && gg_shapes_ok(n_rows, n_dim, k_dim) && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0, PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_tn_f32: n_first=%lld n=%lld k=%lld must be multiples of 256 (and the row tensors < 2 GiB)", (long long)n_first, (long long)n_dim,
+             (long long)k_dim);
+  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, as_stream(stream));
+  PM_CHECK_LAUNCH("pm_grouped_gemm_tn_f32");
+  return PM_OK;
+}
+

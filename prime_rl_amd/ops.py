@@ -781,6 +781,27 @@ def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None 
     return dw if n_first is None else (dw, dw2)
 
 
+def grouped_gemm_tn_f32_supported(n_first: int, n: int, k: int) -> bool:
+    return n_first % 256 == 0 and n % 256 == 0 and k % 256 == 0
+
+
+def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2: Tensor | None = None, accumulate: bool = False) -> None:
+    """dw[e] (+)= dy[group e, :n_first].T @ x[group e] and dw2[e] (+)= dy[group e, n_first:].T @ x[group e] in f32, written straight into the given
+    (main-gradient) buffers: dw [E, n_first, K], dw2 [E, N - n_first, K] or None."""
+    lib = _lib.load()
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(offsets, torch.int32, "offsets"); _req(dw, torch.float32, "dw")
+    e = offsets.numel() - 1
+    n, k = dy.shape[1], x.shape[1]
+    n1 = dw.shape[1]
+    if dy.shape[0] != x.shape[0] or tuple(dw.shape) != (e, n1, k) or (n1 < n) != (dw2 is not None):
+        raise PrimeMI355XError(f"grouped_gemm_tn_f32: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}")
+    if dw2 is not None:
+        _req(dw2, torch.float32, "dw2")
+        if tuple(dw2.shape) != (e, n - n1, k):
+            raise PrimeMI355XError(f"grouped_gemm_tn_f32: dw2 {tuple(dw2.shape)} != {(e, n - n1, k)}")
+    check(lib.pm_grouped_gemm_tn_f32(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _stream()), "pm_grouped_gemm_tn_f32")
+
+
 def sgd_step(master: Tensor, momentum_buf: Tensor | None, grad: Tensor, param_bf16: Tensor | None, lr: float, momentum: float, weight_decay: float,
              nesterov: bool, step: int, grad_scale: float = 1.0, clip: Tensor | None = None, zero_grad: bool = True) -> None:
     """torch.optim.SGD(momentum, nesterov, L2 weight decay) on flat f32 buffers (pm_sgd_step)."""

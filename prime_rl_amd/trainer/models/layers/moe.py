@@ -65,6 +65,19 @@ class BCFeedForward(nn.Module):
         nn.init.trunc_normal_(self.w3, mean=0.0, std=init_std)
 
 
+def _main_grads(*params):
+    """Megatron-style main gradients: a trainer engine that owns flat f32 gradient storage hangs `main_grad` (the f32 view of this parameter's slice)
+    and `main_grad_written` (a one-element list: has this step already written the slice?) on the expert parameters; the weight-gradient GEMM then
+    writes / accumulates there in f32 and autograd gets no `.grad` for them (trainer/module_engine.py).  None unless EVERY given parameter has one."""
+    out = []
+    for p in params:
+        mg, st = getattr(p, "main_grad", None), getattr(p, "main_grad_written", None)
+        if mg is None or st is None:
+            return None
+        out.append((mg, st))
+    return out
+
+
 class _GroupedLinearFn(torch.autograd.Function):
     """y[m] = x[m] @ w[expert of m].T over expert-sorted rows — `torch._grouped_mm(x, w.transpose(-2, -1), offs=...)` (moe.py:181-183) and its
     two gradients on the hand-written MFMA kernels of grouped_gemm.hip (pm_grouped_gemm_nt / nn / tn)."""
@@ -72,6 +85,7 @@ class _GroupedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, offsets):
         ctx.save_for_backward(x, w, offsets)
+        ctx.main_grads = _main_grads(w)
         return ops.grouped_gemm_nt(x, w, offsets)
 
     @staticmethod
@@ -79,7 +93,14 @@ class _GroupedLinearFn(torch.autograd.Function):
         x, w, offsets = ctx.saved_tensors
         g = g.contiguous()
         gx = ops.grouped_gemm_nn(g, w, offsets) if ctx.needs_input_grad[0] else None
-        gw = ops.grouped_gemm_tn(g, x, offsets) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            mg = ctx.main_grads
+            if mg is not None and ops.grouped_gemm_tn_f32_supported(w.shape[1], w.shape[1], w.shape[2]):
+                ops.grouped_gemm_tn_f32(g, x, offsets, mg[0][0], None, accumulate=mg[0][1][0])
+                mg[0][1][0] = True
+            else:
+                gw = ops.grouped_gemm_tn(g, x, offsets)
         return gx, gw, None
 
 
@@ -92,6 +113,7 @@ class _GroupedSwiGLUFn(torch.autograd.Function):
     def forward(ctx, x, w1, w3, offsets):
         gate_up = ops.grouped_gemm_nt(x, w1, offsets, w2=w3)
         ctx.save_for_backward(x, w1, w3, offsets, gate_up)
+        ctx.main_grads = _main_grads(w1, w3)
         return ops.swiglu_fwd(gate_up)
 
     @staticmethod
@@ -101,7 +123,13 @@ class _GroupedSwiGLUFn(torch.autograd.Function):
         gx = ops.grouped_gemm_nn(d_gate_up, w1, offsets, w2=w3) if ctx.needs_input_grad[0] else None
         gw1 = gw3 = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])
+            mg = ctx.main_grads
+            if mg is not None and ops.grouped_gemm_tn_f32_supported(w1.shape[1], w1.shape[1] + w3.shape[1], w1.shape[2]):
+                acc = mg[0][1][0]  # both halves were written by the same launches so far
+                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=acc)
+                mg[0][1][0] = mg[1][1][0] = True
+            else:
+                gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])
         return gx, gw1, gw3, None
 
 

@@ -28,6 +28,7 @@ optimizer is ONE fused `pm_adamw_step` launch and gradient reduction is one coll
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -128,6 +129,15 @@ class ModuleEngine:
                 else:  # an f32 parameter IS its master copy; its bf16 shadow is scratch for the fused kernel
                     p.data = self.master[off:off + n].view(p.shape)
                 self._grad_views.append(self.main_grad[off:off + n].view(p.shape))
+        # Expert parameters (97 % of an MoE model's weights) get their gradient written / accumulated in f32 by the grouped weight-gradient GEMM itself
+        # (layers/moe.py `_main_grads`): no bf16 `.grad` tensor and no bf16 -> f32 accumulation pass over them.  PM_MOE_MAIN_GRAD=0 is the A/B switch.
+        self._direct: list[nn.Parameter] = []
+        if self.device.type == "cuda" and os.environ.get("PM_MOE_MAIN_GRAD", "1") != "0":
+            direct_ids = {id(p) for m in model.modules() if isinstance(m, GroupedExperts) for p in m.parameters(recurse=False)}
+            for (pname, p, off), gv in zip(self.entries, self._grad_views):
+                if id(p) in direct_ids and p.dtype == torch.bfloat16:
+                    p.main_grad, p.main_grad_written = gv, [False]
+                    self._direct.append(p)
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
         self._param_readers: list = []
 
@@ -236,6 +246,8 @@ class ModuleEngine:
         coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)
         zero.apply_update(ops, o, self.master, self.exp_avg if self.exp_avg.numel() else None, self.exp_avg_sq if self.exp_avg_sq.numel() else None, g,
                           self.params_bf16, self.step_count, coef, zero_grad=True)
+        for p in self._direct:
+            p.main_grad_written[0] = False  # the buffer is zero again: the next step's first weight-gradient launch may overwrite
         return norm
 
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:

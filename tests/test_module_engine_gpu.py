@@ -117,6 +117,54 @@ def test_train_loop_on_a_qwen3_moe_model(tmp_path, capsys):
     assert ModuleDims(c).active_mm_params() == want
 
 
+def test_expert_gradients_written_in_f32_by_the_weight_gradient_gemm(monkeypatch):
+    """PM_MOE_MAIN_GRAD (default on): the grouped weight-gradient GEMM writes / accumulates the expert gradients in f32 straight into the engine's
+    flat main-gradient buffer (no bf16 `.grad`, no bf16 -> f32 accumulation pass).  Against the autograd path: same gradients up to the ONE bf16
+    rounding that path applies per pass, over two accumulated passes, and the same optimizer step."""
+    from prime_rl_amd.trainer.engine import OptimConfig, pack_micro_batches
+    from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+    from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+    from prime_rl_amd.trainer.module_engine import ModuleEngine
+    from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+    cfg = Qwen3MoeConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, num_experts=8,
+                         num_experts_per_tok=2, moe_intermediate_size=256, norm_topk_prob=True)
+    dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=4), seq_len=256)
+    mbs = dl.get_batch()
+    for mb in mbs:
+        mb["input_ids"] = mb["input_ids"] % cfg.vocab_size
+    passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+    grads, params, norms = {}, {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PM_MOE_MAIN_GRAD", mode)
+        torch.manual_seed(0)
+        with torch.device(DEV):
+            model = Qwen3MoeForCausalLM(cfg)
+        model = model.to(torch.bfloat16)
+        gen = torch.Generator(device=DEV).manual_seed(0)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.fill_(1.0) if p.dim() == 1 else p.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.05).to(p.dtype))
+        inject_prime_lm_head(model, chunk_size=8192)
+        eng = ModuleEngine(model, DEV, optim=OptimConfig(lr=1e-3))
+        assert (len(eng._direct) == 3 * cfg.num_hidden_layers) == (mode == "1")
+        scales = eng.global_scales(tuple(sum(p.local_counts[k] for p in passes) for k in range(3)))
+        for p in passes:
+            ctx = eng.forward_loss(p, scales)
+            eng.backward(ctx)
+        grads[mode] = eng.main_grad.clone()
+        if mode == "1":
+            assert all(p.grad is None and p.main_grad_written[0] for p in eng._direct)
+        norms[mode] = float(eng.optimizer_step())
+        params[mode] = eng.params_bf16.clone()
+        if mode == "1":
+            assert not any(p.main_grad_written[0] for p in eng._direct) and float(eng.main_grad.abs().max()) == 0.0
+    rel = ((grads["1"] - grads["0"]).norm() / grads["0"].norm()).item()
+    assert rel < 4e-3, rel  # the autograd path rounds every pass's expert gradient to bf16 before accumulating
+    assert abs(norms["1"] - norms["0"]) <= 2e-3 * norms["0"]
+    assert (params["1"] != params["0"]).float().mean().item() < 0.02
+
+
 def test_router_replay_through_rollout_files_and_train(tmp_path):
     """`enable_router_replay` end to end (train.py:349-360): rollouts written by the orchestrator-side sender carry `routed_experts` (what vLLM returns
     with --enable-return-routed-experts), travel the msgpack wire, are packed by prepare_batch, reach the MoE layers as forced expert indices.

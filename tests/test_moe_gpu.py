@@ -442,6 +442,38 @@ def test_grouped_gemm_two_weight_sets_equal_two_single_calls():
         o += c
 
 
+def test_grouped_weight_gradient_in_f32_written_and_accumulated_in_place():
+    """pm_grouped_gemm_tn_f32: dw (and dw2) in f32 straight into caller-owned buffers, first call overwrites (garbage in), second accumulates; ragged and
+    empty groups; the bf16-output kernel's result is this one rounded once."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(21)
+    e, n1, n2, k = 6, 512, 256, 768
+    sizes = [300, 0, 1, 255, 513, 64]
+    m = sum(sizes)
+    offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(m, n1 + n2, generator=g).to(torch.bfloat16).to(DEV)
+    assert ops.grouped_gemm_tn_f32_supported(n1, n1 + n2, k)
+    flat = torch.full((e * (n1 + n2) * k + 64,), float("nan"), dtype=torch.float32, device=DEV)  # views into one flat buffer, like a main-grad store
+    dw, dw2 = flat[:e * n1 * k].view(e, n1, k), flat[e * n1 * k:e * (n1 + n2) * k].view(e, n2, k)
+    ops.grouped_gemm_tn_f32(dy, x, offsets, dw, dw2, accumulate=False)
+    assert torch.isnan(flat[-64:]).all()  # nothing written past the views
+    o = 0
+    for i, c in enumerate(sizes):
+        ref = dy[o:o + c].float().T @ x[o:o + c].float()
+        got = torch.cat([dw[i], dw2[i]], 0)
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), i
+        o += c
+    b1, b3 = ops.grouped_gemm_tn(dy, x, offsets, n_first=n1)
+    assert torch.equal(b1, dw.to(torch.bfloat16)) and torch.equal(b3, dw2.to(torch.bfloat16))
+    first = flat[:e * (n1 + n2) * k].clone()
+    ops.grouped_gemm_tn_f32(dy, x, offsets, dw, dw2, accumulate=True)
+    assert torch.allclose(flat[:e * (n1 + n2) * k], 2 * first, rtol=1e-6, atol=0)
+    single = torch.empty(e, n1, k, dtype=torch.float32, device=DEV)
+    ops.grouped_gemm_tn_f32(dy[:, :n1].contiguous(), x, offsets, single)
+    assert torch.equal(single, first[:e * n1 * k].view(e, n1, k))
+
+
 def test_grouped_gemm_rejects_unsupported_shapes_loudly():
     ops = _ops()
     from prime_rl_amd._lib import PrimeMI355XError
