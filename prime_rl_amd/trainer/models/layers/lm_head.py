@@ -11,6 +11,7 @@ memory; with 2k-16k tokens the chunk lives in HBM/Infinity Cache between the GEM
 
 from __future__ import annotations
 
+import os
 import types
 from typing import TypedDict
 
@@ -120,6 +121,67 @@ class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
         return grad_hidden, grad_weight, None, None, None
 
 
+class _StoredLogitsLogProbEntropyFn(torch.autograd.Function):
+    """The same function with the bf16 logits KEPT in HBM between forward and backward (the flat engine's default, `lm_head_impl="library"`): on a
+    288 GB part 2 bytes x N x V is cheap (5 GB for 16 384 tokens of a 152k vocabulary), and it removes the recomputation GEMM of the chunked form
+    from the backward — forward = one GEMM (the MFMA core of csrc/gemm.hip, else the library) + the log-prob / entropy row kernel (K1), backward =
+    K1's backward IN PLACE on the stored logits + the two gradient GEMMs.  The weight gradient goes straight into an f32 `main_grad` when the
+    trainer engine hung one on the weight (layers/moe.py `_main_grads`).  Values: identical to the chunked form wherever that rounds logits to bf16."""
+
+    @staticmethod
+    def forward(ctx, hidden: Tensor, weight: Tensor, labels: Tensor, inv_temperature: Tensor, chunk_size: int):
+        n, vocab = hidden.shape[0], weight.shape[0]
+        dev = hidden.device
+        logprobs = torch.empty(n, dtype=torch.float32, device=dev)
+        entropy = torch.empty_like(logprobs)
+        logz = torch.empty_like(logprobs)
+        labels = labels.contiguous()
+        inv_t = inv_temperature.contiguous().float()
+        hidden, weight_c = hidden.contiguous(), weight.contiguous()
+        logits = torch.empty(n, vocab, dtype=torch.bfloat16, device=dev)
+        own = ops.gemm_supported(hidden[:1], weight_c)
+        for s0 in range(0, n, chunk_size):
+            s1 = min(s0 + chunk_size, n)
+            if own:
+                ops.gemm(hidden[s0:s1], weight_c, out=logits[s0:s1])
+            else:
+                torch.mm(hidden[s0:s1], weight_c.t(), out=logits[s0:s1])
+            lp, en, lz = ops.logprob_entropy_fwd(logits[s0:s1], labels[s0:s1], inv_t[s0:s1])
+            logprobs[s0:s1], entropy[s0:s1], logz[s0:s1] = lp, en, lz
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(hidden, weight_c, labels, inv_t, logz, logits)
+        ctx.chunk_size = chunk_size
+        mg, st = getattr(weight, "main_grad", None), getattr(weight, "main_grad_written", None)
+        ctx.main_grad = (mg, st) if (mg is not None and st is not None) else None
+        return logprobs, entropy
+
+    @staticmethod
+    def backward(ctx, grad_logprobs: Tensor, grad_entropy: Tensor | None):
+        assert grad_entropy is None, "Backward through entropy is not implemented in FusedOutputLinear"
+        assert grad_logprobs is not None, "FusedOutputLinear backward requires logprobs gradients"
+        hidden, weight, labels, inv_t, logz, logits = ctx.saved_tensors
+        n = hidden.shape[0]
+        needs_hidden, needs_weight = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_hidden = torch.empty_like(hidden) if needs_hidden else None
+        g = grad_logprobs.contiguous().float()
+        direct = ctx.main_grad if (needs_weight and ctx.main_grad is not None and ops.gemm_supported(logits[:128].t(), hidden[:128].t())) else None
+        grad_weight = torch.zeros_like(weight) if (needs_weight and direct is None) else None
+        for s0 in range(0, n, ctx.chunk_size):
+            s1 = min(s0 + ctx.chunk_size, n)
+            dl = ops.logprob_bwd(logits[s0:s1], labels[s0:s1], inv_t[s0:s1], logz[s0:s1], g[s0:s1], out=logits[s0:s1])
+            if needs_hidden:
+                if ops.gemm_supported(dl, weight.t()):
+                    ops.gemm(dl, weight.t(), out=grad_hidden[s0:s1])
+                else:
+                    torch.mm(dl, weight, out=grad_hidden[s0:s1])
+            if direct is not None:
+                ops.gemm(dl.t(), hidden[s0:s1].t(), out=direct[0], accumulate=direct[1][0])
+                direct[1][0] = True
+            elif needs_weight:
+                grad_weight.addmm_(dl.t(), hidden[s0:s1])
+        return grad_hidden, grad_weight, None, None, None
+
+
 class FusedOutputLinear(torch.nn.Linear):
     def __init__(self, in_features: int, out_features: int, chunk_size: int):
         super().__init__(in_features, out_features, bias=False)
@@ -132,7 +194,12 @@ class FusedOutputLinear(torch.nn.Linear):
         hidden_states = hidden_states.reshape(b * s, h).contiguous()
         labels = labels.reshape(b * s).contiguous()
         inv_t = 1.0 / temperature.reshape(b * s).contiguous()
-        logprobs, entropy = _SequenceChunkedLogProbEntropyFn.apply(hidden_states, self.weight, labels, inv_t, self.chunk_size)
+        # "stored" (default where it applies: bf16 on the GPU, logits within PM_LM_HEAD_LOGITS_GIB, default 24): keep the logits for the backward instead of
+        # recomputing them; "chunked": the reference's memory-saving form (lm_head.py:89-202) on the fused J1 kernel
+        stored = (os.environ.get("PM_MODULE_LM_HEAD", "stored") == "stored" and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+                  and self.weight.dtype == torch.bfloat16 and 2 * b * s * self.weight.shape[0] <= float(os.environ.get("PM_LM_HEAD_LOGITS_GIB", "24")) * 2**30)
+        fn = _StoredLogitsLogProbEntropyFn if stored else _SequenceChunkedLogProbEntropyFn
+        logprobs, entropy = fn.apply(hidden_states, self.weight, labels, inv_t, self.chunk_size)
         return PrimeLmOutput(logprobs=logprobs.reshape(b, s), entropy=entropy.reshape(b, s))
 
 

@@ -129,11 +129,14 @@ class ModuleEngine:
                 else:  # an f32 parameter IS its master copy; its bf16 shadow is scratch for the fused kernel
                     p.data = self.master[off:off + n].view(p.shape)
                 self._grad_views.append(self.main_grad[off:off + n].view(p.shape))
-        # Expert parameters (97 % of an MoE model's weights) get their gradient written / accumulated in f32 by the grouped weight-gradient GEMM itself
-        # (layers/moe.py `_main_grads`): no bf16 `.grad` tensor and no bf16 -> f32 accumulation pass over them.  PM_MOE_MAIN_GRAD=0 is the A/B switch.
+        # Expert parameters (97 % of an MoE model's weights) and the LM head get their gradient written / accumulated in f32 by the weight-gradient GEMM itself
+        # (layers/moe.py `_main_grads`, layers/lm_head.py `_StoredLogitsLogProbEntropyFn`): no bf16 `.grad` tensor and no bf16 -> f32 accumulation pass over them.  PM_MOE_MAIN_GRAD=0 is the A/B switch.
         self._direct: list[nn.Parameter] = []
         if self.device.type == "cuda" and os.environ.get("PM_MOE_MAIN_GRAD", "1") != "0":
+            from .models.layers.lm_head import FusedOutputLinear
+
             direct_ids = {id(p) for m in model.modules() if isinstance(m, GroupedExperts) for p in m.parameters(recurse=False)}
+            direct_ids |= {id(m.weight) for m in model.modules() if isinstance(m, FusedOutputLinear)}  # the LM head's weight gradient GEMM (stored-logits form)
             for (pname, p, off), gv in zip(self.entries, self._grad_views):
                 if id(p) in direct_ids and p.dtype == torch.bfloat16:
                     p.main_grad, p.main_grad_written = gv, [False]
