@@ -82,7 +82,9 @@ def encode_step(mbs: list[MicroBatch]) -> bytes:
     present = [name for name in _OPTIONAL if any(getattr(mb, name) is not None for mb in mbs)]
     header = dict(n_tokens=sum(counts), mb_tokens=counts, sample_lens=[s for mb in mbs for s in mb.sequence_lengths],
                   mb_samples=[len(mb.sequence_lengths) for mb in mbs], seq_lens=[s for mb in mbs for s in mb.seq_lens],
-                  mb_seqs=[len(mb.seq_lens) for mb in mbs], env_names=list(env_table), sample_env=sample_env, optional=present)
+                  mb_seqs=[len(mb.seq_lens) for mb in mbs], env_names=list(env_table), sample_env=sample_env, optional=present,
+                  # which micro-batches carried NO rl_weights stream (the filled 1.0s below lose that): `PackedBatch.rl_every_sample` needs it
+                  mb_no_rl=[mb.rl_weights is None for mb in mbs])
     if routed is not None:
         header["routed"] = routed
     hbytes = msgpack.packb(header, use_bin_type=True)
@@ -254,12 +256,17 @@ def blob_to_packed_batch(blob: StepBlob, device):
         tdt = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64}[dt.name]
         routed = dev_payload[off:off + cnt * dt.itemsize].view(tdt).view(n, r["layers"], r["top_k"]).to(torch.int32)
 
+    # rows of samples whose micro-batch had no rl_weights stream count for the rl metrics whatever their mask (pack_micro_batches sets the same flag)
+    no_rl = h.get("mb_no_rl")
+    every = None
+    if "rl_weights" in blob.offsets and no_rl is not None and any(no_rl):
+        every = small(np.repeat(np.asarray(no_rl, dtype=bool), h["mb_samples"]))
     return PackedBatch(input_ids=ids, position_ids=sec("position_ids", torch.int32).to(torch.int64), labels=labels,
                        inv_temp=1.0 / sec("temperatures", torch.float32), advantages=sec("advantages", torch.float32),
                        inference_logprobs=sec("inference_logprobs", torch.float32), loss_mask=sec("loss_mask", torch.uint8).view(torch.bool),
                        cu_seqlens=small(cu_seq), cu_samples=small(cu_smp), sample_starts_mb=small(starts), n_micro_batches=len(h["mb_tokens"]),
                        ref_logprobs=opt("ref_logprobs"), rl_weights=opt("rl_weights"), ce_weights=opt("ce_weights"),
-                       ref_kl_weights=opt("ref_kl_weights"), local_counts=(n_rl, n_ce, n_rk), routed_experts=routed)
+                       ref_kl_weights=opt("ref_kl_weights"), local_counts=(n_rl, n_ce, n_rk), routed_experts=routed, rl_every_sample=every)
 
 
 def step_file(output_dir: Path, step: int, rank: int) -> Path:

@@ -37,7 +37,7 @@ def _mb(rng: random.Random, n_samples: int, envs, with_ref=False, with_weights=F
 
 def _assert_packed_equal(a, b):
     for name in ("input_ids", "position_ids", "labels", "inv_temp", "advantages", "inference_logprobs", "loss_mask", "cu_seqlens", "cu_samples",
-                 "sample_starts_mb", "ref_logprobs", "rl_weights", "ce_weights", "ref_kl_weights"):
+                 "sample_starts_mb", "ref_logprobs", "rl_weights", "ce_weights", "ref_kl_weights", "rl_every_sample"):
         x, y = getattr(a, name), getattr(b, name)
         assert (x is None) == (y is None), name
         if x is not None:
@@ -63,6 +63,19 @@ def test_binary_wire_equals_msgpack_path(case):
         assert got["env_names"] == ref["env_names"] and got["sequence_lengths"] == ref["sequence_lengths"]
     # the blob is smaller than msgpack-of-lists (9-byte floats, per-token env strings) even at these toy sizes with 64-byte padding
     assert len(buf) < len(encode_micro_batches(mbs))
+
+
+def test_binary_wire_keeps_which_micro_batches_had_no_rl_stream():
+    """A step that mixes micro-batches with and without an rl_weights stream: the wire fills the absent ones with 1.0, and the per-sample flag the rl
+    metric rows depend on (`PackedBatch.rl_every_sample`, stats.collect_step_tensors) survives the trip exactly as pack_micro_batches builds it."""
+    rng = random.Random(5)
+    mbs = [_mb(rng, 3, ["math"], with_weights=(i == 1)) for i in range(3)]
+    want = pack_micro_batches([DataLoader._micro_batch_to_tensor(mb) for mb in decode_micro_batches(encode_micro_batches(mbs))], "cpu")
+    got = B.blob_to_packed_batch(B.decode_step(B.encode_step(mbs)), "cpu")
+    assert want.rl_every_sample is not None and want.rl_every_sample.tolist() == [True] * 3 + [False] * 3 + [True] * 3
+    assert got.rl_every_sample is not None and torch.equal(got.rl_every_sample, want.rl_every_sample)
+    none = [_mb(rng, 2, ["math"]) for _ in range(2)]  # no rl stream anywhere: no flag on either path
+    assert B.blob_to_packed_batch(B.decode_step(B.encode_step(none)), "cpu").rl_every_sample is None
 
 
 def test_binary_blob_rejects_corruption():
