@@ -42,7 +42,7 @@ def _batches(vocab, n_steps):
 
 
 @pytest.mark.parametrize("one_pass,tied", [(False, False), (True, False), (False, True)])
-def test_forced_collectives_step_equals_plain_step(rccl_world1, one_pass, tied):
+def test_forced_collectives_step_equals_plain_step(rccl_world1, one_pass, tied, monkeypatch):
     """Also the split reduction of the embedding bucket (engine._plan_embed_split) on the device, comm stream and all: dense part of the earlier
     pass reduce-scattered before the last pass, the last pass's rows all-gathered and added by pm_embedding_bwd_window — same f32 additions
     in the same order as the plain engine's accumulate-in-place, so still bit for bit.  `one_pass`: nothing dense; `tied`: the head gradient
@@ -53,6 +53,9 @@ def test_forced_collectives_step_equals_plain_step(rccl_world1, one_pass, tied):
 
     dims = dataclasses.replace(ModelDims.tiny(layers=2, vocab=512), tie_word_embeddings=tied)
     optim = OptimConfig(lr=1e-3, max_norm=0.5)
+    # the plain engine with the streaming norm pass: the epilogue-fused norm (its default) adds the same squares in another order, and this test is
+    # about the collective machinery being bit-transparent (fused vs streaming norm: test_fused_gradient_norm_equals_the_separate_pass)
+    monkeypatch.setenv("PM_FUSED_SUMSQ", "0")
     plain = GRPOEngine(dims, device=DEV, optim=optim, seed=5)
     forced = GRPOEngine(dims, device=DEV, optim=optim, seed=5, force_collectives=True)
     assert not plain.use_collectives and forced.use_collectives
