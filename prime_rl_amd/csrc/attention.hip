@@ -114,7 +114,7 @@ using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   if (kernel == 0) {
-    if (value > 3 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
+    if (value > 7 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
     g_fwd_var = value;
     return PM_OK;
   }
@@ -203,7 +203,8 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     case 0: PM_LAUNCH_FWD(0); break;
     case 1: PM_LAUNCH_FWD(1); break;
     case 2: PM_LAUNCH_FWD(2); break;
-    default: PM_LAUNCH_FWD(3); break;
+    case 3: PM_LAUNCH_FWD(3); break;
+    default: PM_LAUNCH_FWD(7); break;
   }
 #undef PM_LAUNCH_FWD
   PM_CHECK_LAUNCH(who);

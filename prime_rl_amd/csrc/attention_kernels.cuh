@@ -101,6 +101,37 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// The whole row-max reduction of one 16-row block of a 64-row score tile as ONE asm statement: max over the lane's 16 raw scores (v_max3 chain), then
+// across the four 16-lane rows of the wave (v_permlane32_swap / v_permlane16_swap).  As separate statements (max3_f32 / fmax_raw / xrow_max_swap) the same
+// work costs about twice the issue slots: hipcc pads every inline-asm statement with an `s_nop`, and the fmaxf calls between the swaps get canonicalising
+// `v_max_f32 x, x` in front of them — on a kernel that is bounded by VALU issue (profiles/r03_attention.md).  Same values, operation for operation.
+__device__ __forceinline__ float row_max16_xrow(const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) {
+  float mx, t;
+  asm volatile(
+      "v_max3_f32 %0, %2, %3, %4\n\t"
+      "v_max_f32 %0, %0, %5\n\t"
+      "v_max3_f32 %0, %0, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %8, %9\n\t"
+      "v_max3_f32 %0, %0, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\t"
+      "v_max3_f32 %0, %0, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %16, %17\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32 %0, %0, %1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32 %0, %0, %1"
+      : "=&v"(mx), "=&v"(t)
+      : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "v"(s2[0]), "v"(s2[1]), "v"(s2[2]), "v"(s2[3]),
+        "v"(s3[0]), "v"(s3[1]), "v"(s3[2]), "v"(s3[3]));
+  return mx;
+}
+
 __device__ __forceinline__ float xrow_max_swap(float v) {
   float a = v, b = v;
   permlane32_swap(a, b);  // a = [v.lo, v.lo], b = [v.hi, v.hi]
@@ -586,7 +617,9 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     float mx;
-    if constexpr (OPT & 1) {
+    if constexpr ((OPT & 4) != 0) {
+      mx = row_max16_xrow(st[cb][0], st[cb][1], st[cb][2], st[cb][3]) * sc2;
+    } else if constexpr (OPT & 1) {
       mx = max3_f32(st[cb][0][0], st[cb][0][1], st[cb][0][2]);
       mx = fmax_raw(mx, st[cb][0][3]);
 #pragma unroll
@@ -601,7 +634,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[cb][nb][r]);
     }
-    mx = xrow_max_swap(mx) * sc2;
+    if constexpr ((OPT & 4) == 0) mx = xrow_max_swap(mx) * sc2;
     const float m_new = fmaxf(m[cb], mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = fast_exp2(m[cb] - m_use);
