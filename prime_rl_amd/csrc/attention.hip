@@ -104,7 +104,7 @@ static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
 // boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
 // workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
-constexpr int kFwdDefaultOpt = 3;
+constexpr int kFwdDefaultOpt = 15;  // 1 | 2 | 4 (row-max reduction as one asm block) | 8 (16-byte epilogue stores)
 static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.cuh); -1 = the default build
 static int g_dkdv_var = 0;
 static int g_dq_var = 0;
@@ -114,7 +114,7 @@ using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   if (kernel == 0) {
-    if (value > 7 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
+    if (value > 15 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
     g_fwd_var = value;
     return PM_OK;
   }
@@ -204,7 +204,8 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     case 1: PM_LAUNCH_FWD(1); break;
     case 2: PM_LAUNCH_FWD(2); break;
     case 3: PM_LAUNCH_FWD(3); break;
-    default: PM_LAUNCH_FWD(7); break;
+    case 7: PM_LAUNCH_FWD(7); break;
+    default: PM_LAUNCH_FWD(15); break;
   }
 #undef PM_LAUNCH_FWD
   PM_CHECK_LAUNCH(who);
@@ -257,10 +258,10 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
 #define PM_LAUNCH_DKDV(MINB_, FB_, QT_)                                                                                                           \
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q,     \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
-                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0)
-  if (g_dkdv_var == 1) PM_LAUNCH_DKDV(2, 2, 64);
-  else if (g_dkdv_var == 2) PM_LAUNCH_DKDV(2, 8, 64);
-  else if (g_dkdv_var == 3) PM_LAUNCH_DKDV(3, 4, 32);
+                     softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0)
+  if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64);
+  else if ((g_dkdv_var & 15) == 2) PM_LAUNCH_DKDV(2, 8, 64);
+  else if ((g_dkdv_var & 15) == 3) PM_LAUNCH_DKDV(3, 4, 32);
   else PM_LAUNCH_DKDV(2, 4, 64);
 #undef PM_LAUNCH_DKDV
   PM_CHECK_LAUNCH(who);
@@ -268,8 +269,8 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
 #define PM_LAUNCH_DQ(KT_)                                                                                                                        \
   hipLaunchKernelGGL((attn_bwd_dq_kernel<2, KT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                      (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, softmax_scale,    \
-                     (bf16_t*)grad_q, (int)q_row0)
-  if (g_dq_var == 1) PM_LAUNCH_DQ(32);
+                     (bf16_t*)grad_q, (int)q_row0, (g_dq_var & 16) ? 1 : 0)
+  if ((g_dq_var & 15) == 1) PM_LAUNCH_DQ(32);
   else PM_LAUNCH_DQ(64);
 #undef PM_LAUNCH_DQ
   PM_CHECK_LAUNCH(who);

@@ -101,11 +101,33 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// Epilogue of the transposed products: a lane (lr = row, lq) holds, of every 16-wide block nb of its row, the 4 values d = nb*16 + lq*4 .. +3 — stored
+// directly that is 8 x 8-byte stores per row (st8_bf16).  16-byte form: the lanes lq = 2a and 2a + 1 hold d = 8a .. 8a+3 and 8a+4 .. 8a+7 of a block, so for
+// a PAIR of blocks the even lane hands its part of the second block to its partner and receives the partner's part of the first (v_permlane16_swap: odd
+// 16-lane rows of one register <-> even rows of the other): 4 x 16-byte stores per lane instead of 8 x 8 — the store tail of a workgroup is store-ISSUE
+// bound (MI355X_MICROARCH.md).  ALL lanes must call it (cross-lane swaps); `ok` = this lane's row exists; row0 = address of d = 0 of the row.
+__device__ __forceinline__ void store_row_blocks16(bf16_t* row0, const f32x4 (&acc)[8], float mul, int lq, bool ok) {
+  bf16_t* op = row0 + (lq >> 1) * 8 + (lq & 1) * 16;
+#pragma unroll
+  for (int nb = 0; nb < 8; nb += 2) {
+    const f32x4 &a = acc[nb], &b = acc[nb + 1];
+    float x0 = __uint_as_float(pack_bf16_hw(a[0] * mul, a[1] * mul)), x1 = __uint_as_float(pack_bf16_hw(a[2] * mul, a[3] * mul));
+    float y0 = __uint_as_float(pack_bf16_hw(b[0] * mul, b[1] * mul)), y1 = __uint_as_float(pack_bf16_hw(b[2] * mul, b[3] * mul));
+    permlane16_swap(x0, y0);  // even lanes: (x, y) = (own part of block nb, partner's part of it); odd lanes: (partner's part of block nb + 1, own part)
+    permlane16_swap(x1, y1);
+    if (ok) *reinterpret_cast<u32x4*>(op + nb * 16) = u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(y0), __float_as_uint(y1)};
+  }
+}
+
 // The whole row-max reduction of one 16-row block of a 64-row score tile as ONE asm statement: max over the lane's 16 raw scores (v_max3 chain), then
 // across the four 16-lane rows of the wave (v_permlane32_swap / v_permlane16_swap).  As separate statements (max3_f32 / fmax_raw / xrow_max_swap) the same
 // work costs about twice the issue slots: hipcc pads every inline-asm statement with an `s_nop`, and the fmaxf calls between the swaps get canonicalising
 // `v_max_f32 x, x` in front of them — on a kernel that is bounded by VALU issue (profiles/r03_attention.md).  Same values, operation for operation.
-__device__ __forceinline__ float row_max16_xrow(const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) {
+// Also in the block: mx * sc2, the new running maximum max(m_old, mx * sc2), and the value the exponent subtracts — m_new clamped to -FLT_MAX, which
+// stands in for the "(m_new == -inf) ? 0 : m_new" select (two compares' worth of issue slots and a vcc hazard less): while every score so far is -inf,
+// exp2(-inf - (-FLT_MAX)) = exp2(-inf) = 0 exactly like exp2(-inf - 0), for the scores and for the rescale factor alike; a finite maximum is unchanged.
+__device__ __forceinline__ void row_max16_xrow(const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3, float m_old, float sc2, float& m_new,
+                                               float& m_use) {
   float mx, t;
   asm volatile(
       "v_max3_f32 %0, %2, %3, %4\n\t"
@@ -125,11 +147,15 @@ __device__ __forceinline__ float row_max16_xrow(const f32x4& s0, const f32x4& s1
       "s_nop 1\n\t"
       "v_permlane16_swap_b32 %0, %1\n\t"
       "s_nop 1\n\t"
-      "v_max_f32 %0, %0, %1"
+      "v_max_f32 %0, %0, %1\n\t"
+      "v_mul_f32 %0, %0, %19\n\t"
+      "v_max_f32 %0, %18, %0\n\t"
+      "v_max_f32 %1, 0xff7fffff, %0"
       : "=&v"(mx), "=&v"(t)
       : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "v"(s2[0]), "v"(s2[1]), "v"(s2[2]), "v"(s2[3]),
-        "v"(s3[0]), "v"(s3[1]), "v"(s3[2]), "v"(s3[3]));
-  return mx;
+        "v"(s3[0]), "v"(s3[1]), "v"(s3[2]), "v"(s3[3]), "v"(m_old), "v"(sc2));
+  m_new = mx;
+  m_use = t;
 }
 
 __device__ __forceinline__ float xrow_max_swap(float v) {
@@ -261,7 +287,7 @@ template <int MINB, int FB, int QT>
 __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
     const float* __restrict__ nlse, const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
-    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride, int q_row0) {
+    float scale, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t dv_stride, int q_row0, int narrow_stores) {
   // nlse = -lse / scale, ndelta = -delta, both [hq][nq] (attn_delta_kernel)
   // Row window (context parallelism with gathered K / V, pm_attn_varlen_*_rows): k, v, seq_start, dk, dv hold rows [0, n) of the pass, the q-side
   // arrays (q, dout, nlse, ndelta) only the rows [q_row0, n) this rank owns, addressed as row - q_row0; q_row0 is a multiple of 128, so no q
@@ -369,7 +395,14 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     step(smA, smB, j);
     if (j + 1 < total_iters) step(smB, smA, j + 1);
   }
-  if (!active || kvi >= n) return;
+  if (!active) return;  // wave-uniform
+  if (!narrow_stores) {
+    const int row = kvi < n ? kvi : n - 1;
+    store_row_blocks16(dk + ((int64_t)row * hkv + kvh) * kD, dkt, scale, lq, kvi < n);
+    store_row_blocks16(dv + (int64_t)row * dv_stride + (int64_t)kvh * kD, dvt, 1.0f, lq, kvi < n);
+    return;
+  }
+  if (kvi >= n) return;
   bf16_t* pk_ = dk + ((int64_t)kvi * hkv + kvh) * kD + lq * 4;
   bf16_t* pv_ = dv + (int64_t)kvi * dv_stride + (int64_t)kvh * kD + lq * 4;
 #pragma unroll
@@ -464,7 +497,7 @@ template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                   int64_t v_stride, const bf16_t* __restrict__ dout, const float* __restrict__ nlse,
                                                                   const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64,
-                                                                  int hq, int hkv, float scale, bf16_t* __restrict__ dq, int q_row0) {
+                                                                  int hq, int hkv, float scale, bf16_t* __restrict__ dq, int q_row0, int narrow_stores) {
   // q_row0: see attn_bwd_dkdv_kernel — q, dout, nlse, ndelta, dq hold rows [q_row0, n) only
   __shared__ __attribute__((aligned(16))) unsigned char smA[kV5DqBufBytes<KT>];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kV5DqBufBytes<KT>];
@@ -555,7 +588,10 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
   if (!active) return;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    if (qi[cb] < n) {
+    if (!narrow_stores) {
+      const int row = qi[cb] < n ? qi[cb] : n - 1;
+      store_row_blocks16(dq + ((int64_t)(row - q_row0) * hq + qh) * kD, dqt[cb], scale, lq, qi[cb] < n);
+    } else if (qi[cb] < n) {
       bf16_t* op = dq + ((int64_t)(qi[cb] - q_row0) * hq + qh) * kD + lq * 4;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, dqt[cb][nb], scale);
@@ -616,9 +652,9 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
   // 16-lane rows of the wave through v_permlane32_swap / v_permlane16_swap (VALU) instead of ds_bpermute round trips.
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    float mx;
+    float mx = 0.f, m_new4 = 0.f, m_use4 = 0.f;
     if constexpr ((OPT & 4) != 0) {
-      mx = row_max16_xrow(st[cb][0], st[cb][1], st[cb][2], st[cb][3]) * sc2;
+      row_max16_xrow(st[cb][0], st[cb][1], st[cb][2], st[cb][3], m[cb], sc2, m_new4, m_use4);
     } else if constexpr (OPT & 1) {
       mx = max3_f32(st[cb][0][0], st[cb][0][1], st[cb][0][2]);
       mx = fmax_raw(mx, st[cb][0][3]);
@@ -635,8 +671,8 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[cb][nb][r]);
     }
     if constexpr ((OPT & 4) == 0) mx = xrow_max_swap(mx) * sc2;
-    const float m_new = fmaxf(m[cb], mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float m_new = (OPT & 4) ? m_new4 : fmaxf(m[cb], mx);
+    const float m_use = (OPT & 4) ? m_use4 : ((m_new == -INFINITY) ? 0.f : m_new);
     const float alpha = fast_exp2(m[cb] - m_use);
     f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -646,7 +682,8 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[r] = fast_exp2(e[r]);
       st[cb][nb] = p;
-      sum4 += p;
+      if ((OPT & 4) && nb == 0) sum4 = p;  // 0 + p is p: two packed adds less per block
+      else sum4 += p;
     }
     l[cb] = l[cb] * alpha + ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));  // per-lane partial row sum; reduced across lq at the end
     m[cb] = m_new;
@@ -765,9 +802,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     if (qi[cb] < n) {
       const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
       bf16_t* op = out + ((int64_t)(qi[cb] - q_row0) * hq + qh) * kD + lq * 4;
+      if constexpr ((OPT & 8) == 0) {
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, ot[cb][nb], inv);
+        for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, ot[cb][nb], inv);
+      }
       if (lq == 0) lse[(int64_t)qh * nq + qi[cb] - q_row0] = m[cb] * 0.69314718055994530942f + logf(lsum);
+    }
+    if constexpr ((OPT & 8) != 0) {
+      const int row = qi[cb] < n ? qi[cb] : n - 1;
+      store_row_blocks16(out + ((int64_t)(row - q_row0) * hq + qh) * kD, ot[cb], lsum > 0.f ? 1.0f / lsum : 0.f, lq, qi[cb] < n);
     }
   }
 }
