@@ -185,8 +185,9 @@ __device__ __forceinline__ void dma_pieces(__amdgpu_buffer_rsrc_t ra, __amdgpu_b
                                            const int* off_b, int base_a, int base_b) {
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + i * 1024), 16, off_a[i] + base_a, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + b_shift + i * 1024), 16, off_b[i] + base_b, 0, 0, 0);
+    // the tile's base offset rides in the instruction's SCALAR offset: no per-piece vector add (the kernels are bounded by VALU issue)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + i * 1024), 16, off_a[i], base_a, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + b_shift + i * 1024), 16, off_b[i], base_b, 0, 0);
   }
 }
 
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   __shared__ int s_ntiles;
   const int n = (int)n64;
   const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
+  const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (m0) stay on the scalar unit
   const int lr = lane & 15, lq = lane >> 4;
   const int group = hq / hkv;
   const int kvh = blockIdx.x % hkv;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
   constexpr int PPW = KT / 16;       // 1 KiB DMA pieces per wave per operand tile
   const int n = (int)n64;
   const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
+  const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (m0) stay on the scalar unit
   const int lr = lane & 15, lq = lane >> 4;
   const int group = hq / hkv;
   int b = blockIdx.x;
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   constexpr int PPW = 4;  // 1 KiB DMA pieces per wave per operand tile (64 rows x 256 B over 4 waves)
   const int n = (int)n64;
   const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
+  const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (m0) stay on the scalar unit
   const int lr = lane & 15, lq = lane >> 4;
   const int group = hq / hkv;
   int b = blockIdx.x;
