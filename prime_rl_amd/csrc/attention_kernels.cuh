@@ -606,7 +606,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
 // lane of the wave needs it for (diagonal / document-boundary tiles), so interior tiles carry no compare / select code.
 constexpr int kV5FwdBufBytes = 2 * 64 * kD * 2;  // K [64][128] then V [64][128]
 
-template <int OPT>  // A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved (default 3:
+template <int OPT>  // A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved, 4 = the row-max reduction as ONE
+                    // asm statement + clamp instead of the -inf select, 8 = 16-byte epilogue stores (default 15; profiles/r03_attention.md section 4); (bits 1 | 2:
                     // 0.3314 -> 0.3257 ms, bit-identical; an explicit v_pk_fma_f32 for the scale-and-subtract was 4 % SLOWER: pair-building moves)
 __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[2][4],
                                          const int (&qi)[2], const int (&lo)[2], float (&m)[2], float (&l)[2], f32x4 (&ot)[2][8]) {
