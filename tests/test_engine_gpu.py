@@ -527,6 +527,37 @@ def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
     assert (params["1"] != params["0"]).float().mean().item() < 0.01  # an ulp of the clip coefficient may flip a few bf16 roundings
 
 
+@pytest.mark.parametrize("own", ["all", "none", "wgrad,dgrad"])
+def test_engine_step_is_the_same_whichever_gemms_run_on_the_own_core(monkeypatch, own):
+    """PM_GEMM_OWN selects which of the step's GEMM classes run on csrc/gemm.hip instead of the library: every choice computes the same step — bf16
+    products of the same operands with f32 accumulation differ only in summation order (loss to 1e-5, gradients to 1e-3 of their norm, the same
+    parameters after two optimizer steps up to a few bf16 roundings)."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=1024)
+    mbs = _mbs(dims.vocab_size, 256, 4, True)
+    passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+    res = {}
+    for sel in ("wgrad", own):
+        monkeypatch.setenv("PM_GEMM_OWN", sel)
+        eng = GRPOEngine(dims, device=DEV, seed=7, optim=OptimConfig(lr=1e-3, max_norm=1.0))
+        assert eng.gemm_own == ({"fwd", "dgrad", "wgrad"} if sel == "all" else set() if sel == "none" else set(sel.split(",")))
+        scales = eng.global_scales(tuple(sum(p.local_counts[k] for p in passes) for k in range(3)))
+        losses = []
+        for i, p in enumerate(passes):
+            ctx = eng.forward(p); eng.loss(ctx, scales); eng.backward(ctx, accumulate=i > 0, last_pass=i == len(passes) - 1)
+            losses.append(float(ctx["loss"]))
+        grad = eng.store.main_grad.clone()
+        norm = float(eng.optimizer_step())
+        eng.step(passes[0])
+        res[sel] = (losses, grad, norm, eng.store.params.clone())
+    (la, ga, na, pa), (lb, gb, nb, pb) = res["wgrad"], res[own]
+    assert all(abs(x - y) <= 1e-5 for x, y in zip(la, lb)), (la, lb)
+    assert ((ga - gb).norm() / ga.norm()).item() <= 1e-3
+    assert abs(na - nb) <= 1e-3 * na
+    assert torch.allclose(pa.float(), pb.float(), rtol=0, atol=4e-3) and (pa != pb).float().mean().item() < 0.05
+
+
 def test_gemm_layout_copies_track_parameter_updates():
     """The K-contiguous weight copies used by dgrad (and the transposed MLP inputs used by wgrad) change only the operand layout:
     gradients equal the plain-layout engine's up to GEMM summation order, also AFTER optimizer steps moved the weights (a stale
