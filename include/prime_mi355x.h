@@ -488,6 +488,14 @@ int pm_gemm_bf16(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* 
 int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n);
 int pm_gemm_bf16_sumsq(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, float* out_f32, int64_t ldo,
                        int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream);
+/* The general form: optional per-tile sums of squares (as pm_gemm_bf16_sumsq) and an optional workspace of pm_gemm_workspace_bytes(m, n, k) bytes.  With the
+ * workspace, an f32 product without bias whose tile count leaves at most half of the LAST round of 256 tiles occupied (e.g. the q|k|v weight gradient of
+ * Qwen3-8B: 384 tiles = 1.5 rounds) computes that round split along K — 2 or 4 workgroups per tile on different XCDs, partial tiles in the workspace, a small
+ * reduction kernel adds them in a fixed order (deterministic) — instead of leaving half of the chip idle for a whole tile time. */
+int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
+                    int32_t out_dtype, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n, int64_t k,
+                    float* tile_sumsq /* nullable */, int64_t tile_sumsq_len, void* workspace /* nullable */, int64_t workspace_bytes, void* stream);
 int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced fragment reads */
 
 /* --------------------------------------------------------------------------------------------

@@ -145,6 +145,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_gemm_supported": (I, [I64, I64, I64, I32, I32]),
     "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P]),
     "pm_gemm_sumsq_slots": (I64, [I64, I64]),
+    "pm_gemm_workspace_bytes": (I64, [I64, I64, I64]),
+    "pm_gemm_bf16_ws": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P, I64, P, I64, P]),
     "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, P]),
     "pm_gemm_debug_set_variant": (I, [I32]),
 }

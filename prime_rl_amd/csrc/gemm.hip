@@ -70,6 +70,11 @@ struct Params {
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
   int accumulate;     // f32 out only: out += product
+  // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
+  // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
+  // whole f32 tiles into `split_ws` ([tail tile][part - 1][256 x 256]) and splitk_reduce_kernel adds them in part order (deterministic).
+  int split_s, split_rp, split_v0, split_k;
+  float* split_ws;
   float* sumsq;       // f32 out only, optional: [n_blocks][8] — every wave writes the sum of squares of the FINAL values it stored for tile v to [v][wave]
   // grouped products over expert-sorted rows (MODE 1-3 of gemm_kernel; see the tile sources below)
   const int32_t* offsets;  // [n_experts + 1] on the device: rows of expert e = [offsets[e], offsets[e + 1])
@@ -96,6 +101,28 @@ __device__ __forceinline__ bool tile_of_block(int b, int tiles_m, int tiles_n, i
   tm = (patch % patches_m) * 8 + (within & 7);
   tn = (patch / patches_m) * 4 + (within >> 3);
   return tm < tiles_m && tn < tiles_n;
+}
+struct SplitPlan {
+  int s, rp, k_part;
+  int64_t ws_bytes;
+};
+// How the last round of tiles is split along K: rp = patches of the last round (of 8 XCD slots), s = parts per patch (2 or 4), k_part = contraction
+// length of a part (a multiple of 128).  s = 1: no split (full last round, or more than half of it occupied, or a short contraction).
+static inline SplitPlan plan_split(int tiles_m, int tiles_n, int64_t k) {
+  const int patches = ((tiles_m + 7) / 8) * ((tiles_n + 3) / 4);
+  const int rp = patches % 8;
+  SplitPlan sp{1, rp, 0, 0};
+  if (rp == 0 || rp > 4) return sp;
+  int s = rp == 1 ? 4 : rp == 2 ? 4 : 2;
+  if (k < 8192) return sp;                         // measured: below ~8k the per-unit prologue / epilogue and the reduction eat the gain (profiles/r03_gemm.md)
+  while (s > 1 && k < (int64_t)s * 4096) s >>= 1;
+  if (s == 1) return sp;
+  const int64_t k_part = (k + s - 1) / s;
+  sp.k_part = (int)((k_part + 127) / 128 * 128);
+  sp.s = (int)((k + sp.k_part - 1) / sp.k_part);
+  if (sp.s < 2) { sp.s = 1; return sp; }
+  sp.ws_bytes = (int64_t)rp * 32 * (sp.s - 1) * kTile * kTile * 4;
+  return sp;
 }
 static inline int grid_blocks(int tiles_m, int tiles_n) {
   const int patches = ((tiles_m + 7) / 8) * ((tiles_n + 3) / 4);
@@ -379,19 +406,33 @@ template <int MODE, bool XK, bool WK>
 __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, Tile& t) {
   t.first = t.last = true;
   if (MODE == 0) {
-    int tm, tn;
-    if (!tile_of_block(v, p.tiles_m, p.tiles_n, tm, tn)) return false;
+    int tm, tn, kpart = 0, vv = v;
+    if (p.split_s > 1 && v >= p.split_v0) {  // last round, split: XCD slot x computes K-part x / rp of tail patch x % rp
+      const int x = v & 7;
+      if (x >= p.split_rp * p.split_s) return false;
+      kpart = x / p.split_rp;
+      vv = (v & ~7) | (x - kpart * p.split_rp);
+    }
+    if (!tile_of_block(vv, p.tiles_m, p.tiles_n, tm, tn)) return false;
     const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
-    t.xb = p.x + (XK ? m0 : m0 * p.ldx);
-    t.wb = p.w + (WK ? n0 : n0 * p.ldw);
+    const int64_t k0 = (int64_t)kpart * p.split_k;
+    const int klen = p.split_s > 1 && v >= p.split_v0 ? (int)(p.k - k0 < p.split_k ? p.k - k0 : p.split_k) : p.k;
+    t.xb = p.x + (XK ? m0 + k0 * p.ldx : m0 * p.ldx + k0);
+    t.wb = p.w + (WK ? n0 + k0 * p.ldw : n0 * p.ldw + k0);
     t.x_rows = p.m - m0;
     t.w_rows = p.n - n0;
-    t.k = p.k;
-    t.out = reinterpret_cast<unsigned char*>(p.out) + (m0 * p.ldo + n0) * (p.out_f32 ? 4 : 2);
-    t.ldo = p.ldo;
+    t.k = klen;
+    if (kpart == 0) {
+      t.out = reinterpret_cast<unsigned char*>(p.out) + (m0 * p.ldo + n0) * (p.out_f32 ? 4 : 2);
+      t.ldo = p.ldo;
+    } else {  // a private f32 tile of the workspace: tail tile = (patch slot, position inside the patch)
+      const int tail_tile = (vv & 7) * 32 + ((vv >> 3) & 31);
+      t.out = reinterpret_cast<unsigned char*>(p.split_ws + ((int64_t)tail_tile * (p.split_s - 1) + (kpart - 1)) * (kTile * kTile));
+      t.ldo = kTile;
+    }
     t.m_valid = (int)(p.m - m0 < kTile ? p.m - m0 : kTile);
     t.n_valid = (int)(p.n - n0 < kTile ? p.n - n0 : kTile);
-    t.nk = k_tiles(p.k);
+    t.nk = k_tiles(klen);
     return true;
   }
   // grouped: block v runs on XCD v % 8; the `ncol` column tiles of one row tile (MODE 1, 2) / the tiles of one expert (MODE 3) are consecutive ids of ONE
@@ -728,7 +769,7 @@ static void launch(const Params& p, hipStream_t st) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
-  const int v = g_variant & ~4;
+  const int v = g_variant & ~(4 | 32);
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
@@ -743,12 +784,59 @@ static void launch_grouped(const Params& p, hipStream_t st) {
   launch_v<3, XK, WK, MODE>(p, st, grid);
 }
 
+// out[tile] += sum over parts >= 1 of the workspace tiles of a split tail tile, in part order; with `sumsq` also the sum of squares of the FINAL tile.
+// Eight workgroups per tail tile slot (32 rows each, 16-byte accesses); workgroup j's partial of the squared norm goes to wave slot j of part 0's unit,
+// the slots the GEMM epilogues wrote for the other parts of this tile are reset by workgroup 0.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Params p) {
+  __shared__ float red[4];
+  const int slot = blockIdx.x >> 3, sub = blockIdx.x & 7;  // (patch slot, position inside the patch), 32-row band
+  const int x0 = slot >> 5, within = slot & 31;
+  const int vv = p.split_v0 + within * 8 + x0;
+  int tm, tn;
+  if (!tile_of_block(vv, p.tiles_m, p.tiles_n, tm, tn)) return;
+  const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
+  const int mv = (int)(p.m - m0 < kTile ? p.m - m0 : kTile), nv = (int)(p.n - n0 < kTile ? p.n - n0 : kTile);
+  float* out = reinterpret_cast<float*>(p.out) + m0 * p.ldo + n0;
+  const float* ws = p.split_ws + (int64_t)slot * (p.split_s - 1) * (kTile * kTile);
+  const int parts = (p.k + p.split_k - 1) / p.split_k;
+  const int c = (threadIdx.x & 63) * 4;  // 64 lanes x 16 bytes = one 256-float row; the 4 waves take 4 rows at a time
+  float ss = 0.f;
+  const bool vec = nv == kTile && (p.ldo & 3) == 0;
+#pragma unroll 2
+  for (int r = sub * 32 + (threadIdx.x >> 6); r < sub * 32 + 32 && r < mv; r += 4) {
+    if (vec) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(out + (int64_t)r * p.ldo + c);
+      for (int q = 1; q < parts; ++q) v += *reinterpret_cast<const f32x4*>(ws + (int64_t)(q - 1) * (kTile * kTile) + r * kTile + c);
+      *reinterpret_cast<f32x4*>(out + (int64_t)r * p.ldo + c) = v;
+      ss = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], ss))));
+    } else {
+      for (int e = 0; e < 4 && c + e < nv; ++e) {
+        float v = out[(int64_t)r * p.ldo + c + e];
+        for (int q = 1; q < parts; ++q) v += ws[(int64_t)(q - 1) * (kTile * kTile) + r * kTile + c + e];
+        out[(int64_t)r * p.ldo + c + e] = v;
+        ss = fmaf(v, v, ss);
+      }
+    }
+  }
+  if (p.sumsq) {
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) p.sumsq[(int64_t)((vv & ~7) | x0) * 8 + sub] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (sub == 0 && threadIdx.x >= 8 && threadIdx.x < 8 * p.split_s) {  // wave slots of the units of parts >= 1
+      const int part = threadIdx.x >> 3, w = threadIdx.x & 7;
+      p.sumsq[(int64_t)((vv & ~7) | (part * p.split_rp + x0)) * 8 + w] = 0.f;
+    }
+  }
+}
+
 // ---- grouped products on the same core (called by the pm_grouped_gemm_* entry points in grouped_gemm.hip) ----------------------------------------
 static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int64_t n_first) {
   p.bias = nullptr;
   p.out_f32 = 0;
   p.accumulate = 0;
   p.sumsq = nullptr;
+  p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
   p.offsets = offsets;
   p.n_experts = n_experts;
   p.n_first = (int)n_first;
@@ -825,21 +913,23 @@ extern "C" int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n) {
 }
 
 static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
-                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* stream);
+                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                             int32_t out_dtype, const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, void* stream) {
-  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, nullptr, stream);
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int pm_gemm_bf16_sumsq(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, float* out, int64_t ldo,
                                   int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream) {
   PM_REQUIRE(tile_sumsq && tile_sumsq_len >= pm_gemm_sumsq_slots(m, n), PM_ERR_WORKSPACE, "pm_gemm_bf16_sumsq: tile_sumsq needs pm_gemm_sumsq_slots(m, n) floats");
-  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, PM_DTYPE_F32, nullptr, accumulate, m, n, k, tile_sumsq, stream);
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, PM_DTYPE_F32, nullptr, accumulate, m, n, k, tile_sumsq, nullptr, 0, stream);
 }
 
 static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
-                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* stream) {
+                     const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* workspace, int64_t workspace_bytes,
+                     void* stream) {
   if (m == 0 || n == 0) return PM_OK;
   PM_REQUIRE(x && w && out, PM_ERR_INVALID_ARG, "pm_gemm_bf16: null pointer");
   PM_REQUIRE(pm_gemm_supported(m, n, k, x_kmajor, w_kmajor), PM_ERR_UNSUPPORTED,
@@ -870,6 +960,15 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
   hipStream_t st = as_stream(stream);
+  // split-K of the last round (see Params): f32 results without bias, the whole contraction in one launch, a workspace from the caller
+  p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
+  {
+    const gm::SplitPlan sp = gm::plan_split(p.tiles_m, p.tiles_n, k);
+    if (sp.s > 1 && !(gm::g_variant & 32) && p.out_f32 && !bias && k_chunk == k && workspace && workspace_bytes >= sp.ws_bytes) {  // (bit 5 of the debug variant: no split)
+      p.split_s = sp.s; p.split_rp = sp.rp; p.split_v0 = p.n_blocks - 256; p.split_k = sp.k_part; p.split_ws = (float*)workspace;
+      if (accumulate) (void)hipMemsetAsync(workspace, 0, (size_t)sp.ws_bytes, st);  // parts >= 1 then add their product onto zeros
+    }
+  }
   for (int64_t k0 = 0; k0 < k; k0 += k_chunk) {
     p.x = (const bf16_t*)x + (x_kmajor ? k0 * ldx : k0);
     p.w = (const bf16_t*)w + (w_kmajor ? k0 * ldw : k0);
@@ -881,5 +980,22 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
     else gm::launch<true, true>(p, st);
   }
   PM_CHECK_LAUNCH("gemm_kernel");
+  if (p.split_s > 1) {
+    hipLaunchKernelGGL(gm::splitk_reduce_kernel, dim3((unsigned)(p.split_rp * 32 * 8)), dim3(256), 0, st, p);
+    PM_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
   return PM_OK;
+}
+
+extern "C" int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  return gm::plan_split((int)cdiv(m, gm::kTile), (int)cdiv(n, gm::kTile), k).ws_bytes;
+}
+
+extern "C" int pm_gemm_bf16_ws(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
+                               const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  PM_REQUIRE(!tile_sumsq || (out_dtype == PM_DTYPE_F32 && !bias && tile_sumsq_len >= pm_gemm_sumsq_slots(m, n)), PM_ERR_WORKSPACE,
+             "pm_gemm_bf16_ws: tile_sumsq needs an f32 output, no bias and pm_gemm_sumsq_slots(m, n) floats");
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, tile_sumsq, workspace, workspace_bytes, stream);
 }

@@ -880,8 +880,11 @@ def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype
         _req(tile_sumsq, torch.float32, "tile_sumsq")
         if out.dtype != torch.float32 or bias is not None:
             raise PrimeMI355XError("gemm: tile_sumsq needs an f32 output and no bias")
-        check(lib.pm_gemm_bf16_sumsq(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), int(accumulate), m, n, k, _p(tile_sumsq),
-                                     tile_sumsq.numel(), _stream()), "pm_gemm_bf16_sumsq")
+    if out.dtype == torch.float32 and bias is None:  # the f32 (weight-gradient) form: a workspace lets a half-empty last round of tiles split along K
+        ws_bytes = lib.pm_gemm_workspace_bytes(m, n, k)
+        ws = workspace(ws_bytes, x.device, "gemm_splitk") if ws_bytes else None
+        check(lib.pm_gemm_bf16_ws(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], None, int(accumulate), m, n, k,
+                                  _p(tile_sumsq), tile_sumsq.numel() if tile_sumsq is not None else 0, _p(ws), ws_bytes, _stream()), "pm_gemm_bf16_ws")
         return out
     check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
           "pm_gemm_bf16")

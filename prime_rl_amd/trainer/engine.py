@@ -555,7 +555,7 @@ class GRPOEngine:
             # Schedule of the own core: one PERSISTENT workgroup per CU walking its tiles (+0-2 %) when this rank's GPU runs nothing beside the step; one
             # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
             # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
-            ops.gemm_set_variant(3 if self.use_collectives else 7)
+            ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7")))  # (the env override is the in-step A/B hook: + 32 = no split-K)
         # The gradient-norm pass fused into the weight-gradient epilogues (ops.gemm(tile_sumsq=...)): on the LAST backward pass of a step every wgrad GEMM
         # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
         # (norm weights, biases, the embedding) instead of re-reading the whole 4-byte-per-parameter buffer (5.3 ms per Qwen3-8B step).  Only without

@@ -97,7 +97,9 @@ def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
         written = slots[slots >= 0]
         want = g.double().pow(2).sum().item()
         assert abs(written.double().sum().item() - want) <= 1e-5 * want
-        assert written.numel() == 8 * ((n_out + 255) // 256) * ((n_in + 255) // 256)
+        n_tiles = ((n_out + 255) // 256) * ((n_in + 255) // 256)
+        split = _lib_ws_bytes(n_out, n_in, tokens) > 0  # a split last round also resets the slots of its K-part units (zeros)
+        assert written.numel() >= 8 * n_tiles if split else written.numel() == 8 * n_tiles
         ref = dy.float().t() @ x.float()
         _check(g, ref, tokens, False)  # the values themselves are unchanged by the extra output
         first = slots.clone()
@@ -114,6 +116,40 @@ def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
         ops.gemm_set_variant(7)
 
 
+@pytest.mark.parametrize("variant", [3, 7])
+@pytest.mark.parametrize("tokens,n_out,n_in", [(8192, 6144, 4096), (8192, 2048, 1024), (9000, 520, 264), (16384, 3072, 2048), (4096, 6144, 4096)])
+def test_gemm_wgrad_split_k_of_the_last_round(tokens, n_out, n_in, variant):
+    """Tile counts that leave at most half of the last round of 256 tiles occupied (24 x 16 = 384 tiles: the q|k|v weight gradient of Qwen3-8B; a single
+    partial round for small products) run that round split along K with a workspace + fixed-order reduction: same values as the f32 reference, overwrite
+    and accumulate, norm partials of the FINAL values, bit-identical from run to run and between the persistent and the per-tile grid."""
+    from prime_rl_amd import _lib
+
+    lib = _lib.load()
+    dy, x = _rand(tokens, n_out, 1.0, 30), _rand(tokens, n_in, 1.0, 31)
+    ref = dy.float().t() @ x.float()
+    runs = []
+    for v in (variant, 10 - variant):  # 3 <-> 7: the other grid form
+        ops.gemm_set_variant(v)
+        try:
+            g = torch.full((n_out, n_in), 3.0, dtype=torch.float32, device=DEV)
+            slots = torch.zeros(ops.gemm_sumsq_slots(n_out, n_in), dtype=torch.float32, device=DEV)
+            ops.gemm(dy.t(), x.t(), out=g, accumulate=False, tile_sumsq=slots)
+            _check(g, ref, tokens, False)
+            want = g.double().pow(2).sum().item()
+            assert abs(slots.double().sum().item() - want) <= 1e-5 * want
+            first = g.clone()
+            ops.gemm(dy.t(), x.t(), out=g, accumulate=True, tile_sumsq=slots)
+            _check(g, 2 * ref, tokens, False)
+            want2 = g.double().pow(2).sum().item()
+            assert abs(slots.double().sum().item() - want2) <= 1e-5 * want2
+            runs.append((first, g.clone()))
+        finally:
+            ops.gemm_set_variant(7)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    if lib.pm_gemm_workspace_bytes(n_out, n_in, tokens) == 0:
+        pytest.skip("this shape has a full (or mostly full) last round: no split, covered as a plain product")
+
+
 def test_sumsq_segments():
     base = torch.randn(300_000, device=DEV)
     segs = torch.tensor([[0, 4096], [4224, 128], [8192, 1], [10_000, 250_001], [299_999, 1]], dtype=torch.int64, device=DEV)
@@ -122,6 +158,12 @@ def test_sumsq_segments():
     for i, (o, n) in enumerate(segs.tolist()):
         want = base[o:o + n].double().pow(2).sum().item()
         assert abs(part[i].item() - want) <= 1e-5 * max(want, 1e-6), (i, part[i].item(), want)
+
+
+def _lib_ws_bytes(m, n, k):
+    from prime_rl_amd import _lib
+
+    return _lib.load().pm_gemm_workspace_bytes(m, n, k)
 
 
 def test_gemm_is_deterministic_and_matches_itself_across_variants():
