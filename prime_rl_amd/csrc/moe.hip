@@ -309,8 +309,12 @@ __global__ __launch_bounds__(256) void moe_gather_rows_kernel(const bf16_t* __re
 // f32 and rounded once — bit for bit what torch's CPU `out.scatter_add(0, rows, routed_output)` (moe.py:1050-1051) gives for bf16 (its
 // expanded-index path accumulates each output row in f32), and a fixed order where the GPU scatter_add uses bf16 atomics in arrival
 // order.  score = null: plain sum (the backward of the gather).
+// KC = the top-k count at compile time (8: Qwen3-MoE) or 0 = the runtime value: with a constant count the k row loads of a thread are all in flight
+// before the first is used (the runtime loop issued load, use, load, use: 3.4 TB/s at k = 8); same additions in the same order either way.
+template <int KC>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ y, const int32_t* __restrict__ dest_of_slot, const float* __restrict__ score,
-                                                         const bf16_t* __restrict__ base, int64_t n, int k, int64_t H, bf16_t* __restrict__ out) {
+                                                         const bf16_t* __restrict__ base, int64_t n, int k_rt, int64_t H, bf16_t* __restrict__ out) {
+  const int k = KC ? KC : k_rt;
   const int64_t tok = blockIdx.x;
   int d[kMaxTopK];
   float sc[kMaxTopK];
@@ -344,8 +348,14 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     }
-    for (int i = 0; i < k; ++i) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(y + (int64_t)d[i] * H + c);
+    u32x4 rows[KC ? KC : 1];
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < KC; ++i) rows[i] = *reinterpret_cast<const u32x4*>(y + (int64_t)d[i] * H + c);
+    }
+#pragma unroll KC ? KC : 1
+    for (int i = 0; i < (KC ? KC : k); ++i) {
+      const u32x4 v = KC ? rows[KC ? i : 0] : *reinterpret_cast<const u32x4*>(y + (int64_t)d[i] * H + c);
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -515,8 +525,12 @@ extern "C" int pm_moe_combine(const void* y_bf16, const int32_t* dest_of_slot, c
   PM_REQUIRE(y_bf16 && dest_of_slot && out_bf16, PM_ERR_INVALID_ARG, "pm_moe_combine: null pointer");
   PM_REQUIRE(n_tokens >= 0 && top_k > 0 && top_k <= kMaxTopK && row_elems > 0 && row_elems % 8 == 0, PM_ERR_INVALID_ARG, "pm_moe_combine: bad sizes");
   if (n_tokens == 0) return PM_OK;
-  hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)y_bf16, dest_of_slot, scores,
-                     (const bf16_t*)base_bf16, n_tokens, top_k, row_elems, (bf16_t*)out_bf16);
+  if (top_k == 8)
+    hipLaunchKernelGGL(moe_combine_kernel<8>, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)y_bf16, dest_of_slot, scores,
+                       (const bf16_t*)base_bf16, n_tokens, top_k, row_elems, (bf16_t*)out_bf16);
+  else
+    hipLaunchKernelGGL(moe_combine_kernel<0>, dim3((unsigned)n_tokens), dim3(256), 0, as_stream(stream), (const bf16_t*)y_bf16, dest_of_slot, scores,
+                       (const bf16_t*)base_bf16, n_tokens, top_k, row_elems, (bf16_t*)out_bf16);
   PM_CHECK_LAUNCH("pm_moe_combine");
   return PM_OK;
 }
