@@ -560,6 +560,11 @@ class GRPOEngine:
         # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
         # (norm weights, biases, the embedding) instead of re-reading the whole 4-byte-per-parameter buffer (5.3 ms per Qwen3-8B step).  Only without
         # collectives: under ZeRO-2 the norm is taken over the REDUCED shard.  PM_FUSED_SUMSQ=0 is the A/B switch.
+        # dgrad per STEP: the library's dgrad GEMMs are 6-11 % faster than the own core but need the K-contiguous weight copies refreshed after every parameter
+        # update (145 transposes = 5.7 ms for Qwen3-8B, whatever the batch); below ~7k tokens per step the copies cost more than the library gains, and the own
+        # core reads the stored weights as they are (the reference benchmark's 2 x 2048-token step: -2.5 ms).  PM_DGRAD_OWN_BELOW=0 switches the rule off.
+        self.dgrad_own_below = int(os.environ.get("PM_DGRAD_OWN_BELOW", "7168")) if (self.gemm_own and self.gemm_layouts) else 0
+        self._dgrad_own_now = "dgrad" in self.gemm_own
         self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and os.environ.get("PM_FUSED_SUMSQ", "1") != "0"
         self._fs_plan: dict | None = None
         self._fs_covered: set[str] = set()
@@ -716,7 +721,7 @@ class GRPOEngine:
         name = f"model.layers.{layer}.{suffix}"
         if self.gemm_f32:
             return torch.mm(dy.float(), self.store.w[name].float()).to(torch.bfloat16)
-        if "dgrad" in self.gemm_own and ops.gemm_supported(dy, self.store.w[name].t()):
+        if self._dgrad_own_now and ops.gemm_supported(dy, self.store.w[name].t()):
             return ops.gemm(dy, self.store.w[name].t())  # the [out, in] weight read K-major
         if not self.gemm_layouts:
             return torch.mm(dy, self.store.w[name])
@@ -901,7 +906,7 @@ class GRPOEngine:
         hf = ctx["hf"]
         dhf = torch.empty_like(hf)
         acc_head = accumulate
-        head_t = "head" in self._wt and "dgrad" not in self.gemm_own  # K-contiguous [H, V] copy of the head weight for the library's dgrad GEMM (same reasoning as _dgrad)
+        head_t = "head" in self._wt and not self._dgrad_own_now  # K-contiguous [H, V] copy of the head weight for the library's dgrad GEMM (same reasoning as _dgrad)
         if head_t and self._wt_version.get("head") != self.store.version:
             ops.transpose_2d(wh, out=self._wt["head"])
             self._wt_version["head"] = self.store.version
@@ -919,7 +924,7 @@ class GRPOEngine:
                 dl = ops.logprob_bwd(logits, labels[s:e], inv_temp[s:e], ctx["logz"][s:e], grad_lp[s:e], out=logits)
             if self.gemm_f32:
                 dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
-            elif "dgrad" in self.gemm_own and ops.gemm_supported(dl, wh.t()):
+            elif self._dgrad_own_now and ops.gemm_supported(dl, wh.t()):
                 ops.gemm(dl, wh.t(), out=dhf[s:e])
             elif head_t:
                 torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
@@ -1110,6 +1115,7 @@ class GRPOEngine:
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:
         """One optimizer step over one or more packed passes (a list accumulates gradients across passes)."""
         passes = batch if isinstance(batch, list) else [batch]
+        self._dgrad_own_now = "dgrad" in self.gemm_own or sum(p.n_tokens for p in passes) // self.cp_size < self.dgrad_own_below
         counts = tuple(sum(p.local_counts[k] for p in passes) for k in range(3))
         scales = self.global_scales(counts)
         out = {"loss": [], "entropy": [], "logprobs": [], "sample_metrics": [], "sample_stats": []}
