@@ -73,6 +73,7 @@ struct Params {
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
   // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
   // whole f32 tiles into `split_ws` ([tail tile][part - 1][256 x 256]) and splitk_reduce_kernel adds them in part order (deterministic).
+  int k_parts, k_chunk;  // dense: the contraction of every tile as k_parts CHAINED parts of k_chunk (one launch; a K-major operand's 32-bit offsets reach 2 GB)
   int split_s, split_rp, split_v0, split_k;
   float* split_ws;
   float* sumsq;       // f32 out only, optional: [n_blocks][8] — every wave writes the sum of squares of the FINAL values it stored for tile v to [v][wave]
@@ -415,8 +416,14 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
     }
     if (!tile_of_block(vv, p.tiles_m, p.tiles_n, tm, tn)) return false;
     const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
-    const int64_t k0 = (int64_t)kpart * p.split_k;
-    const int klen = p.split_s > 1 && v >= p.split_v0 ? (int)(p.k - k0 < p.split_k ? p.k - k0 : p.split_k) : p.k;
+    int64_t k0 = (int64_t)kpart * p.split_k;
+    int klen = p.split_s > 1 && v >= p.split_v0 ? (int)(p.k - k0 < p.split_k ? p.k - k0 : p.split_k) : p.k;
+    if (p.k_parts > 1) {  // chained parts of one accumulation (never together with the split: gemm_impl)
+      k0 = (int64_t)part * p.k_chunk;
+      klen = (int)(p.k - k0 < p.k_chunk ? p.k - k0 : p.k_chunk);
+      t.first = part == 0;
+      t.last = part == p.k_parts - 1;
+    }
     t.xb = p.x + (XK ? m0 + k0 * p.ldx : m0 * p.ldx + k0);
     t.wb = p.w + (WK ? n0 + k0 * p.ldw : n0 * p.ldw + k0);
     t.x_rows = p.m - m0;
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       phase<0, 0, V, XK, WK>(s, smem);
       phase<1, 0, V, XK, WK>(s, smem);
       if (t + 2 >= nk) {  // the last pair of this unit: every half-tile staged from here on belongs to the next one
-        advance_unit(v_n, part_n, parts_of<MODE>());
+        advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
         Tile nxt;
         has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
         if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
@@ -837,6 +844,7 @@ static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int
   p.accumulate = 0;
   p.sumsq = nullptr;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
+  p.k_parts = 1; p.k_chunk = 0;
   p.offsets = offsets;
   p.n_experts = n_experts;
   p.n_first = (int)n_first;
@@ -969,16 +977,18 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
       if (accumulate) (void)hipMemsetAsync(workspace, 0, (size_t)sp.ws_bytes, st);  // parts >= 1 then add their product onto zeros
     }
   }
-  for (int64_t k0 = 0; k0 < k; k0 += k_chunk) {
-    p.x = (const bf16_t*)x + (x_kmajor ? k0 * ldx : k0);
-    p.w = (const bf16_t*)w + (w_kmajor ? k0 * ldw : k0);
-    p.k = (int)std::min(k_chunk, k - k0);
-    p.accumulate = (accumulate || k0 > 0) ? 1 : 0;
-    p.sumsq = k0 + k_chunk >= k ? tile_sumsq : nullptr;  // only the last K-chunk stores final values
-    if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
-    else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
-    else gm::launch<true, true>(p, st);
-  }
+  // a contraction whose K-major span exceeds the 32-bit offsets runs as chained parts of every tile's accumulation in ONE launch (the accumulators stay
+  // in registers across the parts; only the operand descriptors switch): no read-modify-write of the f32 result between K-chunks
+  p.x = (const bf16_t*)x;
+  p.w = (const bf16_t*)w;
+  p.k = (int)k;
+  p.k_chunk = (int)k_chunk;
+  p.k_parts = (int)cdiv(k, k_chunk);
+  p.accumulate = accumulate ? 1 : 0;
+  p.sumsq = tile_sumsq;
+  if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
+  else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
+  else gm::launch<true, true>(p, st);
   PM_CHECK_LAUNCH("gemm_kernel");
   if (p.split_s > 1) {
     hipLaunchKernelGGL(gm::splitk_reduce_kernel, dim3((unsigned)(p.split_rp * 32 * 8)), dim3(256), 0, st, p);

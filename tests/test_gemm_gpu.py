@@ -150,6 +150,28 @@ def test_gemm_wgrad_split_k_of_the_last_round(tokens, n_out, n_in, variant):
         pytest.skip("this shape has a full (or mostly full) last round: no split, covered as a plain product")
 
 
+def test_gemm_wgrad_with_a_k_major_span_beyond_2_gib():
+    """The LM-head weight gradient's situation (16 384 tokens x 151 936 columns of dlogits = 5 GB): a K-major operand whose k * ld reaches past the 32-bit
+    buffer offsets.  The contraction then runs as chained parts of every tile's accumulation inside ONE launch (descriptors re-based per part, accumulators
+    kept in registers) — here on a 384-column window of a [8192, 151936] matrix (2.5 GB), overwrite and accumulate, with the norm partials."""
+    tokens, ld, n_out, n_in = 8192, 151936, 384, 256
+    g0 = torch.Generator(device=DEV).manual_seed(40)
+    big = torch.empty(tokens, ld, dtype=torch.bfloat16, device=DEV)
+    big[:, 4096:4096 + n_out] = torch.randn(tokens, n_out, device=DEV, generator=g0).to(torch.bfloat16)
+    dy = big[:, 4096:4096 + n_out]  # row stride 151936: k * ld * 2 B = 2.49 GB
+    x = _rand(tokens, n_in, 1.0, 41)
+    ref = dy.float().t() @ x.float()
+    g = torch.full((n_out, n_in), -5.0, dtype=torch.float32, device=DEV)
+    slots = torch.zeros(ops.gemm_sumsq_slots(n_out, n_in), dtype=torch.float32, device=DEV)
+    ops.gemm(dy.t(), x.t(), out=g, accumulate=False, tile_sumsq=slots)
+    _check(g, ref, tokens, False)
+    want = g.double().pow(2).sum().item()
+    assert abs(slots.double().sum().item() - want) <= 1e-5 * want
+    ops.gemm(dy.t(), x.t(), out=g, accumulate=True)
+    _check(g, 2 * ref, tokens, False)
+    del big
+
+
 def test_sumsq_segments():
     base = torch.randn(300_000, device=DEV)
     segs = torch.tensor([[0, 4096], [4224, 128], [8192, 1], [10_000, 250_001], [299_999, 1]], dtype=torch.int64, device=DEV)
