@@ -476,7 +476,8 @@ int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_
  *   wgrad    dw[out][in] = sum_tok dy[tok][out] x[tok][in]: X = dy stored [K = tok, M = out], W = x stored [K = tok, N = in],
  *            f32 output with `accumulate` (gradient accumulation in f32, configs/trainer.py:233-237)              x_kmajor = 1, w_kmajor = 1
  * "kmajor" = the operand is stored [K, rows] (its M / N coordinate is the contiguous one).  ld* are row strides in elements; rows 16-byte
- * aligned.  K % 128 == 0 unless both operands are K-major (pm_gemm_supported).  `bias` (bf16 [N], nullable) is added before the rounding. */
+ * aligned.  K % 128 == 0 unless both operands are K-major (pm_gemm_supported).  `bias` (bf16 [N], nullable) is added before the rounding.  A K-major
+ * operand whose K x ld reaches past 2 GiB (the LM-head weight gradient: 16 384 x 151 936 dlogits) is contracted in chained parts inside one launch. */
 int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmajor, int32_t w_kmajor);
 int pm_gemm_bf16(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                  int32_t out_dtype /* PM_DTYPE_BF16 | PM_DTYPE_F32 */, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n,

@@ -67,3 +67,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(_lib.PrimeMI355XError, match="no CPU or eager-PyTorch fallback"):
         _lib.load()
+
+
+def test_gemm_planning_entry_points_are_pure_host_functions():
+    """pm_gemm_supported / pm_gemm_sumsq_slots / pm_gemm_workspace_bytes decide on the host (no GPU needed): the tile rounds of 256, the split of a
+    half-empty last round for long contractions, and which layouts the core takes."""
+    lib = _lib.load()
+    assert lib.pm_gemm_supported(16384, 6144, 4096, 0, 0) == 1 and lib.pm_gemm_supported(16384, 6144, 4000, 0, 0) == 0  # K-contiguous: K % 128
+    assert lib.pm_gemm_supported(6144, 4096, 1000, 1, 1) == 1 and lib.pm_gemm_supported(100, 4096, 1000, 1, 1) == 0     # K-major rows: % 8, >= 128
+    assert lib.pm_gemm_supported(6144, 4096, 1024, 1, 0) == 0                                                           # no caller has that pair
+    # q|k|v weight gradient of Qwen3-8B: 24 x 16 tiles = 12 patches = 1.5 rounds -> 2 rounds of slots; the last round splits in two along K
+    assert lib.pm_gemm_sumsq_slots(6144, 4096) == 2 * 256 * 8
+    assert lib.pm_gemm_workspace_bytes(6144, 4096, 16384) == 4 * 32 * 1 * 256 * 256 * 4
+    assert lib.pm_gemm_workspace_bytes(6144, 4096, 4096) == 0        # short contraction: not worth a reduction pass
+    assert lib.pm_gemm_workspace_bytes(4096, 4096, 16384) == 0       # 256 tiles: a whole round
+    assert lib.pm_gemm_workspace_bytes(24576, 4096, 16384) == 0      # 1536 tiles: six whole rounds
+    assert lib.pm_gemm_workspace_bytes(0, 4096, 16384) == 0
