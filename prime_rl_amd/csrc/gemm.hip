@@ -761,12 +761,432 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   if (wv == 0) __builtin_amdgcn_s_barrier();
 }
 
+
+// =============================================================================================================================================
+// Round 4: the ONE-WAVE-PER-SIMD form of the same core (`gemm4_kernel`).  Same 256 x 256 x 64 tile, same LDS images (so the DMA swizzles and the fragment
+// read addresses above carry over), same tile stream / units / epilogue arithmetic; what changes is who holds what:
+//   * FOUR waves (2 x 2), one per SIMD, 512 registers each: wave (wv, wt) owns W rows [128 wv, +128) x X rows [128 wt, +128) = 8 x 8 accumulator
+//     fragments of v_mfma_f32_16x16x32_bf16 = 256 registers (the accumulator half of the file).  A wave reads (128 + 128) x 64 operand elements per
+//     K-tile for 128 x 128 x 64 MACs — 2/3 of the LDS fragment bytes per flop of the 128 x 64 register tile of the 8-wave form (profiles/r03_gemm.md
+//     section 2: what the library's kernel has over the ping-pong core under the chip's power limit).
+//   * no partner wave: ONE software-pipelined stream per SIMD.  A K-tile is two k-steps of 32; the fragments of the NEXT k-step (16 ds_read_b128, or 32
+//     transpose reads) are fetched into a second register set while the 64 MFMAs of the current one issue, one read per four MFMAs.
+//   * the ring holds two K-tiles; ONE barrier per K-tile.  Steps of iteration (t, t + 1), buffers 0 / 1:
+//        A: MFMA (t, k0)      | read (t, k1) <- buf 0                          | end: lgkmcnt(0), vmcnt(0) [K-tile t + 1 landed], s_barrier
+//        B: MFMA (t, k1)      | read (t + 1, k0) <- buf 1 | DMA K-tile t + 2 -> buf 0 (16 pieces per wave, one per four MFMAs)
+//        C: MFMA (t + 1, k0)  | read (t + 1, k1) <- buf 1                      | end: lgkmcnt(0), vmcnt(0) [K-tile t + 2 landed], s_barrier
+//        D: MFMA (t + 1, k1)  | read (t + 2, k0) <- buf 0 | DMA K-tile t + 3 -> buf 1
+//     buf 0 is re-staged after the barrier that follows every wave's last read of it (end of A); a K-tile's DMA has one whole step (64 MFMAs ~ 1 k
+//     cycles) plus its own issue step to land before the wait that retires it.
+// V bit 3 / 4: the timing ablations of the 8-wave kernel (no DMA inside the loop / no fragment reads).
+namespace g4 {
+
+constexpr int kSmem4 = kRing + 4 * 4096;
+
+struct Wave4 {
+  f32x4 acc[8][8];                    // [f: 16-row W fragment][g: 16-row X fragment]
+  u32x4 wf[2][8], xf[2][8];           // K-contiguous operands: [register set = k-step of the K-tile][fragment]
+  u32x2 wlo[2][8], whi[2][8], xlo[2][8], xhi[2][8];  // K-major operands: the two transpose-read halves of a fragment
+  __amdgpu_buffer_rsrc_t wr, xr;
+  int vw[4], vx[4];                   // per-lane byte offsets of this wave's four DMA pieces of a slot (piece q minus its q KiB instruction offset)
+  int off[4];                         // wave-uniform running source offsets per slot kind
+  int wk, xk, wstep, xstep, piece_lds;
+  unsigned aw[8], ax[8];              // fragment read addresses: K-contiguous [k-step] (fragment = immediate); K-major [fragment] (k-step = immediate)
+  // register staging (RS): the K-tile travels HBM / L2 -> VGPRs (buffer_load_dwordx4, cheap to issue) -> LDS (ds_write_b128 one step later) instead of
+  // by LDS-DMA, whose ~60-cycle issue cost has no partner wave to hide behind at one wave per SIMD (profiles/r04_gemm.md)
+  u32x4 stg[16];
+  unsigned wrw, wrx;                  // per-lane LDS byte address of this wave's first piece in the W / X window (slot + piece = immediate)
+};
+
+template <bool KM>
+__device__ __forceinline__ void setup_operand4(int64_t ld, int wave, int lane, unsigned lds_slot0, int (&voff)[4], int& half_step, int& k_step, unsigned (&rd)[8]) {
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rd[i] = 0;
+  if (!KM) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rho = (wave * 4 + q) * 8 + (lane >> 3);  // slot row of this lane's 16 bytes (piece = 8 rows x 128 bytes)
+      voff[q] = (int)(rho * ld * 2) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4) - q * 1024;
+    }
+    half_step = (int)(128 * ld * 2);
+    k_step = kBK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) rd[kk] = lds_slot0 + lr * 128 + (((kk * 4 + lq) ^ ((lr >> 1) & 7)) << 4);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int krow = (wave * 4 + q) * 4 + (lane >> 4);  // piece = 4 k-rows x 256 bytes
+      voff[q] = (int)(krow * ld * 2) + (((lane & 15) ^ (((krow & 3) << 2) | (((krow >> 3) & 1) << 1))) << 4) - q * 1024;
+    }
+    half_step = 128 * 2;
+    k_step = (int)(kBK * ld * 2);
+    const int krow = lq * 8 + (lr >> 2);
+    const int swz = ((krow & 3) << 2) | (((krow >> 3) & 1) << 1);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int chunk = f * 2 + ((lr & 3) >> 1);
+      rd[f] = lds_slot0 + krow * 256 + ((chunk ^ swz) << 4) + (lr & 1) * 8;
+    }
+  }
+}
+
+// one DMA piece (1 KiB of this wave's 4 KiB of slot SLOT of buffer BUF); the fourth piece advances the slot's source offset by one K-tile
+template <int SLOT, int BUF, int Q>
+__device__ __forceinline__ void stage_piece(Wave4& s, unsigned char* smem) {
+  constexpr int slot_off = slot_offset(BUF, SLOT);
+  constexpr bool is_w = SLOT == SLOT_W0 || SLOT == SLOT_W1;
+  const __amdgpu_buffer_rsrc_t rsrc = is_w ? s.wr : s.xr;
+  unsigned char* dst = smem + slot_off + s.piece_lds;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[Q] : s.vx[Q], s.off[SLOT], Q * 1024, 0);
+  if (Q == 3) s.off[SLOT] += is_w ? s.wk : s.xk;
+}
+template <int BUF>
+__device__ __forceinline__ void stage_tile(Wave4& s, unsigned char* smem) {  // the whole K-tile at once (prologue of the first unit)
+  stage_piece<SLOT_W0, BUF, 0>(s, smem); stage_piece<SLOT_W0, BUF, 1>(s, smem); stage_piece<SLOT_W0, BUF, 2>(s, smem); stage_piece<SLOT_W0, BUF, 3>(s, smem);
+  stage_piece<SLOT_X0, BUF, 0>(s, smem); stage_piece<SLOT_X0, BUF, 1>(s, smem); stage_piece<SLOT_X0, BUF, 2>(s, smem); stage_piece<SLOT_X0, BUF, 3>(s, smem);
+  stage_piece<SLOT_W1, BUF, 0>(s, smem); stage_piece<SLOT_W1, BUF, 1>(s, smem); stage_piece<SLOT_W1, BUF, 2>(s, smem); stage_piece<SLOT_W1, BUF, 3>(s, smem);
+  stage_piece<SLOT_X1, BUF, 0>(s, smem); stage_piece<SLOT_X1, BUF, 1>(s, smem); stage_piece<SLOT_X1, BUF, 2>(s, smem); stage_piece<SLOT_X1, BUF, 3>(s, smem);
+}
+// piece I (0..15) of the K-tile staged into buffer BUF during a B / D step
+template <int BUF, int I>
+__device__ __forceinline__ void stage_nth(Wave4& s, unsigned char* smem) {
+  constexpr int slot = I < 4 ? SLOT_W0 : I < 8 ? SLOT_X0 : I < 12 ? SLOT_W1 : SLOT_X1;
+  stage_piece<slot, BUF, I & 3>(s, smem);
+}
+
+// ---- register staging: piece I of the NEXT-BUT-ONE K-tile is loaded into stg[I] in a B / D step and written to its ring slot in the following C / A step
+template <int I>
+__device__ __forceinline__ void load_nth(Wave4& s) {
+  constexpr int slot = I < 4 ? SLOT_W0 : I < 8 ? SLOT_X0 : I < 12 ? SLOT_W1 : SLOT_X1;
+  constexpr bool is_w = slot == SLOT_W0 || slot == SLOT_W1;
+  constexpr int q = I & 3;
+  // (vw / vx hold piece q's offset minus q KiB — the LDS-DMA form moves source and destination together through the instruction offset; undo it here)
+  s.stg[I] = __builtin_amdgcn_raw_buffer_load_b128(is_w ? s.wr : s.xr, (is_w ? s.vw[q] : s.vx[q]) + q * 1024, s.off[slot], 0);
+  if (q == 3) s.off[slot] += is_w ? s.wk : s.xk;
+}
+template <int BUF, int I>
+__device__ __forceinline__ void write_nth(Wave4& s) {
+  constexpr int slot = I < 4 ? SLOT_W0 : I < 8 ? SLOT_X0 : I < 12 ? SLOT_W1 : SLOT_X1;
+  constexpr bool is_w = slot == SLOT_W0 || slot == SLOT_W1;
+  constexpr int imm = slot_in_window(BUF, slot) + (I & 3) * 1024;
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(is_w ? s.wrw : s.wrx), "v"(s.stg[I]), "n"(imm) : "memory");
+}
+
+// fragment read I (0..15) of k-step SET of the K-tile in buffer BUF: 0-7 = W fragments, 8-15 = X fragments.  The wave's own half (W^wv, X^wt) is part of
+// the per-lane base address; the buffer is an immediate.
+template <int SET, int BUF, int I, bool XK, bool WK>
+__device__ __forceinline__ void read_nth(Wave4& s) {
+  constexpr int slot = BUF * 2 * kSlot;
+  if constexpr (I < 8) {
+    if constexpr (!WK) s.wf[SET][I] = b128_read<slot + I * 2048>(s.aw[SET]);
+    else {
+      s.wlo[SET][I] = tr_read<slot + SET * 8192>(s.aw[I]);
+      s.whi[SET][I] = tr_read<slot + SET * 8192 + 1024>(s.aw[I]);
+    }
+  } else {
+    constexpr int G = I - 8;
+    if constexpr (!XK) s.xf[SET][G] = b128_read<slot + G * 2048>(s.ax[SET]);
+    else {
+      s.xlo[SET][G] = tr_read<slot + SET * 8192>(s.ax[G]);
+      s.xhi[SET][G] = tr_read<slot + SET * 8192 + 1024>(s.ax[G]);
+    }
+  }
+}
+template <int SET, bool XK, bool WK>
+__device__ __forceinline__ void tie_set(Wave4& s) {
+  if constexpr (WK) {
+    tie(s.wlo[SET][0], s.whi[SET][0], s.wlo[SET][1], s.whi[SET][1], s.wlo[SET][2], s.whi[SET][2], s.wlo[SET][3], s.whi[SET][3]);
+    tie(s.wlo[SET][4], s.whi[SET][4], s.wlo[SET][5], s.whi[SET][5], s.wlo[SET][6], s.whi[SET][6], s.wlo[SET][7], s.whi[SET][7]);
+  } else {
+    tie(s.wf[SET][0], s.wf[SET][1], s.wf[SET][2], s.wf[SET][3]);
+    tie(s.wf[SET][4], s.wf[SET][5], s.wf[SET][6], s.wf[SET][7]);
+  }
+  if constexpr (XK) {
+    tie(s.xlo[SET][0], s.xhi[SET][0], s.xlo[SET][1], s.xhi[SET][1], s.xlo[SET][2], s.xhi[SET][2], s.xlo[SET][3], s.xhi[SET][3]);
+    tie(s.xlo[SET][4], s.xhi[SET][4], s.xlo[SET][5], s.xhi[SET][5], s.xlo[SET][6], s.xhi[SET][6], s.xlo[SET][7], s.xhi[SET][7]);
+  } else {
+    tie(s.xf[SET][0], s.xf[SET][1], s.xf[SET][2], s.xf[SET][3]);
+    tie(s.xf[SET][4], s.xf[SET][5], s.xf[SET][6], s.xf[SET][7]);
+  }
+}
+
+// group I (0..15) of a step: four MFMAs (W fragment I / 2 against X fragments 4 (I % 2) .. + 3), then one fragment read of the next register set and, in a
+// staging step, one DMA piece.  `sched_barrier(0)` after every group pins the interleave: asm reads are invisible to the scheduler's instruction classes.
+template <int SET, int NBUF, int DBUF, bool DMA, int I, int V, bool XK, bool WK>
+__device__ __forceinline__ void group(Wave4& s, unsigned char* smem) {
+  constexpr bool RS = (V & 1) != 0;
+  constexpr int f = I >> 1, g0 = (I & 1) * 4;
+  const u32x4 wfrag = WK ? join(s.wlo[SET][f], s.whi[SET][f]) : s.wf[SET][f];
+#pragma unroll
+  for (int g = g0; g < g0 + 4; ++g) {
+    const u32x4 xfrag = XK ? join(s.xlo[SET][g], s.xhi[SET][g]) : s.xf[SET][g];
+    s.acc[f][g] = mfma16(wfrag, xfrag, s.acc[f][g]);
+  }
+  if (!(V & 16)) read_nth<SET ^ 1, NBUF, I, XK, WK>(s);
+  if (!(V & 8)) {
+    if (!RS) {
+      if (DMA) stage_nth<DBUF, I>(s, smem);
+    } else if (DMA) {
+      load_nth<I>(s);
+    } else {
+      write_nth<DBUF, I>(s);  // a C / A step: the K-tile loaded during the previous step goes to the buffer the NEXT step reads
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One step: MFMAs on register set SET; reads into SET ^ 1 from buffer NBUF; DMA (staging steps) of the next-but-one K-tile into buffer DBUF — or, with
+// register staging, its loads (staging steps) / its ds_writes into DBUF (the step after).
+// SYNC: the step ends a K-tile's reads of its buffer -> wait for the other buffer's DMA (or the ds_writes), barrier.
+template <int SET, int NBUF, int DBUF, bool DMA, bool SYNC, int V, bool XK, bool WK>
+__device__ __forceinline__ void step(Wave4& s, unsigned char* smem) {
+  __builtin_amdgcn_s_setprio(1);
+  group<SET, NBUF, DBUF, DMA, 0, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 1, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 2, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 3, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 4, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 5, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 6, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 7, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 8, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 9, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 10, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 11, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 12, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 13, V, XK, WK>(s, smem);
+  group<SET, NBUF, DBUF, DMA, 14, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 15, V, XK, WK>(s, smem);
+  __builtin_amdgcn_s_setprio(0);
+  if (SYNC) {
+    if (V & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // register staging: nothing LDS-bound is on the vector-memory counter
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (!(V & 16)) tie_set<SET ^ 1, XK, WK>(s);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int V, bool XK, bool WK, int MODE>
+__global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
+  unsigned char* smem = lds_base();
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = wave >> 1, wt = wave & 1;
+  int v = blockIdx.x, part = 0;
+  Tile cur;
+  if (!next_unit<MODE, XK, WK>(p, v, part, lane, cur)) return;
+
+  Wave4 s;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  setup_operand4<WK>(p.ldw, wave, lane, lds0 + wv * kSlot, s.vw, s.wstep, s.wk, s.aw);
+  setup_operand4<XK>(p.ldx, wave, lane, lds0 + 4 * kSlot + wt * kSlot, s.vx, s.xstep, s.xk, s.ax);
+  s.wr = panel_rsrc<WK>(cur.wb, p.ldw, cur.w_rows, cur.k);
+  s.xr = panel_rsrc<XK>(cur.xb, p.ldx, cur.x_rows, cur.k);
+  s.piece_lds = wave * 4096;
+  if (V & 16) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        s.wf[st][f] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        s.xf[st][f] = u32x4{0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u};
+        s.wlo[st][f] = s.whi[st][f] = s.xlo[st][f] = s.xhi[st][f] = u32x2{0x3f803f80u, 0x3f803f80u + lane};
+      }
+  }
+  // ---- prologue of the first unit: K-tiles 0 and 1 on their way, k-step 0 of K-tile 0 in register set 0
+  s.off[SLOT_W0] = 0; s.off[SLOT_W1] = s.wstep; s.off[SLOT_X0] = 0; s.off[SLOT_X1] = s.xstep;
+  s.wrw = lds0 + s.piece_lds + lane * 16;
+  s.wrx = s.wrw + 4 * kSlot;
+  if (V & 1) {  // register staging: K-tile 0 through the registers into buffer 0, K-tile 1 stays in the staging registers until the first A step writes it
+    load_nth<0>(s);  load_nth<1>(s);  load_nth<2>(s);  load_nth<3>(s);  load_nth<4>(s);  load_nth<5>(s);  load_nth<6>(s);  load_nth<7>(s);
+    load_nth<8>(s);  load_nth<9>(s);  load_nth<10>(s); load_nth<11>(s); load_nth<12>(s); load_nth<13>(s); load_nth<14>(s); load_nth<15>(s);
+    write_nth<0, 0>(s);  write_nth<0, 1>(s);  write_nth<0, 2>(s);  write_nth<0, 3>(s);  write_nth<0, 4>(s);  write_nth<0, 5>(s);  write_nth<0, 6>(s);  write_nth<0, 7>(s);
+    write_nth<0, 8>(s);  write_nth<0, 9>(s);  write_nth<0, 10>(s); write_nth<0, 11>(s); write_nth<0, 12>(s); write_nth<0, 13>(s); write_nth<0, 14>(s); write_nth<0, 15>(s);
+    __builtin_amdgcn_sched_barrier(0);
+    load_nth<0>(s);  load_nth<1>(s);  load_nth<2>(s);  load_nth<3>(s);  load_nth<4>(s);  load_nth<5>(s);  load_nth<6>(s);  load_nth<7>(s);
+    load_nth<8>(s);  load_nth<9>(s);  load_nth<10>(s); load_nth<11>(s); load_nth<12>(s); load_nth<13>(s); load_nth<14>(s); load_nth<15>(s);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    stage_tile<0>(s, smem);
+    stage_tile<1>(s, smem);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (!(V & 16)) {
+    read_nth<0, 0, 0, XK, WK>(s);  read_nth<0, 0, 1, XK, WK>(s);  read_nth<0, 0, 2, XK, WK>(s);  read_nth<0, 0, 3, XK, WK>(s);
+    read_nth<0, 0, 4, XK, WK>(s);  read_nth<0, 0, 5, XK, WK>(s);  read_nth<0, 0, 6, XK, WK>(s);  read_nth<0, 0, 7, XK, WK>(s);
+    read_nth<0, 0, 8, XK, WK>(s);  read_nth<0, 0, 9, XK, WK>(s);  read_nth<0, 0, 10, XK, WK>(s); read_nth<0, 0, 11, XK, WK>(s);
+    read_nth<0, 0, 12, XK, WK>(s); read_nth<0, 0, 13, XK, WK>(s); read_nth<0, 0, 14, XK, WK>(s); read_nth<0, 0, 15, XK, WK>(s);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_set<0, XK, WK>(s);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  for (;;) {  // ---- the workgroup's stream of units
+    {
+      int lane_o = lane;  // per-lane DMA offsets / read addresses re-derived per unit: they must not stay live (and spill) across the epilogue
+      asm volatile("" : "+v"(lane_o));
+      int dummy_a, dummy_b;
+      setup_operand4<WK>(p.ldw, wave, lane_o, lds0 + wv * kSlot, s.vw, dummy_a, dummy_b, s.aw);
+      setup_operand4<XK>(p.ldx, wave, lane_o, lds0 + 4 * kSlot + wt * kSlot, s.vx, dummy_a, dummy_b, s.ax);
+      s.wrw = lds0 + s.piece_lds + lane_o * 16;
+      s.wrx = s.wrw + 4 * kSlot;
+    }
+    int v_n = v, part_n = part;
+    bool has_next = false;
+    if (cur.first) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s.acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nk = cur.nk;
+    for (int t = 0; t < nk; t += 2) {
+      if (t + 2 >= nk) {  // the last pair of this unit: both K-tiles staged in this iteration belong to the next one
+        advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
+        Tile nxt;
+        has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+        if (has_next) {
+          s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+          s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
+        }
+        s.off[SLOT_W0] = 0; s.off[SLOT_W1] = s.wstep; s.off[SLOT_X0] = 0; s.off[SLOT_X1] = s.xstep;
+      }
+      step<0, 0, 1, false, true, V, XK, WK>(s, smem);   // A   (register staging: writes the K-tile loaded in the previous D into buffer 1)
+      step<1, 1, 0, true, false, V, XK, WK>(s, smem);   // B
+      step<0, 1, 0, false, true, V, XK, WK>(s, smem);   // C   (register staging: writes the K-tile loaded in B into buffer 0)
+      step<1, 0, 1, true, false, V, XK, WK>(s, smem);   // D
+    }
+    if (cur.last) {
+      // ---- epilogue: the 8-wave kernel's LDS-staged form (every global store instruction writes 8 full 128-byte row segments), walked over this wave's
+      // 4 (row blocks of 32) x 2 (column blocks of 64) blocks.  acc[f][g][r] = OUT[128 wt + 16 g + lr][128 wv + 16 f + 4 lq + r].
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int lr = lane_e & 15, lq = lane_e >> 4;
+      float ss = 0.f;
+      unsigned char* stg = smem + kRing + wave * 4096;
+      const int srow = lane_e >> 3, schunk = lane_e & 7;
+      const bool f32o = (MODE == 0 || MODE == 3) && p.out_f32;
+      const bool wide = f32o ? (p.n % 4 == 0) : (p.n % 8 == 0 && cur.ldo % 8 == 0);
+      const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
+      if (wide) {
+#pragma unroll
+        for (int fq = 0; fq < 2; ++fq) {
+          const int ncol0 = wv * 128 + fq * 64;
+#pragma unroll
+          for (int gp = 0; gp < 4; ++gp) {
+            const int mrow0 = wt * 128 + gp * 32;
+            if (bias) {
+#pragma unroll
+              for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int nb = ncol0 + f * 16 + lq * 4 + r;
+                  const float bv = nb < cur.n_valid ? bf16_to_f32(bias[nb]) : 0.f;
+                  s.acc[fq * 4 + f][gp * 2][r] += bv;
+                  s.acc[fq * 4 + f][gp * 2 + 1][r] += bv;
+                }
+            }
+            if (!f32o) {
+#pragma unroll
+              for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  const f32x4& c = s.acc[fq * 4 + f][gp * 2 + g];
+                  const int ml = g * 16 + lr;
+                  *reinterpret_cast<u32x2*>(stg + ml * 128 + (((f * 2 + (lq >> 1)) ^ (ml & 7)) << 4) + (lq & 1) * 8) = u32x2{pack_bf16_hw(c[0], c[1]), pack_bf16_hw(c[2], c[3])};
+                }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int ml = q * 8 + srow;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
+                const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
+                if (m < cur.m_valid && nn < cur.n_valid) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn) = val;
+              }
+            } else {
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+                  for (int g = 0; g < 2; ++g) {
+                    const int ml = g * 16 + lr;
+                    *reinterpret_cast<f32x4*>(stg + ml * 128 + (((fl * 4 + lq) ^ (ml & 7)) << 4)) = s.acc[fq * 4 + a * 2 + fl][gp * 2 + g];
+                  }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int ml = q * 8 + srow;
+                  f32x4 val = *reinterpret_cast<const f32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
+                  const int m = mrow0 + ml, nn = ncol0 + a * 32 + schunk * 4;
+                  if (m < cur.m_valid && nn < cur.n_valid) {
+                    float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
+                    if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = val;
+                    if (MODE == 0 && p.sumsq) ss = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], ss))));
+                  }
+                }
+              }
+            }
+          }
+        }
+      } else {  // ragged column counts: the direct form
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int m = wt * 128 + g * 16 + lr;
+          if (m >= cur.m_valid) continue;
+#pragma unroll
+          for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int nb = wv * 128 + f * 16 + lq * 4 + r;
+              if (nb >= cur.n_valid) continue;
+              float val = s.acc[f][g][r];
+              if (bias) val += bf16_to_f32(bias[nb]);
+              if (f32o) {
+                float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nb;
+                if (p.accumulate) val += *dst;
+                *dst = val;
+                if (MODE == 0 && p.sumsq) ss = fmaf(val, val, ss);
+              } else {
+                reinterpret_cast<bf16_t*>(cur.out)[(int64_t)m * cur.ldo + nb] = f32_to_bf16(val);
+              }
+            }
+        }
+      }
+      if (MODE == 0 && p.sumsq) {  // 8 slots per tile (the 8-wave kernel's layout): this kernel fills the first four and clears the rest
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane_e == 0) {
+          p.sumsq[(int64_t)v * 8 + wave] = ss;
+          p.sumsq[(int64_t)v * 8 + 4 + wave] = 0.f;
+        }
+      }
+    }  // cur.last
+    if (!has_next) break;
+    v = v_n;
+    part = part_n;
+    tile_at<MODE, XK, WK>(p, v, part, lane, cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) K-tiles must have landed before this workgroup's LDS is handed on
+}
+
+template <int V, bool XK, bool WK, int MODE = 0>
+static void launch_v4(const Params& p, hipStream_t st, dim3 grid) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    (void)hipFuncSetAttribute((const void*)gemm4_kernel<V, XK, WK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem4);
+    attr_done[dev & 63] = true;
+  }
+  hipLaunchKernelGGL((gemm4_kernel<V, XK, WK, MODE>), grid, dim3(256), kSmem4, st, p);
+}
+
+}  // namespace g4
+
 template <int V, bool XK, bool WK, int MODE = 0>
 static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};  // per device: the attribute belongs to the function object of the device the launch goes to
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<V, XK, WK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   hipLaunchKernelGGL((gemm_kernel<V, XK, WK, MODE>), grid, dim3(512), kSmem, st, p);
 }
@@ -776,7 +1196,22 @@ static void launch(const Params& p, hipStream_t st) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
-  const int v = g_variant & ~(4 | 32);
+  if (g_variant & (64 | 128)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
+    const int v4 = g_variant & (8 | 16);
+    if (g_variant & 128) {  // bit 7: register staging instead of LDS-DMA
+      if (!XK && !WK && v4 == 8) g4::launch_v4<1 | 8, false, false>(p, st, grid);
+      else if (!XK && !WK && v4 == 16) g4::launch_v4<1 | 16, false, false>(p, st, grid);
+      else g4::launch_v4<1, XK, WK>(p, st, grid);
+      return;
+    }
+    if (v4 == 0) g4::launch_v4<0, XK, WK>(p, st, grid);
+    else if (!XK && !WK && v4 == 8) g4::launch_v4<8, false, false>(p, st, grid);
+    else if (!XK && !WK && v4 == 16) g4::launch_v4<16, false, false>(p, st, grid);
+    else if (!XK && !WK) g4::launch_v4<24, false, false>(p, st, grid);
+    else g4::launch_v4<0, XK, WK>(p, st, grid);
+    return;
+  }
+  const int v = g_variant & ~(4 | 32 | 64 | 128);
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only

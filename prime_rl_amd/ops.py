@@ -840,8 +840,9 @@ def _gemm_operand(t: Tensor, name: str) -> tuple[int, bool, int, int]:
     raise PrimeMI355XError(f"{name}: one of the two axes must have unit stride, got strides {t.stride()}")
 
 
-def gemm_supported(x: Tensor, w: Tensor) -> bool:
-    """Can `gemm(x, w)` run on the hand-written MFMA core (shape / layout / alignment)?"""
+def gemm_supported(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16) -> bool:
+    """Can `gemm(x, w, out=out)` run on the hand-written MFMA core (shape / layout / alignment of the operands AND of the result)?  `out` None: the
+    result `gemm` would allocate itself ([M, N] contiguous of `out_dtype`) — its rows must still start 16-byte aligned (N % 8 for bf16, N % 4 for f32)."""
     if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
         return False
     try:
@@ -850,6 +851,14 @@ def gemm_supported(x: Tensor, w: Tensor) -> bool:
     except PrimeMI355XError:
         return False
     if ldx % 8 or ldw % 8 or x.data_ptr() % 16 or w.data_ptr() % 16:
+        return False
+    if out is not None:
+        if out.dim() != 2 or tuple(out.shape) != (m, n) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+            return False
+        ldo, esz, base = out.stride(0), out.element_size(), out.data_ptr()
+    else:
+        ldo, esz, base = n, (2 if out_dtype == torch.bfloat16 else 4), 0
+    if ldo % 4 or (ldo * esz) % 16 or base % 16:  # pm_gemm_bf16: ldo a multiple of 4 elements, every output row 16-byte aligned
         return False
     return bool(_lib.load().pm_gemm_supported(m, n, k, int(xk), int(wk)))
 

@@ -555,7 +555,10 @@ class GRPOEngine:
             # Schedule of the own core: one PERSISTENT workgroup per CU walking its tiles (+0-2 %) when this rank's GPU runs nothing beside the step; one
             # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
             # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
-            ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7")))  # (the env override is the in-step A/B hook: + 32 = no split-K)
+            # The schedule is a process-wide switch of the library (pm_gemm_debug_set_variant): this engine re-asserts ITS choice in front of every own-core
+            # launch (`_own_gemm`), so another engine / the nn.Module LM head / the grouped MoE products in the same process cannot change it under us.
+            self._gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7"))  # (the env override is the in-step A/B hook: + 32 = no split-K)
+            ops.gemm_set_variant(self._gemm_variant)
         # The gradient-norm pass fused into the weight-gradient epilogues (ops.gemm(tile_sumsq=...)): on the LAST backward pass of a step every wgrad GEMM
         # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
         # (norm weights, biases, the embedding) instead of re-reading the whole 4-byte-per-parameter buffer (5.3 ms per Qwen3-8B step).  Only without
@@ -611,6 +614,11 @@ class GRPOEngine:
         except Exception:
             return False
 
+    def _own_gemm(self, *args, **kwargs) -> Tensor:
+        """ops.gemm on the hand-written core under THIS engine's schedule variant (the library keeps one process-wide variant word)."""
+        ops.gemm_set_variant(self._gemm_variant)
+        return ops.gemm(*args, **kwargs)
+
     def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False, bias: Tensor | None = None) -> Tensor:
         """y[n,out] = x[n,in] @ w[out,in]^T (+ bias) — the forward projection GEMM (library call; the bias rides in the GEMM epilogue, added
         to the f32 accumulator before the one rounding to bf16, as F.linear does)."""
@@ -619,8 +627,8 @@ class GRPOEngine:
             if bias is not None:
                 y += bias.float()
             return y if out_f32 else y.to(torch.bfloat16)
-        if "fwd" in self.gemm_own and ops.gemm_supported(x, w):
-            return ops.gemm(x, w, out_dtype=torch.float32 if out_f32 else torch.bfloat16, bias=bias)
+        if "fwd" in self.gemm_own and ops.gemm_supported(x, w, out_dtype=torch.float32 if out_f32 else torch.bfloat16):
+            return self._own_gemm(x, w, out_dtype=torch.float32 if out_f32 else torch.bfloat16, bias=bias)
         if bias is not None:
             return torch.addmm(bias, x, w.t())
         return torch.mm(x, w.t(), out_dtype=torch.float32) if out_f32 else torch.mm(x, w.t())
@@ -642,7 +650,7 @@ class GRPOEngine:
             # dw[out, in] (+)= sum_tok dy[tok, out] x[tok, in]: both operands K-major (tokens are their rows), f32 accumulate in the epilogue
             # `final_name`: this call writes the FINAL gradient of that parameter for the step -> its squared norm comes out of the epilogue
             slot = self._fs_slot(final_name) if (final_name is not None and self.fused_sumsq) else None
-            ops.gemm(dy.t(), x.t(), out=gview, accumulate=accumulate, tile_sumsq=slot)
+            self._own_gemm(dy.t(), x.t(), out=gview, accumulate=accumulate, tile_sumsq=slot)
             if slot is not None:
                 self._fs_covered.add(final_name)
             return
@@ -722,7 +730,7 @@ class GRPOEngine:
         if self.gemm_f32:
             return torch.mm(dy.float(), self.store.w[name].float()).to(torch.bfloat16)
         if self._dgrad_own_now and ops.gemm_supported(dy, self.store.w[name].t()):
-            return ops.gemm(dy, self.store.w[name].t())  # the [out, in] weight read K-major
+            return self._own_gemm(dy, self.store.w[name].t())  # the [out, in] weight read K-major
         if not self.gemm_layouts:
             return torch.mm(dy, self.store.w[name])
         if self._wt_version.get(layer) != self.store.version:
@@ -859,19 +867,34 @@ class GRPOEngine:
         return o, (q, kf, vf, o, lse)
 
     def _gathered_kv_attn_bwd(self, do: Tensor, saved, seq_start: Tensor, scale: float, dv_view: Tensor):
+        """Returns (dq, finish): `finish()` -> dk of this rank's rows, with dv written to `dv_view`.  The dK / dV exchange (every rank's contribution to the kv
+        rows of the ranks before it) runs on the comm stream as ONE ragged all-to-all per tensor — only the prefix chunks a peer owns are sent, nothing is
+        zero-padded — so the caller can put the o-projection's weight-gradient GEMM between the attention kernels and `finish()`."""
         cp, grp = self.cp_size, self.cp_group
         q, kf, vf, o, lse = saved
         n_loc, r1 = q.shape[0], kf.shape[0]
         dq, dk_part, dv_part = ops.attn_varlen_bwd_rows(do.contiguous(), q, kf, vf, o, lse, seq_start[:r1], scale, r1 - n_loc)
-        out = []
-        for part in (dk_part, dv_part):  # this rank's contribution to EVERY kv row of the prefix; rows after it get none (ring_attn.py:252-262)
-            full = part.new_zeros((cp * n_loc,) + tuple(part.shape[1:]))
-            full[:r1] = part
-            mine = part.new_empty((n_loc,) + tuple(part.shape[1:]))
-            dist.reduce_scatter_tensor(mine, full, op=dist.ReduceOp.SUM, group=grp)
-            out.append(mine)
-        dv_view.copy_(out[1])
-        return dq, out[0]
+        done = None
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                rk = ulysses.exchange_prefix_chunks(dk_part, self.cp_rank, cp, n_loc, grp)
+                rv = ulysses.exchange_prefix_chunks(dv_part, self.cp_rank, cp, n_loc, grp)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+        else:
+            rk = ulysses.exchange_prefix_chunks(dk_part, self.cp_rank, cp, n_loc, grp)
+            rv = ulysses.exchange_prefix_chunks(dv_part, self.cp_rank, cp, n_loc, grp)
+
+        def finish():
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)  # (dk_part / dv_part / rk / rv stay referenced by this closure until here)
+            dv_view.copy_(ulysses.sum_prefix_chunks(rv, n_loc))
+            return ulysses.sum_prefix_chunks(rk, n_loc)
+
+        return dq, finish
 
     # -- loss -------------------------------------------------------------------------------------------------------
     def loss(self, ctx: dict, scales: tuple[int, int, int]) -> dict:
@@ -925,7 +948,7 @@ class GRPOEngine:
             if self.gemm_f32:
                 dhf[s:e] = torch.mm(dl, wh.float()).to(torch.bfloat16)
             elif self._dgrad_own_now and ops.gemm_supported(dl, wh.t()):
-                ops.gemm(dl, wh.t(), out=dhf[s:e])
+                self._own_gemm(dl, wh.t(), out=dhf[s:e])
             elif head_t:
                 torch.mm(dl, self._wt["head"].t(), out=dhf[s:e])
             else:
@@ -961,16 +984,22 @@ class GRPOEngine:
             dx2 = ops.rmsnorm_bwd(dh2, L["x2"], w[p + "post_attention_layernorm.weight"], L["rstd2"],
                                   self._norm_grad(g[p + "post_attention_layernorm.weight"], accumulate), dresidual=dx)
             do = self._dgrad(dx2, i, "self_attn.o_proj.weight").view(n, d.num_attention_heads, d.kernel_head_dim)
-            self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate, final_name=p + "self_attn.o_proj.weight" if last_pass else None)
+            o_wgrad = lambda: self._wgrad(dx2, L["o"].view(n, d.q_dim), g[p + "self_attn.o_proj.weight"], accumulate,  # noqa: E731
+                                          final_name=p + "self_attn.o_proj.weight" if last_pass else None)
             qkv = L["qkv"]
             v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             dqkv = torch.empty_like(qkv)
             dv_view = dqkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
             if self.cp_size == 1:
+                o_wgrad()
                 dq, dk, _ = ops.attn_varlen_bwd(do, L["q"], L["k"], v, L["o"], L["lse"], ctx["seq_start"], scale, grad_v_out=dv_view)
-            else:
-                bwd = self._ulysses_attn_bwd if self.cp_style == "ulysses" else self._gathered_kv_attn_bwd
-                dq, dk = bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
+            elif self.cp_style == "ulysses":
+                o_wgrad()
+                dq, dk = self._ulysses_attn_bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
+            else:  # gathered K / V: the dK / dV exchange runs on the comm stream under the o-projection's weight-gradient GEMM
+                dq, finish = self._gathered_kv_attn_bwd(do, L["attn_saved"], ctx["seq_start"], scale, dv_view)
+                o_wgrad()
+                dk = finish()
             if d.qk_norm:
                 ops.qknorm_rope_bwd(dq, dk, qkv, w[p + "self_attn.q_norm.weight"], w[p + "self_attn.k_norm.weight"], ctx["cos"], ctx["sin"],
                                     L["rstd_qk"], dqkv, self._norm_grad(g[p + "self_attn.q_norm.weight"], accumulate),

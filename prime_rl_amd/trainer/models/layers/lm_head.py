@@ -139,7 +139,7 @@ class _StoredLogitsLogProbEntropyFn(torch.autograd.Function):
         inv_t = inv_temperature.contiguous().float()
         hidden, weight_c = hidden.contiguous(), weight.contiguous()
         logits = torch.empty(n, vocab, dtype=torch.bfloat16, device=dev)
-        own = ops.gemm_supported(hidden[:1], weight_c)
+        own = ops.gemm_supported(hidden[:1], weight_c, out=logits[:1])  # the result rows too: a vocabulary that is not a multiple of 8 falls back to the library
         for s0 in range(0, n, chunk_size):
             s1 = min(s0 + chunk_size, n)
             if own:
@@ -151,6 +151,7 @@ class _StoredLogitsLogProbEntropyFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(hidden, weight_c, labels, inv_t, logz, logits)
         ctx.chunk_size = chunk_size
+        ctx.logits_consumed = False
         mg, st = getattr(weight, "main_grad", None), getattr(weight, "main_grad_written", None)
         ctx.main_grad = (mg, st) if (mg is not None and st is not None) else None
         return logprobs, entropy
@@ -160,6 +161,10 @@ class _StoredLogitsLogProbEntropyFn(torch.autograd.Function):
         assert grad_entropy is None, "Backward through entropy is not implemented in FusedOutputLinear"
         assert grad_logprobs is not None, "FusedOutputLinear backward requires logprobs gradients"
         hidden, weight, labels, inv_t, logz, logits = ctx.saved_tensors
+        if ctx.logits_consumed:  # the backward overwrites the stored logits in place with dlogits: a second pass (retain_graph) would read garbage
+            raise RuntimeError("FusedOutputLinear (stored logits): backward ran twice on the same forward — the stored logits were consumed in place; "
+                               "set PM_MODULE_LM_HEAD=chunked for a re-entrant backward")
+        ctx.logits_consumed = True
         n = hidden.shape[0]
         needs_hidden, needs_weight = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_hidden = torch.empty_like(hidden) if needs_hidden else None
@@ -170,7 +175,7 @@ class _StoredLogitsLogProbEntropyFn(torch.autograd.Function):
             s1 = min(s0 + ctx.chunk_size, n)
             dl = ops.logprob_bwd(logits[s0:s1], labels[s0:s1], inv_t[s0:s1], logz[s0:s1], g[s0:s1], out=logits[s0:s1])
             if needs_hidden:
-                if ops.gemm_supported(dl, weight.t()):
+                if ops.gemm_supported(dl, weight.t(), out=grad_hidden[s0:s1]):
                     ops.gemm(dl, weight.t(), out=grad_hidden[s0:s1])
                 else:
                     torch.mm(dl, weight, out=grad_hidden[s0:s1])
@@ -196,7 +201,10 @@ class FusedOutputLinear(torch.nn.Linear):
         inv_t = 1.0 / temperature.reshape(b * s).contiguous()
         # "stored" (default where it applies: bf16 on the GPU, logits within PM_LM_HEAD_LOGITS_GIB, default 24): keep the logits for the backward instead of
         # recomputing them; "chunked": the reference's memory-saving form (lm_head.py:89-202) on the fused J1 kernel
-        stored = (os.environ.get("PM_MODULE_LM_HEAD", "stored") == "stored" and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+        # (forward-only passes — torch.no_grad(), or nothing that requires a gradient — never need the [N, V] logits afterwards: the chunked form keeps
+        # one chunk at a time instead of up to 24 GiB)
+        wants_grad = torch.is_grad_enabled() and (hidden_states.requires_grad or self.weight.requires_grad)
+        stored = (wants_grad and os.environ.get("PM_MODULE_LM_HEAD", "stored") == "stored" and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
                   and self.weight.dtype == torch.bfloat16 and 2 * b * s * self.weight.shape[0] <= float(os.environ.get("PM_LM_HEAD_LOGITS_GIB", "24")) * 2**30)
         fn = _StoredLogitsLogProbEntropyFn if stored else _SequenceChunkedLogProbEntropyFn
         logprobs, entropy = fn.apply(hidden_states, self.weight, labels, inv_t, self.chunk_size)

@@ -136,17 +136,28 @@ class ParallelDims:
 def resolve_ep(config, world_size: int) -> int:
     """`model.ep = "auto"` -> an integer, the reference's rule (parallel_dims.py:281-317): MoE models get min(world_size // dp_replicate, 8) — without it
     the default config would replicate every expert with its f32 master, moments and gradient on every rank (~18 B/param: Qwen3-30B-A3B does not fit a
-    288 GB part that way) — dense models 1.  An explicit integer is returned unchanged."""
+    288 GB part that way) — dense models 1, and 1 when `model.impl` is not "custom" / "auto"; a non-torch `ep_comm_backend` with a resolved ep of 1
+    is an error, as in the reference.  An explicit integer is returned unchanged."""
     if isinstance(config.ep, int):
         return config.ep
+    import logging
+
+    log = logging.getLogger("prime_rl_amd")
+    impl = getattr(config, "impl", "auto")
+    if impl not in ("custom", "auto"):  # parallel_dims.py:291-295: expert parallelism needs the custom implementation
+        log.info("EP auto: impl='%s' does not support EP, resolving ep=1", impl)
+        return 1
     from .model import resolve_moe_config  # local import: model.py imports this module
 
     if resolve_moe_config(config) is None:
+        log.info("EP auto: model is not MoE, resolving ep=1")
         return 1
     ep = max(1, min(world_size // max(int(config.dp_replicate), 1), 8))
-    import logging
-
-    logging.getLogger("prime_rl_amd").info("EP auto: world_size=%d, dp_replicate=%d -> resolved ep=%d", world_size, config.dp_replicate, ep)
+    log.info("EP auto: world_size=%d, dp_replicate=%d -> resolved ep=%d", world_size, config.dp_replicate, ep)
+    backend = getattr(config, "ep_comm_backend", "torch")
+    if backend != "torch" and ep <= 1:  # parallel_dims.py:311-316
+        raise ValueError(f"model.ep_comm_backend='{backend}' requires ep > 1, but auto-resolved ep=1 (world_size={world_size}). "
+                         "Set ep explicitly or use ep_comm_backend='torch'.")
     return ep
 
 

@@ -73,3 +73,26 @@ def all_gather_tokens(t: Tensor, cp_size: int, group) -> Tensor:
     out = torch.empty((cp_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     return out
+
+
+def exchange_prefix_chunks(part: Tensor, cp_rank: int, cp_size: int, n_loc: int, group) -> Tensor:
+    """The dK / dV exchange of `cp_style = "ring"` (gathered K / V) without padding.  Rank r attended its q rows against the kv prefix [0, (r + 1) n_loc), so
+    `part` [(r + 1) n_loc, ...] holds its contribution to the rows of ranks 0..r and NOTHING for later ranks: chunk j goes to rank j, and rank r receives
+    chunk r of every rank >= r.  One all-to-all with ragged splits (each pair's block on its own xGMI link) moves r chunks per rank instead of the
+    cp chunks of a reduce-scatter over zero-padded [cp n_loc] buffers (the reference: ring_attn.py:252-262).  Returns [(cp - r) n_loc, ...]: block i = rank
+    r + i's contribution to MY rows; `sum_prefix_chunks` adds the blocks in rank order."""
+    if part.shape[0] != (cp_rank + 1) * n_loc:
+        raise ValueError(f"rank {cp_rank}: expected {(cp_rank + 1) * n_loc} prefix rows, got {part.shape[0]}")
+    in_splits = [n_loc] * (cp_rank + 1) + [0] * (cp_size - 1 - cp_rank)
+    out_splits = [0] * cp_rank + [n_loc] * (cp_size - cp_rank)
+    recv = part.new_empty(((cp_size - cp_rank) * n_loc,) + tuple(part.shape[1:]))
+    dist.all_to_all_single(recv, part.contiguous(), out_splits, in_splits, group=group)
+    return recv
+
+
+def sum_prefix_chunks(recv: Tensor, n_loc: int) -> Tensor:
+    """[(blocks) n_loc, ...] -> [n_loc, ...]: the blocks summed in f32 in rank order, rounded once (deterministic; a bf16 ring reduction rounds per hop)."""
+    blocks = recv.shape[0] // n_loc
+    if blocks == 1:
+        return recv
+    return recv.float().view((blocks, n_loc) + tuple(recv.shape[1:])).sum(0).to(recv.dtype)

@@ -215,7 +215,7 @@ class RCCLWeightBroadcast(WeightBroadcast):
         self.ready_timeout, self.trainer_group = ready_timeout, trainer_group
         self._stream = None
         self._events: tuple | None = None
-        self._in_flight: tuple | None = None  # (completion event, tensors the push stream still reads) of the previous asynchronous push
+        self._in_flight: tuple | None = None  # (completion event, None) of the previous asynchronous push (its temporaries are owned by record_stream)
 
     @torch.no_grad()
     def broadcast_weights(self, model, step: int) -> None:
@@ -242,7 +242,7 @@ class RCCLWeightBroadcast(WeightBroadcast):
         if device.type == "cuda":
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=device)
-            if self._in_flight is not None:  # the previous push has long finished (the optimizer step waited for it); only now may its tensors go
+            if self._in_flight is not None:  # the previous push has long finished (the optimizer step waited for it)
                 self._in_flight[0].synchronize()
                 self._in_flight = None
             final = torch.cuda.Event()
@@ -255,9 +255,15 @@ class RCCLWeightBroadcast(WeightBroadcast):
                 t1.record(self._stream)
             self._events = (t0, t1)
             # `named` of an nn.Module engine holds TEMPORARIES allocated on the main stream (bf16 copies of f32 router gates, all-gathered expert
-            # tensors) that the push stream reads later: they must outlive this call, or the caching allocator hands their blocks to the next step's
-            # forward while the push kernels still read them.  Kept until the push's completion event has fired.
-            self._in_flight = (t1, named)
+            # tensors) that the push stream reads later.  record_stream() hands their lifetime to the caching allocator: a block is reused only after the
+            # push-stream work enqueued so far has finished, so the references can be dropped NOW — an expert-parallel MoE model's gathered state dict
+            # (tens of GB) is released when the push completes instead of being pinned through the whole next training step.
+            if named is not None:
+                for t in named.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(self._stream)
+            del named
+            self._in_flight = (t1, None)
             if hasattr(model, "add_param_reader"):
                 model.add_param_reader(t1)  # the next optimizer step waits for the push on the device, the host never blocks
             else:

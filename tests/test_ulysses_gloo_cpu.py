@@ -77,3 +77,34 @@ def test_shard_for_cp_rejects_uneven_lengths():
 
     with pytest.raises(ValueError, match="divisible"):
         shard_for_cp(torch.zeros(10), 0, 4)
+
+
+def _prefix_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prime_rl_amd.trainer import ulysses as U
+
+    n_loc = 6
+    g = torch.Generator().manual_seed(100 + rank)
+    part = torch.randn((rank + 1) * n_loc, 2, 4, generator=g).to(torch.bfloat16)  # this rank's contribution to the kv rows of ranks 0..rank
+    recv = U.exchange_prefix_chunks(part, rank, world, n_loc, None)
+    assert recv.shape[0] == (world - rank) * n_loc
+    mine = U.sum_prefix_chunks(recv, n_loc)
+    # what the reference's form does (ring_attn.py:252-262): reduce-scatter of zero-padded [world * n_loc] buffers — here in f32 so the comparison is exact
+    full = torch.zeros(world * n_loc, 2, 4)
+    full[: (rank + 1) * n_loc] = part.float()
+    out = torch.empty(n_loc, 2, 4)
+    dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+    torch.save(dict(mine=mine, ref=out), os.path.join(out_dir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_prefix_chunk_exchange_equals_the_padded_reduce_scatter(tmp_path, world):
+    """cp_style "ring" backward: the ragged all-to-all that sends each peer only the dK / dV chunk it owns equals the reference's reduce-scatter over
+    zero-padded buffers (sum in f32 in rank order, rounded once to bf16)."""
+    mp.start_processes(_prefix_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    for i in range(world):
+        r = torch.load(tmp_path / f"p{i}.pt")
+        assert torch.equal(r["mine"], r["ref"].to(torch.bfloat16)), i

@@ -167,7 +167,9 @@ def bench_gemm(out):
         torch.cuda.empty_cache()
 
 
-def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=3):  # 39 = 7 without the split-K of a half-empty last round
+def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=3):  # 39 = 7 without the split-K of a half-empty last round; 68 = the one-wave-per-SIMD kernel
+    if os.environ.get("PM_GEMM_VARIANTS"):
+        variants = tuple(int(v) for v in os.environ["PM_GEMM_VARIANTS"].split(","))
     """The hand-written MFMA GEMM core (csrc/gemm.hip) against the library call it replaces, per Qwen3-8B projection and layout, interleaved in one
     process (boxes differ by a few %).  Random operands (guide §5.4 rule 25: zero-filled operands clock ~15 % higher)."""
     shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
@@ -464,7 +466,9 @@ def main():
                 return f
             cases = [("own fwd", lambda: ops.gemm(x, w)), ("lib fwd", lambda: torch.mm(x, w.t())), ("own wgrad", lambda: ops.gemm(dy.t(), x.t(), out=g)),
                      ("lib wgrad", lambda: torch.mm(dy.t(), x, out_dtype=torch.float32, out=g))]
-            cases += [(f"own fwd variant {v} ({d})", own_v(v)) for v, d in ((1, "one WG per tile"), (4, "no setprio"), (7, "balanced reads"), (13, "ABLATION no DMA"), (21, "ABLATION no reads"), (29, "ABLATION no DMA, no reads"))]
+            cases += [(f"own fwd variant {v} ({d})", own_v(v)) for v, d in ((1, "one WG per tile"), (4, "no setprio"), (7, "balanced reads"), (13, "ABLATION no DMA"), (21, "ABLATION no reads"), (29, "ABLATION no DMA, no reads"),
+                                                                             (68, "4-wave kernel, persistent"), (64, "4-wave kernel, one WG per tile"), (76, "4-wave ABLATION no DMA"),
+                                                                             (84, "4-wave ABLATION no reads"), (92, "4-wave ABLATION no DMA, no reads"))]
             for label, fn in cases:
                 med, best = timeit(fn, iters=10, warmup=2)
                 print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
