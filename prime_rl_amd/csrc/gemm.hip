@@ -941,7 +941,6 @@ __device__ __forceinline__ void group(Wave4& s, unsigned char* smem) {
 // SYNC: the step ends a K-tile's reads of its buffer -> wait for the other buffer's DMA (or the ds_writes), barrier.
 template <int SET, int NBUF, int DBUF, bool DMA, bool SYNC, int V, bool XK, bool WK>
 __device__ __forceinline__ void step(Wave4& s, unsigned char* smem) {
-  __builtin_amdgcn_s_setprio(1);
   group<SET, NBUF, DBUF, DMA, 0, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 1, V, XK, WK>(s, smem);
   group<SET, NBUF, DBUF, DMA, 2, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 3, V, XK, WK>(s, smem);
   group<SET, NBUF, DBUF, DMA, 4, V, XK, WK>(s, smem);  group<SET, NBUF, DBUF, DMA, 5, V, XK, WK>(s, smem);
@@ -950,7 +949,6 @@ __device__ __forceinline__ void step(Wave4& s, unsigned char* smem) {
   group<SET, NBUF, DBUF, DMA, 10, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 11, V, XK, WK>(s, smem);
   group<SET, NBUF, DBUF, DMA, 12, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 13, V, XK, WK>(s, smem);
   group<SET, NBUF, DBUF, DMA, 14, V, XK, WK>(s, smem); group<SET, NBUF, DBUF, DMA, 15, V, XK, WK>(s, smem);
-  __builtin_amdgcn_s_setprio(0);
   if (SYNC) {
     if (V & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // register staging: nothing LDS-bound is on the vector-memory counter
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1198,16 +1196,10 @@ static void launch(const Params& p, hipStream_t st) {
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
   if (g_variant & (64 | 128)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
     const int v4 = g_variant & (8 | 16);
-    if (g_variant & 128) {  // bit 7: register staging instead of LDS-DMA
-      if (!XK && !WK && v4 == 8) g4::launch_v4<1 | 8, false, false>(p, st, grid);
-      else if (!XK && !WK && v4 == 16) g4::launch_v4<1 | 16, false, false>(p, st, grid);
-      else g4::launch_v4<1, XK, WK>(p, st, grid);
-      return;
-    }
-    if (v4 == 0) g4::launch_v4<0, XK, WK>(p, st, grid);
+    if (g_variant & 128) g4::launch_v4<1, XK, WK>(p, st, grid);  // bit 7: register staging instead of LDS-DMA
     else if (!XK && !WK && v4 == 8) g4::launch_v4<8, false, false>(p, st, grid);
     else if (!XK && !WK && v4 == 16) g4::launch_v4<16, false, false>(p, st, grid);
-    else if (!XK && !WK) g4::launch_v4<24, false, false>(p, st, grid);
+    else if (!XK && !WK && v4 == 24) g4::launch_v4<24, false, false>(p, st, grid);
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }

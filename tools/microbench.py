@@ -468,7 +468,8 @@ def main():
                      ("lib wgrad", lambda: torch.mm(dy.t(), x, out_dtype=torch.float32, out=g))]
             cases += [(f"own fwd variant {v} ({d})", own_v(v)) for v, d in ((1, "one WG per tile"), (4, "no setprio"), (7, "balanced reads"), (13, "ABLATION no DMA"), (21, "ABLATION no reads"), (29, "ABLATION no DMA, no reads"),
                                                                              (68, "4-wave kernel, persistent"), (64, "4-wave kernel, one WG per tile"), (76, "4-wave ABLATION no DMA"),
-                                                                             (84, "4-wave ABLATION no reads"), (92, "4-wave ABLATION no DMA, no reads"))]
+                                                                             (84, "4-wave ABLATION no reads"), (92, "4-wave ABLATION no DMA, no reads"),
+                                                                             (132, "4-wave kernel, register staging"))]
             for label, fn in cases:
                 med, best = timeit(fn, iters=10, warmup=2)
                 print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
