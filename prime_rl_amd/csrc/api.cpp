@@ -1,5 +1,5 @@
 // api.cpp — error plumbing + version/device queries of libprime_mi355x.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdarg.h>
 #include <string.h>
 

@@ -7,20 +7,20 @@
 // P = softmax_row(S), O = P V; backward dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(dO o O)), dQ = scale dS K,
 // dK = scale dS^T Q.
 //
-// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_kernels.cuh; earlier
+// MI355X design (this file: shared helpers, layout probes, delta kernel, host dispatch; kernels in attention_kernels.hip.h; earlier
 // generations are in the git history only):
 //   * tiles live on the GLOBAL token grid of the packed row: row i may attend to j in [seq_start[i], i].  No per-document
 //     tile scheduling on the host, no max_seqlen, no host sync: grid = ceil(N/BM) * heads.
 //   * v_mfma_f32_16x16x32_bf16; every A/B fragment is 16 bytes along the contraction dim (lane l: row l&15,
 //     k = (l>>4)*8..+8), C layout row = (l>>4)*4 + r, col = l&15 (guide §3, verified by pm_mfma_probe_16x16x32).
 //   * TRANSPOSED products (S^T = K.Q^T, ...): probabilities stay in registers, the C layout is the B-fragment layout up to a
-//     permutation of the contraction index (attention_kernels.cuh).
+//     permutation of the contraction index (attention_kernels.hip.h).
 //   * operands whose contraction dim is the token axis (V in PV; Q, dO in dK/dV; K in dQ) are read out of the row-major LDS
 //     tile with ds_read_b64_tr_b16 (pinned by pm_ds_read_tr16_probe): no transposed copies in global memory, no pre-pass.
 //   * blockIdx -> (kv head fastest): the workgroups that share K/V land on the same XCD (block b runs on XCD b%8),
 //     q tiles are issued heaviest-first (causal imbalance).
 //   * backward is two kernels (dK/dV per kv tile, dQ per q tile): no atomics, bitwise reproducible.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace pm {
@@ -97,15 +97,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-#include "attention_kernels.cuh"
-#include "attention_fwd_pp.cuh"
+#include "attention_kernels.hip.h"
+#include "attention_fwd_pp.hip.h"
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
 // boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
 // workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
 constexpr int kFwdDefaultOpt = 15;  // 1 | 2 | 4 (row-max reduction as one asm block) | 8 (16-byte epilogue stores)
-static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.cuh); -1 = the default build
+static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.hip.h); -1 = the default build
 static int g_dkdv_var = 0;
 static int g_dq_var = 0;
 }  // namespace pm
@@ -114,7 +114,7 @@ using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   if (kernel == 0) {
-    if (value > 15 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.cuh)
+    if (value > 15 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
     g_fwd_var = value;
     return PM_OK;
   }

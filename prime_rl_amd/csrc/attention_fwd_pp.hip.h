@@ -1,5 +1,5 @@
-// attention_fwd_pp.cuh — EXPERIMENT, not the default: the forward attention kernel as an 8-wave ping-pong with a software-pipelined softmax
-// (included by attention.hip after attention_kernels.cuh, whose LDS image, fragment maps and softmax arithmetic it reuses UNCHANGED: outputs and lse
+// attention_fwd_pp.hip.h — EXPERIMENT, not the default: the forward attention kernel as an 8-wave ping-pong with a software-pipelined softmax
+// (included by attention.hip after attention_kernels.hip.h, whose LDS image, fragment maps and softmax arithmetic it reuses UNCHANGED: outputs and lse
 // are bit-identical to attn_fwd_kernel).  Reached only through pm_attn_debug_set_variant(0, 64 + OPT); measured SLOWER than the shipped kernel
 // (0.42 vs 0.34 ms at the bench shape) — profiles/r03_attention.md has the phase-by-phase cycle counts and the reasons (the forward pass is bounded
 // by VALU issue, and barrier-coupled phases leave only one wave per SIMD issuing it).  Kept in the tree as the A/B partner those numbers come from.

@@ -1,4 +1,4 @@
-// attention_kernels.cuh — the three varlen GQA attention kernels (forward, dK/dV, dQ) for gfx950.  Earlier generations (v1 correct-first,
+// attention_kernels.hip.h — the three varlen GQA attention kernels (forward, dK/dV, dQ) for gfx950.  Earlier generations (v1 correct-first,
 // v2 LDS round trip, v3 padded tiles + transposed global copies, v4 register-staged tiles) are in the git history; what each step bought
 // is recorded in DESIGN.md §3 and profiles/r01_attention_pmc.md, profiles/r02_attention.md.
 //

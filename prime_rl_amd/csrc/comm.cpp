@@ -7,7 +7,7 @@
 //
 // librccl is resolved at first use with dlopen: a process that already carries an RCCL (PyTorch-ROCm bundles one with the same
 // SONAME) keeps using that single copy — two RCCL runtimes in one process would each own half of the xGMI bootstrap state.
-#include "common.cuh"
+#include "common.hip.h"
 #include <dlfcn.h>
 #include <string.h>
 #include <rccl/rccl.h>

@@ -1,4 +1,4 @@
-// common.cuh — shared device/host helpers for libprime_mi355x (gfx950 only; wave64).
+// common.hip.h — shared device/host helpers for libprime_mi355x (gfx950 only; wave64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -5,7 +5,7 @@
 // Reference arithmetic (src/prime_rl/): MLP.forward (trainer/models/layers/mlp.py:27-29), nn.Embedding
 // (trainer/models/qwen3/modeling_qwen3.py:139,174), scale_gradients_ / clip_grad_norm_ (trainer/utils.py:78-98),
 // AdamW (trainer/optim/__init__.py:101-108; torch.optim.AdamW semantics: decoupled decay, bias correction).
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 

@@ -14,12 +14,13 @@
 // activation exists in HBM.
 //
 // MI355X design (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md §5 "256² 8-phase template"):
-//   * 256 x 256 output tile per workgroup, contraction step 64, 8 waves = 2 (W rows) x 4 (X rows), 128 x 64 outputs per wave held as 2 x 2 x 2
-//     accumulator fragments of v_mfma_f32_32x32x16_bf16 (128 registers).  TRANSPOSED product: the MFMA A operand is the W fragment, so a lane
-//     owns ONE X row (token) and 4 x 4 consecutive W rows (output columns): 8 / 16-byte stores along the contiguous axis of OUT, and per-lane
-//     softmax state for the fused log-prob epilogue.
+//   * 256 x 256 output tile per workgroup, contraction step 64, 8 waves = 2 (W rows) x 4 (X rows), 128 x 64 outputs per wave held as 2
+//     x 4 x 2 x 2 accumulator fragments of v_mfma_f32_16x16x32_bf16 (128 registers; the first version used 32x32x16, which the chip's power limit
+//     makes 8-13 % more expensive per flop: profiles/r03_gemm.md section 3b).  TRANSPOSED product: the MFMA A operand is the W fragment, so a lane
+//     owns ONE X row (token) and 4 consecutive W rows (output columns) of every 16-column block: 8 / 16-byte stores along the contiguous axis of
+//     OUT, and per-lane softmax state for the fused log-prob epilogue.
 //   * PING-PONG: waves 0-3 (one per SIMD) and waves 4-7 (their SIMD partners) run the same phase stream one barrier apart.  A phase =
-//     [load segment: LDS fragment reads + 2 LDS-DMA pieces] s_barrier [compute segment: 8 MFMAs = one 64 x 32 quadrant x K 64] s_barrier, so on
+//     [load segment: LDS fragment reads + 2 LDS-DMA pieces] s_barrier [compute segment: 16 MFMAs = one 64 x 32 quadrant x K 64] s_barrier, so on
 //     every SIMD one wave is in its compute segment while its partner is in its load segment; the matrix pipe never waits for an LDS read and
 //     no wave mixes LDS / VMEM issue into its MFMA stream.
 //   * LDS = a ring of 8 half-tile slots of 16 KB (two K-tiles): per K-tile W0 | W1 | X0 | X1, where W^i holds every wave's i-th 64-row W sub-tile
@@ -30,11 +31,11 @@
 //     `s_waitcnt vmcnt(6)` + barrier that retires it (RAW; the wait leaves the 3 newest half-tiles in flight, never 0 inside the loop).
 //   * tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write.  The DMA writes lane-linear, so the
 //     bank-conflict swizzle is applied to the per-lane SOURCE address: 16-byte chunk c of tile row r (128-byte rows) lives at chunk
-//     c ^ ((r >> 1) & 7) — conflict-free for the 32-row fragments of the 32x32x16 MFMA against the real ds_read_b128 service groups
+//     c ^ ((r >> 1) & 7) — conflict-free for the 16-row fragments of the 16x16x32 MFMA (and the 32-row ones of 32x32x16) against the real ds_read_b128 service groups
 //     {0-3,12-15,20-27} {4-11,16-19,28-31} (+32).  Rows past the end of a tensor read as zeros through the buffer range check.
 //   * blockIdx -> tile: block b runs on XCD b % 8; the 32 tiles an XCD runs concurrently form an 8 (X) x 4 (W) patch that walks K in step,
 //     so 12 row panels feed 32 tiles through one L2, and the 8 XCDs work on patches that share their W panels.
-#include "common.cuh"
+#include "common.hip.h"
 #include <algorithm>
 
 namespace pm {

@@ -26,11 +26,11 @@
 //       ds_read_b64_tr_b16 addressed so that a fragment holds its 8 contraction values in NATURAL order (rows lq*8 .. lq*8+7: first
 //       read rows +0..3, second +4..7) — the partner operand can then be a plain ds_read_b128 fragment.
 //   * the two LDS buffers are two static arrays and the stage loop is unrolled by two (hipcc guards transpose-reads that may alias a
-//     pending LDS-DMA with vmcnt(0); see attention_kernels.cuh), explicit `s_waitcnt vmcnt(0)` before each barrier.
+//     pending LDS-DMA with vmcnt(0); see attention_kernels.hip.h), explicit `s_waitcnt vmcnt(0)` before each barrier.
 //   * NT / NN: 128-row tiles of the SORTED rows x 128-column tiles, block order XCD-aware (tile_of_block: 0.44 -> 0.72 PFLOP/s on the forward
 //     product); a row tile never straddles two experts (per expert ceil(rows / 128) tiles), the tile -> expert search is a wave-parallel
 //     prefix scan over the offsets, rows past the group's end are computed and not stored.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 namespace gg {

@@ -27,7 +27,7 @@
 //     XCD's L2 (8x less traffic beyond L2 than a row-major block order).
 //   * per-token partial states (one per super-chunk and vocab half of the workgroup) go to a small workspace
 //     (N x 2S x 4 floats) and a finalize kernel merges them: logz, logprob, entropy.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 

@@ -15,7 +15,7 @@
 //   * small n_rows: split the vocab across several workgroups per row (partials in workspace + finalize kernel)
 //     so a launch still has >=2048 workgroups for 256 CUs.
 // Algorithmic bytes: (sizeof(T)*V + 20) per row forward; (sizeof(Tin)+sizeof(Tout))*V backward.
-#include "common.cuh"
+#include "common.hip.h"
 #include <float.h>
 
 namespace pm {

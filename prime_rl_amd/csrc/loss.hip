@@ -10,7 +10,7 @@
 // the micro-batch (one workgroup per sample = one segment of cu_samples), emits the scaled loss, dL/dlogprob and the raw
 // per-sample sums, and a second single-workgroup launch folds the per-sample sums in the reference's order.
 // HBM: 17 B/token read (+4 per weight stream, +4 ref) and 4 B/token written; latency-bound at 2k tokens.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 

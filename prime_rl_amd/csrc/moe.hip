@@ -11,7 +11,7 @@
 // on floating point, bitwise reproducible), 16-byte row copies for the permutations, and the combine written as a GATHER over each
 // token's k slots (deterministic; the reference's scatter_add is an atomic accumulation on the GPU) that reproduces the reference's CPU
 // result bit for bit: contributions are added in ascending sorted-row order in f32 and rounded to bf16 once.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 

@@ -6,7 +6,7 @@
 // FlashAttention.attn_projections (attn.py:123-160); get_cu_seqlens_from_seq_lens (utils/sequence.py:38-52).
 // bf16 rounding points follow the reference's eager bf16 ops so forward values match it bit-for-bit up to the
 // reduction order of the sum of squares.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace pm {
 

@@ -15,8 +15,10 @@ MI355X-first choices (DESIGN.md has the numbers):
     gradients are reduce-scattered per layer bucket while backward is still running, master weights + Adam moments are
     sharded, updated bf16 shards are all-gathered in place.  One reduce-scatter + one all-gather of the model per step
     instead of two all-gathers per layer per micro-batch (xGMI is per-link bound: fewer, larger collectives).
-  * GEMMs are plain library calls (hipBLASLt through torch.mm); everything else on the path is a kernel in
-    libprime_mi355x.so.
+  * Every weight-gradient GEMM runs on the hand-written MFMA core of libprime_mi355x.so (csrc/gemm.hip: token-major operands read as they
+    are, f32 accumulation straight into the gradient buffer, the gradient norm out of the epilogue); the forward / dgrad products are
+    hipBLASLt calls by default because the library measures 5-10 % faster there (`PM_GEMM_OWN=all` puts them on the own core as well:
+    profiles/r03_gemm.md, r04_gemm.md); everything else on the path is a kernel in libprime_mi355x.so.
 """
 
 from __future__ import annotations

@@ -5,7 +5,7 @@
 #include <cmath>
 #include <cstdio>
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-__device__ float xrow_max_swap(float v) {  // the version used by attention_kernels.cuh: inline asm, both registers read-write
+__device__ float xrow_max_swap(float v) {  // the version used by attention_kernels.hip.h: inline asm, both registers read-write
   float a = v, b = v;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   a = fmaxf(a, b);
