@@ -497,7 +497,10 @@ int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                     int32_t out_dtype, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n, int64_t k,
                     float* tile_sumsq /* nullable */, int64_t tile_sumsq_len, void* workspace /* nullable */, int64_t workspace_bytes, void* stream);
-int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced fragment reads */
+int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py), one PROCESS-WIDE word: bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced
+                                               * fragment reads, bit 2 = persistent grid, bit 5 = no split-K of a half-empty last round, bits 3-4 = timing ablations; bit 6 = the
+                                               * one-wave-per-SIMD kernel (gemm4_kernel: 4 waves, 128 x 128 register tile; same results bit for bit), bit 7 = the same with register
+                                               * staging instead of LDS-DMA.  Callers that care re-assert their value before a launch (GRPOEngine._own_gemm). */
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

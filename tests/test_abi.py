@@ -83,3 +83,24 @@ def test_gemm_planning_entry_points_are_pure_host_functions():
     assert lib.pm_gemm_workspace_bytes(4096, 4096, 16384) == 0       # 256 tiles: a whole round
     assert lib.pm_gemm_workspace_bytes(24576, 4096, 16384) == 0      # 1536 tiles: six whole rounds
     assert lib.pm_gemm_workspace_bytes(0, 4096, 16384) == 0
+
+
+def test_gemm_supported_also_checks_the_result(monkeypatch):
+    """ops.gemm_supported (host logic only: strides, alignment, pm_gemm_supported) must refuse what pm_gemm_bf16 would reject with PM_ERR_INVALID_ARG:
+    a result whose rows do not start 16-byte aligned (a vocabulary that is not a multiple of 8: the stored-logits LM head then takes the library GEMM).
+    (The device check of `ops._req` is lifted for this test: the decision is pure host arithmetic on shapes, strides and addresses.)"""
+    import torch
+
+    from prime_rl_amd import ops
+
+    monkeypatch.setattr(ops, "_req", lambda t, dtype, name, contiguous=True: t)
+
+    x = torch.zeros(256, 128, dtype=torch.bfloat16)
+    w_ok, w_odd = torch.zeros(512, 128, dtype=torch.bfloat16), torch.zeros(516, 128, dtype=torch.bfloat16)
+    assert ops.gemm_supported(x, w_ok) and ops.gemm_supported(x, w_ok, out=torch.zeros(256, 512, dtype=torch.bfloat16))
+    assert not ops.gemm_supported(x, w_odd)  # bf16 rows of 516 elements: 1032 bytes, not a multiple of 16
+    assert ops.gemm_supported(x, w_odd, out_dtype=torch.float32)  # f32 rows of 516 elements are 16-byte aligned
+    assert not ops.gemm_supported(x, w_odd, out=torch.zeros(256, 516, dtype=torch.bfloat16))
+    wide = torch.zeros(256, 1024, dtype=torch.bfloat16)
+    assert ops.gemm_supported(x, w_ok, out=wide[:, :512]) and not ops.gemm_supported(x, w_ok, out=wide[:, 4:516])  # strided is fine, a 8-byte-aligned base is not
+    assert not ops.gemm_supported(x, w_ok, out=torch.zeros(256, 512, dtype=torch.float16))

@@ -201,3 +201,10 @@ def test_ep_auto_resolves_like_the_reference():
     assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", dp_replicate=2), 8) == 4
     assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep=2), 8) == 2
     assert get_parallel_dims(moe, world_size=8).ep == 8 and get_parallel_dims(dense, world_size=8).ep == 1
+    # the two remaining branches of the reference rule (parallel_dims.py:291-295, 311-316)
+    assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", impl="hf"), 8) == 1  # expert parallelism needs the custom implementation
+    import pytest
+
+    with pytest.raises(ValueError, match="requires ep > 1"):
+        resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep_comm_backend="deepep"), 1)
+    assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep_comm_backend="deepep"), 8) == 8  # (rejected later by validate_supported, not by the resolution)
