@@ -174,6 +174,54 @@ class ModuleEngine:
             sd = prime_to_hf(sd)
         return sd
 
+    # -- the sharded ("named") weight push: every trainer rank sends what it holds, nothing is gathered first --------------------------------
+    def push_plan(self, n_trainers: int) -> list[dict]:
+        """Who sends what in the multi-source push of an nn.Module engine (transports/weights `protocol="sharded"`): a list of groups (the non-layer
+        tensors, then one group per decoder layer — the order a layer-wise loader wants), each a list of messages `{src, shape, names | experts}`.
+        Replicated tensors travel whole, round-robin over the trainer ranks (every rank holds them; every rank sends 1 / T of the bytes over its own
+        links); the stacked expert tensors of an expert-parallel model are sent BY THE RANK THAT OWNS THEM (ep position e of the first ep group), one
+        message per stacked tensor, and the receiver cuts the per-expert HF tensors out of it — no all-gather of the experts over the ep group and no
+        single-source funnel (the reference: full_tensor() on every parameter, then rank 0 broadcasts everything, transports/weights/nccl.py:33-84).
+        Computed from names and shapes alone, so every rank (and the manifest the master writes) agrees without communication."""
+        from .models.qwen3_moe.converting_qwen3_moe import _PROJ
+
+        if n_trainers != self.dp_size:
+            raise PrimeMI355XError(f"push_plan: {n_trainers} trainer ranks in the push group, {self.dp_size} in the engine")
+        groups: dict[str, list[dict]] = {}
+        rr = 0
+        for key, t in self.model.state_dict().items():
+            gname = ".".join(key.split(".")[:3]) if key.startswith("model.layers.") else ""
+            msgs = groups.setdefault(gname, [])
+            hit = next(((wn, hf) for wn, hf in _PROJ if key.endswith(f".mlp.experts.{wn}")), None)
+            if hit is not None and self.ep_size > 1:
+                n_local = t.shape[0]
+                for e in range(self.ep_size):  # ep groups are blocks of `ep` consecutive trainer ranks: position e of the first block sends shard e
+                    msgs.append(dict(src=e, shape=list(t.shape), experts=dict(base=key[: -len(hit[0])], proj=hit[1], first=e * n_local), key=key))
+                continue
+            if hit is not None:
+                msgs.append(dict(src=rr % n_trainers, shape=list(t.shape), experts=dict(base=key[: -len(hit[0])], proj=hit[1], first=0), key=key))
+            else:
+                name = key[: -len("router.gate.weight")] + "gate.weight" if key.endswith(".mlp.router.gate.weight") else key
+                msgs.append(dict(src=rr % n_trainers, shape=list(t.shape), names=[name], key=key))
+            rr += 1
+        order = [""] + sorted((g for g in groups if g), key=lambda g: int(g.split(".")[2]))
+        return [dict(name=g or "non_layer", messages=groups[g]) for g in order if g in groups]
+
+    def push_tensors(self, plan: list[dict], rank: int) -> list[list[Tensor | None]]:
+        """The bf16 tensors this rank sends, aligned with `plan` (None where another rank is the source)."""
+        sd = self.model.state_dict()
+        out = []
+        for g in plan:
+            row = []
+            for m in g["messages"]:
+                if m["src"] != rank:
+                    row.append(None)
+                    continue
+                t = sd[m["key"]].detach()
+                row.append((t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)).contiguous())
+            out.append(row)
+        return out
+
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:
         if self.dp_size == 1:
             return tuple(max(int(c), 1) for c in local_counts)

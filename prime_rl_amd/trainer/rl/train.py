@@ -112,9 +112,9 @@ def train(config: TrainerConfig) -> list[dict]:
         if wbc.type == "nccl":
             from ...transports.weights import init_push_communicator
 
-            # "reference" = the reference's single-source byte stream; the sharded push walks the dense engine's flat buckets, so nn.Module
-            # engines (MoE models) always speak the reference protocol
-            protocol = "reference" if uses_module_engine(config, parallel_dims) else os.environ.get("PRIME_PUSH_PROTOCOL", "sharded")
+            # "sharded" = the multi-source push (dense engine: 1 / T of every flat bucket per trainer rank; nn.Module engines: named tensors, the expert
+            # shards straight from the ranks that own them); "reference" = the reference's single-source byte stream for a receiver that speaks only that
+            protocol = os.environ.get("PRIME_PUSH_PROTOCOL", "sharded")
             comm = init_push_communicator(wbc.host, wbc.port, rank, trainer_world, wbc.inference_world_size, device, wbc.timeout, protocol)
             wb = setup_weight_broadcast(out_dir, wbc, comm=comm, trainer_rank=rank, n_trainers=trainer_world, n_inference=wbc.inference_world_size,
                                         protocol=protocol, ready_timeout=wbc.timeout, trainer_group=parallel_dims.get_group("dp_cp"))

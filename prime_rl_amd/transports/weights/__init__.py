@@ -15,6 +15,9 @@ is written by the trainer master and `NCCL_READY` awaited before anything is enq
 format.  The layout manifest (`LAYOUT.json`: bucket -> [(name, offset, shape)]) replaces the per-dict pickled metadata broadcast.
 The push is asynchronous (own stream; the next optimizer step waits for it on the device).  For a receiver that speaks the
 reference's byte protocol there is `protocol="reference"` (single source, pickled metadata, one flat tensor per dtype).
+nn.Module engines (MoE models; trainer/module_engine.py) push sharded too, on NAMED tensors: `ModuleEngine.push_plan()` lists one message per tensor
+with its source rank — replicated tensors round-robin over the trainers, every stacked expert tensor from the ep rank that owns the shard — so nothing is
+gathered before the push and every inference rank receives each tensor straight from its owner (`push_named` / `receive_named`).
 """
 
 from __future__ import annotations
@@ -148,6 +151,37 @@ def receive_sharded(comm, layout: list[dict], n_trainers: int, device):
             yield name, buf[off: off + math.prod(shape)].view(shape)
 
 
+# Protocol 1b — "sharded" for nn.Module engines (MoE models, expert parallel): the same idea on NAMED tensors.  `plan` (ModuleEngine.push_plan) lists,
+# group by group, one message per tensor with its source rank: replicated tensors round-robin over the trainers, the stacked expert tensors from the rank
+# that owns the shard.  Every inference rank receives each message straight from its source; per-expert HF tensors are views of the received stack.
+def push_named(comm, plan: list[dict], tensors: list[list], trainer_rank: int, n_trainers: int, n_inference: int) -> None:
+    for g, row in zip(plan, tensors):
+        comm.group_start()
+        for m, t in zip(g["messages"], row):
+            if m["src"] == trainer_rank:
+                for i in range(n_inference):
+                    comm.send(t, n_trainers + i)
+        comm.group_end()
+
+
+def receive_named(comm, plan: list[dict], device):
+    """Yields (hf_name, tensor) group by group: the non-layer tensors, then layer 0, 1, ..."""
+    for g in plan:
+        bufs = [torch.empty(m["shape"], dtype=torch.bfloat16, device=device) for m in g["messages"]]
+        comm.group_start()
+        for m, b in zip(g["messages"], bufs):
+            comm.recv(b, m["src"])
+        comm.group_end()
+        for m, b in zip(g["messages"], bufs):
+            if "experts" in m:
+                ex = m["experts"]
+                for e in range(b.shape[0]):
+                    yield f"{ex['base']}{ex['first'] + e}.{ex['proj']}.weight", b[e]
+            else:
+                for name in m["names"]:
+                    yield name, b
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Protocol 2 — "reference": the byte stream of the reference's single-source broadcast, for a receiver that speaks it
 # (transports/weights/nccl.py:27-84 sender, inference/vllm/worker/nccl.py:28-89 receiver; SURVEY.md section 9.3).  World =
@@ -221,19 +255,29 @@ class RCCLWeightBroadcast(WeightBroadcast):
     def broadcast_weights(self, model, step: int) -> None:
         store = getattr(model, "store", model)
         flat = hasattr(store, "buckets")  # GRPOEngine / ParamStore; otherwise an nn.Module engine (trainer/module_engine.py: MoE, expert parallel)
-        if not flat and self.protocol != "reference":
-            raise NotImplementedError("the sharded push walks the flat parameter buckets of the dense engine; nn.Module engines (MoE models) push with the "
-                                      "reference byte protocol: PRIME_PUSH_PROTOCOL=reference")
+        if not flat and self.protocol != "reference" and not hasattr(model, "push_plan"):
+            raise NotImplementedError("the sharded push needs either the flat parameter buckets of the dense engine or an engine with push_plan() / push_tensors() "
+                                      "(trainer/module_engine.py); anything else pushes with the reference byte protocol: PRIME_PUSH_PROTOCOL=reference")
         if hasattr(model, "wait_params_ready"):
             model.wait_params_ready()
-        # HF-named tensors; an expert-parallel model assembles them with collectives over its ep group, so every trainer rank takes part
-        named = None if flat else (model.state_dict() if (self.rank == 0 or getattr(model, "collective_state_dict", False)) else None)
+        plan = model.push_plan(self.dp) if (not flat and self.protocol == "sharded") else None
+        # reference protocol of an nn.Module engine: HF-named tensors; an expert-parallel model assembles them with collectives over its ep group, so every
+        # trainer rank takes part.  The sharded protocol gathers nothing: every rank sends what it holds (`plan`).
+        if flat or plan is not None:
+            named = None
+        else:
+            named = model.state_dict() if (self.rank == 0 or getattr(model, "collective_state_dict", False)) else None
+        if plan is not None:
+            named = {f"{gi}.{mi}": t for gi, row in enumerate(model.push_tensors(plan, self.rank)) for mi, t in enumerate(row) if t is not None}
         device = store.params.device if flat else torch.device(model.device)
         save_dir = get_step_path(get_broadcast_dir(self.output_dir), step)
         if self.rank == 0:
             save_dir.mkdir(parents=True, exist_ok=True)
             if flat and (self.protocol == "sharded" or not getattr(store.dims, "head_padded", False)):
                 (save_dir / "LAYOUT.json").write_text(json.dumps(build_layout(store)))  # refuses padded-head storage: those models push by name
+            elif plan is not None:
+                (save_dir / "LAYOUT.json").write_text(json.dumps(dict(kind="named", groups=[dict(name=g["name"], messages=[{k: v for k, v in m.items() if k != "key"}
+                                                                                                                          for m in g["messages"]]) for g in plan])))
             self._notify_orchestrator(save_dir)
             sync_wait_for_path(save_dir / NCCL_READY_MARKER, interval=0.05, timeout=self.ready_timeout)
         # every trainer rank waits for the inference pool before enqueuing collectives (nccl.py:203-211)
@@ -251,7 +295,7 @@ class RCCLWeightBroadcast(WeightBroadcast):
                 self._stream.wait_event(final)
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self._stream)
-                self._push(store, named, device)
+                self._push(store, named, device, plan)
                 t1.record(self._stream)
             self._events = (t0, t1)
             # `named` of an nn.Module engine holds TEMPORARIES allocated on the main stream (bf16 copies of f32 router gates, all-gathered expert
@@ -269,10 +313,13 @@ class RCCLWeightBroadcast(WeightBroadcast):
             else:
                 torch.cuda.current_stream().wait_event(t1)
         else:
-            self._push(store, named, device)
+            self._push(store, named, device, plan)
 
-    def _push(self, store, named, device) -> None:
-        if self.protocol == "sharded":
+    def _push(self, store, named, device, plan=None) -> None:
+        if plan is not None:
+            rows = [[named.get(f"{gi}.{mi}") for mi in range(len(g["messages"]))] for gi, g in enumerate(plan)]
+            push_named(self.comm, plan, rows, self.rank, self.dp, self.n_inf)
+        elif self.protocol == "sharded":
             push_sharded(self.comm, store, self.rank, self.dp, self.n_inf)
         elif self.rank == 0:
             send_reference_protocol(self.comm, named if named is not None else store.state_dict(), device)
@@ -298,7 +345,10 @@ class RCCLWeightReceiver:
             yield from receive_reference_protocol(self.comm, self.device)
             return
         layout = json.loads((Path(weight_dir) / "LAYOUT.json").read_text())
-        yield from receive_sharded(self.comm, layout, self.dp, self.device)
+        if isinstance(layout, dict) and layout.get("kind") == "named":  # an nn.Module engine's push: named messages, one source rank each
+            yield from receive_named(self.comm, layout["groups"], self.device)
+        else:
+            yield from receive_sharded(self.comm, layout, self.dp, self.device)
 
 
 def init_push_communicator(host: str, port: int, rank: int, n_trainers: int, n_inference: int, device, timeout: float = 1200.0,

@@ -188,11 +188,6 @@ def _moe_worker(rank, world, port, out_dir):
             torch.save({k: v.clone() for k, v in prime_to_hf({k: v.detach() for k, v in full.state_dict().items()}).items()}, out / "sent.pt")
         wb = RCCLWeightBroadcast(out, comm, rank, 2, 1, protocol="reference", ready_timeout=60, trainer_group=trainers)
         wb.broadcast_weights(eng, 3)
-        if rank == 0:
-            import pytest as _pytest
-
-            with _pytest.raises(NotImplementedError, match="reference byte protocol"):
-                RCCLWeightBroadcast(out, comm, rank, 2, 1, protocol="sharded").broadcast_weights(eng, 4)
     else:
         t0 = time.time()
         while not (step_dir / "STABLE").exists():
@@ -206,7 +201,8 @@ def _moe_worker(rank, world, port, out_dir):
 
 
 def test_push_of_an_expert_parallel_moe_model(tmp_path):
-    """The module engine's push (MoE models always speak the reference byte protocol): the expert shards of the two ep ranks are gathered, names
+    """The module engine's push in the REFERENCE byte protocol (for a receiver that speaks only that; the multi-source form is
+    test_sharded_push_of_an_expert_parallel_module_engine): the expert shards of the two ep ranks are gathered, names
     converted to HF's per-expert form (what vLLM's `load_weights` expects; the reference does this with `revert_weight_conversion`,
     transports/weights/nccl.py:87-98), and the inference rank receives the WHOLE model bit-exactly, layer by layer."""
     mp.start_processes(_moe_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True, start_method="spawn")
@@ -241,3 +237,80 @@ def test_sharded_layout_speaks_hf_names_for_attention_bias_models():
             seen += 1
     assert names == set(sd) - ({"lm_head.weight"} if dims.tie_word_embeddings else set())
     assert any(n.endswith("q_proj.bias") for n in names) and not any("qkv_proj" in n for n in names)
+
+
+def _moe_sharded_worker(rank, world, port, out_dir, n_tr):
+    """n_tr trainer ranks run an expert-parallel (ep = 2) Qwen3-MoE ModuleEngine; the other ranks are inference receivers."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from prime_rl_amd.comm import TorchGroupCommunicator
+    from prime_rl_amd.transports.weights import NCCL_READY_MARKER, RCCLWeightBroadcast, RCCLWeightReceiver
+
+    comm = TorchGroupCommunicator(None)
+    trainers = dist.new_group(list(range(n_tr)))
+    ep_groups = [dist.new_group(list(range(b, b + 2))) for b in range(0, n_tr, 2)]            # blocks of 2 consecutive trainer ranks
+    replica_groups = [dist.new_group(list(range(pos, n_tr, 2))) for pos in range(2)] if n_tr > 2 else [None, None]
+    out = Path(out_dir)
+    step_dir = out / "broadcasts" / "step_3"
+    if rank < n_tr:
+        from prime_rl_amd.trainer.engine import OptimConfig
+        from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+        from prime_rl_amd.trainer.module_engine import ModuleEngine
+
+        cfg = Qwen3MoeConfig(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                             num_experts=4, num_experts_per_tok=2, moe_intermediate_size=32, mlp_only_layers=[0], use_grouped_mm=False)
+        torch.manual_seed(5)
+        full = Qwen3MoeForCausalLM(cfg)
+        for p in full.parameters():
+            torch.nn.init.normal_(p, std=0.1)
+        full = full.to(torch.bfloat16)
+        ep_group = ep_groups[rank // 2]
+        local = Qwen3MoeForCausalLM(cfg, ep_group=ep_group).to(torch.bfloat16)
+        er = rank % 2
+        local.load_state_dict({k: (v[er * 2:(er + 1) * 2].clone() if ".experts.w" in k else v.clone()) for k, v in full.state_dict().items()})
+        eng = ModuleEngine(local, "cpu", optim=OptimConfig(type="sign_sgd"), dp_group=trainers, dp_size=n_tr, ep_group=ep_group, ep_size=2,
+                           ep_replica_group=replica_groups[er])
+        if rank == 0:
+            ref = ModuleEngine(full, "cpu", optim=OptimConfig(type="sign_sgd"))
+            torch.save({k: v.clone() for k, v in ref.state_dict().items()}, out / "sent_moe.pt")
+            plan = eng.push_plan(n_tr)
+            # every stacked expert tensor is sent by the rank that owns the shard; replicated tensors are spread over all trainers
+            srcs = {m["src"] for g in plan for m in g["messages"] if "experts" in m}
+            assert srcs == {0, 1} and {m["src"] for g in plan for m in g["messages"] if "names" in m} == set(range(n_tr))
+        RCCLWeightBroadcast(out, comm, rank, n_tr, world - n_tr, protocol="sharded", ready_timeout=60, trainer_group=trainers).broadcast_weights(eng, 3)
+    else:
+        t0 = time.time()
+        while not (step_dir / "STABLE").exists():
+            time.sleep(0.05)
+            assert time.time() - t0 < 60
+        if rank == n_tr:
+            (step_dir / NCCL_READY_MARKER).touch()
+        got = {name: t.clone() for name, t in RCCLWeightReceiver(comm, n_tr, "cpu", "sharded").receive_state_dict(step_dir)}
+        torch.save(got, out / f"received_moe_{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_tr", [2, 4])
+def test_sharded_push_of_an_expert_parallel_module_engine(tmp_path, n_tr):
+    """The multi-source push of an nn.Module engine (MoE, ep = 2; n_tr = 4: two ep groups): nothing is gathered — the stacked expert shards travel from the
+    ranks that own them, replicated tensors round-robin over the trainers — and both inference ranks end up with every per-expert HF-named tensor of the
+    WHOLE model bit for bit, non-layer tensors first, then layer by layer."""
+    world = n_tr + 2
+    mp.start_processes(_moe_sharded_worker, args=(world, _free_port(), str(tmp_path), n_tr), nprocs=world, join=True, start_method="spawn")
+    sent = torch.load(tmp_path / "sent_moe.pt")
+    assert "model.layers.1.mlp.experts.3.down_proj.weight" in sent and "model.layers.1.mlp.gate.weight" in sent
+    for r in range(n_tr, world):
+        got = torch.load(tmp_path / f"received_moe_{r}.pt")
+        assert set(got) == set(sent), (sorted(set(sent) - set(got))[:4], sorted(set(got) - set(sent))[:4])
+        for k in sent:
+            assert got[k].shape == sent[k].shape and torch.equal(got[k], sent[k]), k
+        names = list(got)
+        first_layer = next(i for i, n in enumerate(names) if n.startswith("model.layers."))
+        assert all(not n.startswith("model.layers.") for n in names[:first_layer])
+        assert max(i for i, n in enumerate(names) if n.startswith("model.layers.0.")) < min(i for i, n in enumerate(names) if n.startswith("model.layers.1."))
+    import json
+
+    layout = json.loads((tmp_path / "broadcasts" / "step_3" / "LAYOUT.json").read_text())
+    assert layout["kind"] == "named" and [g["name"] for g in layout["groups"]] == ["non_layer", "model.layers.0", "model.layers.1"]
