@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--skip-bisect", action="store_true")
     ap.add_argument("--skip-a", action="store_true", help="no f32 oracle: the sampling policy is oracle B + N(0, 0.02^2) (the large-N run)")
     ap.add_argument("--modes", default="bf16,f32", help="engine GEMM modes to run")
+    ap.add_argument("--ref", default="b", choices=["b", "bfa"], help="the oracle every row is paired against: B (f32 softmax in attention) or B_fa (B + flash-attention's bf16 P)")
     ap.add_argument("--out", default="gpurun_out/parity_bisect.json")
     args = ap.parse_args()
 
@@ -257,6 +258,10 @@ def main():
     torch.cuda.empty_cache()
     print(f"[oracles] A {ta:.1f}s  B {tb:.1f}s  C {tc:.1f}s  B_fa {tf:.1f}s   ({time.time() - t00:.0f}s since start)", flush=True)
 
+    ref_name = "B"
+    if args.ref == "bfa":  # pair everything against the restatement that shares flash-attention's rounding point (what the reference actually runs)
+        lp_b, lp_f, ref_name = lp_f, lp_b, "B_fa"
+    report["paired_against"] = ref_name
     l_b, inv_b = per_token_loss(lp_b, inf, adv, mask, lcfg)
     loss_b = float(l_b.sum() / n_tr)
 
@@ -280,11 +285,11 @@ def main():
               f"|dlp| mean {r['lp_abs_mean']:.2e} rms {r['lp_rms']:.2e} max {r['lp_max']:.2e}  flips {r['flips_vs_B']}  {note}", flush=True)
         return r
 
-    print(f"[{dims.name} x{dims.num_hidden_layers}, {R} x {n} tokens, {n_tr} trained] loss(B) = {loss_b:+.7f}")
+    print(f"[{dims.name} x{dims.num_hidden_layers}, {R} x {n} tokens, {n_tr} trained] loss({ref_name}) = {loss_b:+.7f}   (every '-B' column below is paired against {ref_name})")
     if lp_a is not None:
         row("oracle A (f32 end to end)", lp_a)
     row("oracle C (bf16 points, torch bf16 GEMMs)", lp_c)
-    row("oracle B_fa (B + bf16 P into P.V)", lp_f)
+    row("oracle B_fa (B + bf16 P into P.V)" if args.ref == "b" else "oracle B (f32 softmax into P.V)", lp_f)
 
     # ---- engine runs -----------------------------------------------------------------------------------------------
     sw = Swapper(ops, [n] * args.per_pass, dims.rms_norm_eps)
