@@ -500,7 +500,7 @@ int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const voi
 int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py), one PROCESS-WIDE word: bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced
                                                * fragment reads, bit 2 = persistent grid, bit 5 = no split-K of a half-empty last round, bits 3-4 = timing ablations; bit 6 = the
                                                * one-wave-per-SIMD kernel (gemm4_kernel: 4 waves, 128 x 128 register tile; same results bit for bit), bit 7 = the same with register
-                                               * staging instead of LDS-DMA.  Callers that care re-assert their value before a launch (GRPOEngine._own_gemm). */
+                                               * staging instead of LDS-DMA, bit 8 = the same with the fine (three barriers per K-tile) schedule.  Callers that care re-assert their value before a launch (GRPOEngine._own_gemm). */
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

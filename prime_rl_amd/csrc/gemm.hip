@@ -961,6 +961,79 @@ __device__ __forceinline__ void step(Wave4& s, unsigned char* smem) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- the FINE schedule (V bit 1; variant bit 8): the main loop the library's 4-wave kernel runs (profiles/r04_gemm.md section 3: disassembled from the shipped
+// code object), on this kernel's LDS images.  One K-tile = 32 groups of four MFMAs (16 on the k-step-0 registers, 16 on the k-step-1 registers):
+//     groups 0-2    read the W fragments of (t, k1)                                  | end of group 4: lgkmcnt(0), BARRIER 1 -> the W half of buffer b is free
+//     groups 5-7    read the X fragments of (t, k1)                                  | end of group 9: lgkmcnt(0), BARRIER 2 -> the X half of buffer b is free
+//     groups 5-15   the 8 W pieces of K-tile t + 2 -> buffer b, two every three groups
+//     groups 17-27  the 8 X pieces of K-tile t + 2 -> buffer b                       | end of group 21: vmcnt(12), BARRIER 3 -> K-tile t + 1 has landed in buffer b ^ 1
+//     groups 22-27  read the fragments of (t + 1, k0) from buffer b ^ 1              | end of group 31: lgkmcnt(0)
+// Against the two-step schedule above: the DMA pieces are spread over 23 of the 32 groups instead of bunched into 16 (one texture-addresser queue, four
+// waves), a piece has MORE than a whole K-tile to land (issued in iteration t, waited for at barrier 3 of iteration t + 1; `vmcnt` never 0), and every
+// fragment read is issued >= 2 groups before the wait that retires it.  Three barriers per K-tile.
+__host__ __device__ constexpr int fine_dma_piece(int j) {  // the piece (0-3 W0, 4-7 X0, 8-11 W1, 12-15 X1) issued after group j, or -1
+  if (j < 5 || j > 27) return -1;
+  const int r = j - 5;
+  if (r % 3 == 2) return -1;
+  const int n = (r / 3) * 2 + r % 3;  // 0-7: the W pieces, 8-15: the X pieces
+  return n < 4 ? n : n < 8 ? n + 4 : n < 12 ? n - 4 : n;
+}
+template <int SET, int BUF, int I0, int N, bool XK, bool WK>
+__device__ __forceinline__ void read_run(Wave4& s) {
+  if constexpr (N > 0) {
+    read_nth<SET, BUF, I0, XK, WK>(s);
+    read_run<SET, BUF, I0 + 1, N - 1, XK, WK>(s);
+  }
+}
+template <int BUF, int J, int V, bool XK, bool WK>
+__device__ __forceinline__ void fine_group(Wave4& s, unsigned char* smem) {
+  constexpr int SET = J >> 4, I = J & 15, f = I >> 1, g0 = (I & 1) * 4;
+  const u32x4 wfrag = WK ? join(s.wlo[SET][f], s.whi[SET][f]) : s.wf[SET][f];
+#pragma unroll
+  for (int g = g0; g < g0 + 4; ++g) {
+    const u32x4 xfrag = XK ? join(s.xlo[SET][g], s.xhi[SET][g]) : s.xf[SET][g];
+    s.acc[f][g] = mfma16(wfrag, xfrag, s.acc[f][g]);
+  }
+  if (!(V & 16)) {
+    if constexpr (J == 0) read_run<1, BUF, 0, 3, XK, WK>(s);
+    if constexpr (J == 1) read_run<1, BUF, 3, 3, XK, WK>(s);
+    if constexpr (J == 2) read_run<1, BUF, 6, 2, XK, WK>(s);
+    if constexpr (J == 5) read_run<1, BUF, 8, 3, XK, WK>(s);
+    if constexpr (J == 6) read_run<1, BUF, 11, 3, XK, WK>(s);
+    if constexpr (J == 7) read_run<1, BUF, 14, 2, XK, WK>(s);
+    if constexpr (J == 22) read_run<0, BUF ^ 1, 0, 3, XK, WK>(s);
+    if constexpr (J == 23) read_run<0, BUF ^ 1, 3, 3, XK, WK>(s);
+    if constexpr (J == 24) read_run<0, BUF ^ 1, 6, 3, XK, WK>(s);
+    if constexpr (J == 25) read_run<0, BUF ^ 1, 9, 3, XK, WK>(s);
+    if constexpr (J == 26) read_run<0, BUF ^ 1, 12, 2, XK, WK>(s);
+    if constexpr (J == 27) read_run<0, BUF ^ 1, 14, 2, XK, WK>(s);
+  }
+  if constexpr (fine_dma_piece(J) >= 0) {
+    if (!(V & 8)) stage_nth<BUF, fine_dma_piece(J)>(s, smem);
+  }
+  if constexpr (J == 4 || J == 9) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (J == 9 && !(V & 16)) tie_set<1, XK, WK>(s);
+  }
+  if constexpr (J == 21) {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (J == 31) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(V & 16)) tie_set<0, XK, WK>(s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int BUF, int J, int V, bool XK, bool WK>
+__device__ __forceinline__ void fine_groups(Wave4& s, unsigned char* smem) {
+  if constexpr (J < 32) {
+    fine_group<BUF, J, V, XK, WK>(s, smem);
+    fine_groups<BUF, J + 1, V, XK, WK>(s, smem);
+  }
+}
+
 template <int V, bool XK, bool WK, int MODE>
 __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
   unsigned char* smem = lds_base();
@@ -1046,10 +1119,15 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
         }
         s.off[SLOT_W0] = 0; s.off[SLOT_W1] = s.wstep; s.off[SLOT_X0] = 0; s.off[SLOT_X1] = s.xstep;
       }
-      step<0, 0, 1, false, true, V, XK, WK>(s, smem);   // A   (register staging: writes the K-tile loaded in the previous D into buffer 1)
-      step<1, 1, 0, true, false, V, XK, WK>(s, smem);   // B
-      step<0, 1, 0, false, true, V, XK, WK>(s, smem);   // C   (register staging: writes the K-tile loaded in B into buffer 0)
-      step<1, 0, 1, true, false, V, XK, WK>(s, smem);   // D
+      if constexpr ((V & 2) != 0) {  // the fine schedule: K-tile t out of buffer 0, K-tile t + 1 out of buffer 1
+        fine_groups<0, 0, V, XK, WK>(s, smem);
+        fine_groups<1, 0, V, XK, WK>(s, smem);
+      } else {
+        step<0, 0, 1, false, true, V, XK, WK>(s, smem);   // A   (register staging: writes the K-tile loaded in the previous D into buffer 1)
+        step<1, 1, 0, true, false, V, XK, WK>(s, smem);   // B
+        step<0, 1, 0, false, true, V, XK, WK>(s, smem);   // C   (register staging: writes the K-tile loaded in B into buffer 0)
+        step<1, 0, 1, true, false, V, XK, WK>(s, smem);   // D
+      }
     }
     if (cur.last) {
       // ---- epilogue: the 8-wave kernel's LDS-staged form (every global store instruction writes 8 full 128-byte row segments), walked over this wave's
@@ -1195,16 +1273,20 @@ static void launch(const Params& p, hipStream_t st) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
-  if (g_variant & (64 | 128)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
+  if (g_variant & (64 | 128 | 256)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
     const int v4 = g_variant & (8 | 16);
-    if (g_variant & 128) g4::launch_v4<1, XK, WK>(p, st, grid);  // bit 7: register staging instead of LDS-DMA
+    if (g_variant & 256) {  // bit 8: the fine schedule (bits 3 / 4: its timing ablations, forward layout)
+      if (!XK && !WK && v4 == 8) g4::launch_v4<2 | 8, false, false>(p, st, grid);
+      else if (!XK && !WK && v4 == 16) g4::launch_v4<2 | 16, false, false>(p, st, grid);
+      else g4::launch_v4<2, XK, WK>(p, st, grid);
+    } else if (g_variant & 128) g4::launch_v4<1, XK, WK>(p, st, grid);  // bit 7: register staging instead of LDS-DMA
     else if (!XK && !WK && v4 == 8) g4::launch_v4<8, false, false>(p, st, grid);
     else if (!XK && !WK && v4 == 16) g4::launch_v4<16, false, false>(p, st, grid);
     else if (!XK && !WK && v4 == 24) g4::launch_v4<24, false, false>(p, st, grid);
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }
-  const int v = g_variant & ~(4 | 32 | 64 | 128);
+  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256);
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only

@@ -27,7 +27,7 @@ def _check(out, ref, k, bf16_out):
     assert err <= tol, f"max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 64, 68, 128, 132])  # 64 / 68: the one-wave-per-SIMD kernel (per tile / persistent); 128 / 132: the same with register staging
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 64, 68, 128, 132, 256, 260])  # 64 / 68: the one-wave-per-SIMD kernel (per tile / persistent); 128 / 132: with register staging; 256 / 260: its fine schedule
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (300, 520, 384), (1000, 256, 1024), (77, 1000, 128)])
 def test_gemm_forward_layout(m, n, k, variant):
     ops.gemm_set_variant(variant)
@@ -53,7 +53,7 @@ def test_gemm_bias_and_strided_operands():
     assert torch.count_nonzero(out[:, :n]) == 0
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132])
+@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 384, 256), (300, 520, 640), (77, 1024, 128)])
 def test_gemm_dgrad_layout(m, n, k, variant):
     """dx[m, in] = dy[m, out] @ W[out, in]: the weight is read K-major (no transposed copy)."""
@@ -66,7 +66,7 @@ def test_gemm_dgrad_layout(m, n, k, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132])
+@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
 @pytest.mark.parametrize("tokens,n_out,n_in", [(128, 256, 256), (1024, 512, 384), (1000, 264, 520), (77, 256, 128), (4096, 256, 256)])
 def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
     """dw[out, in] (+)= dy[tok, out]^T @ x[tok, in], f32, any token count (rows past the last token read as zeros)."""
@@ -83,7 +83,7 @@ def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [3, 7, 68, 132])
+@pytest.mark.parametrize("variant", [3, 7, 68, 132, 260])
 @pytest.mark.parametrize("tokens,n_out,n_in", [(256, 256, 256), (1024, 768, 512), (1000, 264, 520), (2048, 4096, 1024)])
 def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
     """The gradient-norm pass fused into the weight-gradient epilogue: the per-(tile, wave) partials add up to sum(dw^2) of the FINAL values (also
@@ -191,7 +191,7 @@ def _lib_ws_bytes(m, n, k):
 def test_gemm_is_deterministic_and_matches_itself_across_variants():
     x, w = _rand(512, 512, 1.0, 10), _rand(512, 512, 0.05, 11)
     outs = []
-    for v in (0, 1, 3, 5, 7, 64, 68, 128, 132):  # the one-wave-per-SIMD kernel walks K in the same order: same bits
+    for v in (0, 1, 3, 5, 7, 64, 68, 128, 132, 256, 260):  # the one-wave-per-SIMD kernel walks K in the same order: same bits
         ops.gemm_set_variant(v)
         outs.append(ops.gemm(x, w, out_dtype=torch.float32))
     ops.gemm_set_variant(7)
@@ -210,7 +210,7 @@ def test_gemm_identity_with_asymmetric_operand():
     assert torch.equal(ops.gemm(eye, wk.t(), out_dtype=torch.float32), w[:256].float().t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132])
+@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
 def test_gemm_many_tiles_per_workgroup(variant):
     """More output tiles than CUs: the persistent form (variant bit 2) walks several tiles per workgroup, staging the next tile's first K-tiles under
     the current tile's last ones; results must equal the one-workgroup-per-tile form bit for bit."""
