@@ -70,6 +70,7 @@ struct Params {
   int tiles_m, tiles_n;
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
+  int nt_out;         // store the result with the non-temporal cache policy (it is not read again by this launch: keeps the operand panels in L2)
   int accumulate;     // f32 out only: out += product
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
   // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
@@ -690,7 +691,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                 const int ml = q * 8 + srow;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
                 const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
-                if (m < cur.m_valid && nn < cur.n_valid) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn) = val;
+                if (m < cur.m_valid && nn < cur.n_valid) {
+                  u32x4* dstv = reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn);
+                  if (p.nt_out) __builtin_nontemporal_store(val, dstv);
+                  else *dstv = val;
+                }
               }
             } else {  // two blocks of [32 rows][32 columns: f & 1, lq, r] f32
 #pragma unroll
@@ -710,7 +715,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                   if (m < cur.m_valid && nn < cur.n_valid) {
                     float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
                     if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = val;
+                    if (p.nt_out) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = val;
                     if (MODE == 0 && p.sumsq) ss = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], ss))));
                   }
                 }
@@ -1173,7 +1179,11 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
                 const int ml = q * 8 + srow;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
                 const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
-                if (m < cur.m_valid && nn < cur.n_valid) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn) = val;
+                if (m < cur.m_valid && nn < cur.n_valid) {
+                  u32x4* dstv = reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn);
+                  if (p.nt_out) __builtin_nontemporal_store(val, dstv);
+                  else *dstv = val;
+                }
               }
             } else {
 #pragma unroll
@@ -1193,7 +1203,8 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
                   if (m < cur.m_valid && nn < cur.n_valid) {
                     float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
                     if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = val;
+                    if (p.nt_out) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = val;
                     if (MODE == 0 && p.sumsq) ss = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], ss))));
                   }
                 }
@@ -1286,7 +1297,7 @@ static void launch(const Params& p, hipStream_t st) {
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }
-  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256);
+  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512);
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
@@ -1351,6 +1362,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Params p) {
 static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int64_t n_first) {
   p.bias = nullptr;
   p.out_f32 = 0;
+  p.nt_out = 0;
   p.accumulate = 0;
   p.sumsq = nullptr;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
@@ -1477,6 +1489,7 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
+  p.nt_out = (gm::g_variant & 512) ? 1 : 0;  // bit 9 of the debug variant: non-temporal result stores (A/B)
   hipStream_t st = as_stream(stream);
   // split-K of the last round (see Params): f32 results without bias, the whole contraction in one launch, a workspace from the caller
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;

@@ -470,7 +470,7 @@ def main():
                                                                              (68, "4-wave kernel, persistent"), (64, "4-wave kernel, one WG per tile"), (76, "4-wave ABLATION no DMA"),
                                                                              (84, "4-wave ABLATION no reads"), (92, "4-wave ABLATION no DMA, no reads"),
                                                                              (132, "4-wave kernel, register staging"), (260, "4-wave kernel, fine schedule"), (268, "4-wave fine ABLATION no DMA"),
-                                                                             (276, "4-wave fine ABLATION no reads"))]
+                                                                             (276, "4-wave fine ABLATION no reads"), (7 + 512, "8-wave core, nt result stores"), (260 + 512, "4-wave fine, nt result stores"))]
             for label, fn in cases:
                 med, best = timeit(fn, iters=10, warmup=2)
                 print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
