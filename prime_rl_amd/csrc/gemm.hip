@@ -71,6 +71,7 @@ struct Params {
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
   int nt_out;         // store the result with the non-temporal cache policy (it is not read again by this launch: keeps the operand panels in L2)
+  int sweep_n;        // patch order of the dense product (tile_of_block): 1 = consecutive patches share their X block and cycle through W
   int accumulate;     // f32 out only: out += product
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
   // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
@@ -94,15 +95,22 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-// virtual block id -> (tile_m, tile_n); false for the padding ids of the last patch round
-__device__ __forceinline__ bool tile_of_block(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
+// virtual block id -> (tile_m, tile_n); false for the padding ids of the last patch round.
+// `sweep_n`: the order in which consecutive patches (the 8 XCDs of a round, then the next round) walk the patch grid.  A patch (i, j) reads X block i and
+// W block j through its XCD's L2; across XCDs and rounds the blocks are shared through the 256 MB Infinity Cache.  Sweeping i fastest (0) holds W block j
+// while the whole X operand cycles past it once per j: right when X fits the Infinity Cache (forward: X = 134 MB of activations).  Sweeping j fastest (1)
+// holds X block i and cycles W: right when X is the big operand (the gate|up weight gradient: X = dy, 805 MB, otherwise re-read from HBM once per column
+// block of patches: 4 x; the LM-head weight gradient: X = dlogits, 5 GB).  gemm_impl picks the order that cycles the SMALLER operand.
+__device__ __forceinline__ bool tile_of_block(int b, int tiles_m, int tiles_n, int sweep_n, int& tm, int& tn) {
   const int xcd = b & 7, s = b >> 3;
   const int patch = (s >> 5) * 8 + xcd, within = s & 31;
   const int patches_m = (tiles_m + 7) >> 3;
   const int patches_n = (tiles_n + 3) >> 2;
   if (patch >= patches_m * patches_n) return false;
-  tm = (patch % patches_m) * 8 + (within & 7);
-  tn = (patch / patches_m) * 4 + (within >> 3);
+  const int pi = sweep_n ? patch / patches_n : patch % patches_m;
+  const int pj = sweep_n ? patch % patches_n : patch / patches_m;
+  tm = pi * 8 + (within & 7);
+  tn = pj * 4 + (within >> 3);
   return tm < tiles_m && tn < tiles_n;
 }
 struct SplitPlan {
@@ -416,7 +424,7 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
       kpart = x / p.split_rp;
       vv = (v & ~7) | (x - kpart * p.split_rp);
     }
-    if (!tile_of_block(vv, p.tiles_m, p.tiles_n, tm, tn)) return false;
+    if (!tile_of_block(vv, p.tiles_m, p.tiles_n, p.sweep_n, tm, tn)) return false;
     const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
     int64_t k0 = (int64_t)kpart * p.split_k;
     int klen = p.split_s > 1 && v >= p.split_v0 ? (int)(p.k - k0 < p.split_k ? p.k - k0 : p.split_k) : p.k;
@@ -1297,7 +1305,7 @@ static void launch(const Params& p, hipStream_t st) {
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }
-  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512);
+  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512 | 1024);
   if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
@@ -1321,7 +1329,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Params p) {
   const int x0 = slot >> 5, within = slot & 31;
   const int vv = p.split_v0 + within * 8 + x0;
   int tm, tn;
-  if (!tile_of_block(vv, p.tiles_m, p.tiles_n, tm, tn)) return;
+  if (!tile_of_block(vv, p.tiles_m, p.tiles_n, p.sweep_n, tm, tn)) return;
   const int64_t m0 = (int64_t)tm * kTile, n0 = (int64_t)tn * kTile;
   const int mv = (int)(p.m - m0 < kTile ? p.m - m0 : kTile), nv = (int)(p.n - n0 < kTile ? p.n - n0 : kTile);
   float* out = reinterpret_cast<float*>(p.out) + m0 * p.ldo + n0;
@@ -1363,6 +1371,7 @@ static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int
   p.bias = nullptr;
   p.out_f32 = 0;
   p.nt_out = 0;
+  p.sweep_n = 0;
   p.accumulate = 0;
   p.sumsq = nullptr;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
@@ -1490,6 +1499,8 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
   p.nt_out = (gm::g_variant & 512) ? 1 : 0;  // bit 9 of the debug variant: non-temporal result stores (A/B)
+  // cycle the smaller operand past the held block of the bigger one (X has m x k elements, W n x k); bit 10 of the debug variant: always the round-3 order (A/B)
+  p.sweep_n = (m > n && !(gm::g_variant & 1024)) ? 1 : 0;
   hipStream_t st = as_stream(stream);
   // split-K of the last round (see Params): f32 results without bias, the whole contraction in one launch, a workspace from the caller
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
