@@ -417,6 +417,8 @@ def main() -> None:
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in one extra untimed step after the timed region)")
     ap.add_argument("--no-realistic-parity", action="store_true", help="skip parity.realistic (one extra untimed step on rollout-like data vs the oracle forward)")
+    ap.add_argument("--overlap-update", action="store_true",
+                    help="A/B switch: run the optimizer update on its own stream under the next forward (measured: together = serial on this part, so off)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements reported under config.extra (2 micro-batches/GPU line, weight push)")
     args = ap.parse_args()
 
@@ -448,7 +450,7 @@ def main() -> None:
     dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "qwen2.5-0.5b": ModelDims.qwen2_5_0_5b,
             "tiny": ModelDims.tiny}[args.model]()
     engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1,
-                        recompute=args.recompute)
+                        recompute=args.recompute, overlap_update=args.overlap_update)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 
     per_pass = max(args.tokens_per_pass // args.seq_len, 1)

@@ -27,6 +27,19 @@ static inline unsigned capped_grid(int64_t work_items, int block) {
   return (unsigned)g;
 }
 
+// Optimizer kernels: grid-stride over 16-byte vectors.  PM_UPDATE_GRID caps their grid (default 256 CUs x 16 workgroups): when the update runs on its
+// own stream under the next forward (engine.overlap_update) a smaller grid leaves wave slots for the GEMM workgroups it shares the CUs with.
+static inline unsigned update_grid(int64_t n_vec) {
+  static const int64_t cap = [] {
+    const char* e = getenv("PM_UPDATE_GRID");
+    const long v = e ? atol(e) : 0;
+    return (int64_t)(v > 0 ? v : 256 * 16);
+  }();
+  int64_t g = cdiv(n_vec, (int64_t)256);
+  if (g > cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
 // ---------------------------------- SwiGLU -------------------------------------------------------
 // act = bf16( bf16(silu(gate)) * up ): torch computes silu on bf16 in f32 and rounds, then a bf16 multiply.
 // Thread layout (both kernels): blockIdx.x * 256 + threadIdx.x = 16-byte column vector, blockIdx.y = block of kSwigluRows rows walked
@@ -533,7 +546,7 @@ extern "C" int pm_sgd_step(float* master, float* momentum_buf, float* grad, void
                  (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
              PM_ERR_INVALID_ARG, "pm_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
   if (n == 0) return PM_OK;
-  hipLaunchKernelGGL(sgd_kernel<false>, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, momentum_buf, grad, (bf16_t*)param_bf16, n,
+  hipLaunchKernelGGL(sgd_kernel<false>, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, momentum_buf, grad, (bf16_t*)param_bf16, n,
                      lr, momentum, weight_decay, (int)nesterov, (int)(step == 1), grad_scale, clip_coef, (int)zero_grad);
   PM_CHECK_LAUNCH("pm_sgd_step");
   return PM_OK;
@@ -545,7 +558,7 @@ extern "C" int pm_sign_sgd_step(float* master, float* grad, void* param_bf16, in
   PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0 && (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
              PM_ERR_INVALID_ARG, "pm_sign_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
   if (n == 0) return PM_OK;
-  hipLaunchKernelGGL(sgd_kernel<true>, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, (float*)nullptr, grad, (bf16_t*)param_bf16,
+  hipLaunchKernelGGL(sgd_kernel<true>, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, (float*)nullptr, grad, (bf16_t*)param_bf16,
                      n, lr, 0.f, weight_decay, 0, 0, grad_scale, clip_coef, (int)zero_grad);
   PM_CHECK_LAUNCH("pm_sign_sgd_step");
   return PM_OK;
@@ -561,7 +574,7 @@ extern "C" int pm_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, f
   if (n == 0) return PM_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(capped_grid(n >> 2, 256)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
+  hipLaunchKernelGGL(adamw_kernel, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
                      (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, clip_coef, zero_grad);
   PM_CHECK_LAUNCH("pm_adamw_step");
   return PM_OK;

@@ -457,7 +457,8 @@ class GRPOEngine:
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
-                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None):
+                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None,
+                 overlap_update: bool | None = None):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -529,6 +530,15 @@ class GRPOEngine:
         # stand-in kernels) issues them synchronously
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_collectives and self.device.type == "cuda") else None
         self._gather_events: dict[str, torch.cuda.Event] = {}
+        # Single-rank engines: the optimizer update (HBM-bound: 30 bytes per parameter, 41 ms for Qwen3-8B) can run on its own stream UNDER the
+        # next step's forward (MFMA-bound), bucket by bucket in the order forward() reads the buckets; forward() waits per bucket through the
+        # same `_gather_events` the sharded path uses for its parameter all-gathers.  Anything else that reads the parameters or the optimizer
+        # state after step() must call wait_params_ready() first (the weight push does).  Opt-in (PM_OVERLAP_UPDATE=1 / overlap_update=True /
+        # `bench.py --overlap-update`): bit-identical, but measured twice (round 3 probe, round 4 in-step: 677.8 vs 676.9 ms) the two kernels
+        # do not share the CUs on this part — together = serial, whatever the update's grid (tools/probes/overlap_probe.py with PM_UPDATE_GRID).
+        if overlap_update is None:
+            overlap_update = os.environ.get("PM_OVERLAP_UPDATE", "0") == "1"
+        self.update_stream = torch.cuda.Stream(device=self.device) if (overlap_update and not self.use_collectives and self.device.type == "cuda") else None
         # The embedding bucket's gradient is complete only when the LAST pass's backward ends, so its dense reduce-scatter (vocab x hidden f32,
         # 2.5 GB for Qwen3-8B) would trail the step with nothing to hide behind.  With sharding on, step() splits it: the dense part (earlier
         # passes; the tied head gradient) is reduce-scattered while the last pass still runs, and the last pass's own embedding gradient —
@@ -1104,6 +1114,8 @@ class GRPOEngine:
         step): anything that reads `store.params` outside forward() — the weight push, a checkpoint — must call this first."""
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.update_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.update_stream)
         self._gather_events.clear()
 
     def add_param_reader(self, event) -> None:
@@ -1131,8 +1143,10 @@ class GRPOEngine:
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(ev)
         self._param_readers.clear()
+        if self.update_stream is not None:  # a previous update nobody waited for (a step without a forward): keep the updates ordered
+            torch.cuda.current_stream().wait_stream(self.update_stream)
         return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq,
-                                           local_sumsq=self._fs_norm if self.fused_sumsq else None)
+                                           local_sumsq=self._fs_norm if self.fused_sumsq else None, update_stream=self.update_stream)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:

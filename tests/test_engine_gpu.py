@@ -757,3 +757,30 @@ def test_custom_loss_plugin_through_the_engines_and_train(tmp_path):
     moe_cus = moe_def.model_copy(update=dict(output_dir=str(tmp_path / "m1"), loss=cfg.loss))
     r0, r1 = train(moe_def)[0], train(moe_cus)[0]
     assert r1["loss/mean"] == pytest.approx(r0["loss/mean"], abs=5e-6) and r1["plugin_tokens/mean"] > 0
+
+
+@pytest.mark.parametrize("kind", ["adamw", "sgd"])
+def test_update_under_the_next_forward_is_bit_identical(kind):
+    """`overlap_update=True`: the optimizer update runs bucket by bucket on its own stream while the next step's forward already runs; forward waits per
+    bucket.  Same kernels on the same slices: losses, gradient norms, parameters, masters and both moments equal the in-line update bit for bit over
+    several steps of accumulated passes — and nothing is waited for until wait_params_ready()."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=3, vocab=512)
+    oc = dict(type=kind, lr=1e-3, momentum=0.9) if kind == "sgd" else dict(lr=1e-3)
+    plain = GRPOEngine(dims, device=DEV, optim=OptimConfig(**oc), seed=7, overlap_update=False)
+    over = GRPOEngine(dims, device=DEV, optim=OptimConfig(**oc), seed=7, overlap_update=True)
+    assert plain.update_stream is None and over.update_stream is not None
+    outs = []
+    for step in range(4):
+        mbs = _mbs(dims.vocab_size, 192, 4, True, seed_shift=step)
+        passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+        outs.append((plain.step(passes), over.step(passes)))
+        assert set(over._gather_events) == {b.name for b in over.store.buckets}  # one event per bucket, in flight until the next forward
+    over.wait_params_ready()
+    assert not over._gather_events
+    torch.cuda.synchronize()
+    for a, b in outs:
+        assert all(torch.equal(x, y) for x, y in zip(a["loss"], b["loss"])) and torch.equal(a["grad_norm"], b["grad_norm"])
+    for name in ("params", "master", "exp_avg", "exp_avg_sq", "main_grad"):
+        assert torch.equal(getattr(plain.store, name), getattr(over.store, name)), name
