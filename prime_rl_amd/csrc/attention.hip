@@ -255,14 +255,17 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
                      n_q_heads, 1.0f / softmax_scale, ndelta, nlse);
   PM_CHECK_LAUNCH(who);
 
-#define PM_LAUNCH_DKDV(MINB_, FB_, QT_)                                                                                                           \
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_>), dim3((unsigned)(cdiv(n, 64) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q,     \
+#define PM_LAUNCH_DKDV(MINB_, FB_, QT_, KVB_)                                                                                                     \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_, KVB_>), dim3((unsigned)(cdiv(n, 64 * KVB_) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
                      softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0)
-  if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64);
-  else if ((g_dkdv_var & 15) == 2) PM_LAUNCH_DKDV(2, 8, 64);
-  else if ((g_dkdv_var & 15) == 3) PM_LAUNCH_DKDV(3, 4, 32);
-  else PM_LAUNCH_DKDV(2, 4, 64);
+  if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64, 1);
+  else if ((g_dkdv_var & 15) == 2) PM_LAUNCH_DKDV(2, 8, 64, 1);
+  else if ((g_dkdv_var & 15) == 3) PM_LAUNCH_DKDV(3, 4, 32, 1);
+  else if ((g_dkdv_var & 15) == 4) PM_LAUNCH_DKDV(1, 4, 64, 2);  // 32 kv rows per wave, one wave per SIMD (accumulators in AGPRs)
+  else if ((g_dkdv_var & 15) == 5) PM_LAUNCH_DKDV(1, 8, 64, 2);
+  else if ((g_dkdv_var & 15) == 6) PM_LAUNCH_DKDV(1, 4, 32, 2);
+  else PM_LAUNCH_DKDV(2, 4, 64, 1);
 #undef PM_LAUNCH_DKDV
   PM_CHECK_LAUNCH(who);
 

@@ -199,9 +199,11 @@ constexpr int kV5DkdvBufBytes = 2 * QT * kD * 2 + 3 * 64 * 4;
 // dV^T += dO^T . P and dK^T += Q^T . dS through transpose-reads of the same tiles.  The S accumulators start at -lse / scale and the dP
 // accumulators at -delta (rows prepared by attn_delta_kernel and DMA'd next to the tiles), so that P = exp2(acc_S * scale * log2 e) and
 // dS / scale = P * acc_dP: no zero-fill, no per-score subtraction of the row statistics.
-template <int FB, int QT>
+template <int FB, int QT, int KVB>
 __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int kvb, int kvi, unsigned nk_u, int n, float sc2, int bq, int bt, int lq,
-                                          const u32x4 (&kf)[4], const u32x4 (&vf)[4], f32x4 (&dkt)[8], f32x4 (&dvt)[8]) {
+                                          const u32x4 (&kf)[KVB][4], const u32x4 (&vf)[KVB][4], f32x4 (&dkt)[KVB][8], f32x4 (&dvt)[KVB][8]) {
+  // KVB = 16-row kv blocks per wave: every Q / dO fragment read from LDS feeds KVB MFMAs (the kernel is bounded by the LDS port at KVB = 1:
+  // 1 KiB of fragment reads per 16-cycle MFMA and wave = twice what the port delivers to four SIMDs).  kvi / nk_u are those of block 0.
   constexpr int TILE = QT * kD;
   constexpr int kDO = TILE;  // element offset of the dO tile
   const bf16_t* Qt = reinterpret_cast<const bf16_t*>(sm);
@@ -210,14 +212,19 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
   const int* Los = reinterpret_cast<const int*>(nLs + 128);
   // fully visible tile (wave-uniform; read first so that its LDS wait does not sit behind the fragment reads)
   const int lo_last = __builtin_amdgcn_readfirstlane(Los[QT - 1]);
-  const bool full = (qi0 >= kvb + 15) && (qi0 + QT <= n) && (lo_last <= kvb);
-  f32x4 s[QT / 16], dp[QT / 16];
+  const bool full = (qi0 >= kvb + 16 * KVB - 1) && (qi0 + QT <= n) && (lo_last <= kvb);
+  f32x4 s[KVB][QT / 16], dp[KVB][QT / 16];
 #pragma unroll
   for (int nb = 0; nb < QT / 16; ++nb) {
-    s[nb] = *reinterpret_cast<const f32x4*>(nLs + nb * 16 + lq * 4);
-    dp[nb] = *reinterpret_cast<const f32x4*>(nDs + nb * 16 + lq * 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(nLs + nb * 16 + lq * 4);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(nDs + nb * 16 + lq * 4);
+#pragma unroll
+    for (int b = 0; b < KVB; ++b) {
+      s[b][nb] = s0;
+      dp[b][nb] = d0;
+    }
   }
-  // k-step outermost: the 2 * QT/16 accumulators of one batch are independent, so consecutive MFMAs never wait for each other
+  // k-step outermost: the 2 * KVB * QT/16 accumulators of one batch are independent, so consecutive MFMAs never wait for each other
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     u32x4 qa[QT / 16], da[QT / 16];
@@ -229,38 +236,49 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nb = 0; nb < QT / 16; ++nb) {
-      s[nb] = mfma16(qa[nb], kf[kk], s[nb]);
-      dp[nb] = mfma16(da[nb], vf[kk], dp[nb]);
-    }
+    for (int nb = 0; nb < QT / 16; ++nb)
+#pragma unroll
+      for (int b = 0; b < KVB; ++b) {
+        s[b][nb] = mfma16(qa[nb], kf[b][kk], s[b][nb]);
+        dp[b][nb] = mfma16(da[nb], vf[b][kk], dp[b][nb]);
+      }
   }
   if (full) {
 #pragma unroll
-    for (int nb = 0; nb < QT / 16; ++nb)
+    for (int b = 0; b < KVB; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = fast_exp2(s[nb][r] * sc2);
-        s[nb][r] = p;
-        dp[nb][r] *= p;  // dS / scale
-      }
+      for (int nb = 0; nb < QT / 16; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(s[b][nb][r] * sc2);
+          s[b][nb][r] = p;
+          dp[b][nb][r] *= p;  // dS / scale
+        }
   } else {
 #pragma unroll
     for (int nb = 0; nb < QT / 16; ++nb) {
       const u32x4 lo4 = *reinterpret_cast<const u32x4*>(Los + nb * 16 + lq * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qg = qi0 + nb * 16 + lq * 4 + r;
-        const bool ok = ((unsigned)(qg - kvi) < nk_u) && (kvi >= (int)lo4[r]);
-        const float p = ok ? fast_exp2(s[nb][r] * sc2) : 0.f;
-        s[nb][r] = p;
-        dp[nb][r] *= p;
-      }
+      for (int b = 0; b < KVB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qg = qi0 + nb * 16 + lq * 4 + r;
+          const int kvi_b = kvi + 16 * b;
+          const bool ok = ((unsigned)(qg - kvi_b) < nk_u - 16u * b) && (kvi_b >= (int)lo4[r]);
+          const float p = ok ? fast_exp2(s[b][nb][r] * sc2) : 0.f;
+          s[b][nb][r] = p;
+          dp[b][nb][r] *= p;
+        }
     }
   }
 #pragma unroll
-  for (int h = 0; h < QT / 32; ++h) {  // 32-row halves of the q tile: one packed P / dS operand each
-    const u32x4 pb = pack_c_pair(s[2 * h], s[2 * h + 1]);
-    const u32x4 sb = pack_c_pair(dp[2 * h], dp[2 * h + 1]);
+  for (int h = 0; h < QT / 32; ++h) {  // 32-row halves of the q tile: one packed P / dS operand per kv block each
+    u32x4 pb[KVB], sb[KVB];
+#pragma unroll
+    for (int b = 0; b < KVB; ++b) {
+      pb[b] = pack_c_pair(s[b][2 * h], s[b][2 * h + 1]);
+      sb[b] = pack_c_pair(dp[b][2 * h], dp[b][2 * h + 1]);
+    }
 #pragma unroll
     for (int n0 = 0; n0 < 8; n0 += FB) {
       u32x4 doa[FB], qa[FB];
@@ -272,10 +290,12 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < FB; ++i) {
-        dvt[n0 + i] = mfma16(doa[i], pb, dvt[n0 + i]);
-        dkt[n0 + i] = mfma16(qa[i], sb, dkt[n0 + i]);
-      }
+      for (int i = 0; i < FB; ++i)
+#pragma unroll
+        for (int b = 0; b < KVB; ++b) {
+          dvt[b][n0 + i] = mfma16(doa[i], pb[b], dvt[b][n0 + i]);
+          dkt[b][n0 + i] = mfma16(qa[i], sb[b], dkt[b][n0 + i]);
+        }
     }
   }
 }
@@ -284,7 +304,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
 // `ds_read_b64_tr_b16` that MAY alias a pending LDS-DMA with `s_waitcnt vmcnt(0)` (plain ds_reads are not guarded), which with one dynamic
 // array made every iteration wait for the NEXT tile's DMA in the middle of its own compute.  With the read buffer and the DMA target in
 // different arrays the alias query is answered at compile time and the prefetch stays in flight.
-template <int MINB, int FB, int QT>
+template <int MINB, int FB, int QT, int KVB = 1>
 __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
     const float* __restrict__ nlse, const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   // arrays (q, dout, nlse, ndelta) only the rows [q_row0, n) this rank owns, addressed as row - q_row0; q_row0 is a multiple of 128, so no q
   // tile straddles it.  q_row0 = 0 is the ordinary call.
   constexpr int NT = 256;
-  constexpr int ROWS = 64;           // kv rows per workgroup (4 waves x 16)
+  constexpr int ROWS = 64 * KVB;     // kv rows per workgroup (4 waves x KVB blocks of 16)
   constexpr int PPW = QT / 16;       // 1 KiB DMA pieces per wave per operand tile
   static_assert(QT % 32 == 0, "q tile is consumed in 32-row halves");
   constexpr int TILE = QT * kD;      // elements of one [QT][128] tile
@@ -308,20 +328,21 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   const int group = hq / hkv;
   const int kvh = blockIdx.x % hkv;
   const int kv0 = (blockIdx.x / hkv) * ROWS;
-  const int kvb = kv0 + w * 16;
+  const int kvb = kv0 + w * 16 * KVB;
   const bool active = kvb < n;
   const int kvi = kvb + lr;
-  u32x4 kf[4], vf[4];
-  f32x4 dkt[8], dvt[8];
-  {
-    const int row = kvi < n ? kvi : n - 1;
+  u32x4 kf[KVB][4], vf[KVB][4];
+  f32x4 dkt[KVB][8], dvt[KVB][8];
+#pragma unroll
+  for (int b = 0; b < KVB; ++b) {
+    const int row = kvi + 16 * b < n ? kvi + 16 * b : n - 1;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      kf[kk] = ldg16(k + ((int64_t)row * hkv + kvh) * kD + kk * 32 + lq * 8);
-      vf[kk] = ldg16(v + (int64_t)row * v_stride + (int64_t)kvh * kD + kk * 32 + lq * 8);
+      kf[b][kk] = ldg16(k + ((int64_t)row * hkv + kvh) * kD + kk * 32 + lq * 8);
+      vf[b][kk] = ldg16(v + (int64_t)row * v_stride + (int64_t)kvh * kD + kk * 32 + lq * 8);
     }
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) dkt[nb] = dvt[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < 8; ++nb) dkt[b][nb] = dvt[b][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int wg_last = (kv0 + ROWS - 1 < n - 1) ? kv0 + ROWS - 1 : n - 1;
   const float sc2 = scale * 1.44269504088896340736f;
@@ -380,36 +401,42 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
   const unsigned nk_u = (unsigned)(n - kvi);  // q row qg is inside the tensor and at or past this lane's kv row iff (unsigned)(qg - kvi) < nk_u
   if (total_iters > 0) dma(smA);
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    pin_loaded(kf[kk]);
-    pin_loaded(vf[kk]);
-  }
+  for (int b = 0; b < KVB; ++b)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      pin_loaded(kf[b][kk]);
+      pin_loaded(vf[b][kk]);
+    }
   auto step = [&](const unsigned char* rd, unsigned char* wr, int j) {
     const int qi0 = kv0 + QT * c_cur.tile;
     advance(c_cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile j have landed ...
     __syncthreads();                                  // ... so have everyone's, and compute(j-1) is finished everywhere
     if (j + 1 < total_iters) dma(wr);
-    if (active && qi0 + QT - 1 >= kvb) dkdv_tile<FB, QT>(rd, qi0, kvb, kvi, nk_u, n, sc2, bq, bt, lq, kf, vf, dkt, dvt);
+    if (active && qi0 + QT - 1 >= kvb) dkdv_tile<FB, QT, KVB>(rd, qi0, kvb, kvi, nk_u, n, sc2, bq, bt, lq, kf, vf, dkt, dvt);
   };
   for (int j = 0; j < total_iters; j += 2) {
     step(smA, smB, j);
     if (j + 1 < total_iters) step(smB, smA, j + 1);
   }
   if (!active) return;  // wave-uniform
-  if (!narrow_stores) {
-    const int row = kvi < n ? kvi : n - 1;
-    store_row_blocks16(dk + ((int64_t)row * hkv + kvh) * kD, dkt, scale, lq, kvi < n);
-    store_row_blocks16(dv + (int64_t)row * dv_stride + (int64_t)kvh * kD, dvt, 1.0f, lq, kvi < n);
-    return;
-  }
-  if (kvi >= n) return;
-  bf16_t* pk_ = dk + ((int64_t)kvi * hkv + kvh) * kD + lq * 4;
-  bf16_t* pv_ = dv + (int64_t)kvi * dv_stride + (int64_t)kvh * kD + lq * 4;
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb) {
-    st8_bf16(pk_ + nb * 16, dkt[nb], scale);
-    st8_bf16(pv_ + nb * 16, dvt[nb], 1.0f);
+  for (int b = 0; b < KVB; ++b) {
+    const int kvr = kvi + 16 * b;
+    if (!narrow_stores) {
+      const int row = kvr < n ? kvr : n - 1;
+      store_row_blocks16(dk + ((int64_t)row * hkv + kvh) * kD, dkt[b], scale, lq, kvr < n);
+      store_row_blocks16(dv + (int64_t)row * dv_stride + (int64_t)kvh * kD, dvt[b], 1.0f, lq, kvr < n);
+      continue;
+    }
+    if (kvr >= n) continue;
+    bf16_t* pk_ = dk + ((int64_t)kvr * hkv + kvh) * kD + lq * 4;
+    bf16_t* pv_ = dv + (int64_t)kvr * dv_stride + (int64_t)kvh * kD + lq * 4;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      st8_bf16(pk_ + nb * 16, dkt[b][nb], scale);
+      st8_bf16(pv_ + nb * 16, dvt[b][nb], 1.0f);
+    }
   }
 }
 
