@@ -215,12 +215,35 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int n_partials, float* __restrict__ out) {
-  __shared__ float smem[4];
+// out[0] += sum(partials), one workgroup, fixed order.  The fused gradient norm hands it ~1 M tile partials (4 MB): 1024 threads with eight 16-byte
+// loads in flight each (a single load per thread and trip made this 1.5 ms of pure latency); the unaligned head / tail go through scalar loads.
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ partials, int n_partials, float* __restrict__ out) {
+  __shared__ float smem[16];
+  const int t = threadIdx.x;
+  int head = (int)((16 - (reinterpret_cast<uintptr_t>(partials) & 15)) & 15) >> 2;
+  if (head > n_partials) head = n_partials;
+  const int nvec = (n_partials - head) >> 2;
+  const f32x4v* pv = reinterpret_cast<const f32x4v*>(partials + head);
+  f32x4v a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  int i = t;
+  for (; i + 7 * 1024 < nvec; i += 8 * 1024) {
+    f32x4v v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pv[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
+  }
+  for (; i < nvec; i += 1024) a[0] += pv[i];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
-  const float tot = block_sum<4>(s, smem);
-  if (threadIdx.x == 0) out[0] += tot;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+  if (t < head) s += partials[t];
+  const int tail0 = head + (nvec << 2);
+  if (tail0 + t < n_partials) s += partials[tail0 + t];
+  const float tot = block_sum<16>(s, smem);
+  if (t == 0) out[0] += tot;
 }
 
 // One workgroup per segment (offset, length) of a flat f32 buffer: the small tensors between the GEMM weights of a bucket (norm weights, biases), whose
@@ -508,7 +531,7 @@ extern "C" int pm_sumsq(const float* x, int64_t n, float* out_sumsq, void* works
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, st, x, n, (float*)workspace);
   PM_CHECK_LAUNCH("pm_sumsq");
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, out_sumsq);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, grid, out_sumsq);
   PM_CHECK_LAUNCH("pm_sumsq(final)");
   return PM_OK;
 }
@@ -525,7 +548,7 @@ extern "C" int pm_sumsq_segments(const float* base, const int64_t* segments, int
 extern "C" int pm_sum_partials(const float* partials, int64_t n, float* out, void* stream) {
   PM_REQUIRE(partials && out && n >= 0 && n < (1ll << 31), PM_ERR_INVALID_ARG, "pm_sum_partials: bad args");
   if (n == 0) return PM_OK;
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, (int)n, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, (int)n, out);
   PM_CHECK_LAUNCH("pm_sum_partials");
   return PM_OK;
 }
