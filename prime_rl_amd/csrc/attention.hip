@@ -114,7 +114,7 @@ using namespace pm;
 
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   if (kernel == 0) {
-    if (value > 15 && value < 64) return PM_ERR_INVALID_ARG;  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
+    if (value > 15 && value < 64 && value != 47) return PM_ERR_INVALID_ARG;  // 47 = 15 + 32: eight waves x 16 q rows  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
     g_fwd_var = value;
     return PM_OK;
   }
@@ -205,6 +205,10 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     case 2: PM_LAUNCH_FWD(2); break;
     case 3: PM_LAUNCH_FWD(3); break;
     case 7: PM_LAUNCH_FWD(7); break;
+    case 47:  // eight waves x 16 q rows per workgroup, four waves per SIMD (A/B: twice the K / V fragment reads per MFMA, twice the waves to hide latency)
+      hipLaunchKernelGGL((attn_fwd_kernel<2, 15, 1, 8>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(512), 0, as_stream(stream), (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse, (int)q_row0);
+      break;
     default: PM_LAUNCH_FWD(15); break;
   }
 #undef PM_LAUNCH_FWD

@@ -633,17 +633,17 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
 // lane of the wave needs it for (diagonal / document-boundary tiles), so interior tiles carry no compare / select code.
 constexpr int kV5FwdBufBytes = 2 * 64 * kD * 2;  // K [64][128] then V [64][128]
 
-template <int OPT>  // A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved, 4 = the row-max reduction as ONE
+template <int OPT, int CB = 2>  // CB = 16-row q blocks per wave (2: the shipped 4-wave kernel; 1: the 8-wave build).  A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved, 4 = the row-max reduction as ONE
                     // asm statement + clamp instead of the -inf select, 8 = 16-byte epilogue stores (default 15; profiles/r03_attention.md section 4); (bits 1 | 2:
                     // 0.3314 -> 0.3257 ms, bit-identical; an explicit v_pk_fma_f32 for the scale-and-subtract was 4 % SLOWER: pair-building moves)
-__device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[2][4],
-                                         const int (&qi)[2], const int (&lo)[2], float (&m)[2], float (&l)[2], f32x4 (&ot)[2][8]) {
+__device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[CB][4],
+                                         const int (&qi)[CB], const int (&lo)[CB], float (&m)[CB], float (&l)[CB], f32x4 (&ot)[CB][8]) {
   const bf16_t* Kt = reinterpret_cast<const bf16_t*>(sm);
   const bf16_t* Vt = Kt + 64 * kD;
   // S^T[kv][q]: rows kv = nb*16 + lq*4 + r, column q = lr of block cb
-  f32x4 st[2][4];
+  f32x4 st[CB][4];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) st[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   {  // k-step outermost: 8 independent accumulators per batch (no back-to-back dependent MFMAs), next batch's fragments prefetched
@@ -657,17 +657,19 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
         for (int nb = 0; nb < 4; ++nb) ka[(kk + 1) & 1][nb] = lds16(Kt + (bq ^ ((kk + 1) << 5)) + nb * 16 * kD);
       }
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        st[0][nb] = mfma16(ka[kk & 1][nb], qf[0][kk], st[0][nb]);
-        st[1][nb] = mfma16(ka[kk & 1][nb], qf[1][kk], st[1][nb]);
-      }
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) st[cb][nb] = mfma16(ka[kk & 1][nb], qf[cb][kk], st[cb][nb]);
     }
   }
   // wave-uniform mask decision (masking a score that needs no mask is exact, so "any lane" is enough); a separate pass, so that the
   // interior-tile path carries no mask code at all
-  if (__any((kv0 + 63 > q0) || (kv0 < lo[0]) || (kv0 < lo[1]))) {
+  bool need_mask = kv0 + 63 > q0;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < CB; ++cb) need_mask = need_mask || (kv0 < lo[cb]);
+  if (__any(need_mask)) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -680,7 +682,7 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
   // one fma feeding v_exp_f32, the f32x4 accumulators are rescaled with vector multiplies (v_pk_mul_f32), and the max crosses the four
   // 16-lane rows of the wave through v_permlane32_swap / v_permlane16_swap (VALU) instead of ds_bpermute round trips.
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     float mx = 0.f, m_new4 = 0.f, m_use4 = 0.f;
     if constexpr ((OPT & 4) != 0) {
       row_max16_xrow(st[cb][0], st[cb][1], st[cb][2], st[cb][3], m[cb], sc2, m_new4, m_use4);
@@ -724,8 +726,9 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
   // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
 #pragma unroll
   for (int kk2 = 0; kk2 < 2; ++kk2) {
-    const u32x4 pb0 = pack_c_pair(st[0][2 * kk2], st[0][2 * kk2 + 1]);
-    const u32x4 pb1 = pack_c_pair(st[1][2 * kk2], st[1][2 * kk2 + 1]);
+    u32x4 pb[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) pb[cb] = pack_c_pair(st[cb][2 * kk2], st[cb][2 * kk2 + 1]);
 #pragma unroll
     for (int h4 = 0; h4 < 2; ++h4) {
       u32x4 va[4];
@@ -735,22 +738,23 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nb = h4 * 4 + i;
-        ot[0][nb] = mfma16(va[i], pb0, ot[0][nb]);
-        ot[1][nb] = mfma16(va[i], pb1, ot[1][nb]);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) ot[cb][nb] = mfma16(va[i], pb[cb], ot[cb][nb]);
       }
     }
   }
 }
 
-template <int MINW, int OPT = 0>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+template <int MINW, int OPT = 0, int CB = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                int64_t v_stride, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
                                                                float scale, bf16_t* __restrict__ out, float* __restrict__ lse, int q_row0) {
   // q_row0 (a multiple of 128; 0 = the ordinary call): q, out, lse hold rows [q_row0, n) only — addressed as row - q_row0 — while k, v, seq_start
   // hold rows [0, n): one rank's share of a pass under context parallelism with gathered K / V (pm_attn_varlen_fwd_rows)
   __shared__ __attribute__((aligned(16))) unsigned char smA[kV5FwdBufBytes];
   __shared__ __attribute__((aligned(16))) unsigned char smB[kV5FwdBufBytes];
-  constexpr int PPW = 4;  // 1 KiB DMA pieces per wave per operand tile (64 rows x 256 B over 4 waves)
+  static_assert(NW * CB * 16 == 128 && 16 % NW == 0, "a workgroup covers one 128-row q tile");
+  constexpr int PPW = 16 / NW;  // 1 KiB DMA pieces per wave per operand tile (64 rows x 256 B over NW waves)
   const int n = (int)n64;
   const int t = threadIdx.x;
   const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (m0) stay on the scalar unit
@@ -766,15 +770,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   const int qh = kvh * group + gi;
   const int qt0 = q_row0 + tile * 128;
   const int nq = n - q_row0;
-  const int q0 = qt0 + w * 32;
+  const int q0 = qt0 + w * 16 * CB;
   const bool active = q0 < n;
 
-  u32x4 qf[2][4];
-  int qi[2], lo[2];
-  float m[2], l[2];
-  f32x4 ot[2][8];
+  u32x4 qf[CB][4];
+  int qi[CB], lo[CB];
+  float m[CB], l[CB];
+  f32x4 ot[CB][8];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     qi[cb] = q0 + cb * 16 + lr;
     const int row = qi[cb] < n ? qi[cb] : n - 1;
     lo[cb] = seq_start[row];
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     for (int nb = 0; nb < 8; ++nb) ot[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int tile_last = (qt0 + 127 < n - 1) ? qt0 + 127 : n - 1;
-  const int wave_last = (q0 + 31 < n - 1) ? q0 + 31 : n - 1;
+  const int wave_last = (q0 + 16 * CB - 1 < n - 1) ? q0 + 16 * CB - 1 : n - 1;
   const int kv_begin = (seq_start[qt0] / 64) * 64;
   const int n_iters = (tile_last - kv_begin) / 64 + 1;
   const float sc2 = scale * 1.44269504088896340736f;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   const int bt = r0 * kD + (((((lr & 3) >> 1) ^ swz_f(r0)) << 3) | ((lr & 1) << 2));
   dma_pieces<PPW>(krsrc, vrsrc, smA + w * PPW * 1024, 64 * kD * 2, koff, voff, kv_begin * krow, kv_begin * vrow);
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     pin_loaded(lo[cb]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) pin_loaded(qf[cb][kk]);
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (j + 1 < n_iters) dma_pieces<PPW>(krsrc, vrsrc, wr + w * PPW * 1024, 64 * kD * 2, koff, voff, (kv0 + 64) * krow, (kv0 + 64) * vrow);
-    if (active && kv0 <= wave_last) fwd_tile<OPT>(rd, kv0, q0, sc2, bq, bt, lq, qf, qi, lo, m, l, ot);
+    if (active && kv0 <= wave_last) fwd_tile<OPT, CB>(rd, kv0, q0, sc2, bq, bt, lq, qf, qi, lo, m, l, ot);
   };
   for (int j = 0; j < n_iters; j += 2) {
     step(smA, smB, j);
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   }
   if (!active) return;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB; ++cb) {
     const float lsum = xrow_sum(l[cb]);
     if (qi[cb] < n) {
       const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;

@@ -628,6 +628,34 @@ def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
         lib.pm_attn_debug_set_variant(1, 0)
 
 
+@pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([5], 2, 1), ([128], 4, 2), ([129], 4, 2),
+                                             ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1), ([255, 257], 8, 2), ([2048] * 3 + [777], 8, 2)])
+def test_attention_fwd_variants_are_bit_identical(ops, seq_lens, hq, hkv):
+    """Forward build variants (pm_attn_debug_set_variant(0, v)): the A/B bits of the shipped 4-wave kernel and the 8-wave x 16-row build (47) do the
+    same per-row arithmetic over the same kv tiles: out and lse equal the default build bit for bit, full calls and row windows."""
+    from prime_rl_amd import _lib
+
+    lib = _lib.load()
+    n, d = sum(seq_lens), 128
+    q, k, v = (t.to(DEV) for t in _attn_case(n, seq_lens, hq, hkv, 13 * n))
+    scale = d**-0.5
+    ss = ops.seq_start_from_cu(torch.tensor([0] + list(np.cumsum(seq_lens)), dtype=torch.int32, device=DEV), n)
+    r0 = (n // 2) // 128 * 128
+
+    def run():
+        full = ops.attn_varlen_fwd(q, k, v, ss, scale)
+        return full if r0 == 0 else full + ops.attn_varlen_fwd_rows(q[r0:].contiguous(), k, v, ss, scale, r0)
+
+    try:
+        base = run()
+        for var in (7, 47):
+            assert lib.pm_attn_debug_set_variant(0, var) == 0
+            got = run()
+            assert all(torch.equal(a, b) for a, b in zip(base, got)), f"forward variant {var} differs from the default build"
+    finally:
+        lib.pm_attn_debug_set_variant(0, -1)
+
+
 @pytest.mark.parametrize("seq_lens,hq,hkv,window", [([300, 212], 4, 2, 64), ([1024], 4, 1, 100), ([64, 1, 100, 37, 98], 8, 2, 7), ([700], 2, 2, 1), ([200], 2, 1, 4096)])
 def test_attention_sliding_window(ops, seq_lens, hq, hkv, window):
     """The optional sliding window of the reference's attention (attn.py:97-99) with the SAME kernels: `seq_start_with_window` raises each row's first
