@@ -350,6 +350,13 @@ int pm_adamw_step(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, 
                   void* param_bf16 /* nullable */, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */,
                   int32_t zero_grad, void* stream);
+/* The same step on ONE [rows, cols] weight matrix of the shard (rows % 64 == 0, cols % 256 == 0), element for element identical, that also writes the
+ * bf16 copy TRANSPOSED (param_t_bf16[c * ld_t + r]): the K-contiguous [in, out] layout the dgrad GEMM dy . W wants (reference: the autograd
+ * backward of F.linear in trainer/models/layers/mlp.py:27-29, attn.py:60-84) leaves the optimizer pass with 2 more bytes per parameter instead of
+ * a separate transpose pass (pm_transpose_2d) after every update. */
+int pm_adamw_step_2d(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, float* grad_f32, void* param_bf16, void* param_t_bf16,
+                     int64_t rows, int64_t cols, int64_t ld_t, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */, int32_t zero_grad, void* stream);
 /* The reference's other elementwise optimizers on the same flat shards (trainer/optim/__init__.py:74-95), same gradient scaling /
  * clipping / bf16-shadow / zero_grad contract as pm_adamw_step.
  * pm_sgd_step: torch.optim.SGD(lr, momentum, nesterov, weight_decay) — g += wd * p; buf = g at step 1, else momentum * buf + g;

@@ -108,6 +108,7 @@ SIGNATURES: dict[str, tuple] = {
     "pm_sum_partials": (I, [P, I64, P, P]),
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
+    "pm_adamw_step_2d": (I, [P, P, P, P, P, P, I64, I64, I64, F, F, F, F, F, I64, F, P, I32, P]),
     "pm_sgd_step": (I, [P, P, P, P, I64, F, F, F, I32, I64, F, P, I32, P]),
     "pm_sign_sgd_step": (I, [P, P, P, I64, F, F, F, P, I32, P]),
     "pm_comm_available": (c_int, []),

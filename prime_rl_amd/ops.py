@@ -586,6 +586,31 @@ def adamw_step(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor
     )
 
 
+def adamw_step_2d_supported(rows: int, cols: int) -> bool:
+    return rows > 0 and cols > 0 and rows % 64 == 0 and cols % 256 == 0 and rows // 64 <= 65535
+
+
+def adamw_step_2d(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor, param_bf16: Tensor, param_t_bf16: Tensor, lr: float, beta1: float,
+                  beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0, clip: Tensor | None = None, zero_grad: bool = True) -> None:
+    """adamw_step on one [rows, cols] matrix (the f32 arrays and `param_bf16` are its contiguous flat ranges) that also writes `param_t_bf16` [cols, rows]:
+    the transposed bf16 copy.  Element for element the same arithmetic as adamw_step."""
+    lib = _lib.load()
+    cols, rows = param_t_bf16.shape
+    for t, nm in ((master, "master"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grad, "grad")):
+        _req(t, torch.float32, nm)
+        if t.numel() != rows * cols:
+            raise PrimeMI355XError(f"adamw_step_2d: {nm} has {t.numel()} elements, the matrix {rows} x {cols}")
+    _req(param_bf16, torch.bfloat16, "param_bf16")
+    _req(param_t_bf16, torch.bfloat16, "param_t_bf16", contiguous=False)
+    if param_bf16.numel() != rows * cols or param_t_bf16.stride(1) != 1:
+        raise PrimeMI355XError("adamw_step_2d: param_bf16 must hold rows x cols elements and param_t_bf16 be [cols, rows] with unit inner stride")
+    check(
+        lib.pm_adamw_step_2d(_p(master), _p(exp_avg), _p(exp_avg_sq), _p(grad), _p(param_bf16), _p(param_t_bf16), rows, cols, param_t_bf16.stride(0), lr,
+                             beta1, beta2, eps, weight_decay, step, grad_scale, _p(clip), 1 if zero_grad else 0, _stream()),
+        "pm_adamw_step_2d",
+    )
+
+
 def ds_read_tr16_probe(elem_index: Tensor) -> Tensor:
     """int32[64] element indices (multiples of 4) -> int32[64, 4] values returned by `ds_read_b64_tr_b16` over the image lds[i] = i."""
     lib = _lib.load()

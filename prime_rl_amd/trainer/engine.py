@@ -594,6 +594,40 @@ class GRPOEngine:
             for nm, (o, k) in mats:
                 self._wt[nm] = slab[cursor:cursor + o * k].view(k, o)
                 cursor += o * k
+        # Single-rank AdamW engines, opt-in (PM_ADAMW_2D=1): the optimizer pass itself writes the [in, out] copies (ops.adamw_step_2d per weight matrix:
+        # + 2 bytes written per parameter) instead of 145 pm_transpose_2d launches (2 + 2 bytes) in the next backward.  Bit-identical; per matrix the
+        # fused kernel beats update + transpose (0.595 vs 0.730 ms for gate|up), but the step trades ONE 8.2 G-parameter launch at 6.0 TB/s for 255
+        # launches at 5.3-5.4 TB/s: 651.5 / 653.5 ms against 650.4 / 651.3 (profiles/r04_adamw_2d.log) — hence off.
+        self._update_plan: list | None = None
+        if (self._wt and not self.use_collectives and self.optim.type == "adamw" and self.device.type == "cuda" and not self.gemm_f32
+                and os.environ.get("PM_ADAMW_2D", "0") == "1"):
+            spans = {}
+            for b in self.store.buckets:
+                for pname, off, shape in b.params:
+                    spans[pname] = (off, shape)
+            mats = []
+            for nm in self._wt:
+                pname = "lm_head.weight" if nm == "head" else nm
+                if nm == "head" and dims.tie_word_embeddings:
+                    continue  # the tied head is the embedding: its copy keeps the lazy transpose
+                off, shape = spans[pname]
+                if ops.adamw_step_2d_supported(shape[0], shape[1]):
+                    mats.append((off, shape[0], shape[1], nm))
+            mats.sort()
+            plan, cursor = [], 0
+            for off, rows, cols, nm in mats:
+                if off > cursor:
+                    plan.append(("flat", cursor, off, None))
+                plan.append(("2d", off, off + rows * cols, nm))
+                cursor = off + rows * cols
+            if cursor < self.store.total:
+                plan.append(("flat", cursor, self.store.total, None))
+            self._update_plan = plan if mats else None
+            covered = {nm for _, _, _, nm in mats}
+            # the copies a pass of the plan leaves current: whole layers (the lazy refresh of _dgrad works per layer) and the head
+            self._update_fresh = [i for i in range(dims.num_hidden_layers) if all(f"model.layers.{i}.{x}" in covered for x in self._DGRAD_MATRICES)]
+            if "head" in covered:
+                self._update_fresh.append("head")
         # LM head: "library" = hipBLASLt logits [N, V] bf16 in HBM -> K1 (kept for backward, overwritten in place by dlogits);
         # "fused" = J1 (csrc/lmhead.hip): GEMM tile + log-prob epilogue in one kernel, no logits in HBM, backward recomputes them on the
         # MFMA units per token chunk.  The default is whichever measured faster for the step (profiles/: the library GEMM runs at
@@ -1145,8 +1179,25 @@ class GRPOEngine:
         self._param_readers.clear()
         if self.update_stream is not None:  # a previous update nobody waited for (a step without a forward): keep the updates ordered
             torch.cuda.current_stream().wait_stream(self.update_stream)
+        # the copies are only worth writing when the next backward will read them (steps below dgrad_own_below tokens run dgrad on the stored weights)
+        local_update = self._update_2d if (self._update_plan is not None and self.update_stream is None and not self._dgrad_own_now) else None
         return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq,
-                                           local_sumsq=self._fs_norm if self.fused_sumsq else None, update_stream=self.update_stream)
+                                           local_sumsq=self._fs_norm if self.fused_sumsq else None, update_stream=self.update_stream, local_update=local_update)
+
+    def _update_2d(self, coef: Tensor) -> None:
+        """AdamW over the flat buffers as [flat range | weight matrix | flat range | ...]: every projection matrix (and the untied head) through
+        ops.adamw_step_2d, which also writes its [in, out] copy; what lies between them (norm weights, biases, the embedding, padding) through the flat kernel.
+        Same arithmetic element for element as the single flat launch."""
+        st, o = self.store, self.optim
+        for kind, a, b, nm in self._update_plan:
+            if kind == "flat":
+                zero.apply_update(ops, o, st.master[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b], st.grad_shard[a:b], st.params[a:b], self.step_count, coef,
+                                  zero_grad=False)
+            else:
+                ops.adamw_step_2d(st.master[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b], st.grad_shard[a:b], st.params[a:b], self._wt[nm], o.lr, o.betas1,
+                                  o.betas2, o.eps, o.weight_decay, self.step_count, 1.0, coef, zero_grad=False)
+        for key in self._update_fresh:  # every copy the plan wrote is current
+            self._wt_version[key] = st.version
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:

@@ -784,3 +784,45 @@ def test_update_under_the_next_forward_is_bit_identical(kind):
         assert all(torch.equal(x, y) for x, y in zip(a["loss"], b["loss"])) and torch.equal(a["grad_norm"], b["grad_norm"])
     for name in ("params", "master", "exp_avg", "exp_avg_sq", "main_grad"):
         assert torch.equal(getattr(plain.store, name), getattr(over.store, name)), name
+
+
+def test_adamw_that_writes_the_transposed_copies_is_bit_identical(monkeypatch):
+    """Single-rank AdamW engines update every projection matrix through pm_adamw_step_2d, which writes the [in, out] copy the library's dgrad reads
+    next to the [out, in] parameters: parameters, masters and both moments equal the one flat launch bit for bit over several steps, the copies
+    ARE the transposed parameters, and the next backward launches no transpose."""
+    from prime_rl_amd import ops as ops_mod
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    monkeypatch.setenv("PM_DGRAD_OWN_BELOW", "0")  # small test steps would otherwise run dgrad on the stored weights and skip the copies
+    dims = ModelDims.tiny(layers=3, vocab=512)
+    monkeypatch.setenv("PM_ADAMW_2D", "0")
+    flat = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), seed=7)
+    monkeypatch.setenv("PM_ADAMW_2D", "1")
+    two_d = GRPOEngine(dims, device=DEV, optim=OptimConfig(lr=1e-3), seed=7)
+    assert flat._update_plan is None and two_d._update_plan is not None
+    assert [e[0] for e in two_d._update_plan].count("2d") == 3 * 4 + 1  # four projections per layer and the untied head
+    assert two_d._update_plan[0][1] == 0 and two_d._update_plan[-1][2] == two_d.store.total
+    assert all(a[2] == b[1] for a, b in zip(two_d._update_plan, two_d._update_plan[1:]))  # the ranges tile the flat buffer
+    calls = []
+    real = ops_mod.transpose_2d
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    for step in range(3):
+        mbs = _mbs(dims.vocab_size, 192, 4, True, seed_shift=step)
+        passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+        a = flat.step(passes)
+        monkeypatch.setattr(ops_mod, "transpose_2d", counting)
+        b = two_d.step(passes)
+        monkeypatch.setattr(ops_mod, "transpose_2d", real)
+        if step > 0:
+            assert not calls, "the copies written by the optimizer pass must be current: no transpose in the next backward"
+        calls.clear()
+        assert all(torch.equal(x, y) for x, y in zip(a["loss"], b["loss"])) and torch.equal(a["grad_norm"], b["grad_norm"])
+        for name in ("params", "master", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(flat.store, name), getattr(two_d.store, name)), (step, name)
+        for nm, wt in two_d._wt.items():
+            w = two_d.store.head_weight() if nm == "head" else two_d.store.w[nm]
+            assert torch.equal(wt, w.t()), (step, nm)
