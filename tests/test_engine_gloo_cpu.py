@@ -109,7 +109,8 @@ def _worker(rank, world, port, out_dir, cp=1, mode="two", tied=False, cp_style="
 
 @pytest.mark.parametrize("world,cp,mode,tied,cp_style", [(2, 1, "two", False, "ulysses"), (2, 2, "two", False, "ulysses"), (4, 2, "two", False, "ulysses"),
                                                           (2, 1, "ragged", False, "ulysses"), (2, 1, "one", False, "ulysses"), (2, 1, "two", True, "ulysses"),
-                                                          (2, 2, "two", False, "ring"), (4, 2, "one", False, "ring")])
+                                                          (2, 2, "two", False, "ring"), (4, 2, "one", False, "ring"),
+                                                          (8, 1, "two", False, "ulysses")])  # dp 8: the widest data-parallel width of one xGMI node
 def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode, tied, cp_style):
     """(2, 1): ZeRO-2 data parallel.  (2, 2): one dp position, Ulysses context parallel over two ranks (heads <-> sequence all-to-all around
     attention, log-probs gathered for the full-pass loss, gradients reduce-scattered over dp x cp).  (4, 2): both at once.  The "ragged" / "one" /
