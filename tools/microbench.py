@@ -68,6 +68,12 @@ def bench_k1_step_shape(out):
 
 def bench_attn(out, cases=((2048, [2048]), (16384, [2048] * 8))):
     hq, hkv, d = 32, 8, 128
+    if os.environ.get("PM_ATTN_VARIANTS"):  # "kernel:variant,..." (0 forward, 1 dK/dV, 2 dQ): which build the PMC passes of tools/pmc_attn.sh look at
+        from prime_rl_amd import _lib
+
+        for kv in os.environ["PM_ATTN_VARIANTS"].split(","):
+            kern, var = (int(x) for x in kv.split(":"))
+            assert _lib.load().pm_attn_debug_set_variant(kern, var) == 0
     for n, seqs in cases:
         q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
         k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
