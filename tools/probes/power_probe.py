@@ -22,13 +22,19 @@ n = 1_000_000_000
 master = torch.empty(n, device=dev).normal_(0, 0.02); m1 = torch.zeros_like(master); m2 = torch.full_like(master, 1e-6); g = torch.empty(n, device=dev).normal_(0, 1e-3)
 pb = torch.empty(n, dtype=torch.bfloat16, device=dev); coef = torch.ones(1, device=dev)
 q = torch.randn(T, 32, 128, device=dev).to(torch.bfloat16); k = torch.randn(T, 8, 128, device=dev).to(torch.bfloat16); v = torch.randn(T, 8, 128, device=dev).to(torch.bfloat16)
+gu = torch.randn(T, 2 * I, device=dev).to(torch.bfloat16); dact = torch.randn(T, I, device=dev).to(torch.bfloat16); wn = torch.ones(H, dtype=torch.bfloat16, device=dev)
 ss = ops.seq_start_from_cu(torch.tensor([0] + [2048 * (i + 1) for i in range(8)], dtype=torch.int32, device=dev), T)
 work = {
     "library GEMM (gate|up forward)": lambda: torch.mm(x, w.t()),
     "own GEMM core (gate|up wgrad)": lambda: ops.gemm(dy.t(), x.t(), out=gw),
     "AdamW (1 G parameters)": lambda: ops.adamw_step(master, m1, m2, g, pb, 1e-6, 0.9, 0.999, 1e-8, 0.01, 1, 1.0, coef, zero_grad=False),
     "attention forward": lambda: ops.attn_varlen_fwd(q, k, v, ss, 128**-0.5),
+    "SwiGLU backward": lambda: ops.swiglu_bwd(dact, gu),
+    "SwiGLU forward": lambda: ops.swiglu_fwd(gu),
+    "RMSNorm forward (+ residual)": lambda: ops.rmsnorm_fwd(x, wn, 1e-6, residual=x),
 }
+if os.environ.get("PM_POWER_ONLY"):
+    work = {k_: v_ for k_, v_ in work.items() if any(t in k_ for t in os.environ["PM_POWER_ONLY"].split(","))}
 
 
 def smi():
