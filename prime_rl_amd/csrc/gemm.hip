@@ -72,6 +72,7 @@ struct Params {
   int out_f32;        // 0: bf16 out; 1: f32 out
   int nt_out;         // store the result with the non-temporal cache policy (it is not read again by this launch: keeps the operand panels in L2)
   int sweep_n;        // patch order of the dense product (tile_of_block): 1 = consecutive patches share their X block and cycle through W
+  int pf_dist;        // cooperative L2 prefetch (two-phase K loop): K-tiles between the line-touching loads and the K loop's position (even, >= 4)
   int accumulate;     // f32 out only: out += product
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
   // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
@@ -183,15 +184,17 @@ __device__ __forceinline__ unsigned char* lds_base() {
 
 // stage one half-tile (this wave's 2 KiB of it) of slot kind SLOT into buffer BUF from the source offset `s.off[SLOT]`, then advance that offset by
 // one K-tile.
-template <int SLOT, int BUF>
+template <int SLOT, int BUF, int PIECES = 3, int AUX = 0, bool ADV = true>  // PIECES: bit 0 = the first 1 KiB piece, bit 1 = the second one (+ the K-tile advance of the source offset)
 __device__ __forceinline__ void stage(Wave& s, unsigned char* smem) {
   constexpr int slot_off = slot_offset(BUF, SLOT);
   constexpr bool is_w = SLOT == SLOT_W0 || SLOT == SLOT_W1;
   const __amdgpu_buffer_rsrc_t rsrc = is_w ? s.wr : s.xr;
   unsigned char* dst = smem + slot_off + s.piece_lds;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[0] : s.vx[0], s.off[SLOT], 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[1] : s.vx[1], s.off[SLOT], 1024, 0);
-  s.off[SLOT] += is_w ? s.wk : s.xk;
+  if constexpr ((PIECES & 1) != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[0] : s.vx[0], s.off[SLOT], 0, AUX);
+  if constexpr ((PIECES & 2) != 0) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[1] : s.vx[1], s.off[SLOT], 1024, AUX);
+    if (ADV) s.off[SLOT] += is_w ? s.wk : s.xk;  // (ADV false: timing ablation — every K-tile re-reads K-tile 0, i.e. the DMA always hits L2)
+  }
 }
 // source offsets of K-tile 0 (slot kinds of buffer 0: W0 X0 X1 W1 of K-tile 0; the loop then alternates buffers, so every kind advances one K-tile
 // per use)
@@ -239,6 +242,21 @@ __device__ __forceinline__ void read_w(Wave& s) {
     s.whi[I][F][KK] = tr_read<slot + KK * 8192 + 1024>(s.aw[F]);
     PM_TRW(0, 0) PM_TRW(1, 0) PM_TRW(2, 0) PM_TRW(3, 0) PM_TRW(0, 1) PM_TRW(1, 1) PM_TRW(2, 1) PM_TRW(3, 1)
 #undef PM_TRW
+  }
+}
+// a quarter (PART 0..3) of read_w: fragments PART / 2 * 2 .. + 1 of k-step... in issue order of read_w
+template <int I, int BUF, bool KM, int PART>
+__device__ __forceinline__ void read_w_part(Wave& s) {
+  constexpr int slot = slot_in_window(BUF, I ? SLOT_W1 : SLOT_W0);
+  constexpr int KK = PART >> 1, F0 = (PART & 1) * 2;
+  if constexpr (!KM) {
+    s.wf[I][F0][KK] = b128_read<slot + F0 * 16 * 128>(s.aw[KK]);
+    s.wf[I][F0 + 1][KK] = b128_read<slot + (F0 + 1) * 16 * 128>(s.aw[KK]);
+  } else {
+    s.wlo[I][F0][KK] = tr_read<slot + KK * 8192>(s.aw[F0]);
+    s.whi[I][F0][KK] = tr_read<slot + KK * 8192 + 1024>(s.aw[F0]);
+    s.wlo[I][F0 + 1][KK] = tr_read<slot + KK * 8192>(s.aw[F0 + 1]);
+    s.whi[I][F0 + 1][KK] = tr_read<slot + KK * 8192 + 1024>(s.aw[F0 + 1]);
   }
 }
 template <int J, int BUF, bool KM>
@@ -292,6 +310,21 @@ __device__ __forceinline__ void quadrant(Wave& s) {  // 64 W rows x 32 X rows x 
 template <int P, int BUF, int V, bool XK, bool WK>
 __device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
   constexpr bool kBalanced = (V & 2) != 0, kNoDma = (V & 8) != 0, kNoReads = (V & 16) != 0;
+  // V bits 5 / 6 (round 5): WHERE the two LDS-DMA pieces of the phase sit in the load segment.  The four loading waves of a group run in lockstep, so with
+  // both pieces after the reads (the default) eight 1 KiB requests reach the CU's one texture addresser at the same instant at the END of the segment and
+  // every wave sits in its second `buffer_load` until the queue has room.  32: piece 0 BEFORE the fragment reads, piece 1 after them (two bursts of four,
+  // the first one accepted while the waves issue their LDS reads).  64: both pieces before the reads.  The counted wait moves with them: `vmcnt` counts the
+  // pieces issued in this phase too.
+  constexpr int kDmaEarly = (V & 32) ? 1 : (V & 64) ? 2 : 0;
+#define PM_STAGE_PHASE(PIECES)                                        \
+  if (!kNoDma) {                                                      \
+    if (P == 0) stage<SLOT_X1, BUF ^ 1, PIECES>(s, smem);             \
+    else if (P == 1) stage<SLOT_W1, BUF ^ 1, PIECES>(s, smem);        \
+    else if (P == 2) stage<SLOT_W0, BUF, PIECES>(s, smem);            \
+    else stage<SLOT_X0, BUF, PIECES>(s, smem);                        \
+  }
+  if (kDmaEarly == 1) { PM_STAGE_PHASE(1) }
+  if (kDmaEarly == 2) { PM_STAGE_PHASE(3) }
   // ---- load segment
   if (!kNoReads) {
     if (P == 0) {
@@ -305,13 +338,16 @@ __device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
       read_w<0, BUF ^ 1, WK>(s);
     }
   }
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if (!kNoDma) {
-    if (P == 0) stage<SLOT_X1, BUF ^ 1>(s, smem);
-    else if (P == 1) stage<SLOT_W1, BUF ^ 1>(s, smem);
-    else if (P == 2) stage<SLOT_W0, BUF>(s, smem);
-    else stage<SLOT_X0, BUF>(s, smem);
+  if (kDmaEarly == 0) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    PM_STAGE_PHASE(3)
+  } else if (kDmaEarly == 1) {
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    PM_STAGE_PHASE(2)
+  } else {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   }
+#undef PM_STAGE_PHASE
   __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // the asm reads of this phase: their registers become usable only here
@@ -334,6 +370,89 @@ __device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
   else if (P == 1) quadrant<0, 1, XK, WK>(s);
   else if (P == 2) quadrant<1, 1, XK, WK>(s);
   else quadrant<1, 0, XK, WK>(s);
+  if (V & 1) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_barrier();
+}
+
+// Round 5: the TWO-PHASE K-tile (V bit 8).  Same ping-pong, same ring, same fragments — but a compute segment is TWO quadrants (32 MFMAs = 512 matrix-pipe
+// cycles) instead of one, so a K-tile has 2 role swaps per wave group instead of 4 (each swap idles the matrix pipe for a barrier latency: the no-DMA
+// ablation of the four-phase loop runs at 89 % of the MFMA rate) and a load segment has 512 cycles to get its reads and its DMA pieces accepted.
+// Plain form (V bit 1 clear): W0 and W1 are never live together, 64 fragment registers instead of 96:
+//     A(t):  stage W1(t+1) -> b^1 | read W0(t), X0(t), X1(t) <- b                        | vmcnt(8) lgkmcnt(0) BARRIER | (W0,X0)(W0,X1) 32 MFMAs | BARRIER
+//     B(t):  stage W0(t+2) -> b   | read W1(t) <- b | stage X0(t+2), X1(t+2) -> b        | vmcnt(8) lgkmcnt(0) BARRIER | (W1,X1)(W1,X0) 32 MFMAs | BARRIER
+// Pre-read form (V bit 1): W0(t+1) is read in B(t), the stages are two half-tiles per segment:
+//     A(t):  stage W1(t+1) -> b^1 | read X0(t), X1(t) <- b | stage W0(t+2) -> b          | ...
+//     B(t):  stage X0(t+2) -> b   | read W1(t) <- b, W0(t+1) <- b^1 | stage X1(t+2) -> b | ...
+// Hazards (b = t & 1; group 1 runs one barrier behind group 0):
+//   RAW  a half-tile is read in a load segment AFTER the one whose counted wait + barrier retired it: every half-tile is staged three segments before its
+//        read (W1(t+1): A(t) -> B(t+1); W0 / X0 / X1(t+2): B(t) -> A(t+2)); both forms issue 8 pieces per wave per two segments, and `vmcnt(8)` after a
+//        segment's own pieces retires everything older than the two newest segments — exactly what the NEXT segment reads.
+//   WAR  a slot is re-staged in the segment after the one that read it: legal because the reads are RETIRED (`lgkmcnt(0)`) before the reading segment's
+//        barrier and the other group's DMA is issued after that barrier (guide, 8-phase template: "1 phase after when an lgkmcnt before the reading
+//        phase's first barrier retired those reads").
+// The unit switch of the persistent stream sits right after A's first stage of the last K-tile pair: W1(t+1) still belongs to this unit, everything
+// staged after it to the next one.
+template <int S, int BUF, int V, bool XK, bool WK>
+__device__ __forceinline__ void superphase(Wave& s, unsigned char* smem) {
+  constexpr bool kPre = (V & 2) != 0, kNoDma = (V & 8) != 0, kNoReads = (V & 16) != 0, kSplit = (V & 1024) != 0;
+  constexpr bool kAdv = (V & 4096) == 0, kNoWait = (V & 2048) != 0;  // timing ablations (wrong results): DMA always hits L2 / never waited for
+  constexpr int AUX = (V & 512) ? 1 : 0;  // experiment: sc0 on the LDS-DMA (every line is used once by this CU: nothing to gain from its L1)
+  if (S == 0) {
+    if (!kNoReads) {
+      if (!kPre) read_w<0, BUF, WK>(s);
+      read_x<0, BUF, XK>(s);
+      read_x<1, BUF, XK>(s);
+    }
+    if (kPre && !kNoDma) stage<SLOT_W0, BUF, 3, AUX, kAdv>(s, smem);
+  } else {
+    if (kPre) {
+      if (!kNoDma) stage<SLOT_X0, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoReads) {
+        read_w<1, BUF, WK>(s);
+        read_w<0, BUF ^ 1, WK>(s);
+      }
+      if (!kNoDma) stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+    } else if (kSplit) {  // one piece, two fragment reads, one piece, ...: six bursts of four requests instead of one of eight and one of sixteen
+      if (!kNoDma) stage<SLOT_W0, BUF, 1, AUX, kAdv>(s, smem);
+      if (!kNoReads) read_w_part<1, BUF, WK, 0>(s);
+      if (!kNoDma) stage<SLOT_W0, BUF, 2, AUX, kAdv>(s, smem);
+      if (!kNoReads) read_w_part<1, BUF, WK, 1>(s);
+      if (!kNoDma) stage<SLOT_X0, BUF, 1, AUX, kAdv>(s, smem);
+      if (!kNoReads) read_w_part<1, BUF, WK, 2>(s);
+      if (!kNoDma) stage<SLOT_X0, BUF, 2, AUX, kAdv>(s, smem);
+      if (!kNoReads) read_w_part<1, BUF, WK, 3>(s);
+      if (!kNoDma) stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+    } else {
+      if (!kNoDma) stage<SLOT_W0, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoReads) read_w<1, BUF, WK>(s);
+      if (!kNoDma) {
+        stage<SLOT_X0, BUF, 3, AUX, kAdv>(s, smem);
+        stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+      }
+    }
+  }
+  // (V bit 13: the prefetch load issued at the top of the K-tile pair is one of the newest nine operations in the two segments of buffer 0)
+  if (kNoWait) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else if ((V & 8192) != 0 && BUF == 0) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (S == 0) {
+    tie_w<0, WK>(s);  // pre-read form: read in the previous B segment (or the prologue)
+    tie_x<0, XK>(s);
+    tie_x<1, XK>(s);
+  } else {
+    tie_w<1, WK>(s);
+    if (kPre) tie_w<0, WK>(s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (V & 1) __builtin_amdgcn_s_setprio(1);
+  if (S == 0) {
+    quadrant<0, 0, XK, WK>(s);
+    quadrant<0, 1, XK, WK>(s);
+  } else {
+    quadrant<1, 1, XK, WK>(s);
+    quadrant<1, 0, XK, WK>(s);
+  }
   if (V & 1) __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_s_barrier();
 }
@@ -601,11 +720,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   stage<SLOT_W1, 0>(s, smem);
   stage<SLOT_W0, 1>(s, smem);
   stage<SLOT_X0, 1>(s, smem);
+  if constexpr ((V & 256) != 0) {  // two-phase K-tile: X1(1) as well (what B(-1) would have staged); W0(0), X0(0), X1(0) have landed behind vmcnt(8)
+    stage<SLOT_X1, 1>(s, smem);
+  }
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // W0(0) and X0(0) of this wave have landed
   __builtin_amdgcn_s_barrier();
   if ((V & 2) != 0 && !(V & 16)) read_w<0, 0, WK>(s);  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1), later ones in phase 4 of the previous K-tile
   if (wv == 1) __builtin_amdgcn_s_barrier();           // the second wave group runs one barrier behind the first
 
+  int pf_junk = 0;  // destination of the prefetch loads (never read)
   for (;;) {  // ---- the workgroup's stream of units (output tiles, or parts of an accumulation chain)
     {
       // Re-derive the per-lane DMA offsets / read addresses from an OPAQUE copy of the lane id at the top of every unit: otherwise they stay live across
@@ -618,6 +741,27 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     // Only what the epilogue needs of `cur` stays live across the K loop; the NEXT unit is looked up at the point where the staging switches to it,
     // its two descriptors are built and the rest is dropped again (it is looked up once more as `cur` at the top of its own turn): scalar registers
     // are the scarce resource of this kernel (spilled SGPRs land in VGPR lanes and push the vector allocation over 256).
+    // Cooperative L2 prefetch (V bit 13; dense products).  The 32 workgroups of an XCD's 8 x 4 tile patch walk K in step, so a panel line's 4 (X) or 8 (W)
+    // readers ask for it within the same few hundred cycles: one of them misses in L2, the others merge into the miss — and ALL of them hold their
+    // vector-memory slots for the full fabric latency.  The timing ablations say that is what the DMA costs (profiles/r05_gemm.md: the same DMA instruction
+    // stream always hitting L2 runs at the no-DMA rate, never WAITING for the DMA changes nothing).  So the lines are touched `pf_dist` K-tiles ahead by ONE
+    // load instruction per wave and K-tile pair — 64 lines per instruction, every line of the patch's 12 panels by two of its readers — and the DMA that
+    // follows finds them in L2.  Waves 0-3: X lines of K-tile t + D + (wave & 1); waves 4-5: W lines; waves 6-7: out-of-range offsets (no memory access, the
+    // same `vmcnt` count in every wave).  The loaded dword is never used; its register stays reserved until the loop's loads have drained.
+    int pf_off = -1;
+    if constexpr ((V & 8192) != 0 && MODE == 0) {
+      int lane_p = lane;
+      asm volatile("" : "+v"(lane_p));
+      const int within = (v >> 3) & 31;  // position inside the XCD's patch (tile_of_block): X panel shared by `within >> 3` = 0..3, W panel by `within & 7`
+      if (wave < 6) {
+        const bool is_x = wave < 4;
+        const int line = is_x ? (((within >> 3) & 1) * 128 + (wave >> 1) * 64 + lane_p) : ((within & 3) * 64 + lane_p);  // of the K-tile's 256 lines of 128 bytes
+        const bool km = is_x ? XK : WK;
+        const int64_t ld = is_x ? p.ldx : p.ldw;
+        const int kstep = is_x ? s.xk : s.wk;
+        pf_off = (km ? (int)((line >> 2) * ld * 2) + (line & 3) * 128 : (int)(line * ld * 2)) + (wave & 1) * kstep;
+      }
+    }
     int v_n = v, part_n = part;
     bool has_next = false;
     if (cur.first) {
@@ -631,6 +775,33 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
             for (int g = 0; g < 2; ++g) s.acc[i][f][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nk = cur.nk;
+    if constexpr ((V & 256) != 0) {
+      for (int t = 0; t < nk; t += 2) {
+        if constexpr ((V & 8192) != 0 && MODE == 0) {
+          const bool live = t + p.pf_dist < nk;
+          const int soff = (t + p.pf_dist) * (wave < 4 ? s.xk : s.wk);
+          const __amdgpu_buffer_rsrc_t rs = wave < 4 ? s.xr : s.wr;
+          const int voff = live ? pf_off : -1;
+          asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_junk) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+        }
+        if (!(V & 8)) stage<SLOT_W1, 1, 3, (V & 512) ? 1 : 0, (V & 4096) == 0>(s, smem);  // A(t), first stage: W1(t + 1)
+        if (t + 2 >= nk) {
+          advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
+          Tile nxt;
+          has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+          if (has_next) {
+            s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+            s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
+          }
+          reset_offsets(s);
+        }
+        superphase<0, 0, V, XK, WK>(s, smem);
+        superphase<1, 0, V, XK, WK>(s, smem);
+        if (!(V & 8)) stage<SLOT_W1, 0, 3, (V & 512) ? 1 : 0, (V & 4096) == 0>(s, smem);  // A(t + 1), first stage: W1(t + 2)
+        superphase<0, 1, V, XK, WK>(s, smem);
+        superphase<1, 1, V, XK, WK>(s, smem);
+      }
+    } else
     for (int t = 0; t < nk; t += 2) {  // two K-tiles per iteration: t in buffer 0, t + 1 in buffer 1
       phase<0, 0, V, XK, WK>(s, smem);
       phase<1, 0, V, XK, WK>(s, smem);
@@ -773,10 +944,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     tile_at<MODE, XK, WK>(p, v, part, lane, cur);
   }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
+  asm volatile("" : : "v"(pf_junk));
   if (wv == 0) __builtin_amdgcn_s_barrier();
 }
 
 
+#if PM_VARIANTS  // `make VARIANTS=1`: the measured-and-not-adopted builds (profiles/r04_gemm.md, r05_gemm.md) stay out of the product library
 // =============================================================================================================================================
 // Round 4: the ONE-WAVE-PER-SIMD form of the same core (`gemm4_kernel`).  Same 256 x 256 x 64 tile, same LDS images (so the DMA swizzles and the fragment
 // read addresses above carry over), same tile stream / units / epilogue arithmetic; what changes is who holds what:
@@ -1274,6 +1447,7 @@ static void launch_v4(const Params& p, hipStream_t st, dim3 grid) {
 }
 
 }  // namespace g4
+#endif  // PM_VARIANTS
 
 template <int V, bool XK, bool WK, int MODE = 0>
 static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
@@ -1292,6 +1466,7 @@ static void launch(const Params& p, hipStream_t st) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
+#if PM_VARIANTS
   if (g_variant & (64 | 128 | 256)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
     const int v4 = g_variant & (8 | 16);
     if (g_variant & 256) {  // bit 8: the fine schedule (bits 3 / 4: its timing ablations, forward layout)
@@ -1305,13 +1480,30 @@ static void launch(const Params& p, hipStream_t st) {
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }
-  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512 | 1024);
-  if (v == 0) launch_v<0, XK, WK>(p, st, grid);
+#endif
+  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512 | 1024 | (15 << 24));
+  if (v == (1 | 32768)) { launch_v<1 | 256, XK, WK>(p, st, grid); return; }  // bit 15: the two-phase K-tile (32 MFMAs per compute segment)
+  // round-5 experiments on the two-phase loop (bits 16 / 17 / 18 -> sc0 DMA / split B segment / no setprio; 8 / 16: timing ablations, forward layout)
+  if (v == (1 | 32768 | 65536)) { launch_v<1 | 256 | 512, XK, WK>(p, st, grid); return; }
+  if (v == (1 | 32768 | 131072)) { launch_v<1 | 256 | 1024, XK, WK>(p, st, grid); return; }
+  if (v == (0 | 32768)) { launch_v<0 | 256, XK, WK>(p, st, grid); return; }
+  if (v == (1 | 32768 | 1048576)) { launch_v<1 | 256 | 8192, XK, WK>(p, st, grid); return; }  // bit 20: cooperative L2 prefetch (bits 24-27: distance / 2)
+  if (!XK && !WK && v == (1 | 32768 | 262144)) { launch_v<1 | 256 | 2048, false, false>(p, st, grid); return; }  // bit 18: the DMA is never waited for
+  if (!XK && !WK && v == (1 | 32768 | 524288)) { launch_v<1 | 256 | 4096, false, false>(p, st, grid); return; }  // bit 19: the DMA always hits L2
+  if (!XK && !WK && v == (1 | 8 | 32768)) { launch_v<1 | 8 | 256, false, false>(p, st, grid); return; }
+  if (!XK && !WK && v == (1 | 16 | 32768)) { launch_v<1 | 16 | 256, false, false>(p, st, grid); return; }
+#if PM_VARIANTS
+  if (v == (3 | 32768)) launch_v<3 | 256, XK, WK>(p, st, grid);      // ... its W0 pre-read form (spills on the K-major layouts)
+  else if (v == (3 | 2048)) launch_v<3 | 32, XK, WK>(p, st, grid);   // bit 11: first DMA piece of a phase before the fragment reads
+  else if (v == (3 | 4096)) launch_v<3 | 64, XK, WK>(p, st, grid);   // bit 12: both DMA pieces before the fragment reads
+  else if (v == 0) launch_v<0, XK, WK>(p, st, grid);
   else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
   else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16, false, false>(p, st, grid);
   else if (!XK && !WK && v == (1 | 8 | 16)) launch_v<1 | 8 | 16, false, false>(p, st, grid);
-  else launch_v<3, XK, WK>(p, st, grid);
+  else
+#endif
+  launch_v<3, XK, WK>(p, st, grid);
 }
 // grouped products: always the balanced + setprio schedule; persistent unless the debug variant clears bit 2
 template <bool XK, bool WK, int MODE>
@@ -1431,7 +1623,14 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
 
 using namespace pm;
 
+// Schedule word of the dense core.  The product library holds the two shipped K-loop schedules (four-phase, two-phase K-tile) with the persistent / per-tile
+// grid (bit 2), the split-K switch (bit 5), non-temporal result stores (bit 9) and the patch sweep order (bit 10); every other bit selects a build that was
+// measured and not adopted and exists only in a `make VARIANTS=1` library — PM_ERR_UNSUPPORTED otherwise (the GPU tests skip on it).
 extern "C" int pm_gemm_debug_set_variant(int32_t v) {
+#if !PM_VARIANTS
+  const int sched = v & ~(4 | 32 | 512 | 1024 | (15 << 24));
+  PM_REQUIRE(sched == 3 || (sched & 32768), PM_ERR_UNSUPPORTED, "pm_gemm_debug_set_variant(%d): this schedule exists only in a `make VARIANTS=1` build", (int)v);
+#endif
   gm::g_variant = v;
   return PM_OK;
 }
@@ -1498,6 +1697,7 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
+  p.pf_dist = ((gm::g_variant >> 24) & 15) ? 2 * ((gm::g_variant >> 24) & 15) : 4;
   p.nt_out = (gm::g_variant & 512) ? 1 : 0;  // bit 9 of the debug variant: non-temporal result stores (A/B)
   // cycle the smaller operand past the held block of the bigger one (X has m x k elements, W n x k); bit 10 of the debug variant: always the round-3 order (A/B)
   p.sweep_n = (m > n && !(gm::g_variant & 1024)) ? 1 : 0;

@@ -206,8 +206,14 @@ def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=3):  # 39 = 7 with
                 ref, got = dy[:, idx].float().t() @ x.float(), g[idx]
             rel = ((got - ref).abs().max() / (ref.abs().max() + 1e-9)).item()
             res = {"lib": []}
+            base = (y if cname == "fwd" else dx if cname == "dgrad" else g).clone()
+            same = {}
             for v in variants:
                 res[f"v{v}"] = []
+                ops.gemm_set_variant(v)
+                own_fn()
+                same[f"v{v}"] = bool(torch.equal(y if cname == "fwd" else dx if cname == "dgrad" else g, base))
+            del base
             for _ in range(rounds):
                 med, _ = timeit(lib_fn, iters=5, warmup=1)
                 res["lib"].append(med)
@@ -216,7 +222,7 @@ def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=3):  # 39 = 7 with
                     med, _ = timeit(own_fn, iters=5, warmup=1)
                     res[f"v{v}"].append(med)
             ops.gemm_set_variant(7)
-            rec = dict(kernel=f"gemm_core {name} {cname} t={t}", max_rel_err=rel)
+            rec = dict(kernel=f"gemm_core {name} {cname} t={t}", max_rel_err=rel, bit_identical_to_default=same)
             for key, ts in res.items():
                 ts.sort()
                 rec[key + "_ms"] = ts[len(ts) // 2] * 1e3
@@ -459,7 +465,7 @@ def main():
         dy = torch.randn(t, o, device=DEV).to(torch.bfloat16)
         w = (torch.randn(o, i, device=DEV) * 0.02).to(torch.bfloat16)
         g = torch.zeros(o, i, dtype=torch.float32, device=DEV)
-        ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "5")))
+        ops.gemm_set_variant(int(os.environ.get("PM_GEMM_VARIANT", "7")))
         wt = w.t().contiguous()
         if os.environ.get("PM_PROBE_ZERO") == "1":  # DVFS check (guide: zero-filled operands clock ~15-19 % higher)
             x.zero_(); dy.zero_(); w.zero_(); wt.zero_()
@@ -476,7 +482,24 @@ def main():
                                                                              (68, "4-wave kernel, persistent"), (64, "4-wave kernel, one WG per tile"), (76, "4-wave ABLATION no DMA"),
                                                                              (84, "4-wave ABLATION no reads"), (92, "4-wave ABLATION no DMA, no reads"),
                                                                              (132, "4-wave kernel, register staging"), (260, "4-wave kernel, fine schedule"), (268, "4-wave fine ABLATION no DMA"),
-                                                                             (276, "4-wave fine ABLATION no reads"), (7 + 512, "8-wave core, nt result stores"), (260 + 512, "4-wave fine, nt result stores"))]
+                                                                             (276, "4-wave fine ABLATION no reads"), (7 + 512, "8-wave core, nt result stores"), (260 + 512, "4-wave fine, nt result stores"),
+                                                                             (7 + 2048, "8-wave, DMA piece 0 before the reads"), (7 + 4096, "8-wave, both DMA pieces before the reads"),
+                                                                             (7 + 32768, "8-wave, two-phase K-tile, W0 pre-read"), (5 + 32768, "8-wave, two-phase K-tile, plain"),
+                                                                             (5 + 32768 + 65536, "8-wave, two-phase, sc0 DMA"), (5 + 32768 + 131072, "8-wave, two-phase, split B segment"),
+                                                                             (4 + 32768, "8-wave, two-phase, no setprio"), (5 + 8 + 32768, "8-wave, two-phase ABLATION no DMA"),
+                                                                             (5 + 16 + 32768, "8-wave, two-phase ABLATION no reads"),
+                                                                             (5 + 32768 + 262144, "8-wave, two-phase ABLATION DMA never waited for"),
+                                                                             (5 + 32768 + 524288, "8-wave, two-phase ABLATION DMA always hits L2"),
+                                                                             (5 + 32768 + 1048576 + (2 << 24), "8-wave, two-phase, L2 prefetch 4 K-tiles ahead"),
+                                                                             (5 + 32768 + 1048576 + (3 << 24), "8-wave, two-phase, L2 prefetch 6 K-tiles ahead"),
+                                                                             (5 + 32768 + 1048576 + (4 << 24), "8-wave, two-phase, L2 prefetch 8 K-tiles ahead"),
+                                                                             (5 + 32768 + 1048576 + (6 << 24), "8-wave, two-phase, L2 prefetch 12 K-tiles ahead"))]
+            if os.environ.get("PM_PROBE_VARIANTS"):  # only these variant numbers (+ the library)
+                keepv = {int(v) for v in os.environ["PM_PROBE_VARIANTS"].split(",")}
+                cases = [c for c in cases if c[0] == "lib fwd" or any(f"variant {v} " in c[0] for v in keepv)]
+            if os.environ.get("PM_PROBE_ONLY"):
+                keep = os.environ["PM_PROBE_ONLY"].split(",")
+                cases = [c for c in cases if any(k in c[0] for k in keep)]
             for label, fn in cases:
                 med, best = timeit(fn, iters=10, warmup=2)
                 print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
