@@ -69,6 +69,49 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
                             "note": "reference benchmark default batch (run_single_benchmark.py:91,187); same engine, same build, measured after the headline"}
     except Exception as e:  # pragma: no cover
         extra["mb2"] = {"error": repr(e)[:300]}
+    # -- the GEMM routing of rounds 3-4 on the SAME engine: library (hipBLASLt) forward + dgrad on [in, out] weight copies, own weight gradients --------
+    # (VERDICT r4 'next' 1: "add config.extra.all_own so the hand-written-only step is driver-measured".  Since round 5 the hand-written-only step IS
+    # the headline (PM_GEMM_OWN=all); `all_own` repeats its numbers under the name the review asked for and `library_mix` times the old default next to it.)
+    try:
+        if engine.gemm_own == {"fwd", "dgrad", "wgrad"} and hasattr(engine, "set_gemm_own"):
+            kx = max(2, min(args.steps, 4))
+            per_pass = max(args.tokens_per_pass // args.seq_len, 1)
+
+            def time_steps(k):
+                bs = []
+                for _ in range(k + 1):
+                    mbs = loader.get_batch()
+                    bs.append([pack_micro_batches(mbs[i:i + per_pass], device) for i in range(0, len(mbs), per_pass)])
+                engine.step(bs[0])
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(1, k + 1):
+                    engine.step(bs[i])
+                barrier()
+                dt = time.perf_counter() - t0
+                if dist.is_initialized():
+                    t = torch.tensor([dt], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                return dt
+
+            engine.set_gemm_own("wgrad")
+            try:
+                dt = time_steps(kx)
+            finally:
+                engine.set_gemm_own("all")
+                torch.cuda.empty_cache()
+            extra["library_mix"] = {"gemm_own": ["wgrad"], "steps": kx, "ms_per_step": round(dt / kx * 1e3, 3),
+                                    "samples_per_s": round(args.micro_batches * world * kx / dt, 4),
+                                    "note": "PM_GEMM_OWN=wgrad, the default of rounds 3-4: hipBLASLt forward + dgrad on K-contiguous [in, out] weight copies "
+                                            "(refreshed by pm_transpose_2d after every update), weight gradients on the own core, stand-alone SwiGLU pass; "
+                                            "same engine, same build, measured after the headline"}
+            dt = time_steps(kx)
+            extra["all_own"] = {"gemm_own": sorted(engine.gemm_own), "steps": kx, "ms_per_step": round(dt / kx * 1e3, 3),
+                                "samples_per_s": round(args.micro_batches * world * kx / dt, 4),
+                                "note": "every GEMM of the step on csrc/gemm.hip (= the headline configuration since round 5), re-timed right after library_mix"}
+    except Exception as e:  # pragma: no cover
+        extra["library_mix"] = {"error": repr(e)[:300]}
     # -- weight push with stand-in receivers -----------------------------------------------------------------------------------------------
     try:
         store = engine.store
@@ -206,7 +249,9 @@ def parity_block(probe: dict, dims, seq_len: int) -> dict:
                          (logit[label] * inv_T) - logz bit for bit
       logprob_max_abs /  K1 (selective log-softmax + entropy on the step's bf16 logits) vs torch.log_softmax in f32 on 64 sampled rows
       entropy_max_abs    (test_fused_lm_head.py:398-457 bound: rtol 1e-3, atol 1e-4)
-      loss_abs_delta     K2's scalar loss vs the oracle's restatement of compute_loss (loss.py:285-403) on the SAME log-probs; north_star <= 1e-4
+      k2_loss_abs_delta_on_own_logprobs
+                         K2's scalar loss vs the oracle's restatement of compute_loss (loss.py:285-403) on the SAME (K2's own input) log-probs: a check
+                         of the LOSS KERNEL, not of the forward — the forward is checked by `realistic` below and by tests/test_engine_gpu.py
       flips              DPPO trust-region mask decisions (loss.py:124-133) that differ between K2 and the oracle, summed over samples
       metric keys        K2's per-sample metrics == the reference's keys (loss.py:151-159), values compared too."""
     import math
@@ -237,7 +282,8 @@ def parity_block(probe: dict, dims, seq_len: int) -> dict:
                                       rl_scale=probe["scales"][0])
     out["loss_engine"] = float(probe["loss"].item())
     out["loss_oracle"] = float(loss_o)
-    out["loss_abs_delta"] = abs(out["loss_engine"] - out["loss_oracle"])
+    out["k2_loss_abs_delta_on_own_logprobs"] = abs(out["loss_engine"] - out["loss_oracle"])
+    out["k2_loss_note"] = "K2 (pm_grpo_loss_fwd_bwd) vs oracle.compute_loss on K2's own input log-probs: a loss-kernel check; forward parity = parity.realistic"
     stats = probe["sample_stats"].cpu().numpy()
     mask = b.loss_mask.cpu().numpy()
     n_mask = np.array([mask[cu[i]:cu[i + 1]].sum() for i in range(len(lens))], dtype=np.float64)
@@ -251,7 +297,7 @@ def parity_block(probe: dict, dims, seq_len: int) -> dict:
     out["metric_keys_identical"] = (list(keys_e) == keys_ref) and (sorted(met_o.keys()) == sorted(keys_ref))
     met_e = probe["sample_metrics"].cpu().numpy()
     out["metrics_max_abs"] = float(max(np.abs(met_e[:, i] - met_o[k]).max() for i, k in enumerate(keys_ref)))
-    out["gates"] = {"loss_abs_delta<=1e-4": out["loss_abs_delta"] <= 1e-4, "logprob atol 1e-4 rtol 1e-3": out["logprob_max_abs"] <= 1e-4 + 1e-3 * float(lp_ref.abs().max().item()),
+    out["gates"] = {"K2 loss vs oracle on its own log-probs <= 1e-4": out["k2_loss_abs_delta_on_own_logprobs"] <= 1e-4, "logprob atol 1e-4 rtol 1e-3": out["logprob_max_abs"] <= 1e-4 + 1e-3 * float(lp_ref.abs().max().item()),
                     "gather_bit_exact": out["gather_bit_exact"], "metric_keys_identical": out["metric_keys_identical"], "flips==0": out["flips"] == 0}
     out["source"] = "one extra untimed step of this run's engine right after the timed region (device copies taken inside that step)"
     return out
@@ -301,13 +347,13 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
     n_tr = int(mask.sum())
     pad = math.log(1.0 / dims.vocab_size)
 
-    def oracle_logprobs(sd, cfg, labels, mm):
+    def oracle_logprobs(sd, cfg, labels, mm, attn_p_bf16=False):
         """per-token log-prob of `labels` (or, labels None: the greedy tokens, returned as well) under the oracle forward; shifted right per rollout"""
         lps, labs = [], []
         with torch.no_grad():
             for i, mb in enumerate(mbs):
                 ids = mb["input_ids"][0].to(device)
-                h = O.qwen3_forward(sd, cfg, ids, mb["position_ids"][0].to(device), [n], mm=mm)
+                h = O.qwen3_forward(sd, cfg, ids, mb["position_ids"][0].to(device), [n], mm=mm, attn_p_bf16=attn_p_bf16)
                 hw = sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"]
                 logits = (mm(h, hw) if mm is not O.exact_mm else h.float() @ hw.float().T).float() / temperature
                 lab = logits.argmax(-1) if labels is None else labels[i]
@@ -333,6 +379,7 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
                                 attention_bias=dims.attention_bias, rope_scaling=dims.rope_scaling)
         lp_b, labels = oracle_logprobs(live_sd, cfg, None, O.exact_mm)                                      # B: reference dtype, exact GEMMs; greedy labels
         lp_c, _ = oracle_logprobs(live_sd, cfg, labels, lambda a, w, b=None: torch.nn.functional.linear(a, w, b))  # C: same arithmetic, torch bf16 GEMMs
+        lp_f, _ = oracle_logprobs(live_sd, cfg, labels, O.exact_mm, attn_p_bf16=True)  # B_fa: B + the ONE rounding point inside flash-attention (bf16 P into P.V)
         pb = pack_micro_batches(mbs, device)
         pb.labels = torch.cat(labels).to(torch.int64)  # the scored tokens: the policy's greedy tokens instead of the next input id
         ctx = eng.forward(pb)  # ONE forward of the engine; the loss kernel then runs once per sampling policy
@@ -340,8 +387,12 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
         lp_e = torch.cat([torch.cat([lp_raw.new_full((1,), pad), lp_raw[i * n:(i + 1) * n - 1]]) for i in range(n_rollouts)])
         p_lab = torch.exp(lp_b[mask])
         res = {"layers": n_layers, "trained_tokens": n_tr, "logprob_abs_mean": float((lp_e - lp_b)[mask].abs().mean()),
-               "yardstick_logprob_abs_mean": float((lp_c - lp_b)[mask].abs().mean()), "label_prob_median": float(p_lab.median()),
-               "label_prob_gt_0.2": float((p_lab > 0.2).float().mean())}
+               "logprob_abs_mean_vs_bfa": float((lp_e - lp_f)[mask].abs().mean()),
+               "yardstick_logprob_abs_mean": float((lp_c - lp_b)[mask].abs().mean()), "yardstick_bfa_logprob_abs_mean": float((lp_f - lp_b)[mask].abs().mean()),
+               "label_prob_median": float(p_lab.median()), "label_prob_gt_0.2": float((p_lab > 0.2).float().mean())}
+        # noise LEVEL, the stable statistic: the engine's mean |d log-prob| to its nearest reference restatement (B or B_fa) against the distance between
+        # the reference restatements themselves (C vs B: GEMM summation order; B_fa vs B: flash-attention's bf16 P)
+        res["noise_ratio"] = min(res["logprob_abs_mean"], res["logprob_abs_mean_vs_bfa"]) / max(res["yardstick_logprob_abs_mean"], res["yardstick_bfa_logprob_abs_mean"], 1e-12)
         for name, sigma in sigmas:
             gi = torch.Generator().manual_seed(77)
             inf = lp_b + sigma * torch.randn(lp_b.shape, generator=gi)
@@ -352,8 +403,11 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
             l_b, inv_b, near_b = per_token(lp_b, inf)
             l_e, inv_e, _ = per_token(lp_e, inf)
             l_c, inv_c, _ = per_token(lp_c, inf)
+            l_f, inv_f, _ = per_token(lp_f, inf)
             d = (l_e - l_b)[mask]
             dc = (l_c - l_b)[mask]
+            df = (l_e - l_f)[mask]
+            dfb = (l_f - l_b)[mask]
             res[name] = {
                 "lp_inf": f"lp_oracle + N(0, {sigma}^2)",
                 "loss_engine": loss_k2, "loss_oracle": float(l_b.sum() / n_tr), "loss_abs_delta": abs(loss_k2 - float(l_b.sum() / n_tr)),
@@ -361,6 +415,11 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
                 "yardstick_loss_abs_delta": abs(float(dc.sum() / n_tr)), "yardstick_loss_delta_se": float(dc.std() / math.sqrt(n_tr)),
                 "masked_tokens_oracle": int(inv_b.sum()), "masked_tokens_engine": drop_k2, "masked_tokens_engine_host_formula": int(inv_e.sum()),
                 "tokens_within_0.02_of_threshold": int(near_b.sum()), "flips": int((inv_e != inv_b).sum()), "yardstick_flips": int((inv_c != inv_b).sum()),
+                # the second oracle column: B_fa = B with flash-attention's bf16 P (the engine's attention rounds P to bf16 as flash-attn does)
+                "loss_oracle_bfa": float(l_f.sum() / n_tr), "loss_abs_delta_vs_bfa": abs(float(df.sum() / n_tr)), "loss_delta_vs_bfa_se": float(df.std() / math.sqrt(n_tr)),
+                "yardstick_bfa_loss_abs_delta": abs(float(dfb.sum() / n_tr)), "yardstick_bfa_loss_delta_se": float(dfb.std() / math.sqrt(n_tr)),
+                "masked_tokens_oracle_bfa": int(inv_f.sum()), "masked_tokens_yardstick": int(inv_c.sum()), "flips_vs_bfa": int((inv_e != inv_f).sum()),
+                "yardstick_bfa_flips": int((inv_f != inv_b).sum()),
             }
         del ctx, pb
         return res
@@ -368,8 +427,9 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
     out: dict = {"data": f"{n_rollouts} x {seq_len} tokens, ids over the full vocab, {prompt_len} masked prompt tokens, labels = greedy tokens at T={temperature}, "
                          f"lp_inf = lp_oracle + N(0, sigma^2) with sigma = 0.02 (fresh policy) and {stale_sigma} (stale policy: the DPPO mask is active), group-relative advantages; "
                          "live weights after the timed steps",
-                 "oracle": "oracle/grpo_oracle.py qwen3_forward with the reference's bf16 rounding points and exact GEMMs (B), on the device; yardstick = the same "
-                           "arithmetic with torch bf16 GEMMs (C) against B"}
+                 "oracle": "oracle/grpo_oracle.py qwen3_forward with the reference's bf16 rounding points and exact GEMMs (B), and the same with flash-attention's "
+                           "bf16 P (B_fa: the engine's attention rounds P to bf16 as flash-attn does), on the device; yardsticks = the same arithmetic with torch "
+                           "bf16 GEMMs (C) against B, and B_fa against B"}
     d2 = dataclasses.replace(dims, num_hidden_layers=min(2, dims.num_hidden_layers))
     eng2 = GRPOEngine(d2, device=device, optim=OptimConfig(type="sign_sgd"), loss=LossConfig(), seed=0)
     keep = {k: v for k, v in live_sd.items() if not k.startswith("model.layers.") or int(k.split(".")[2]) < d2.num_hidden_layers}
@@ -382,18 +442,28 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
     out["full_depth"] = one_depth(engine, dims.num_hidden_layers, (("fresh", 0.02), ("stale", stale_sigma)))
     t2, tf = out["two_layer"], out["full_depth"]
 
-    def within(r):  # the engine is no further from the oracle than 3 standard errors of the paired difference, or 2 x the oracle's own bf16-GEMM yardstick
-        return r["loss_abs_delta"] <= max(1e-4, 3 * r["loss_delta_se"], 2 * r["yardstick_loss_abs_delta"])
+    def within(r):
+        """Scalar loss: the engine is within max(1e-4, 3 standard errors) of its nearer oracle (B or B_fa), the standard error taken from the YARDSTICK pairs
+        (C vs B, B_fa vs B: the reference arithmetic against itself), never from the engine under test (a noisier engine must not widen its own
+        tolerance).  The yardstick multiplier of round 4 (2 x |C - B|) is gone from this gate: |E - B| and |C - B| are two draws of the same zero-mean noise,
+        their ratio is not a statistic; the 1.25 x bound sits on the noise LEVELS (noise_ratio) and the flip counts below."""
+        se = max(r["yardstick_loss_delta_se"], r["yardstick_bfa_loss_delta_se"])
+        return min(r["loss_abs_delta"], r["loss_abs_delta_vs_bfa"]) <= max(1e-4, 3 * se)
+
+    def flips_ok(r):  # mask decisions that differ from the nearer oracle: <= 1.25 x the reference restatements' own disagreement (+ 3 sigma of that count)
+        y = max(r["yardstick_flips"], r["yardstick_bfa_flips"])
+        return min(r["flips"], r["flips_vs_bfa"]) <= 1.25 * y + 3 * math.sqrt(max(y, 1)) + 2
 
     out["mean_advantage"] = float(adv[mask].mean())
-    out["note"] = ("the <= 1e-4 loss tolerance is asserted where it is resolvable (tests/test_engine_gpu.py: 2 layers 2-4e-5; 57k tokens at full depth with paired "
+    out["note"] = ("the <= 1e-4 loss tolerance is asserted where it is resolvable (tests/test_engine_gpu.py: 2 layers 2-4e-5; 229k tokens at full depth with paired "
                    "standard errors); here T = 0.25 multiplies every logit error by 4 and 14k tokens give a standard error of ~2e-4 (2 layers) / ~8e-4 (36 layers)")
     out["gates"] = {
-        "two_layer fresh policy: |loss delta| <= max(1e-4, 3 SE, 2 x yardstick)": within(t2["fresh"]),
-        "two_layer stale policy: |loss delta| <= max(1e-4, 3 SE, 2 x yardstick)": within(t2["stale"]),
-        "full_depth fresh policy: |loss delta| <= max(1e-4, 3 SE, 2 x yardstick)": within(tf["fresh"]),
-        "full_depth stale policy: |loss delta| <= max(1e-4, 3 SE, 2 x yardstick)": within(tf["stale"]),
-        "flips <= 2 x yardstick + 2 (both depths, stale policy)": all(r["stale"]["flips"] <= 2 * r["stale"]["yardstick_flips"] + 2 for r in (t2, tf)),
+        "two_layer fresh policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(t2["fresh"]),
+        "two_layer stale policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(t2["stale"]),
+        "full_depth fresh policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(tf["fresh"]),
+        "full_depth stale policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(tf["stale"]),
+        "per-token noise level <= 1.25 x the reference restatements' own (both depths)": t2["noise_ratio"] <= 1.25 and tf["noise_ratio"] <= 1.25,
+        "flips <= 1.25 x yardstick + 3 sigma (both depths, stale policy)": flips_ok(t2["stale"]) and flips_ok(tf["stale"]),
         "mask decisions near the threshold exist": t2["stale"]["tokens_within_0.02_of_threshold"] > 0 and tf["stale"]["tokens_within_0.02_of_threshold"] > 0,
         "K2 masked count == host formula on the engine's log-probs": all(r[k]["masked_tokens_engine"] == r[k]["masked_tokens_engine_host_formula"]
                                                                          for r in (t2, tf) for k in ("fresh", "stale")),
@@ -417,25 +487,38 @@ def main() -> None:
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in one extra untimed step after the timed region)")
     ap.add_argument("--no-realistic-parity", action="store_true", help="skip parity.realistic (one extra untimed step on rollout-like data vs the oracle forward)")
-    ap.add_argument("--overlap-update", action="store_true",
-                    help="A/B switch: run the optimizer update on its own stream under the next forward (measured: together = serial on this part, so off)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements reported under config.extra (2 micro-batches/GPU line, weight push)")
     args = ap.parse_args()
 
     from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
     from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run exactly as the driver would launch it (one rank per GPU,
+        # rendezvous on 127.0.0.1 — the container hostname may not resolve)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching as `{' '.join(cmd[1:9])} bench.py ...`", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
     # PM_BENCH_DRYRUN_SHARED_GPU=1: rehearsal of the N > 1 launch on a ONE-GPU box — every rank uses device 0 and the group runs over gloo (RCCL refuses
     # two ranks on one device).  Same script, same engine, same barriers / reductions / extras; the line it prints carries config.diagnostic and is
     # not a measurement (tests/test_multirank_one_gpu.py runs it).
     dryrun = os.environ.get("PM_BENCH_DRYRUN_SHARED_GPU") == "1"
     if dryrun:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():  # preflight: every rank needs its own visible GPU
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible — one rank per GPU (PM_BENCH_DRYRUN_SHARED_GPU=1 "
+                         "rehearses the launch on one GPU over gloo)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 and dryrun:
@@ -450,7 +533,7 @@ def main() -> None:
     dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "qwen2.5-0.5b": ModelDims.qwen2_5_0_5b,
             "tiny": ModelDims.tiny}[args.model]()
     engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1,
-                        recompute=args.recompute, overlap_update=args.overlap_update)
+                        recompute=args.recompute)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 
     per_pass = max(args.tokens_per_pass // args.seq_len, 1)
@@ -472,8 +555,14 @@ def main() -> None:
     for s in range(args.warmup):
         out = engine.step(batches[s])
     barrier()
+    if dist.is_initialized() and not (args.force_collectives and world == 1):
+        # preflight: the group the timed region runs on has exactly one rank per requested GPU, and the engine shards over all of them
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+        assert engine.dp_size == world and engine.use_collectives == (world > 1), (engine.dp_size, engine.use_collectives)
+        if not dryrun:
+            assert dist.get_backend() == "nccl" and torch.cuda.device_count() >= world, (dist.get_backend(), torch.cuda.device_count())
     if rank == 0 and dist.is_initialized():
-        print(f"[bench preflight] RCCL group up: world={dist.get_world_size()} backend={dist.get_backend()} dp={engine.dp_size} "
+        print(f"[bench preflight] RCCL group up: world={dist.get_world_size()} backend={dist.get_backend()} dp={engine.dp_size} visible_gpus={torch.cuda.device_count()} "
               f"collectives={'reduce-scatter/all-gather on a side stream' if engine.use_collectives else 'none (single rank)'}", file=sys.stderr, flush=True)
     from prime_rl_amd.trainer import zero
 
@@ -658,6 +747,59 @@ def main() -> None:
                           f"optimizer step, charged 1/{cpu['micro_batches_per_step']} per sample: one step per {cpu['micro_batches_per_step']} micro-batches, train.py:566-570); "
                           f"{cpu['threads']} of {cpu['cores_available']} usable cores ({cpu['cpu_model']})",
             }
+        if world == 1 and not args.force_collectives and not args.no_extra and not dryrun and args.recompute == "none":
+            # the N > 1 CODE PATH on one GPU, driver-visible (VERDICT r4 'next' 5): a second engine with force_collectives=True over a world_size-1 RCCL
+            # group — per-bucket reduce-scatter / all-gather on the comm stream, sharded norm + AdamW, per-tile GEMM grid — timed for a few steps after
+            # everything else (the headline engine is released first: two 8B engines do not fit one GPU).  Guarded by its own watchdog.
+            import gc
+            import threading
+
+            headline = json.dumps(result)
+            fc_done = threading.Event()
+
+            def fc_watchdog():
+                if not fc_done.wait(float(os.environ.get("PM_BENCH_FC_TIMEOUT", "240"))):
+                    line = json.loads(headline)
+                    line["config"]["extra"]["forced_collectives"] = {"error": "the forced-collectives leg did not finish in time"}
+                    print(json.dumps(line), flush=True)
+                    os._exit(0)
+
+            threading.Thread(target=fc_watchdog, daemon=True).start()
+            try:
+                del engine
+                probe = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29531")
+                dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
+                from prime_rl_amd.trainer import zero as _zero
+
+                eng_fc = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=True)
+                kfc = max(2, min(args.steps, 3))
+                eng_fc.step(batches[0])
+                barrier()
+                _zero.COMM_EVENTS = []
+                t0 = time.perf_counter()
+                for i in range(kfc):
+                    eng_fc.step(batches[(1 + i) % len(batches)])
+                barrier()
+                dt = time.perf_counter() - t0
+                evs, _zero.COMM_EVENTS = _zero.COMM_EVENTS, None
+                cfc = {"rs_ms": 0.0, "ag_ms": 0.0, "exposed_ms": 0.0}
+                for kind, e0, e1 in evs:
+                    cfc[f"{kind}_ms"] += e0.elapsed_time(e1)
+                result["config"]["extra"]["forced_collectives"] = {
+                    "steps": kfc, "ms_per_step": round(dt / kfc * 1e3, 3), "samples_per_s": round(args.micro_batches * kfc / dt, 4),
+                    "delta_ms_vs_headline": round(dt / kfc * 1e3 - elapsed / args.steps * 1e3, 3),
+                    "comm": {k: round(v / kfc, 3) for k, v in cfc.items()}, "gemm_variant": getattr(eng_fc, "_gemm_variant", None),
+                    "note": "the multi-GPU code path at N = 1: RCCL reduce-scatter (f32 gradients, one bucket per decoder layer) / all-gather (bf16 parameters) of a "
+                            "world_size-1 group on the comm stream, norm over the reduced shard, per-tile GEMM grid; comm = busy time of the comm stream per step and the "
+                            "time the compute stream stood still waiting for it.  What it cannot show is link time: at world 1 a collective is a local copy"}
+                del eng_fc
+            except Exception as e:  # pragma: no cover
+                result["config"]["extra"]["forced_collectives"] = {"error": repr(e)[:300]}
+            fc_done.set()
         if args.force_collectives and world == 1:
             result["config"]["diagnostic"] = "force_collectives: world_size-1 RCCL reduce-scatter/all-gather on the comm stream (not the headline run)"
         if args.recompute != "none":

@@ -350,13 +350,6 @@ int pm_adamw_step(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, 
                   void* param_bf16 /* nullable */, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */,
                   int32_t zero_grad, void* stream);
-/* The same step on ONE [rows, cols] weight matrix of the shard (rows % 64 == 0, cols % 256 == 0), element for element identical, that also writes the
- * bf16 copy TRANSPOSED (param_t_bf16[c * ld_t + r]): the K-contiguous [in, out] layout the dgrad GEMM dy . W wants (reference: the autograd
- * backward of F.linear in trainer/models/layers/mlp.py:27-29, attn.py:60-84) leaves the optimizer pass with 2 more bytes per parameter instead of
- * a separate transpose pass (pm_transpose_2d) after every update. */
-int pm_adamw_step_2d(float* master_f32, float* exp_avg_f32, float* exp_avg_sq_f32, float* grad_f32, void* param_bf16, void* param_t_bf16,
-                     int64_t rows, int64_t cols, int64_t ld_t, float lr, float beta1, float beta2, float eps, float weight_decay,
-                     int64_t step, float grad_scale, const float* clip_coef /* device, nullable=1 */, int32_t zero_grad, void* stream);
 /* The reference's other elementwise optimizers on the same flat shards (trainer/optim/__init__.py:74-95), same gradient scaling /
  * clipping / bf16-shadow / zero_grad contract as pm_adamw_step.
  * pm_sgd_step: torch.optim.SGD(lr, momentum, nesterov, weight_decay) — g += wd * p; buf = g at step 1, else momentum * buf + g;
@@ -504,10 +497,21 @@ int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                     int32_t out_dtype, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n, int64_t k,
                     float* tile_sumsq /* nullable */, int64_t tile_sumsq_len, void* workspace /* nullable */, int64_t workspace_bytes, void* stream);
-int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py), one PROCESS-WIDE word: bit 0 = s_setprio around the MFMA clusters, bit 1 = balanced
-                                               * fragment reads, bit 2 = persistent grid, bit 5 = no split-K of a half-empty last round, bits 3-4 = timing ablations; bit 6 = the
-                                               * one-wave-per-SIMD kernel (gemm4_kernel: 4 waves, 128 x 128 register tile; same results bit for bit), bit 7 = the same with register
-                                               * staging instead of LDS-DMA, bit 8 = the same with the fine (three barriers per K-tile) schedule.  Callers that care re-assert their value before a launch (GRPOEngine._own_gemm). */
+/* The fused gate|up projection of the MLP with the SwiGLU activation in its epilogue (mlp.py:27-29: down_proj(act_fn(gate_proj(x)) * up_proj(x)); the
+ * reference runs two F.linear, F.silu and a multiply as separate kernels): w = [gate rows ; up rows] ([2 inter, k], row stride ldw, the HF order of a
+ * concatenated gate_proj / up_proj), gate_up[m, 2 inter] = x . w^T exactly as pm_gemm_bf16 writes it (kept for the backward pass), and
+ * act[m, inter] = bf16(bf16(silu(gate)) * up) computed from the ROUNDED bf16 gate / up values — bit-identical to pm_swiglu_fwd on gate_up — without
+ * reading gate_up back from HBM: a tile holds 128 features' gate and up columns in the same lanes.  inter % 128 == 0, k % 128 == 0. */
+int pm_gemm_swiglu_supported(int64_t m, int64_t inter, int64_t k);
+int pm_gemm_swiglu_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, int64_t ldw, void* gate_up_bf16, int64_t ldo, void* act_bf16, int64_t ldo2, int64_t m,
+                        int64_t inter, int64_t k, void* stream);
+int pm_gemm_debug_set_variant(int32_t value); /* one PROCESS-WIDE schedule word around the core's one K loop (setprio around the MFMA clusters, two compute segments
+                                               * of 32 MFMAs per K-tile): bit 2 = persistent grid (one workgroup per CU walking its tiles) instead of one workgroup per
+                                               * tile, bit 5 = no split-K of a half-empty last round, bit 9 = non-temporal result stores, bit 10 = the round-3 patch sweep
+                                               * order; bits 0-1 are accepted and ignored (rounds 3-4 wrote 3 / 7).  Any other bit selects a measured-and-not-adopted build
+                                               * that exists only in a `make VARIANTS=1` library (four-phase loop, one-wave-per-SIMD kernel, timing ablations:
+                                               * profiles/r04_gemm.md, r05_gemm.md) and returns PM_ERR_UNSUPPORTED otherwise.  Callers that care re-assert their value
+                                               * before a launch (GRPOEngine._own_gemm). */
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
@@ -515,7 +519,7 @@ int pm_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbenc
 int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);
 /* Kernel-variant switch for in-process A/B timing (tools/microbench.py): kernel 0 = attention forward (bits: 1 = asm row max, 2 = skip the O rescale
  * when no row max moved, 4 = row-max reduction as one asm block, 8 = 16-byte epilogue stores; default 15; 64 + OPT = the 8-wave ping-pong experiment of
- * csrc/attention_fwd_pp.cuh), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles; + 16: 8-byte epilogue stores), 2 = dQ (1: 32 kv rows per
+ * csrc/attention_fwd_pp.hip.h), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles; + 16: 8-byte epilogue stores), 2 = dQ (1: 32 kv rows per
  * barrier; + 16: 8-byte epilogue stores); value <= 0
  * restores the default.  Not part of the training path. */
 int pm_attn_debug_set_variant(int32_t kernel, int32_t value);

@@ -108,7 +108,6 @@ SIGNATURES: dict[str, tuple] = {
     "pm_sum_partials": (I, [P, I64, P, P]),
     "pm_clip_coef": (I, [P, F, F, P, P, P]),
     "pm_adamw_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P, I32, P]),
-    "pm_adamw_step_2d": (I, [P, P, P, P, P, P, I64, I64, I64, F, F, F, F, F, I64, F, P, I32, P]),
     "pm_sgd_step": (I, [P, P, P, P, I64, F, F, F, I32, I64, F, P, I32, P]),
     "pm_sign_sgd_step": (I, [P, P, P, I64, F, F, F, P, I32, P]),
     "pm_comm_available": (c_int, []),
@@ -149,6 +148,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_gemm_workspace_bytes": (I64, [I64, I64, I64]),
     "pm_gemm_bf16_ws": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P, I64, P, I64, P]),
     "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, P]),
+    "pm_gemm_swiglu_supported": (I, [I64, I64, I64]),
+    "pm_gemm_swiglu_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "pm_gemm_debug_set_variant": (I, [I32]),
 }
 

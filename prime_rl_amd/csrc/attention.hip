@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 #include "attention_kernels.hip.h"
+#if PM_VARIANTS  // `make VARIANTS=1`: the measured-and-not-adopted builds (profiles/r03_attention.md, r04_attention.md)
 #include "attention_fwd_pp.hip.h"
+#endif
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
@@ -112,7 +114,13 @@ static int g_dq_var = 0;
 
 using namespace pm;
 
+// Product library: only the shipped builds (value <= 0).  Every other value selects an A/B build of a `make VARIANTS=1` library.
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
+#if !PM_VARIANTS
+  PM_REQUIRE(kernel >= 0 && kernel <= 2, PM_ERR_INVALID_ARG, "pm_attn_debug_set_variant: kernel %d", (int)kernel);
+  PM_REQUIRE(value <= 0 || (kernel == 0 && value == 15), PM_ERR_UNSUPPORTED, "pm_attn_debug_set_variant(%d, %d): this build exists only in a `make VARIANTS=1` library",
+             (int)kernel, (int)value);
+#endif
   if (kernel == 0) {
     if (value > 15 && value < 64 && value != 47) return PM_ERR_INVALID_ARG;  // 47 = 15 + 32: eight waves x 16 q rows  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
     g_fwd_var = value;
@@ -167,6 +175,7 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
   hipLaunchKernelGGL((attn_fwd_kernel<2, OPT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse,  \
                      (int)q_row0)
+#if PM_VARIANTS
   if (g_fwd_var >= 64) {
     const int group = n_q_heads / n_kv_heads;
     const int by_rows = (group & 1) ? 1 : 0;
@@ -199,6 +208,8 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     PM_CHECK_LAUNCH(who);
     return PM_OK;
   }
+#endif
+#if PM_VARIANTS
   switch (g_fwd_var < 0 ? kFwdDefaultOpt : g_fwd_var) {
     case 0: PM_LAUNCH_FWD(0); break;
     case 1: PM_LAUNCH_FWD(1); break;
@@ -211,6 +222,9 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
       break;
     default: PM_LAUNCH_FWD(15); break;
   }
+#else
+  PM_LAUNCH_FWD(15);
+#endif
 #undef PM_LAUNCH_FWD
   PM_CHECK_LAUNCH(who);
   return PM_OK;
@@ -263,13 +277,16 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_, KVB_>), dim3((unsigned)(cdiv(n, 64 * KVB_) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
                      softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0)
+#if PM_VARIANTS
   if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64, 1);
   else if ((g_dkdv_var & 15) == 2) PM_LAUNCH_DKDV(2, 8, 64, 1);
   else if ((g_dkdv_var & 15) == 3) PM_LAUNCH_DKDV(3, 4, 32, 1);
   else if ((g_dkdv_var & 15) == 4) PM_LAUNCH_DKDV(1, 4, 64, 2);  // 32 kv rows per wave, one wave per SIMD (accumulators in AGPRs)
   else if ((g_dkdv_var & 15) == 5) PM_LAUNCH_DKDV(1, 8, 64, 2);
   else if ((g_dkdv_var & 15) == 6) PM_LAUNCH_DKDV(1, 4, 32, 2);
-  else PM_LAUNCH_DKDV(2, 4, 64, 1);
+  else
+#endif
+  PM_LAUNCH_DKDV(2, 4, 64, 1);
 #undef PM_LAUNCH_DKDV
   PM_CHECK_LAUNCH(who);
 
@@ -277,8 +294,11 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   hipLaunchKernelGGL((attn_bwd_dq_kernel<2, KT_>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                      (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, softmax_scale,    \
                      (bf16_t*)grad_q, (int)q_row0, (g_dq_var & 16) ? 1 : 0)
+#if PM_VARIANTS
   if ((g_dq_var & 15) == 1) PM_LAUNCH_DQ(32);
-  else PM_LAUNCH_DQ(64);
+  else
+#endif
+  PM_LAUNCH_DQ(64);
 #undef PM_LAUNCH_DQ
   PM_CHECK_LAUNCH(who);
   return PM_OK;

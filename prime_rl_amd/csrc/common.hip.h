@@ -53,6 +53,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf
 // round an f32 to the nearest bf16 and return it as f32 (emulates a bf16 torch op's output rounding)
 __device__ __forceinline__ float round_bf16(float f) { return __uint_as_float(pack_bf16_hw(f, 0.f) << 16); }
 
+// SwiGLU activation on bf16-valued inputs: bf16(silu(gate)) * up — torch computes silu on a bf16 tensor in f32 and rounds, then a bf16 multiply whose
+// result the caller rounds (mlp.py:27-29).  ONE definition for pm_swiglu_fwd and the gate|up GEMM's fused epilogue (bit-identical by construction).
+__device__ __forceinline__ float swiglu_act(float gate, float up) {
+  const float s = gate / (1.0f + __expf(-gate));
+  return round_bf16(s) * up;
+}
+
 // low / high halves of a packed pair
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -27,16 +27,11 @@ static inline unsigned capped_grid(int64_t work_items, int block) {
   return (unsigned)g;
 }
 
-// Optimizer kernels: grid-stride over 16-byte vectors.  PM_UPDATE_GRID caps their grid (default 256 CUs x 16 workgroups): when the update runs on its
-// own stream under the next forward (engine.overlap_update) a smaller grid leaves wave slots for the GEMM workgroups it shares the CUs with.
+// Optimizer kernels: grid-stride over 16-byte vectors, at most 256 CUs x 16 workgroups (profiles/r04_adamw_grid_probe.log: 96 % of the achievable
+// streaming rate at every grid size from 256 to 4096 workgroups).
 static inline unsigned update_grid(int64_t n_vec) {
-  static const int64_t cap = [] {
-    const char* e = getenv("PM_UPDATE_GRID");
-    const long v = e ? atol(e) : 0;
-    return (int64_t)(v > 0 ? v : 256 * 16);
-  }();
   int64_t g = cdiv(n_vec, (int64_t)256);
-  if (g > cap) g = cap;
+  if (g > 256 * 16) g = 256 * 16;
   return (unsigned)(g < 1 ? 1 : g);
 }
 
@@ -70,8 +65,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
       unpack8e(uv[j], u);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float s = g[k] / (1.0f + __expf(-g[k]));
-        o[k] = round_bf16(s) * u[k];
+        o[k] = swiglu_act(g[k], u[k]);
       }
       reinterpret_cast<u32x4*>(act + (rb + j) * inter)[c] = pack8e(o);
     }
@@ -332,73 +326,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
-constexpr int kTrTile = 64, kTrLd = 66;  // 2-D transpose tiles (transpose16_kernel, adamw_2d_kernel): 64 x 64 elements, rows 33 dwords apart
-constexpr int kTrSub = kTrTile * kTrLd / 2 + 32;  // dword stride between the four sub-tiles of adamw_2d_kernel (+ 32: the sub-tiles' rows start on opposite halves of the 64 banks)
+constexpr int kTrTile = 64, kTrLd = 66;  // 2-D transpose tiles (transpose16_kernel): 64 x 64 elements, rows 33 dwords apart
 
-// AdamW on one [rows, cols] weight matrix, same arithmetic as adamw_kernel element for element, that ALSO writes the bf16 copy transposed
-// (pbt[c][r], leading dimension ldt): the K-contiguous [in, out] layout the library's dgrad GEMMs want (trainer/engine.py:_dgrad) comes out of
-// the optimizer pass — 2 more bytes written per parameter — instead of a separate 2 + 2 byte transpose pass after every update.
-// One workgroup per 64 x 256 tile: thread t owns the float4 column group (t & 63) of rows (t >> 6) + 4 j, so a wave streams 1 KiB contiguous per
-// array and row like the flat kernel; the bf16 results are parked in LDS as four 64 x 64 sub-tiles with the row pitch of transpose16_kernel (33
-// dwords: conflict-free column gathers) and leave as 16-byte vectors along the rows of pbt (8 lanes = 128 contiguous bytes).
-__global__ __launch_bounds__(256) void adamw_2d_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g,
-                                                      bf16_t* __restrict__ pb, bf16_t* __restrict__ pbt, int64_t cols, int64_t ldt, float lr, float b1,
-                                                      float b2, float eps, float wd, float bc1, float bc2_sqrt, float grad_scale,
-                                                      const float* __restrict__ clip_coef, int zero_grad) {
-  __shared__ uint32_t tile32[4 * kTrSub];
-  const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
-  const float step_size = lr / bc1;
-  const float decay = 1.0f - lr * wd, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  const int t = threadIdx.x;
-  const int cg = t & 63, rs = t >> 6;
-  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 256;
-  const int sub = cg >> 4, cl = (cg & 15) * 4;  // 64-column sub-tile of this thread's column group, first column inside it
-#pragma unroll 2
-  for (int j = 0; j < 16; ++j) {
-    const int r = j * 4 + rs;
-    const int64_t i = ((r0 + r) * cols + c0) / 4 + cg;
-    f32x4v P = __builtin_nontemporal_load(reinterpret_cast<f32x4v*>(p) + i), M = __builtin_nontemporal_load(reinterpret_cast<f32x4v*>(m) + i),
-           V = __builtin_nontemporal_load(reinterpret_cast<f32x4v*>(v) + i);
-    const f32x4v G = __builtin_nontemporal_load(reinterpret_cast<f32x4v*>(g) + i);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gr = G[k] * gs;
-      P[k] = P[k] * decay;
-      M[k] = M[k] + (gr - M[k]) * omb1;
-      V[k] = V[k] * b2 + omb2 * gr * gr;
-      const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
-      P[k] = P[k] - step_size * (M[k] / denom);
-    }
-    __builtin_nontemporal_store(P, reinterpret_cast<f32x4v*>(p) + i);
-    __builtin_nontemporal_store(M, reinterpret_cast<f32x4v*>(m) + i);
-    __builtin_nontemporal_store(V, reinterpret_cast<f32x4v*>(v) + i);
-    if (zero_grad) __builtin_nontemporal_store(f32x4v{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4v*>(g) + i);
-    u32x2 o;
-    o.x = pack_bf16(P[0], P[1]);
-    o.y = pack_bf16(P[2], P[3]);
-    __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(pb) + i);
-    uint32_t* d = tile32 + sub * kTrSub + r * (kTrLd / 2) + (cl >> 1);
-    d[0] = o.x;
-    d[1] = o.y;
-  }
-  __syncthreads();
-  const uint16_t* tile = reinterpret_cast<const uint16_t*>(tile32);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int ch = t + 256 * k;            // 2048 chunks of 8 rows x 1 column: 256 columns x 8 row groups
-    const int jr = ch & 7, c = ch >> 3;    // lanes run along the rows of pbt: 8 lanes = the 64 rows of one column = 128 contiguous bytes
-    const uint16_t* src = tile + (c >> 6) * (2 * kTrSub) + (c & 63);
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = src[(jr * 8 + i) * kTrLd];
-    const u32x4 o = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-    *reinterpret_cast<u32x4*>(pbt + (c0 + c) * ldt + r0 + jr * 8) = o;
-  }
-}
-
-// SGD with momentum (torch.optim.SGD: L2 weight decay folded into the gradient, dampening 0, optional Nesterov — the reference's `SGD(...)`,
-// trainer/optim/__init__.py:74-81) and SignSGD (trainer/sign_sgd.py:34-51: decoupled decay, then p -= lr * sign(g); no state).  Same streaming
-// layout as adamw_kernel: f32 master (+ momentum buffer), f32 gradient scaled by grad_scale * clip, bf16 shadow written in the same pass.
 template <bool SIGN>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ buf, float* __restrict__ g, bf16_t* __restrict__ pb,
                                                  int64_t n, float lr, float momentum, float wd, int nesterov, int first_step, float grad_scale,
@@ -666,21 +595,3 @@ extern "C" int pm_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, f
   return PM_OK;
 }
 
-extern "C" int pm_adamw_step_2d(float* master, float* exp_avg, float* exp_avg_sq, float* grad, void* param_bf16, void* param_t_bf16, int64_t rows,
-                                int64_t cols, int64_t ld_t, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                float grad_scale, const float* clip_coef, int32_t zero_grad, void* stream) {
-  PM_REQUIRE(master && exp_avg && exp_avg_sq && grad && param_bf16 && param_t_bf16 && step >= 1, PM_ERR_INVALID_ARG, "pm_adamw_step_2d: bad args");
-  PM_REQUIRE(rows > 0 && cols > 0 && rows % 64 == 0 && cols % 256 == 0 && ld_t >= rows && ld_t % 8 == 0 && rows / 64 <= 65535, PM_ERR_UNSUPPORTED,
-             "pm_adamw_step_2d: rows=%lld cols=%lld ld_t=%lld (rows a multiple of 64, cols of 256, ld_t >= rows and a multiple of 8)", (long long)rows,
-             (long long)cols, (long long)ld_t);
-  PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
-               reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(param_t_bf16)) & 15) == 0 && (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
-             PM_ERR_INVALID_ARG, "pm_adamw_step_2d: buffers must be 16-byte (f32, transposed copy) / 8-byte (bf16) aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_2d_kernel, dim3((unsigned)(cols / 256), (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq,
-                     grad, (bf16_t*)param_bf16, (bf16_t*)param_t_bf16, cols, ld_t, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
-                     grad_scale, clip_coef, zero_grad);
-  PM_CHECK_LAUNCH("pm_adamw_step_2d");
-  return PM_OK;
-}

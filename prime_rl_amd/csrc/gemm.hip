@@ -58,7 +58,7 @@ enum { SLOT_W0 = 0, SLOT_W1 = 1, SLOT_X0 = 2, SLOT_X1 = 3 };
 __host__ __device__ constexpr int slot_in_window(int buf, int slot) { return (buf * 2 + (slot & 1)) * kSlot; }            // offset inside the operand's 64 KiB window
 __host__ __device__ constexpr int slot_offset(int buf, int slot) { return (slot >= SLOT_X0 ? 4 * kSlot : 0) + slot_in_window(buf, slot); }
 
-static int g_variant = 7;  // bit 0 s_setprio, bit 1 balanced reads, bit 2 persistent grid, bits 3-4 timing ablations (pm_gemm_debug_set_variant)
+static int g_variant = 7;  // bit 2: persistent grid; the other bits: pm_gemm_debug_set_variant
 
 struct Params {
   const bf16_t* x;    // M-side operand: [M, K] (K-contiguous) or [K, M] (K-major), row stride ldx (elements)
@@ -72,7 +72,6 @@ struct Params {
   int out_f32;        // 0: bf16 out; 1: f32 out
   int nt_out;         // store the result with the non-temporal cache policy (it is not read again by this launch: keeps the operand panels in L2)
   int sweep_n;        // patch order of the dense product (tile_of_block): 1 = consecutive patches share their X block and cycle through W
-  int pf_dist;        // cooperative L2 prefetch (two-phase K loop): K-tiles between the line-touching loads and the K loop's position (even, >= 4)
   int accumulate;     // f32 out only: out += product
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
   // patch is computed by split_s workgroups on different XCDs, every one over 1 / split_s of the contraction; part 0 writes `out` as usual, parts >= 1 write
@@ -84,7 +83,8 @@ struct Params {
   // grouped products over expert-sorted rows (MODE 1-3 of gemm_kernel; see the tile sources below)
   const int32_t* offsets;  // [n_experts + 1] on the device: rows of expert e = [offsets[e], offsets[e + 1])
   const bf16_t* w2;        // second weight set (the experts' up projection next to the gate projection), or null
-  void* out2;              // second output (MODE 3: its weight gradient)
+  void* out2;              // second output (MODE 3: its weight gradient; MODE 4: act = silu(gate) * up, [M, n_first] bf16, row stride ldo2)
+  int64_t ldo2;
   int n_experts;
   int n_first;             // columns / contraction rows served by the first weight set
 };
@@ -184,16 +184,16 @@ __device__ __forceinline__ unsigned char* lds_base() {
 
 // stage one half-tile (this wave's 2 KiB of it) of slot kind SLOT into buffer BUF from the source offset `s.off[SLOT]`, then advance that offset by
 // one K-tile.
-template <int SLOT, int BUF, int PIECES = 3, int AUX = 0, bool ADV = true>  // PIECES: bit 0 = the first 1 KiB piece, bit 1 = the second one (+ the K-tile advance of the source offset)
+template <int SLOT, int BUF, int PIECES = 3>  // PIECES: bit 0 = the first 1 KiB piece, bit 1 = the second one (+ the K-tile advance of the source offset)
 __device__ __forceinline__ void stage(Wave& s, unsigned char* smem) {
   constexpr int slot_off = slot_offset(BUF, SLOT);
   constexpr bool is_w = SLOT == SLOT_W0 || SLOT == SLOT_W1;
   const __amdgpu_buffer_rsrc_t rsrc = is_w ? s.wr : s.xr;
   unsigned char* dst = smem + slot_off + s.piece_lds;
-  if constexpr ((PIECES & 1) != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[0] : s.vx[0], s.off[SLOT], 0, AUX);
+  if constexpr ((PIECES & 1) != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[0] : s.vx[0], s.off[SLOT], 0, 0);
   if constexpr ((PIECES & 2) != 0) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[1] : s.vx[1], s.off[SLOT], 1024, AUX);
-    if (ADV) s.off[SLOT] += is_w ? s.wk : s.xk;  // (ADV false: timing ablation — every K-tile re-reads K-tile 0, i.e. the DMA always hits L2)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, is_w ? s.vw[1] : s.vx[1], s.off[SLOT], 1024, 0);
+    s.off[SLOT] += is_w ? s.wk : s.xk;
   }
 }
 // source offsets of K-tile 0 (slot kinds of buffer 0: W0 X0 X1 W1 of K-tile 0; the loop then alternates buffers, so every kind advances one K-tile
@@ -395,46 +395,41 @@ __device__ __forceinline__ void phase(Wave& s, unsigned char* smem) {
 template <int S, int BUF, int V, bool XK, bool WK>
 __device__ __forceinline__ void superphase(Wave& s, unsigned char* smem) {
   constexpr bool kPre = (V & 2) != 0, kNoDma = (V & 8) != 0, kNoReads = (V & 16) != 0, kSplit = (V & 1024) != 0;
-  constexpr bool kAdv = (V & 4096) == 0, kNoWait = (V & 2048) != 0;  // timing ablations (wrong results): DMA always hits L2 / never waited for
-  constexpr int AUX = (V & 512) ? 1 : 0;  // experiment: sc0 on the LDS-DMA (every line is used once by this CU: nothing to gain from its L1)
   if (S == 0) {
     if (!kNoReads) {
       if (!kPre) read_w<0, BUF, WK>(s);
       read_x<0, BUF, XK>(s);
       read_x<1, BUF, XK>(s);
     }
-    if (kPre && !kNoDma) stage<SLOT_W0, BUF, 3, AUX, kAdv>(s, smem);
+    if (kPre && !kNoDma) stage<SLOT_W0, BUF>(s, smem);
   } else {
     if (kPre) {
-      if (!kNoDma) stage<SLOT_X0, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_X0, BUF>(s, smem);
       if (!kNoReads) {
         read_w<1, BUF, WK>(s);
         read_w<0, BUF ^ 1, WK>(s);
       }
-      if (!kNoDma) stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_X1, BUF>(s, smem);
     } else if (kSplit) {  // one piece, two fragment reads, one piece, ...: six bursts of four requests instead of one of eight and one of sixteen
-      if (!kNoDma) stage<SLOT_W0, BUF, 1, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_W0, BUF, 1>(s, smem);
       if (!kNoReads) read_w_part<1, BUF, WK, 0>(s);
-      if (!kNoDma) stage<SLOT_W0, BUF, 2, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_W0, BUF, 2>(s, smem);
       if (!kNoReads) read_w_part<1, BUF, WK, 1>(s);
-      if (!kNoDma) stage<SLOT_X0, BUF, 1, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_X0, BUF, 1>(s, smem);
       if (!kNoReads) read_w_part<1, BUF, WK, 2>(s);
-      if (!kNoDma) stage<SLOT_X0, BUF, 2, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_X0, BUF, 2>(s, smem);
       if (!kNoReads) read_w_part<1, BUF, WK, 3>(s);
-      if (!kNoDma) stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_X1, BUF>(s, smem);
     } else {
-      if (!kNoDma) stage<SLOT_W0, BUF, 3, AUX, kAdv>(s, smem);
+      if (!kNoDma) stage<SLOT_W0, BUF>(s, smem);
       if (!kNoReads) read_w<1, BUF, WK>(s);
       if (!kNoDma) {
-        stage<SLOT_X0, BUF, 3, AUX, kAdv>(s, smem);
-        stage<SLOT_X1, BUF, 3, AUX, kAdv>(s, smem);
+        stage<SLOT_X0, BUF>(s, smem);
+        stage<SLOT_X1, BUF>(s, smem);
       }
     }
   }
-  // (V bit 13: the prefetch load issued at the top of the K-tile pair is one of the newest nine operations in the two segments of buffer 0)
-  if (kNoWait) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  else if ((V & 8192) != 0 && BUF == 0) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (S == 0) {
     tie_w<0, WK>(s);  // pre-read form: read in the previous B segment (or the prologue)
@@ -472,7 +467,7 @@ struct Tile {
   int nk;                  // K-tiles: even, >= 2
   bool first, last;
 };
-template <bool KM>
+template <bool KM, bool CLAMP = true>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int64_t ld, int64_t rows_left, int k) {
   // K-contiguous [rows, K]: rows past the tensor's (or the group's) end are out of range -> zeros.  K-major [K, rows]: the descriptor ends with the
   // last k-row, so k-rows past K read as zeros.
@@ -482,7 +477,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base,
   const uint64_t addr_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)addr);
   int bytes;
   if (!KM) {
-    const int64_t rows = rows_left < kTile ? rows_left : kTile;
+    const int64_t rows = (rows_left < kTile || !CLAMP) ? rows_left : kTile;
     bytes = rows > 0 ? (int)(((rows - 1) * ld + k) * 2) : 0;
   } else {
     bytes = k > 0 ? (int)((((int64_t)k - 1) * ld + rows_left) * 2) : 0;
@@ -569,6 +564,26 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
     t.m_valid = (int)(p.m - m0 < kTile ? p.m - m0 : kTile);
     t.n_valid = (int)(p.n - n0 < kTile ? p.n - n0 : kTile);
     t.nk = k_tiles(klen);
+    return true;
+  }
+  if (MODE == 4) {
+    // dense forward of a fused gate|up projection with the SwiGLU epilogue: OUT = [gate | up] = X . [Wg ; Wu]^T with Wg = rows [0, n_first) and Wu = rows
+    // [n_first, 2 n_first) of W.  A tile is 128 FEATURES wide: its W^0 half-tile is 128 rows of Wg, its W^1 half-tile the SAME 128 rows of Wu (the half-tile
+    // step of the DMA is n_first rows instead of 128), so a lane holds gate and up of one (token, feature) in acc[0][..] and acc[1][..] and the epilogue
+    // writes act = silu(gate) * up next to the two halves of OUT (mlp.py:27-29: down_proj(act_fn(gate_proj(x)) * up_proj(x))).
+    int tm, tn;
+    if (!tile_of_block(v, p.tiles_m, p.tiles_n, p.sweep_n, tm, tn)) return false;
+    const int64_t m0 = (int64_t)tm * kTile, f0 = (int64_t)tn * 128;
+    t.xb = p.x + m0 * p.ldx;
+    t.wb = p.w + f0 * p.ldw;
+    t.x_rows = p.m - m0;
+    t.w_rows = p.n_first + 128;  // rows from the panel base to the end of the up half (panel_rsrc<.., false>: not clamped to the tile)
+    t.k = p.k;
+    t.out = reinterpret_cast<unsigned char*>(p.out) + (m0 * p.ldo + f0) * 2;
+    t.ldo = p.ldo;
+    t.m_valid = (int)(p.m - m0 < kTile ? p.m - m0 : kTile);
+    t.n_valid = p.n_first + 128;
+    t.nk = k_tiles(p.k);
     return true;
   }
   // grouped: block v runs on XCD v % 8; the `ncol` column tiles of one row tile (MODE 1, 2) / the tiles of one expert (MODE 3) are consecutive ids of ONE
@@ -696,8 +711,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   Wave s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   setup_operand<WK>(p.ldw, wave, lane, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
+  if (MODE == 4) s.wstep = (int)(p.n_first * p.ldw * 2);  // W^1 = the up rows of the same features
   setup_operand<XK>(p.ldx, wave, lane, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);  // the X window is the second 64 KiB of the ring
-  s.wr = panel_rsrc<WK>(cur.wb, p.ldw, cur.w_rows, cur.k);
+  s.wr = panel_rsrc<WK, MODE != 4>(cur.wb, p.ldw, cur.w_rows, cur.k);
   s.xr = panel_rsrc<XK>(cur.xb, p.ldx, cur.x_rows, cur.k);
   s.piece_lds = wave * 2048;
   if (V & 16) {  // timing ablation: fragments are never read; give them defined (non-zero) contents
@@ -728,7 +744,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   if ((V & 2) != 0 && !(V & 16)) read_w<0, 0, WK>(s);  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1), later ones in phase 4 of the previous K-tile
   if (wv == 1) __builtin_amdgcn_s_barrier();           // the second wave group runs one barrier behind the first
 
-  int pf_junk = 0;  // destination of the prefetch loads (never read)
   for (;;) {  // ---- the workgroup's stream of units (output tiles, or parts of an accumulation chain)
     {
       // Re-derive the per-lane DMA offsets / read addresses from an OPAQUE copy of the lane id at the top of every unit: otherwise they stay live across
@@ -736,32 +751,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       setup_operand<WK>(p.ldw, wave, lane_o, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
+      if (MODE == 4) s.wstep = (int)(p.n_first * p.ldw * 2);
       setup_operand<XK>(p.ldx, wave, lane_o, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);
     }
     // Only what the epilogue needs of `cur` stays live across the K loop; the NEXT unit is looked up at the point where the staging switches to it,
     // its two descriptors are built and the rest is dropped again (it is looked up once more as `cur` at the top of its own turn): scalar registers
     // are the scarce resource of this kernel (spilled SGPRs land in VGPR lanes and push the vector allocation over 256).
-    // Cooperative L2 prefetch (V bit 13; dense products).  The 32 workgroups of an XCD's 8 x 4 tile patch walk K in step, so a panel line's 4 (X) or 8 (W)
-    // readers ask for it within the same few hundred cycles: one of them misses in L2, the others merge into the miss — and ALL of them hold their
-    // vector-memory slots for the full fabric latency.  The timing ablations say that is what the DMA costs (profiles/r05_gemm.md: the same DMA instruction
-    // stream always hitting L2 runs at the no-DMA rate, never WAITING for the DMA changes nothing).  So the lines are touched `pf_dist` K-tiles ahead by ONE
-    // load instruction per wave and K-tile pair — 64 lines per instruction, every line of the patch's 12 panels by two of its readers — and the DMA that
-    // follows finds them in L2.  Waves 0-3: X lines of K-tile t + D + (wave & 1); waves 4-5: W lines; waves 6-7: out-of-range offsets (no memory access, the
-    // same `vmcnt` count in every wave).  The loaded dword is never used; its register stays reserved until the loop's loads have drained.
-    int pf_off = -1;
-    if constexpr ((V & 8192) != 0 && MODE == 0) {
-      int lane_p = lane;
-      asm volatile("" : "+v"(lane_p));
-      const int within = (v >> 3) & 31;  // position inside the XCD's patch (tile_of_block): X panel shared by `within >> 3` = 0..3, W panel by `within & 7`
-      if (wave < 6) {
-        const bool is_x = wave < 4;
-        const int line = is_x ? (((within >> 3) & 1) * 128 + (wave >> 1) * 64 + lane_p) : ((within & 3) * 64 + lane_p);  // of the K-tile's 256 lines of 128 bytes
-        const bool km = is_x ? XK : WK;
-        const int64_t ld = is_x ? p.ldx : p.ldw;
-        const int kstep = is_x ? s.xk : s.wk;
-        pf_off = (km ? (int)((line >> 2) * ld * 2) + (line & 3) * 128 : (int)(line * ld * 2)) + (wave & 1) * kstep;
-      }
-    }
     int v_n = v, part_n = part;
     bool has_next = false;
     if (cur.first) {
@@ -777,27 +772,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     const int nk = cur.nk;
     if constexpr ((V & 256) != 0) {
       for (int t = 0; t < nk; t += 2) {
-        if constexpr ((V & 8192) != 0 && MODE == 0) {
-          const bool live = t + p.pf_dist < nk;
-          const int soff = (t + p.pf_dist) * (wave < 4 ? s.xk : s.wk);
-          const __amdgpu_buffer_rsrc_t rs = wave < 4 ? s.xr : s.wr;
-          const int voff = live ? pf_off : -1;
-          asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_junk) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-        }
-        if (!(V & 8)) stage<SLOT_W1, 1, 3, (V & 512) ? 1 : 0, (V & 4096) == 0>(s, smem);  // A(t), first stage: W1(t + 1)
+        if (!(V & 8)) stage<SLOT_W1, 1>(s, smem);  // A(t), first stage: W1(t + 1)
         if (t + 2 >= nk) {
           advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
           Tile nxt;
           has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
           if (has_next) {
-            s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+            s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
             s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
           }
           reset_offsets(s);
         }
         superphase<0, 0, V, XK, WK>(s, smem);
         superphase<1, 0, V, XK, WK>(s, smem);
-        if (!(V & 8)) stage<SLOT_W1, 0, 3, (V & 512) ? 1 : 0, (V & 4096) == 0>(s, smem);  // A(t + 1), first stage: W1(t + 2)
+        if (!(V & 8)) stage<SLOT_W1, 0>(s, smem);  // A(t + 1), first stage: W1(t + 2)
         superphase<0, 1, V, XK, WK>(s, smem);
         superphase<1, 1, V, XK, WK>(s, smem);
       }
@@ -810,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         Tile nxt;
         has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
         if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
-          s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+          s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
           s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
         }
         reset_offsets(s);
@@ -841,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       if (wide) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int ncol0 = i * 128 + wv * 64;
+          const int ncol0 = (MODE == 4 ? i * p.n_first : i * 128) + wv * 64;  // MODE 4: the up half sits n_first columns to the right of the gate half
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int mrow0 = j * 128 + wt * 32;
@@ -903,6 +891,33 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
             }
           }
         }
+        if constexpr (MODE == 4) {  // act[m][f0 + 64 wv + ..] = bf16(bf16(silu(gate)) * up) on the ROUNDED gate / up values (what pm_swiglu_fwd computes from OUT)
+          bf16_t* act = reinterpret_cast<bf16_t*>(p.out2) + ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 / p.ldo) * p.ldo2 +
+                        ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 % p.ldo);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int mrow0 = j * 128 + wt * 32;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const f32x4& cg = s.acc[0][f][j][g];
+                const f32x4& cu = s.acc[1][f][j][g];
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = swiglu_act(round_bf16(cg[r]), round_bf16(cu[r]));
+                const int ml = g * 16 + lr;
+                *reinterpret_cast<u32x2*>(stg + ml * 128 + (((f * 2 + (lq >> 1)) ^ (ml & 7)) << 4) + (lq & 1) * 8) = u32x2{pack_bf16_hw(o[0], o[1]), pack_bf16_hw(o[2], o[3])};
+              }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int ml = q * 8 + srow;
+              const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
+              const int m = mrow0 + ml;
+              if (m < cur.m_valid) *reinterpret_cast<u32x4*>(act + (int64_t)m * p.ldo2 + wv * 64 + schunk * 8) = val;
+            }
+          }
+        }
       } else {  // ragged column counts: the direct form
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -944,7 +959,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     tile_at<MODE, XK, WK>(p, v, part, lane, cur);
   }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
-  asm volatile("" : : "v"(pf_junk));
   if (wv == 0) __builtin_amdgcn_s_barrier();
 }
 
@@ -1461,12 +1475,16 @@ static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
   hipLaunchKernelGGL((gemm_kernel<V, XK, WK, MODE>), grid, dim3(512), kSmem, st, p);
 }
 
+// The shipped K loop (round 5): setprio around the MFMA clusters, two-phase K-tile, split B segment.  profiles/r05_gemm.md has the A/B against the
+// four-phase loop of rounds 3-4 (weight gradients +2-4 %, dgrad on the stored [out, in] weight +5-7 %, forward +0-2 %, bit-identical results).
+constexpr int kShippedLoop = 1 | 256 | 1024;
+
 template <bool XK, bool WK>
 static void launch(const Params& p, hipStream_t st) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
-#if PM_VARIANTS
+#if PM_VARIANTS  // A/B partners (`make VARIANTS=1`); the numbers are the round-3 / round-4 variant words so that the profiles' command lines still run
   if (g_variant & (64 | 128 | 256)) {  // bit 6: the one-wave-per-SIMD kernel (bits 3 / 4: its timing ablations)
     const int v4 = g_variant & (8 | 16);
     if (g_variant & 256) {  // bit 8: the fine schedule (bits 3 / 4: its timing ablations, forward layout)
@@ -1480,36 +1498,39 @@ static void launch(const Params& p, hipStream_t st) {
     else g4::launch_v4<0, XK, WK>(p, st, grid);
     return;
   }
+  if (g_variant & 65536) {  // bit 16: the FOUR-PHASE loop of rounds 3-4 (bits 0 / 1: setprio / balanced reads; 3 / 4: ablations; 11 / 12: DMA piece placement)
+    const int v = g_variant & (1 | 2 | 8 | 16 | 2048 | 4096);
+    if (v == (3 | 2048)) launch_v<3 | 32, XK, WK>(p, st, grid);
+    else if (v == (3 | 4096)) launch_v<3 | 64, XK, WK>(p, st, grid);
+    else if (v == 0) launch_v<0, XK, WK>(p, st, grid);
+    else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
+    else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
+    else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16, false, false>(p, st, grid);
+    else if (!XK && !WK && v == (1 | 8 | 16)) launch_v<1 | 8 | 16, false, false>(p, st, grid);
+    else launch_v<3, XK, WK>(p, st, grid);
+    return;
+  }
+  if (g_variant & 32768) {  // bit 15: other forms of the two-phase loop
+    const int v = g_variant & (1 | 2 | 8 | 16 | 131072);
+    if (v == 3) launch_v<3 | 256, XK, WK>(p, st, grid);                                        // W0 pre-read (spills on the K-major layouts)
+    else if (v == 1) launch_v<1 | 256, XK, WK>(p, st, grid);                                   // B segment not split
+    else if (v == 0) launch_v<0 | 256, XK, WK>(p, st, grid);                                   // no setprio
+    else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8 | 256, false, false>(p, st, grid);     // timing ablations (forward layout)
+    else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16 | 256, false, false>(p, st, grid);
+    else launch_v<kShippedLoop, XK, WK>(p, st, grid);
+    return;
+  }
 #endif
-  const int v = g_variant & ~(4 | 32 | 64 | 128 | 256 | 512 | 1024 | (15 << 24));
-  if (v == (1 | 32768)) { launch_v<1 | 256, XK, WK>(p, st, grid); return; }  // bit 15: the two-phase K-tile (32 MFMAs per compute segment)
-  // round-5 experiments on the two-phase loop (bits 16 / 17 / 18 -> sc0 DMA / split B segment / no setprio; 8 / 16: timing ablations, forward layout)
-  if (v == (1 | 32768 | 65536)) { launch_v<1 | 256 | 512, XK, WK>(p, st, grid); return; }
-  if (v == (1 | 32768 | 131072)) { launch_v<1 | 256 | 1024, XK, WK>(p, st, grid); return; }
-  if (v == (0 | 32768)) { launch_v<0 | 256, XK, WK>(p, st, grid); return; }
-  if (v == (1 | 32768 | 1048576)) { launch_v<1 | 256 | 8192, XK, WK>(p, st, grid); return; }  // bit 20: cooperative L2 prefetch (bits 24-27: distance / 2)
-  if (!XK && !WK && v == (1 | 32768 | 262144)) { launch_v<1 | 256 | 2048, false, false>(p, st, grid); return; }  // bit 18: the DMA is never waited for
-  if (!XK && !WK && v == (1 | 32768 | 524288)) { launch_v<1 | 256 | 4096, false, false>(p, st, grid); return; }  // bit 19: the DMA always hits L2
-  if (!XK && !WK && v == (1 | 8 | 32768)) { launch_v<1 | 8 | 256, false, false>(p, st, grid); return; }
-  if (!XK && !WK && v == (1 | 16 | 32768)) { launch_v<1 | 16 | 256, false, false>(p, st, grid); return; }
-#if PM_VARIANTS
-  if (v == (3 | 32768)) launch_v<3 | 256, XK, WK>(p, st, grid);      // ... its W0 pre-read form (spills on the K-major layouts)
-  else if (v == (3 | 2048)) launch_v<3 | 32, XK, WK>(p, st, grid);   // bit 11: first DMA piece of a phase before the fragment reads
-  else if (v == (3 | 4096)) launch_v<3 | 64, XK, WK>(p, st, grid);   // bit 12: both DMA pieces before the fragment reads
-  else if (v == 0) launch_v<0, XK, WK>(p, st, grid);
-  else if (v == 1) launch_v<1, XK, WK>(p, st, grid);
-  else if (!XK && !WK && v == (1 | 8)) launch_v<1 | 8, false, false>(p, st, grid);  // timing ablations, forward layout only
-  else if (!XK && !WK && v == (1 | 16)) launch_v<1 | 16, false, false>(p, st, grid);
-  else if (!XK && !WK && v == (1 | 8 | 16)) launch_v<1 | 8 | 16, false, false>(p, st, grid);
-  else
-#endif
-  launch_v<3, XK, WK>(p, st, grid);
+  launch_v<kShippedLoop, XK, WK>(p, st, grid);
 }
-// grouped products: always the balanced + setprio schedule; persistent unless the debug variant clears bit 2
+// grouped products: the shipped loop; persistent unless the debug variant clears bit 2
 template <bool XK, bool WK, int MODE>
 static void launch_grouped(const Params& p, hipStream_t st) {
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
-  launch_v<3, XK, WK, MODE>(p, st, grid);
+#if PM_VARIANTS
+  if (g_variant & 65536) { launch_v<3, XK, WK, MODE>(p, st, grid); return; }
+#endif
+  launch_v<kShippedLoop, XK, WK, MODE>(p, st, grid);
 }
 
 // out[tile] += sum over parts >= 1 of the workspace tiles of a split tail tile, in part order; with `sumsq` also the sum of squares of the FINAL tile.
@@ -1623,13 +1644,13 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
 
 using namespace pm;
 
-// Schedule word of the dense core.  The product library holds the two shipped K-loop schedules (four-phase, two-phase K-tile) with the persistent / per-tile
-// grid (bit 2), the split-K switch (bit 5), non-temporal result stores (bit 9) and the patch sweep order (bit 10); every other bit selects a build that was
-// measured and not adopted and exists only in a `make VARIANTS=1` library — PM_ERR_UNSUPPORTED otherwise (the GPU tests skip on it).
+// Schedule word of the dense core.  The product library has ONE K loop (kShippedLoop); the word selects around it: bit 2 = persistent grid (one workgroup
+// per CU walking its tiles) instead of one workgroup per tile, bit 5 = no split-K of a half-empty last tile round, bit 9 = non-temporal result stores,
+// bit 10 = the round-3 patch sweep order (A/B); bits 0 / 1 are accepted and ignored (rounds 3-4 wrote 3 / 7 for "per tile" / "persistent").  Every other bit
+// selects a build that was measured and not adopted and exists only in a `make VARIANTS=1` library — PM_ERR_UNSUPPORTED otherwise (the GPU tests skip).
 extern "C" int pm_gemm_debug_set_variant(int32_t v) {
 #if !PM_VARIANTS
-  const int sched = v & ~(4 | 32 | 512 | 1024 | (15 << 24));
-  PM_REQUIRE(sched == 3 || (sched & 32768), PM_ERR_UNSUPPORTED, "pm_gemm_debug_set_variant(%d): this schedule exists only in a `make VARIANTS=1` build", (int)v);
+  PM_REQUIRE((v & ~(1 | 2 | 4 | 32 | 512 | 1024)) == 0, PM_ERR_UNSUPPORTED, "pm_gemm_debug_set_variant(%d): this schedule exists only in a `make VARIANTS=1` build", (int)v);
 #endif
   gm::g_variant = v;
   return PM_OK;
@@ -1697,7 +1718,6 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
-  p.pf_dist = ((gm::g_variant >> 24) & 15) ? 2 * ((gm::g_variant >> 24) & 15) : 4;
   p.nt_out = (gm::g_variant & 512) ? 1 : 0;  // bit 9 of the debug variant: non-temporal result stores (A/B)
   // cycle the smaller operand past the held block of the bigger one (X has m x k elements, W n x k); bit 10 of the debug variant: always the round-3 order (A/B)
   p.sweep_n = (m > n && !(gm::g_variant & 1024)) ? 1 : 0;
@@ -1743,3 +1763,39 @@ extern "C" int pm_gemm_bf16_ws(const void* x, int64_t ldx, int32_t x_kmajor, con
              "pm_gemm_bf16_ws: tile_sumsq needs an f32 output, no bias and pm_gemm_sumsq_slots(m, n) floats");
   return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, tile_sumsq, workspace, workspace_bytes, stream);
 }
+
+// ---- gate|up forward with the SwiGLU epilogue (MODE 4 of the tile stream) ------------------------------------------------------------------------------
+extern "C" int pm_gemm_swiglu_supported(int64_t m, int64_t inter, int64_t k) {
+  return m > 0 && inter > 0 && inter % 128 == 0 && k > 0 && k % 128 == 0 && 2 * inter < (1ll << 31) && m < (1ll << 31);
+}
+
+extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, void* gate_up, int64_t ldo, void* act, int64_t ldo2, int64_t m, int64_t inter,
+                                   int64_t k, void* stream) {
+  if (m == 0 || inter == 0) return PM_OK;
+  PM_REQUIRE(x && w && gate_up && act, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bf16: null pointer");
+  PM_REQUIRE(pm_gemm_swiglu_supported(m, inter, k), PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bf16: needs inter %% 128 == 0 and k %% 128 == 0 (m %lld, inter %lld, k %lld)",
+             (long long)m, (long long)inter, (long long)k);
+  PM_REQUIRE(ldx >= k && ldw >= k && ldo >= 2 * inter && ldo2 >= inter, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bf16: leading dimension too small");
+  PM_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldo2 % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)gate_up & 15) == 0 &&
+                 ((uintptr_t)act & 15) == 0,
+             PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bf16: rows must start 16-byte aligned (leading dimensions multiples of 8, 16-byte aligned bases)");
+  const int64_t kLimit = (1ll << 31) - 4096;
+  PM_REQUIRE(256 * ldx * 2 < kLimit && (inter + 128) * ldw * 2 < kLimit, PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bf16: a tile's weight panel (inter + 128 rows) beyond int32 offsets");
+  gm::Params p;
+  p.offsets = nullptr; p.w2 = nullptr; p.n_experts = 0; p.bias = nullptr; p.sumsq = nullptr;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w;
+  p.out = gate_up; p.out2 = act;
+  p.ldx = ldx; p.ldw = ldw; p.ldo = ldo; p.ldo2 = ldo2;
+  p.m = (int)m; p.n = (int)(2 * inter); p.k = (int)k; p.n_first = (int)inter;
+  p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)(inter / 128);
+  p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
+  p.out_f32 = 0; p.accumulate = 0;
+  p.nt_out = (gm::g_variant & 512) ? 1 : 0;
+  p.sweep_n = (m > 2 * inter && !(gm::g_variant & 1024)) ? 1 : 0;
+  p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
+  p.k_chunk = (int)k; p.k_parts = 1;
+  gm::launch_grouped<false, false, 4>(p, as_stream(stream));
+  PM_CHECK_LAUNCH("gemm_kernel<swiglu>");
+  return PM_OK;
+}
+

@@ -586,31 +586,6 @@ def adamw_step(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor
     )
 
 
-def adamw_step_2d_supported(rows: int, cols: int) -> bool:
-    return rows > 0 and cols > 0 and rows % 64 == 0 and cols % 256 == 0 and rows // 64 <= 65535
-
-
-def adamw_step_2d(master: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, grad: Tensor, param_bf16: Tensor, param_t_bf16: Tensor, lr: float, beta1: float,
-                  beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0, clip: Tensor | None = None, zero_grad: bool = True) -> None:
-    """adamw_step on one [rows, cols] matrix (the f32 arrays and `param_bf16` are its contiguous flat ranges) that also writes `param_t_bf16` [cols, rows]:
-    the transposed bf16 copy.  Element for element the same arithmetic as adamw_step."""
-    lib = _lib.load()
-    cols, rows = param_t_bf16.shape
-    for t, nm in ((master, "master"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grad, "grad")):
-        _req(t, torch.float32, nm)
-        if t.numel() != rows * cols:
-            raise PrimeMI355XError(f"adamw_step_2d: {nm} has {t.numel()} elements, the matrix {rows} x {cols}")
-    _req(param_bf16, torch.bfloat16, "param_bf16")
-    _req(param_t_bf16, torch.bfloat16, "param_t_bf16", contiguous=False)
-    if param_bf16.numel() != rows * cols or param_t_bf16.stride(1) != 1:
-        raise PrimeMI355XError("adamw_step_2d: param_bf16 must hold rows x cols elements and param_t_bf16 be [cols, rows] with unit inner stride")
-    check(
-        lib.pm_adamw_step_2d(_p(master), _p(exp_avg), _p(exp_avg_sq), _p(grad), _p(param_bf16), _p(param_t_bf16), rows, cols, param_t_bf16.stride(0), lr,
-                             beta1, beta2, eps, weight_decay, step, grad_scale, _p(clip), 1 if zero_grad else 0, _stream()),
-        "pm_adamw_step_2d",
-    )
-
-
 def ds_read_tr16_probe(elem_index: Tensor) -> Tensor:
     """int32[64] element indices (multiples of 4) -> int32[64, 4] values returned by `ds_read_b64_tr_b16` over the image lds[i] = i."""
     lib = _lib.load()
@@ -888,8 +863,28 @@ def gemm_supported(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: t
     return bool(_lib.load().pm_gemm_supported(m, n, k, int(xk), int(wk)))
 
 
+_gemm_variant_word = 7  # what pm_gemm_debug_set_variant currently holds (the library's default)
+
+
+class _gemm_variant_scope:
+    """`with _gemm_variant_scope(v):` — run launches under schedule word v and restore the previous word (None: leave the word alone)."""
+
+    def __init__(self, v: int | None):
+        self.v, self.prev = v, None
+
+    def __enter__(self):
+        if self.v is not None and self.v != _gemm_variant_word:
+            self.prev = _gemm_variant_word
+            gemm_set_variant(self.v)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            gemm_set_variant(self.prev)
+        return False
+
+
 def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16, bias: Tensor | None = None, accumulate: bool = False,
-         tile_sumsq: Tensor | None = None) -> Tensor:
+         tile_sumsq: Tensor | None = None, variant: int | None = None) -> Tensor:
     """out[M, N] (+)= x[M, K] @ w[N, K]^T (+ bias) on the MFMA core — F.linear's product for any of the three layouts the trainer step has:
     forward `gemm(x, W)`, dgrad `gemm(dy, W.t())` (W.t() = the [in, out] view of the stored [out, in] weight), wgrad
     `gemm(dy.t(), x.t(), out=grad, out_dtype=f32, accumulate=...)`.  Operands are passed as LOGICAL [rows, K] matrices; their strides say how
@@ -914,15 +909,49 @@ def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype
         _req(tile_sumsq, torch.float32, "tile_sumsq")
         if out.dtype != torch.float32 or bias is not None:
             raise PrimeMI355XError("gemm: tile_sumsq needs an f32 output and no bias")
-    if out.dtype == torch.float32 and bias is None:  # the f32 (weight-gradient) form: a workspace lets a half-empty last round of tiles split along K
-        ws_bytes = lib.pm_gemm_workspace_bytes(m, n, k)
-        ws = workspace(ws_bytes, x.device, "gemm_splitk") if ws_bytes else None
-        check(lib.pm_gemm_bf16_ws(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], None, int(accumulate), m, n, k,
-                                  _p(tile_sumsq), tile_sumsq.numel() if tile_sumsq is not None else 0, _p(ws), ws_bytes, _stream()), "pm_gemm_bf16_ws")
-        return out
-    check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
-          "pm_gemm_bf16")
+    with _gemm_variant_scope(variant):  # `variant`: the schedule word for THIS launch only (the library keeps one process-wide word)
+        if out.dtype == torch.float32 and bias is None:  # the f32 (weight-gradient) form: a workspace lets a half-empty last round of tiles split along K
+            ws_bytes = lib.pm_gemm_workspace_bytes(m, n, k)
+            ws = workspace(ws_bytes, x.device, "gemm_splitk") if ws_bytes else None
+            check(lib.pm_gemm_bf16_ws(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], None, int(accumulate), m, n, k,
+                                      _p(tile_sumsq), tile_sumsq.numel() if tile_sumsq is not None else 0, _p(ws), ws_bytes, _stream()), "pm_gemm_bf16_ws")
+            return out
+        check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
+              "pm_gemm_bf16")
     return out
+
+
+def gemm_swiglu_supported(x: Tensor, w_gate_up: Tensor) -> bool:
+    """Can `gemm_swiglu` take these operands (K-contiguous x [M, K] and w [2 inter, K], inter % 128 == 0, K % 128 == 0)?"""
+    if x.dim() != 2 or w_gate_up.dim() != 2 or x.dtype != torch.bfloat16 or w_gate_up.dtype != torch.bfloat16 or x.device.type != "cuda":
+        return False
+    if x.stride(1) != 1 or w_gate_up.stride(1) != 1 or x.shape[1] != w_gate_up.shape[1] or w_gate_up.shape[0] % 2:
+        return False
+    if x.stride(0) % 8 or w_gate_up.stride(0) % 8 or x.data_ptr() % 16 or w_gate_up.data_ptr() % 16:
+        return False
+    return bool(_lib.load().pm_gemm_swiglu_supported(x.shape[0], w_gate_up.shape[0] // 2, x.shape[1]))
+
+
+def gemm_swiglu(x: Tensor, w_gate_up: Tensor, gate_up: Tensor | None = None, act: Tensor | None = None, variant: int | None = None) -> tuple[Tensor, Tensor]:
+    """(gate_up [M, 2 inter], act [M, inter]) = (x @ w^T, silu(gate) * up): the MLP's fused gate|up projection with the SwiGLU activation in the GEMM
+    epilogue (mlp.py:27-29) — `gate_up` equals gemm(x, w) and `act` equals swiglu_fwd(gate_up) bit for bit; gate_up is not read back from HBM."""
+    _req(x, torch.bfloat16, "x", contiguous=False); _req(w_gate_up, torch.bfloat16, "w_gate_up", contiguous=False)
+    if not gemm_swiglu_supported(x, w_gate_up):
+        raise PrimeMI355XError(f"gemm_swiglu: unsupported operands x {tuple(x.shape)} {x.stride()} w {tuple(w_gate_up.shape)} {w_gate_up.stride()}")
+    m, k = x.shape
+    inter = w_gate_up.shape[0] // 2
+    if gate_up is None:
+        gate_up = torch.empty((m, 2 * inter), dtype=torch.bfloat16, device=x.device)
+    if act is None:
+        act = torch.empty((m, inter), dtype=torch.bfloat16, device=x.device)
+    for t, cols, nm in ((gate_up, 2 * inter, "gate_up"), (act, inter, "act")):
+        _req(t, torch.bfloat16, nm, contiguous=False)
+        if tuple(t.shape) != (m, cols) or t.stride(1) != 1 or t.stride(0) % 8:
+            raise PrimeMI355XError(f"gemm_swiglu: {nm} must be [{m}, {cols}] bf16 with unit column stride and a row stride that is a multiple of 8")
+    with _gemm_variant_scope(variant):
+        check(_lib.load().pm_gemm_swiglu_bf16(_p(x), x.stride(0), _p(w_gate_up), w_gate_up.stride(0), _p(gate_up), gate_up.stride(0), _p(act), act.stride(0), m, inter, k,
+                                              _stream()), "pm_gemm_swiglu_bf16")
+    return gate_up, act
 
 
 def gemm_sumsq_slots(m: int, n: int) -> int:
@@ -944,4 +973,7 @@ def sum_partials(partials: Tensor, out_scalar: Tensor) -> None:
 
 
 def gemm_set_variant(v: int) -> None:
+    """The library's process-wide schedule word (include/prime_mi355x.h: pm_gemm_debug_set_variant).  Product code passes `variant=` to gemm() instead."""
+    global _gemm_variant_word
     check(_lib.load().pm_gemm_debug_set_variant(v), "pm_gemm_debug_set_variant")
+    _gemm_variant_word = v

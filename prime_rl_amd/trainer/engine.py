@@ -457,8 +457,8 @@ class GRPOEngine:
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
-                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None,
-                 overlap_update: bool | None = None):
+                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None, fused_sumsq: bool = True,
+                 embed_split: bool = True):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -530,32 +530,26 @@ class GRPOEngine:
         # stand-in kernels) issues them synchronously
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_collectives and self.device.type == "cuda") else None
         self._gather_events: dict[str, torch.cuda.Event] = {}
-        # Single-rank engines: the optimizer update (HBM-bound: 30 bytes per parameter, 41 ms for Qwen3-8B) can run on its own stream UNDER the
-        # next step's forward (MFMA-bound), bucket by bucket in the order forward() reads the buckets; forward() waits per bucket through the
-        # same `_gather_events` the sharded path uses for its parameter all-gathers.  Anything else that reads the parameters or the optimizer
-        # state after step() must call wait_params_ready() first (the weight push does).  Opt-in (PM_OVERLAP_UPDATE=1 / overlap_update=True /
-        # `bench.py --overlap-update`): bit-identical, but measured twice (round 3 probe, round 4 in-step: 677.8 vs 676.9 ms) the two kernels
-        # do not share the CUs on this part — together = serial, whatever the update's grid (tools/probes/overlap_probe.py with PM_UPDATE_GRID).
-        if overlap_update is None:
-            overlap_update = os.environ.get("PM_OVERLAP_UPDATE", "0") == "1"
-        self.update_stream = torch.cuda.Stream(device=self.device) if (overlap_update and not self.use_collectives and self.device.type == "cuda") else None
         # The embedding bucket's gradient is complete only when the LAST pass's backward ends, so its dense reduce-scatter (vocab x hidden f32,
         # 2.5 GB for Qwen3-8B) would trail the step with nothing to hide behind.  With sharding on, step() splits it: the dense part (earlier
         # passes; the tied head gradient) is reduce-scattered while the last pass still runs, and the last pass's own embedding gradient —
         # n_tokens rows — is all-gathered as (ids, bf16 rows) and added by the rank that owns the rows (ops.embedding_bwd_window).
-        # PM_EMBED_SPLIT=0 keeps the single trailing reduce-scatter (A/B switch).
-        self.embed_split = self.use_collectives and os.environ.get("PM_EMBED_SPLIT", "1") != "0"
+        # `embed_split=False` keeps the single trailing reduce-scatter (A/B switch of the tests).
+        self.embed_split = self.use_collectives and embed_split
         self._embed_plan: dict | None = None
         self._embed_bufs: dict | None = None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._wgrad_direct = self._probe_wgrad_direct()
-        # keep GEMM-friendly operand layouts (K-contiguous weight copies for dgrad, transposed MLP inputs for wgrad); PM_GEMM_LAYOUTS=0 is the A/B switch
-        self.gemm_layouts = gemm_layouts and os.environ.get("PM_GEMM_LAYOUTS", "1") != "0" and not self.gemm_f32
+        # library-dgrad configurations (PM_GEMM_OWN without "dgrad") keep K-contiguous [in, out] copies of the projection weights for hipBLASLt's dgrad GEMMs
+        # (`gemm_layouts=False`: the plain layout, A/B switch of the tests); the default configuration has neither the copies nor the library
+        self.gemm_layouts = gemm_layouts and not self.gemm_f32
         # Which of the step's GEMM classes run on the hand-written MFMA core (csrc/gemm.hip, ops.gemm) instead of the library: a subset of
-        # {"fwd", "dgrad", "wgrad"} ("all" / "none" accepted).  Default = what measured faster on the MI355X (profiles/r03_gemm.md): the weight
-        # gradients — the core reads dy and x in their native token-major layout (no transposed activations) and accumulates straight into the f32
-        # gradient buffer, 15-20 % faster than the library on the o / gate|up / down products; forward and dgrad stay on hipBLASLt (1.5 vs 1.3 PFLOP/s).
-        sel = os.environ.get("PM_GEMM_OWN", "wgrad")
+        # {"fwd", "dgrad", "wgrad"} ("all" / "none" accepted).  Default since round 5: ALL of them — no hipBLASLt kernel is left in the step.  The core reads
+        # every operand where it lies (dgrad: the stored [out, in] weight K-major; wgrad: dy and x token-major, f32 accumulate into the gradient buffer), so
+        # there are no [in, out] weight copies (13.9 GB for Qwen3-8B), no pm_transpose_2d launches, and the gate|up forward carries the SwiGLU activation in
+        # its epilogue (ops.gemm_swiglu).  Measured in the step (profiles/r05_gemm.md): all 629.5 ms, `wgrad` (library forward + dgrad on weight copies,
+        # the default of rounds 3-4) 632.6 ms on the same box.  `PM_GEMM_OWN=wgrad | none | fwd,wgrad ...` remain as documented configurations.
+        sel = os.environ.get("PM_GEMM_OWN", "all")
         self.gemm_own = {"all": {"fwd", "dgrad", "wgrad"}, "none": set()}.get(sel, set(filter(None, sel.split(","))))
         if self.gemm_own - {"fwd", "dgrad", "wgrad"}:
             raise PrimeMI355XError(f"PM_GEMM_OWN: unknown GEMM class in {sel!r} (fwd, dgrad, wgrad, all, none)")
@@ -567,20 +561,19 @@ class GRPOEngine:
             # Schedule of the own core: one PERSISTENT workgroup per CU walking its tiles (+0-2 %) when this rank's GPU runs nothing beside the step; one
             # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
             # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
-            # The schedule is a process-wide switch of the library (pm_gemm_debug_set_variant): this engine re-asserts ITS choice in front of every own-core
-            # launch (`_own_gemm`), so another engine / the nn.Module LM head / the grouped MoE products in the same process cannot change it under us.
+            # The schedule word is process-wide in the library (pm_gemm_debug_set_variant); this engine passes ITS word with every launch (`_own_gemm`).
             self._gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7"))  # (the env override is the in-step A/B hook: + 32 = no split-K)
-            ops.gemm_set_variant(self._gemm_variant)
         # The gradient-norm pass fused into the weight-gradient epilogues (ops.gemm(tile_sumsq=...)): on the LAST backward pass of a step every wgrad GEMM
         # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
         # (norm weights, biases, the embedding) instead of re-reading the whole 4-byte-per-parameter buffer (5.3 ms per Qwen3-8B step).  Only without
-        # collectives: under ZeRO-2 the norm is taken over the REDUCED shard.  PM_FUSED_SUMSQ=0 is the A/B switch.
+        # collectives: under ZeRO-2 the norm is taken over the REDUCED shard.  `fused_sumsq=False` is the A/B switch of the tests.
         # dgrad per STEP: the library's dgrad GEMMs are 6-11 % faster than the own core but need the K-contiguous weight copies refreshed after every parameter
         # update (145 transposes = 5.7 ms for Qwen3-8B, whatever the batch); below ~7k tokens per step the copies cost more than the library gains, and the own
-        # core reads the stored weights as they are (the reference benchmark's 2 x 2048-token step: -2.5 ms).  PM_DGRAD_OWN_BELOW=0 switches the rule off.
-        self.dgrad_own_below = int(os.environ.get("PM_DGRAD_OWN_BELOW", "7168")) if (self.gemm_own and self.gemm_layouts) else 0
+        # core reads the stored weights as they are (the reference benchmark's 2 x 2048-token step: -2.5 ms).  (Only configurations with a library dgrad.)
+        self.dgrad_own_below = 7168 if (self.gemm_own and self.gemm_layouts) else 0
         self._dgrad_own_now = "dgrad" in self.gemm_own
-        self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and os.environ.get("PM_FUSED_SUMSQ", "1") != "0"
+        self._fused_sumsq_wanted = fused_sumsq
+        self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and fused_sumsq
         self._fs_plan: dict | None = None
         self._fs_covered: set[str] = set()
         self._wt: dict[str, Tensor] = {}
@@ -594,40 +587,6 @@ class GRPOEngine:
             for nm, (o, k) in mats:
                 self._wt[nm] = slab[cursor:cursor + o * k].view(k, o)
                 cursor += o * k
-        # Single-rank AdamW engines, opt-in (PM_ADAMW_2D=1): the optimizer pass itself writes the [in, out] copies (ops.adamw_step_2d per weight matrix:
-        # + 2 bytes written per parameter) instead of 145 pm_transpose_2d launches (2 + 2 bytes) in the next backward.  Bit-identical; per matrix the
-        # fused kernel beats update + transpose (0.595 vs 0.730 ms for gate|up), but the step trades ONE 8.2 G-parameter launch at 6.0 TB/s for 255
-        # launches at 5.3-5.4 TB/s: 651.5 / 653.5 ms against 650.4 / 651.3 (profiles/r04_adamw_2d.log) — hence off.
-        self._update_plan: list | None = None
-        if (self._wt and not self.use_collectives and self.optim.type == "adamw" and self.device.type == "cuda" and not self.gemm_f32
-                and os.environ.get("PM_ADAMW_2D", "0") == "1"):
-            spans = {}
-            for b in self.store.buckets:
-                for pname, off, shape in b.params:
-                    spans[pname] = (off, shape)
-            mats = []
-            for nm in self._wt:
-                pname = "lm_head.weight" if nm == "head" else nm
-                if nm == "head" and dims.tie_word_embeddings:
-                    continue  # the tied head is the embedding: its copy keeps the lazy transpose
-                off, shape = spans[pname]
-                if ops.adamw_step_2d_supported(shape[0], shape[1]):
-                    mats.append((off, shape[0], shape[1], nm))
-            mats.sort()
-            plan, cursor = [], 0
-            for off, rows, cols, nm in mats:
-                if off > cursor:
-                    plan.append(("flat", cursor, off, None))
-                plan.append(("2d", off, off + rows * cols, nm))
-                cursor = off + rows * cols
-            if cursor < self.store.total:
-                plan.append(("flat", cursor, self.store.total, None))
-            self._update_plan = plan if mats else None
-            covered = {nm for _, _, _, nm in mats}
-            # the copies a pass of the plan leaves current: whole layers (the lazy refresh of _dgrad works per layer) and the head
-            self._update_fresh = [i for i in range(dims.num_hidden_layers) if all(f"model.layers.{i}.{x}" in covered for x in self._DGRAD_MATRICES)]
-            if "head" in covered:
-                self._update_fresh.append("head")
         # LM head: "library" = hipBLASLt logits [N, V] bf16 in HBM -> K1 (kept for backward, overwritten in place by dlogits);
         # "fused" = J1 (csrc/lmhead.hip): GEMM tile + log-prob epilogue in one kernel, no logits in HBM, backward recomputes them on the
         # MFMA units per token chunk.  The default is whichever measured faster for the step (profiles/: the library GEMM runs at
@@ -660,10 +619,35 @@ class GRPOEngine:
         except Exception:
             return False
 
+    def set_gemm_own(self, classes) -> None:
+        """Re-route the step's GEMM classes at run time ("all", "none", or an iterable of fwd / dgrad / wgrad): what PM_GEMM_OWN selects at construction.
+        bench.py uses it to time the library mix of rounds 3-4 next to the headline on the same engine; a library dgrad builds its [in, out] weight
+        copies lazily on first use (no up-front slab)."""
+        own = {"all": {"fwd", "dgrad", "wgrad"}, "none": set()}.get(classes, None) if isinstance(classes, str) else set(classes)
+        if own is None:
+            own = set(filter(None, classes.split(",")))
+        if own - {"fwd", "dgrad", "wgrad"}:
+            raise PrimeMI355XError(f"set_gemm_own: unknown GEMM class in {classes!r} (fwd, dgrad, wgrad, all, none)")
+        if self.gemm_f32 or self.device.type != "cuda":
+            own = set()
+        self.gemm_own = own
+        self.gemm_layouts = "dgrad" not in own and not self.gemm_f32
+        self.dgrad_own_below = 7168 if (own and self.gemm_layouts) else 0
+        self._dgrad_own_now = "dgrad" in own
+        self.fused_sumsq = "wgrad" in own and not self.use_collectives and self._fused_sumsq_wanted
+        self._fs_covered.clear()
+        if not self.gemm_layouts:
+            self._wt.clear()
+            self._wt_version.clear()
+        elif "head" not in self._wt and self.dims.vocab_size % 8 == 0:  # the layer copies appear lazily in _dgrad; the head's is used only if it exists
+            self._wt["head"] = torch.empty((self.dims.hidden_size, self.dims.vocab_size), dtype=torch.bfloat16, device=self.device)
+        if own and not hasattr(self, "_gemm_variant"):
+            self._gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7"))
+
     def _own_gemm(self, *args, **kwargs) -> Tensor:
-        """ops.gemm on the hand-written core under THIS engine's schedule variant (the library keeps one process-wide variant word)."""
-        ops.gemm_set_variant(self._gemm_variant)
-        return ops.gemm(*args, **kwargs)
+        """ops.gemm on the hand-written core under THIS engine's schedule word: passed per call (ops.gemm sets it for the launch and puts the previous word
+        back), so that no other caller in the process — the nn.Module LM head, the grouped MoE products, a second engine — inherits or disturbs it."""
+        return ops.gemm(*args, variant=self._gemm_variant, **kwargs)
 
     def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False, bias: Tensor | None = None) -> Tensor:
         """y[n,out] = x[n,in] @ w[out,in]^T (+ bias) — the forward projection GEMM (library call; the bias rides in the GEMM epilogue, added
@@ -873,8 +857,14 @@ class GRPOEngine:
             lse = None
         attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
         h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
-        gu = self._fwd_mm(h2, w[p + "mlp.gate_up_proj.weight"])
-        act = ops.swiglu_fwd(gu)
+        wgu = w[p + "mlp.gate_up_proj.weight"]
+        if "fwd" in self.gemm_own and not self.gemm_f32 and ops.gemm_swiglu_supported(h2, wgu):
+            # the own core writes act = silu(gate) * up from the accumulators of the gate|up product (a tile = 128 features' gate AND up columns): the
+            # stand-alone SwiGLU pass (read 2 I, write I bytes x 2 per token) disappears; gu is still written once, for the backward
+            gu, act = ops.gemm_swiglu(h2, wgu, variant=self._gemm_variant)
+        else:
+            gu = self._fwd_mm(h2, wgu)
+            act = ops.swiglu_fwd(gu)
         pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
         saved = dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2, gu=gu,
                      act=None if self.recompute_act else act, attn_saved=attn_saved)
@@ -937,6 +927,10 @@ class GRPOEngine:
         def finish():
             if done is not None:
                 torch.cuda.current_stream().wait_event(done)  # (dk_part / dv_part / rk / rv stay referenced by this closure until here)
+                # rk / rv were allocated under the comm stream and are read (and, for one chunk, returned as dk) on the main stream from here on: tell the
+                # caching allocator, or a later comm-stream allocation could be handed their blocks while main-stream kernels still read them
+                for t in (rk, rv):
+                    t.record_stream(torch.cuda.current_stream())
             dv_view.copy_(ulysses.sum_prefix_chunks(rv, n_loc))
             return ulysses.sum_prefix_chunks(rk, n_loc)
 
@@ -1148,8 +1142,6 @@ class GRPOEngine:
         step): anything that reads `store.params` outside forward() — the weight push, a checkpoint — must call this first."""
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        if self.update_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.update_stream)
         self._gather_events.clear()
 
     def add_param_reader(self, event) -> None:
@@ -1177,27 +1169,8 @@ class GRPOEngine:
             if self.comm_stream is not None:
                 self.comm_stream.wait_event(ev)
         self._param_readers.clear()
-        if self.update_stream is not None:  # a previous update nobody waited for (a step without a forward): keep the updates ordered
-            torch.cuda.current_stream().wait_stream(self.update_stream)
-        # the copies are only worth writing when the next backward will read them (steps below dgrad_own_below tokens run dgrad on the stored weights)
-        local_update = self._update_2d if (self._update_plan is not None and self.update_stream is None and not self._dgrad_own_now) else None
         return zero.sharded_optimizer_step(self.store, self.optim, self.step_count, self.shard_group, ops, self.comm_stream, self._gather_events, self._sumsq,
-                                           local_sumsq=self._fs_norm if self.fused_sumsq else None, update_stream=self.update_stream, local_update=local_update)
-
-    def _update_2d(self, coef: Tensor) -> None:
-        """AdamW over the flat buffers as [flat range | weight matrix | flat range | ...]: every projection matrix (and the untied head) through
-        ops.adamw_step_2d, which also writes its [in, out] copy; what lies between them (norm weights, biases, the embedding, padding) through the flat kernel.
-        Same arithmetic element for element as the single flat launch."""
-        st, o = self.store, self.optim
-        for kind, a, b, nm in self._update_plan:
-            if kind == "flat":
-                zero.apply_update(ops, o, st.master[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b], st.grad_shard[a:b], st.params[a:b], self.step_count, coef,
-                                  zero_grad=False)
-            else:
-                ops.adamw_step_2d(st.master[a:b], st.exp_avg[a:b], st.exp_avg_sq[a:b], st.grad_shard[a:b], st.params[a:b], self._wt[nm], o.lr, o.betas1,
-                                  o.betas2, o.eps, o.weight_decay, self.step_count, 1.0, coef, zero_grad=False)
-        for key in self._update_fresh:  # every copy the plan wrote is current
-            self._wt_version[key] = st.version
+                                           local_sumsq=self._fs_norm if self.fused_sumsq else None)
 
     # -- one full trainer step -------------------------------------------------------------------------------------------
     def global_scales(self, local_counts: tuple[int, int, int]) -> tuple[int, int, int]:

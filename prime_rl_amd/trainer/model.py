@@ -351,8 +351,7 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     loss = loss_from_config(config.loss)
     engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
                         dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp,
-                        shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style,
-                        overlap_update=os.environ.get("PM_OVERLAP_UPDATE", "0") == "1")  # single-rank runs: update under the next forward (opt-in: no gain measured)
+                        shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style)
     sd = _local_safetensors(m.name)
     if sd is not None:
         engine.store.load_state_dict({k: v.to(device) for k, v in sd.items()})

@@ -218,6 +218,8 @@ class ModuleEngine:
                     row.append(None)
                     continue
                 t = sd[m["key"]].detach()
+                if not t.is_floating_point():  # state_dict() keeps integer buffers as they are; the sharded push announces ONE dtype (bf16) per message
+                    raise PrimeMI355XError(f"push_tensors: {m['key']} is {t.dtype}; the sharded weight push carries floating tensors as bf16 only")
                 row.append((t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)).contiguous())
             out.append(row)
         return out

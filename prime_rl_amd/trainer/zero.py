@@ -71,14 +71,9 @@ def apply_update(kernels, optim, master, exp_avg, exp_avg_sq, grad, params_bf16,
 
 
 def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=None, gather_events: dict | None = None, scratch: torch.Tensor | None = None,
-                           local_sumsq=None, update_stream=None, local_update=None):
+                           local_sumsq=None):
     """Global-norm clip + AdamW on this rank's shard + in-place all-gather of the bf16 parameters.
     `local_sumsq(out)`: optional replacement of the norm pass over the local gradient (single-rank engines only).
-    `update_stream` (single-rank engines only): run the update bucket by bucket on that stream, in the order the next forward reads the
-    buckets, and leave one event per bucket in `gather_events` — the HBM-bound update then runs under the MFMA-bound GEMMs of the next
-    forward, which waits bucket by bucket exactly as it waits for the all-gathers of the sharded path.
-    `local_update(coef)` (single-rank engines only): replaces the one flat update launch (the engine's per-matrix AdamW that also writes the
-    transposed weight copies).
     Returns the global gradient norm (1-element tensor)."""
     dp = store.dp_size
     sumsq = scratch if scratch is not None else torch.zeros(1, dtype=torch.float32, device=store.main_grad.device)
@@ -94,25 +89,8 @@ def sharded_optimizer_step(store, optim, step: int, group, kernels, comm_stream=
     if collectives:
         dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=group)
     coef, norm = kernels.clip_coef(sumsq, 1.0, optim.max_norm if optim.max_norm else 0.0)
-    if not collectives and update_stream is not None and gpu and gather_events is not None:
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
-        coef.record_stream(update_stream)
-        with torch.cuda.stream(update_stream):
-            update_stream.wait_event(ready)
-            for b in store.buckets:
-                s = slice(b.offset, b.offset + b.size)
-                apply_update(kernels, optim, store.master[s], store.exp_avg[s] if store.exp_avg.numel() else None,
-                             store.exp_avg_sq[s] if store.exp_avg_sq.numel() else None, store.grad_shard[s], store.params[s], step, coef, zero_grad=False)
-                done = torch.cuda.Event()
-                done.record(update_stream)
-                gather_events[b.name] = done
-        return norm
     if not collectives:
-        if local_update is not None:
-            local_update(coef)
-        else:
-            apply_update(kernels, optim, store.master, store.exp_avg, store.exp_avg_sq, store.grad_shard, store.params, step, coef, zero_grad=False)
+        apply_update(kernels, optim, store.master, store.exp_avg, store.exp_avg_sq, store.grad_shard, store.params, step, coef, zero_grad=False)
         return norm
     for b in store.buckets:
         full, local = store.shard_slices(b)

@@ -55,8 +55,7 @@ def test_forced_collectives_step_equals_plain_step(rccl_world1, one_pass, tied, 
     optim = OptimConfig(lr=1e-3, max_norm=0.5)
     # the plain engine with the streaming norm pass: the epilogue-fused norm (its default) adds the same squares in another order, and this test is
     # about the collective machinery being bit-transparent (fused vs streaming norm: test_fused_gradient_norm_equals_the_separate_pass)
-    monkeypatch.setenv("PM_FUSED_SUMSQ", "0")
-    plain = GRPOEngine(dims, device=DEV, optim=optim, seed=5)
+    plain = GRPOEngine(dims, device=DEV, optim=optim, seed=5, fused_sumsq=False)
     forced = GRPOEngine(dims, device=DEV, optim=optim, seed=5, force_collectives=True)
     assert not plain.use_collectives and forced.use_collectives
     assert forced.comm_stream is not None and forced.store.grad_shard.data_ptr() != forced.store.main_grad.data_ptr()

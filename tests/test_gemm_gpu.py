@@ -14,6 +14,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _set_variant(v):
+    """Select a schedule word of the core; the measured-and-not-adopted builds (four-phase loop, one-wave-per-SIMD kernel) exist only in a
+    `make VARIANTS=1` library: skip on the product build."""
+    from prime_rl_amd._lib import PrimeMI355XError
+
+    try:
+        ops.gemm_set_variant(v)
+    except PrimeMI355XError as e:
+        if "VARIANTS=1" in str(e):
+            pytest.skip(f"variant {v}: only in a `make VARIANTS=1` build")
+        raise
+
+
 def _rand(rows, cols, scale=1.0, seed=0):
     g = torch.Generator(device=DEV).manual_seed(seed)
     return (torch.randn(rows, cols, device=DEV, generator=g) * scale).to(torch.bfloat16)
@@ -27,10 +40,10 @@ def _check(out, ref, k, bf16_out):
     assert err <= tol, f"max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 64, 68, 128, 132, 256, 260])  # 64 / 68: the one-wave-per-SIMD kernel (per tile / persistent); 128 / 132: with register staging; 256 / 260: its fine schedule
+@pytest.mark.parametrize("variant", [3, 7, 65536 + 3, 65536 + 7, 64, 68, 128, 132, 256, 260])  # 3 / 7: the shipped loop, per tile / persistent; VARIANTS=1 builds only: 65536 + .: the four-phase loop of rounds 3-4; 64 / 68: the one-wave-per-SIMD kernel; 128 / 132: with register staging; 256 / 260: its fine schedule
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (300, 520, 384), (1000, 256, 1024), (77, 1000, 128)])
 def test_gemm_forward_layout(m, n, k, variant):
-    ops.gemm_set_variant(variant)
+    _set_variant(variant)
     try:
         x, w = _rand(m, k, 1.0, 1), _rand(n, k, 0.05, 2)
         ref = x.float() @ w.float().t()
@@ -53,11 +66,11 @@ def test_gemm_bias_and_strided_operands():
     assert torch.count_nonzero(out[:, :n]) == 0
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 384, 256), (300, 520, 640), (77, 1024, 128)])
 def test_gemm_dgrad_layout(m, n, k, variant):
     """dx[m, in] = dy[m, out] @ W[out, in]: the weight is read K-major (no transposed copy)."""
-    ops.gemm_set_variant(variant)
+    _set_variant(variant)
     try:
         dy, w = _rand(m, k, 1.0, 6), _rand(k, n, 0.05, 7)  # w stored [out = K, in = N]
         ref = dy.float() @ w.float()
@@ -66,11 +79,11 @@ def test_gemm_dgrad_layout(m, n, k, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
 @pytest.mark.parametrize("tokens,n_out,n_in", [(128, 256, 256), (1024, 512, 384), (1000, 264, 520), (77, 256, 128), (4096, 256, 256)])
 def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
     """dw[out, in] (+)= dy[tok, out]^T @ x[tok, in], f32, any token count (rows past the last token read as zeros)."""
-    ops.gemm_set_variant(variant)
+    _set_variant(variant)
     try:
         dy, x = _rand(tokens, n_out, 1.0, 8), _rand(tokens, n_in, 1.0, 9)
         ref = dy.float().t() @ x.float()
@@ -83,12 +96,12 @@ def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [3, 7, 68, 132, 260])
+@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 68, 132, 260])
 @pytest.mark.parametrize("tokens,n_out,n_in", [(256, 256, 256), (1024, 768, 512), (1000, 264, 520), (2048, 4096, 1024)])
 def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
     """The gradient-norm pass fused into the weight-gradient epilogue: the per-(tile, wave) partials add up to sum(dw^2) of the FINAL values (also
     after an accumulating call), bit-identically from run to run; slots of tiles that do not exist are not written."""
-    ops.gemm_set_variant(variant)
+    _set_variant(variant)
     try:
         dy, x = _rand(tokens, n_out, 1.0, 12), _rand(tokens, n_in, 1.0, 13)
         g = torch.empty((n_out, n_in), dtype=torch.float32, device=DEV)
@@ -129,7 +142,7 @@ def test_gemm_wgrad_split_k_of_the_last_round(tokens, n_out, n_in, variant):
     ref = dy.float().t() @ x.float()
     runs = []
     for v in (variant, 10 - variant):  # 3 <-> 7: the other grid form
-        ops.gemm_set_variant(v)
+        _set_variant(v)
         try:
             g = torch.full((n_out, n_in), 3.0, dtype=torch.float32, device=DEV)
             slots = torch.zeros(ops.gemm_sumsq_slots(n_out, n_in), dtype=torch.float32, device=DEV)
@@ -191,10 +204,16 @@ def _lib_ws_bytes(m, n, k):
 def test_gemm_is_deterministic_and_matches_itself_across_variants():
     x, w = _rand(512, 512, 1.0, 10), _rand(512, 512, 0.05, 11)
     outs = []
-    for v in (0, 1, 3, 5, 7, 64, 68, 128, 132, 256, 260):  # the one-wave-per-SIMD kernel walks K in the same order: same bits
-        ops.gemm_set_variant(v)
+    from prime_rl_amd._lib import PrimeMI355XError
+
+    for v in (3, 7, 65536 + 3, 65536 + 7, 64, 68, 128, 132, 256, 260):  # every K loop walks K in the same order per output element: same bits
+        try:
+            ops.gemm_set_variant(v)
+        except PrimeMI355XError:
+            continue  # a `make VARIANTS=1` build only
         outs.append(ops.gemm(x, w, out_dtype=torch.float32))
     ops.gemm_set_variant(7)
+    assert len(outs) >= 2
     for o in outs[1:]:
         assert torch.equal(o, outs[0])  # same summation order in every schedule variant
     assert torch.equal(ops.gemm(x, w, out_dtype=torch.float32), outs[1])
@@ -210,11 +229,11 @@ def test_gemm_identity_with_asymmetric_operand():
     assert torch.equal(ops.gemm(eye, wk.t(), out_dtype=torch.float32), w[:256].float().t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [1, 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
 def test_gemm_many_tiles_per_workgroup(variant):
     """More output tiles than CUs: the persistent form (variant bit 2) walks several tiles per workgroup, staging the next tile's first K-tiles under
     the current tile's last ones; results must equal the one-workgroup-per-tile form bit for bit."""
-    ops.gemm_set_variant(variant)
+    _set_variant(variant)
     try:
         m, n, k = 2048 + 77, 10240, 256  # 9 x 40 = 360 tiles
         x, w = _rand(m, k, 1.0, 21), _rand(n, k, 0.05, 22)
@@ -227,3 +246,25 @@ def test_gemm_many_tiles_per_workgroup(variant):
         _check(g, dy.float().t() @ xx.float(), 1000, False)
     finally:
         ops.gemm_set_variant(7)
+
+
+@pytest.mark.parametrize("m,inter,k", [(256, 128, 128), (1000, 384, 256), (77, 256, 640), (2048, 1024, 512), (4096, 12288, 1024)])
+def test_gemm_swiglu_epilogue_equals_gemm_then_swiglu(m, inter, k):
+    """pm_gemm_swiglu_bf16 (mlp.py:27-29: act_fn(gate_proj(x)) * up_proj(x) in the epilogue of the fused gate|up product): gate_up must equal the plain
+    product and act must equal pm_swiglu_fwd on it BIT FOR BIT (same accumulation order per element, same activation function on the rounded values);
+    ragged row counts, strided outputs."""
+    x, w = _rand(m, k, 1.0, 11), _rand(2 * inter, k, 0.05, 12)
+    ref_gu = ops.gemm(x, w)
+    ref_act = ops.swiglu_fwd(ref_gu)
+    gu, act = ops.gemm_swiglu(x, w)
+    assert torch.equal(gu, ref_gu)
+    assert torch.equal(act, ref_act)
+    _check(gu, x.float() @ w.float().t(), k, True)
+    # strided outputs (row strides beyond the logical width), untouched padding
+    gu2 = torch.zeros(m, 2 * inter + 64, dtype=torch.bfloat16, device=DEV)
+    act2 = torch.zeros(m, inter + 8, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_swiglu(x, w, gate_up=gu2[:, :2 * inter], act=act2[:, :inter])
+    assert torch.equal(gu2[:, :2 * inter], ref_gu) and torch.equal(act2[:, :inter], ref_act)
+    assert torch.count_nonzero(gu2[:, 2 * inter:]) == 0 and torch.count_nonzero(act2[:, inter:]) == 0
+    assert not ops.gemm_swiglu_supported(x, _rand(2 * inter + 2, k, 0.05, 13))  # inter must be a multiple of 128
+

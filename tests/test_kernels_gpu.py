@@ -621,7 +621,10 @@ def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
     try:
         base = run()
         for var in (1, 2, 4, 5, 4 + 16):
-            assert lib.pm_attn_debug_set_variant(1, var) == 0
+            rc = lib.pm_attn_debug_set_variant(1, var)
+            if rc == -2:
+                pytest.skip("the A/B builds of the dK/dV kernel exist only in a `make VARIANTS=1` library")
+            assert rc == 0
             got = run()
             assert all(torch.equal(a, b) for a, b in zip(base, got)), f"dK/dV variant {var} differs from the default build"
     finally:
@@ -649,7 +652,10 @@ def test_attention_fwd_variants_are_bit_identical(ops, seq_lens, hq, hkv):
     try:
         base = run()
         for var in (7, 47):
-            assert lib.pm_attn_debug_set_variant(0, var) == 0
+            rc = lib.pm_attn_debug_set_variant(0, var)
+            if rc == -2:
+                pytest.skip("the A/B builds of the forward kernel exist only in a `make VARIANTS=1` library")
+            assert rc == 0
             got = run()
             assert all(torch.equal(a, b) for a, b in zip(base, got)), f"forward variant {var} differs from the default build"
     finally:
@@ -777,37 +783,6 @@ def test_attention_long_document_and_ragged_tail(ops):
 
 
 # ================================================================================================ optimizer
-@pytest.mark.parametrize("rows,cols,ld_extra", [(64, 256, 0), (192, 512, 0), (1024, 256, 64), (6144, 4096, 0)])
-def test_adamw_2d_equals_the_flat_kernel_and_writes_the_transposed_copy(ops, rows, cols, ld_extra):
-    """pm_adamw_step_2d: the same update as pm_adamw_step element for element (masters, moments, bf16 copy bit-identical over several steps, with and
-    without zero_grad), plus the [cols, rows] bf16 copy (any leading dimension); shapes outside its tile grid are rejected."""
-    torch.manual_seed(rows + cols)
-    n = rows * cols
-    p0 = (torch.randn(n) * 0.02).to(DEV)
-    state = {k: (p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.empty(n, dtype=torch.bfloat16, device=DEV)) for k in ("flat", "2d")}
-    slab = torch.full((cols, rows + ld_extra), 7.0, dtype=torch.bfloat16, device=DEV)
-    pt = slab[:, :rows]
-    coef = torch.tensor([0.37], device=DEV)
-    for step in range(1, 4):
-        g = torch.randn(n, device=DEV)
-        ga, gb = g.clone(), g.clone()
-        zg = step == 2
-        pa, ma, va, ba = state["flat"]
-        ops.adamw_step(pa, ma, va, ga, ba, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.5, clip=coef, zero_grad=zg)
-        pb_, mb, vb, bb = state["2d"]
-        ops.adamw_step_2d(pb_, mb, vb, gb, bb, pt, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.5, clip=coef, zero_grad=zg)
-        for x, y, nm in ((pa, pb_, "master"), (ma, mb, "exp_avg"), (va, vb, "exp_avg_sq"), (ba, bb, "bf16 copy"), (ga, gb, "gradient")):
-            assert torch.equal(x, y), (step, nm)
-        assert torch.equal(pt, bb.view(rows, cols).t()), (step, "transposed copy")
-        if ld_extra:
-            assert bool((slab[:, rows:] == 7.0).all()), "columns past the matrix stay untouched"
-    assert not ops.adamw_step_2d_supported(100, 256) and not ops.adamw_step_2d_supported(64, 128)
-    with pytest.raises(Exception):
-        bad = torch.empty(128, 64, dtype=torch.bfloat16, device=DEV)
-        z = torch.zeros(64 * 128, device=DEV)
-        ops.adamw_step_2d(z, z.clone(), z.clone(), z.clone(), torch.empty(64 * 128, dtype=torch.bfloat16, device=DEV), bad, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1)
-
-
 def test_adamw_sumsq_clip(ops):
     torch.manual_seed(0)
     n = 100_003

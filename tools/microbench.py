@@ -173,7 +173,7 @@ def bench_gemm(out):
         torch.cuda.empty_cache()
 
 
-def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=3):  # 39 = 7 without the split-K of a half-empty last round; 68 = the one-wave-per-SIMD kernel
+def bench_gemm_core(out, t=16384, variants=(7, 39, 3), rounds=int(os.environ.get("PM_GEMM_ROUNDS", "3"))):  # 39 = 7 without the split-K of a half-empty last round; 68 = the one-wave-per-SIMD kernel
     if os.environ.get("PM_GEMM_VARIANTS"):
         variants = tuple(int(v) for v in os.environ["PM_GEMM_VARIANTS"].split(","))
     """The hand-written MFMA GEMM core (csrc/gemm.hip) against the library call it replaces, per Qwen3-8B projection and layout, interleaved in one
@@ -357,6 +357,50 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     _l.load().pm_grouped_gemm_debug_set_variant(0)
 
 
+def bench_moe_gemm_variants(out, variants=(7, 32773), n=16384, e=128, k=8, h=2048, hidden=768, rounds=5):
+    """The three grouped products of a Qwen3-30B-A3B expert layer on the gemm.hip core (units of its tile stream) under the dense core's K-loop schedules,
+    interleaved in one process; results must be bit-identical between schedules."""
+    if os.environ.get("PM_GEMM_VARIANTS"):
+        variants = tuple(int(v) for v in os.environ["PM_GEMM_VARIANTS"].split(","))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    logits = (torch.randn(n, e, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    x = torch.randn(n, h, generator=g).to(torch.bfloat16).to(DEV)
+    scores, top, idx, counts, conf = ops.moe_router_fwd(logits, k, "softmax", True, 1.0)
+    dest, slot, offsets = ops.moe_sort(idx.reshape(-1), e)
+    y = ops.moe_gather_rows(x, slot, k)
+    w1 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
+    w3 = (torch.randn(e, hidden, h, generator=g) * 0.02).to(torch.bfloat16).to(DEV)
+    hmid = ops.grouped_gemm_nt(y, w1, offsets)
+    dgu = torch.randn(n * k, 2 * hidden, generator=g).to(torch.bfloat16).to(DEV)
+    cases = {
+        "nt (forward, gate|up)": (lambda: ops.grouped_gemm_nt(y, w1, offsets, w2=w3), 2.0 * n * k * h * 2 * hidden),
+        "nn (row gradient, gate|up chained)": (lambda: ops.grouped_gemm_nn(dgu, w1, offsets, w2=w3), 2.0 * n * k * h * 2 * hidden),
+        "tn (weight gradient)": (lambda: ops.grouped_gemm_tn(hmid, y, offsets), 2.0 * n * k * h * hidden),
+    }
+    for name, (fn, fl) in cases.items():
+        res, same, base = {v: [] for v in variants}, {}, None
+        try:
+            for v in variants:
+                ops.gemm_set_variant(v)
+                r = fn()
+                r = r[0] if isinstance(r, (tuple, list)) else r
+                base = r.clone() if base is None else base
+                same[v] = bool(torch.equal(r, base))
+            for _ in range(rounds):
+                for v in variants:
+                    ops.gemm_set_variant(v)
+                    med, _ = timeit(fn, iters=5, warmup=1)
+                    res[v].append(med)
+        finally:
+            ops.gemm_set_variant(7)
+        rec = dict(kernel=f"grouped {name}", bit_identical=same)
+        for v in variants:
+            ts = sorted(res[v])
+            rec[f"v{v}_ms"] = ts[len(ts) // 2] * 1e3
+            rec[f"v{v}_TF"] = fl / ts[len(ts) // 2] / 1e12
+        out.append(rec)
+
+
 def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
     """One Qwen3-30B-A3B MoE layer, forward + backward (for rocprofv3 --kernel-trace)."""
     from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
@@ -451,6 +495,30 @@ def main():
         bench_attn_variants(out, 2, [int(x) for x in sys.argv[2].split(",")])
     if which == "moe":
         bench_moe(out)
+    if which == "gemmswiglu":  # the gate|up forward of a Qwen3-8B layer: library GEMM / own GEMM + pm_swiglu_fwd against the fused epilogue
+        t, inter, k = int(sys.argv[2]) if len(sys.argv) > 2 else 16384, 12288, 4096
+        x = torch.randn(t, k, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(2 * inter, k, device=DEV) * 0.02).to(torch.bfloat16)
+        gu = torch.empty(t, 2 * inter, dtype=torch.bfloat16, device=DEV)
+        act = torch.empty(t, inter, dtype=torch.bfloat16, device=DEV)
+        cases = {"library GEMM + pm_swiglu_fwd": lambda: ops.swiglu_fwd(torch.mm(x, w.t(), out=gu), out=act),
+                 "own GEMM + pm_swiglu_fwd": lambda: ops.swiglu_fwd(ops.gemm(x, w, out=gu), out=act),
+                 "own GEMM alone": lambda: ops.gemm(x, w, out=gu), "library GEMM alone": lambda: torch.mm(x, w.t(), out=gu),
+                 "pm_swiglu_fwd alone": lambda: ops.swiglu_fwd(gu, out=act),
+                 "pm_gemm_swiglu_bf16 (fused epilogue)": lambda: ops.gemm_swiglu(x, w, gate_up=gu, act=act)}
+        ref_act = ops.swiglu_fwd(ops.gemm(x, w)).clone()
+        ops.gemm_swiglu(x, w, gate_up=gu, act=act)
+        same = bool(torch.equal(act, ref_act))
+        res = {k2: [] for k2 in cases}
+        for _ in range(5):
+            for name, fn in cases.items():
+                med, _ = timeit(fn, iters=5, warmup=1)
+                res[name].append(med)
+        for name, ts in res.items():
+            ts.sort()
+            out.append(dict(kernel=f"gate|up forward t={t}: {name}", ms=ts[len(ts) // 2] * 1e3, bit_identical_act=same))
+    if which == "moegemm":
+        bench_moe_gemm_variants(out)
     if which == "moelayer":
         bench_moe_layer(out)
     if which == "lmhead":
