@@ -633,35 +633,40 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_dq_kernel(const bf16_t* __
 // lane of the wave needs it for (diagonal / document-boundary tiles), so interior tiles carry no compare / select code.
 constexpr int kV5FwdBufBytes = 2 * 64 * kD * 2;  // K [64][128] then V [64][128]
 
-template <int OPT, int CB = 2>  // CB = 16-row q blocks per wave (2: the shipped 4-wave kernel; 1: the 8-wave build).  A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved, 4 = the row-max reduction as ONE
-                    // asm statement + clamp instead of the -inf select, 8 = 16-byte epilogue stores (default 15; profiles/r03_attention.md section 4); (bits 1 | 2:
-                    // 0.3314 -> 0.3257 ms, bit-identical; an explicit v_pk_fma_f32 for the scale-and-subtract was 4 % SLOWER: pair-building moves)
-__device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[CB][4],
-                                         const int (&qi)[CB], const int (&lo)[CB], float (&m)[CB], float (&l)[CB], f32x4 (&ot)[CB][8]) {
-  const bf16_t* Kt = reinterpret_cast<const bf16_t*>(sm);
-  const bf16_t* Vt = Kt + 64 * kD;
+// The three parts of one (64-row kv tile, wave) step of the forward pass; fwd_tile runs them back to back.  (Round 5 tried fwd_qk of tile j + 1 in front of
+// fwd_softmax of tile j with a second score register set: hipcc keeps the 32 MFMAs clustered ahead of the softmax's branches instead of interleaving, the
+// build needs 472 registers = one wave per SIMD, and runs 0.58 vs 0.34 ms, bit-identical — profiles/r05_attention.md.  An in-wave overlap of QK^T and the
+// softmax needs a hand-placed instruction stream, not a source-level reordering.)
+template <int CB>
+__device__ __forceinline__ void fwd_qk(const unsigned char* smK, int bq, const u32x4 (&qf)[CB][4], f32x4 (&st)[CB][4]) {
+  const bf16_t* Kt = reinterpret_cast<const bf16_t*>(smK);
   // S^T[kv][q]: rows kv = nb*16 + lq*4 + r, column q = lr of block cb
-  f32x4 st[CB][4];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) st[cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {  // k-step outermost: 8 independent accumulators per batch (no back-to-back dependent MFMAs), next batch's fragments prefetched
-    u32x4 ka[2][4];
+  // k-step outermost: 8 independent accumulators per batch (no back-to-back dependent MFMAs), next batch's fragments prefetched
+  u32x4 ka[2][4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) ka[0][nb] = lds16(Kt + bq + nb * 16 * kD);
+  for (int nb = 0; nb < 4; ++nb) ka[0][nb] = lds16(Kt + bq + nb * 16 * kD);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) {
+  for (int kk = 0; kk < 4; ++kk) {
+    if (kk < 3) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) ka[(kk + 1) & 1][nb] = lds16(Kt + (bq ^ ((kk + 1) << 5)) + nb * 16 * kD);
-      }
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) st[cb][nb] = mfma16(ka[kk & 1][nb], qf[cb][kk], st[cb][nb]);
+      for (int nb = 0; nb < 4; ++nb) ka[(kk + 1) & 1][nb] = lds16(Kt + (bq ^ ((kk + 1) << 5)) + nb * 16 * kD);
     }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) st[cb][nb] = mfma16(ka[kk & 1][nb], qf[cb][kk], st[cb][nb]);
   }
+}
+
+template <int OPT, int CB>  // A/B bits (pm_attn_debug_set_variant(0, OPT)): 1 = asm max3 row max, 2 = skip the O rescale when no row max moved, 4 = the row-max reduction as ONE
+                    // asm statement + clamp instead of the -inf select, 8 = 16-byte epilogue stores (default 15; profiles/r03_attention.md section 4); (bits 1 | 2:
+                    // 0.3314 -> 0.3257 ms, bit-identical; an explicit v_pk_fma_f32 for the scale-and-subtract was 4 % SLOWER: pair-building moves)
+__device__ __forceinline__ void fwd_softmax(int kv0, int q0, float sc2, int lq, const int (&qi)[CB], const int (&lo)[CB], float (&m)[CB], float (&l)[CB],
+                                            f32x4 (&st)[CB][4], f32x4 (&ot)[CB][8]) {
   // wave-uniform mask decision (masking a score that needs no mask is exact, so "any lane" is enough); a separate pass, so that the
   // interior-tile path carries no mask code at all
   bool need_mask = kv0 + 63 > q0;
@@ -723,6 +728,11 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
       for (int nb = 0; nb < 8; ++nb) ot[cb][nb] *= alpha;
     }
   }
+}
+
+template <int CB>
+__device__ __forceinline__ void fwd_pv(const unsigned char* smV, int bt, const f32x4 (&st)[CB][4], f32x4 (&ot)[CB][8]) {
+  const bf16_t* Vt = reinterpret_cast<const bf16_t*>(smV);
   // O^T[d][q] += V^T[d][kv] . P^T[kv][q]
 #pragma unroll
   for (int kk2 = 0; kk2 < 2; ++kk2) {
@@ -743,6 +753,15 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q
       }
     }
   }
+}
+
+template <int OPT, int CB = 2>  // CB = 16-row q blocks per wave (2: the shipped 4-wave kernel; 1: the 8-wave build)
+__device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[CB][4],
+                                         const int (&qi)[CB], const int (&lo)[CB], float (&m)[CB], float (&l)[CB], f32x4 (&ot)[CB][8]) {
+  f32x4 st[CB][4];
+  fwd_qk<CB>(sm, bq, qf, st);
+  fwd_softmax<OPT, CB>(kv0, q0, sc2, lq, qi, lo, m, l, st, ot);
+  fwd_pv<CB>(sm + 64 * kD * 2, bt, st, ot);
 }
 
 template <int MINW, int OPT = 0, int CB = 2, int NW = 4>

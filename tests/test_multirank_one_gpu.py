@@ -219,6 +219,42 @@ def test_bench_script_multi_rank_launch_rehearsal(tmp_path):
     assert "RCCL group up: world=2" in out.stderr or "world=2" in out.stderr
 
 
+def test_bench_script_launches_itself_when_no_launcher_is_present(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-execs itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port <free> bench.py --gpus 2 ...` (VERDICT r4 'next' 5) instead of exiting; with PM_BENCH_DRYRUN_SHARED_GPU=1 the two
+    ranks share the GPU over gloo.  Same single JSON line as under the driver's own launcher; the preflight line names the world."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env.update(PM_BENCH_DRYRUN_SHARED_GPU="1", PM_BENCH_EXTRA_TIMEOUT="240")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny", "--seq-len", "256", "--tokens-per-pass", "512",
+           "--micro-batches", "4", "--no-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "re-launching as" in out.stderr and "--nproc-per-node=2" in out.stderr, out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["rccl"]["world"] == 2
+    assert "world=2" in out.stderr
+
+
+def test_bench_script_refuses_a_world_that_does_not_match_gpus():
+    """--gpus N must equal WORLD_SIZE when a launcher set it (one rank per GPU): a mismatch exits with a message instead of timing the wrong job."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--model", "tiny"], capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    assert out.returncode != 0 and "one rank per GPU" in (out.stderr + out.stdout)
+
+
 @pytest.mark.parametrize("model,extra", [("tiny", []), ("tiny-moe", ["--model.ep", "2"]), ("tiny", ["--model.cp", "2", "--model.cp-style", "ring"]),
                                          ("tiny", ["--model.cp", "2", "--model.cp-style", "ulysses"])])
 def test_train_cli_two_ranks_on_one_gpu(tmp_path, model, extra):
