@@ -219,6 +219,8 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
 
         def fb():
             x.grad = None
+            for p_ in layer.parameters():  # (a trainer's weight gradients go straight into the f32 main-grad buffer: no `.grad +=` passes over 1.2 GB of bf16)
+                p_.grad = None
             layer(x).backward(gy)
 
         fb()
@@ -240,6 +242,53 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
     if dist.is_initialized():
         dist.barrier()
     return extra
+
+
+def moe_step_extra(device, layers: int = 8, n_mb: int = 8, seq: int = 2048, steps: int = 3) -> dict:
+    """BASELINE.json configs[3] on one GPU, driver-visible (VERDICT r4 'next' 4): the module-engine trainer step (trainer/module_engine.py: forward + loss +
+    backward + clip + fused AdamW) of a Qwen3-30B-A3B-width model cut to `layers` of its 48 layers — the full model needs the expert-parallel node (30.5 B
+    parameters x 18 B of f32 state).  Runs after the headline engine has been released."""
+    try:
+        from prime_rl_amd.trainer.engine import OptimConfig, pack_micro_batches
+        from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+        from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+        from prime_rl_amd.trainer.module_engine import ModuleEngine
+        from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+        cfg = Qwen3MoeConfig(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=layers, num_attention_heads=32, num_key_value_heads=4,
+                             num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768, norm_topk_prob=True)
+        with torch.device(device):
+            model = Qwen3MoeForCausalLM(cfg)
+        model = model.to(torch.bfloat16)
+        gen = torch.Generator(device=device).manual_seed(0)
+        with torch.no_grad():
+            for _, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.fill_(1.0)
+                else:
+                    p.copy_((torch.randn(p.shape, device=device, generator=gen) * 0.02).to(p.dtype))
+        inject_prime_lm_head(model, chunk_size=8192)
+        eng = ModuleEngine(model, device, optim=OptimConfig())
+        dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=n_mb), seq_len=seq)
+        batches = [[pack_micro_batches(dl.get_batch(), device)] for _ in range(steps + 1)]
+        eng.step(batches[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches[1:]:
+            eng.step(b)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tok = n_mb * seq
+        flops = eng.dims.flops_per_token(seq) * tok
+        res = {"model": f"Qwen3-30B-A3B width (hidden 2048, 128 experts top-8, expert intermediate 768), {layers} of 48 layers, {n_mb} x {seq}-token rollouts",
+               "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(n_mb / dt, 3), "tokens_per_s": round(tok / dt, 1),
+               "mfu_vs_2.5PF_bf16": round(flops / dt / MFMA_BF16_PEAK, 4), "params_B": round(sum(p.numel() for p in model.parameters()) / 1e9, 2),
+               "note": "nn.Module trainer step (ModuleEngine): router / sort / gather / combine kernels, grouped expert GEMMs on the gemm.hip tile stream, f32 expert "
+                       "main-grads written by the grouped weight-gradient GEMM, stored-logits LM head, one fused AdamW launch over 5.6 B parameters (31 ms of the step)"}
+        del eng, model, batches
+        return res
+    except Exception as e:  # pragma: no cover
+        return {"error": repr(e)[:300]}
 
 
 def parity_block(probe: dict, dims, seq_len: int) -> dict:
@@ -687,6 +736,10 @@ def main() -> None:
                 "rows_per_launch": rows,
                 "launches_timed": len(durs),
                 "mean_launch_ms": round(mean_t * 1e3, 4),
+                "launch_ms": [round(d * 1e3, 4) for d in durs],
+                "note": "in the step K1 starts right behind the LM-head GEMM that wrote its 5 GB of logits: the last 256 MiB of them are still dirty in the Infinity "
+                        "Cache and are written back while K1 streams (+0.04-0.09 ms per launch; tools/microbench.py k1aftergemm, profiles/r05_raw/k1_after_gemm.log: "
+                        "K1 on resident logits 0.74-0.75 ms = 0.83-0.85 of 8 TB/s, behind the own GEMM 0.78-0.84 ms, behind the same GEMM + a 512 MiB flush 0.74 ms)",
             }
         else:  # PM_LM_HEAD=fused: no stand-alone log-prob kernel runs; the dominant hand-written kernel is the fused MFMA LM head (J1)
             result["roofline"] = extra.get("j1_roofline")
@@ -768,6 +821,9 @@ def main() -> None:
             try:
                 del engine
                 probe = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                result["config"]["extra"]["moe_step"] = moe_step_extra(device)
                 gc.collect()
                 torch.cuda.empty_cache()
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

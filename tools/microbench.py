@@ -66,6 +66,47 @@ def bench_k1_step_shape(out):
     out.append(dict(kernel="logprob_entropy_fwd[bf16 16384 rows]", ms=med * 1e3, best_ms=best * 1e3, GBps=nbytes / med / 1e9, frac_hbm=nbytes / med / HBM_PEAK))
 
 
+def bench_k1_after_gemm(out, rounds=5):
+    """K1 right after the LM-head GEMM that produced its logits, as in the step: does WHO wrote the 5 GB of logits (hipBLASLt or the own core, and in
+    which tile order / grid / store policy) change how fast K1 reads them?  HIP events around the K1 launch only; producers interleaved."""
+    n, h, v = 16384, 4096, 151936
+    hid = torch.randn(n, h, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(v, h, device=DEV) * 0.02).to(torch.bfloat16)
+    logits = torch.empty(n, v, device=DEV, dtype=torch.bfloat16)
+    labels = torch.randint(0, v, (n,), device=DEV)
+    inv_t = torch.ones(n, device=DEV)
+    producers = {"hipBLASLt": lambda: torch.mm(hid, w.t(), out=logits)}
+    for var, label in ((7, "own core, persistent grid"), (3, "own core, one workgroup per tile"), (7 + 512, "own core, non-temporal stores"),
+                       (7 + 1024, "own core, round-3 patch sweep order")):
+        producers[label] = (lambda vv: (lambda: ops.gemm(hid, w, out=logits, variant=vv)))(var)
+    scratch = torch.zeros(512 << 20, dtype=torch.uint8, device=DEV)
+
+    def own_then_flush():
+        ops.gemm(hid, w, out=logits, variant=7)
+        scratch.add_(1)  # 512 MiB read + written: pushes the GEMM's last (dirty) output lines out of the 256 MiB Infinity Cache before K1 starts
+
+    producers["own core, then a 512 MiB read-modify-write of unrelated memory"] = own_then_flush
+    producers["none (logits already resident, back-to-back K1)"] = lambda: None
+    res = {k: [] for k in producers}
+    gem = {k: [] for k in producers}
+    for _ in range(rounds):
+        for name, fn in producers.items():
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            fn()
+            e1.record()
+            ops.logprob_entropy_fwd(logits, labels, inv_t)
+            e2.record()
+            torch.cuda.synchronize()
+            gem[name].append(e0.elapsed_time(e1))
+            res[name].append(e1.elapsed_time(e2))
+    nbytes = n * (2 * v + 20)
+    for name in producers:
+        ts, gs = sorted(res[name]), sorted(gem[name])
+        med = ts[len(ts) // 2] * 1e-3
+        out.append(dict(kernel=f"K1 after: {name}", k1_ms=med * 1e3, k1_min_ms=ts[0], frac_hbm=nbytes / med / HBM_PEAK, producer_ms=gs[len(gs) // 2]))
+
+
 def bench_attn(out, cases=((2048, [2048]), (16384, [2048] * 8))):
     hq, hkv, d = 32, 8, 128
     if os.environ.get("PM_ATTN_VARIANTS"):  # "kernel:variant,..." (0 forward, 1 dK/dV, 2 dQ): which build the PMC passes of tools/pmc_attn.sh look at
@@ -413,6 +454,8 @@ def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
 
     def fb():
         x.grad = None
+        for p_ in layer.parameters():  # no `.grad +=` passes: a trainer's expert gradients go straight into the f32 main-grad buffer
+            p_.grad = None
         layer(x).backward(gy)
 
     med, _ = timeit(fb, iters=iters, warmup=2)
@@ -585,6 +628,8 @@ def main():
         bench_gemm_core(out, t=int(sys.argv[2]) if len(sys.argv) > 2 else 16384)
     if which in ("k1", "all"):
         bench_k1(out)
+    if which == "k1aftergemm":
+        bench_k1_after_gemm(out)
     if which == "k1step":
         bench_k1_step_shape(out)
     if which in ("attn", "all"):
