@@ -743,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   __builtin_amdgcn_s_barrier();
   if ((V & 2) != 0 && !(V & 16)) read_w<0, 0, WK>(s);  // balanced reads: W0 of K-tile 0 is read here (tied in phase 1), later ones in phase 4 of the previous K-tile
   if (wv == 1) __builtin_amdgcn_s_barrier();           // the second wave group runs one barrier behind the first
+  bool staggered = true;
 
   for (;;) {  // ---- the workgroup's stream of units (output tiles, or parts of an accumulation chain)
     {
@@ -809,6 +810,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       phase<1, 1, V, XK, WK>(s, smem);
       phase<2, 1, V, XK, WK>(s, smem);
       phase<3, 1, V, XK, WK>(s, smem);
+    }
+    // Seam between two tiles (round 5).  Inside the K loop the second wave group runs one barrier behind the first; left like that across the epilogue, the
+    // groups' epilogues SERIALIZE: group 0 runs its epilogue while group 1 finishes its last compute segment and then sits at the barrier group 0 reaches
+    // only after its epilogue + first load segment, and vice versa one barrier later — two epilogue times of a mostly idle matrix pipe per tile (measured
+    // with s_memtime: the epilogue is 4.6k cycles, the K loop of a 64-K-tile product was 12k cycles slower per tile with it than without, profiles/r05_gemm.md
+    // section 6; aligned: -5 % cycles per tile on zero-filled operands, +1 % on random ones).  So group 0 takes one extra barrier here (= waits for the partner's last compute segment), both groups run their epilogues at the same
+    // time (their LDS staging blocks are per wave), and group 1 takes the extra barrier again in front of the next unit's K loop.
+    if (cur.last) {
+      if (wv == 0) __builtin_amdgcn_s_barrier();
+      staggered = false;
     }
     if (cur.last) {
     // ---- epilogue.  A lane of a C fragment owns ONE output row (lr) and 4 consecutive columns of every 16-column block: stored directly, one wave
@@ -954,12 +965,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     }
     }  // cur.last
     if (!has_next) break;
+    if (!staggered) {  // re-establish the ping-pong offset for the next unit
+      if (wv == 1) __builtin_amdgcn_s_barrier();
+      staggered = true;
+    }
     v = v_n;
     part = part_n;
     tile_at<MODE, XK, WK>(p, v, part, lane, cur);
   }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
-  if (wv == 0) __builtin_amdgcn_s_barrier();
+  if (staggered && wv == 0) __builtin_amdgcn_s_barrier();
 }
 
 
@@ -1798,4 +1813,3 @@ extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, in
   PM_CHECK_LAUNCH("gemm_kernel<swiglu>");
   return PM_OK;
 }
-

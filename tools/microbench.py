@@ -612,7 +612,12 @@ def main():
                 keep = os.environ["PM_PROBE_ONLY"].split(",")
                 cases = [c for c in cases if any(k in c[0] for k in keep)]
             for label, fn in cases:
-                med, best = timeit(fn, iters=10, warmup=2)
+                try:
+                    med, best = timeit(fn, iters=10, warmup=2)
+                except Exception as ex:  # a variant word of a `make VARIANTS=1` library on the product build
+                    print(json.dumps(dict(kernel=f"gemmprobe {label}", skipped=repr(ex)[:120])), flush=True)
+                    ops.gemm_set_variant(7)
+                    continue
                 print(json.dumps(dict(kernel=f"gemmprobe {label} zero={os.environ.get('PM_PROBE_ZERO', '0')}", ms=round(med * 1e3, 4), TF=round(2.0 * t * o * i / med / 1e12, 1))), flush=True)
             return
         for _ in range(4):
