@@ -484,6 +484,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base,
   }
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(addr_u), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+// descriptor of an output block for the epilogue's buffer stores: every word pinned to scalar registers (a descriptor hipcc believes divergent turns each store
+// into a waterfall loop, guide T20)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(const void* base, int bytes) {
+  const uint64_t addr = reinterpret_cast<uint64_t>(base);
+  const uint64_t addr_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(addr >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)addr);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(addr_u), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 __device__ __forceinline__ int k_tiles(int k) {
   const int nk = ((k + 2 * kBK - 1) / (2 * kBK)) * 2;  // even; K-tiles past K read zeros (K-major operands) or do not exist (K % 128 == 0)
   return nk < 2 ? 2 : nk;
@@ -836,6 +843,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       const int srow = lane_e >> 3, schunk = lane_e & 7;
       const bool f32o = (MODE == 0 || MODE == 3) && p.out_f32;  // f32 results: the dense product and the grouped weight gradient (accumulated in f32)
       const bool wide = f32o ? (p.n % 4 == 0) : (p.n % 8 == 0 && cur.ldo % 8 == 0);
+      // the output block as a buffer (bf16 results): rows >= m_valid lie past its end
+      const int ldo_b = (int)cur.ldo * 2;
+      const __amdgpu_buffer_rsrc_t orsrc = out_rsrc(cur.out, cur.m_valid > 0 ? (cur.m_valid - 1) * ldo_b + (MODE == 4 ? p.n_first + 128 : cur.n_valid) * 2 : 0);
       const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
       if (wide) {
 #pragma unroll
@@ -864,16 +874,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                   const int ml = g * 16 + lr;
                   *reinterpret_cast<u32x2*>(stg + ml * 128 + (((f * 2 + (lq >> 1)) ^ (ml & 7)) << 4) + (lq & 1) * 8) = u32x2{pack_bf16_hw(c[0], c[1]), pack_bf16_hw(c[2], c[3])};
                 }
+              // four row-chunk reads, then four BUFFER stores: rows past the block are out of the descriptor's range, a column past it turns the lane's
+              // offset into -1 (one v_cndmask) — no per-store branch, so the four LDS reads are in flight together and the stores issue back to back
+              u32x4 val[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) val[q] = *reinterpret_cast<const u32x4*>(stg + (q * 8 + srow) * 128 + ((schunk ^ srow) << 4));
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const int ml = q * 8 + srow;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
-                const int m = mrow0 + ml, nn = ncol0 + schunk * 8;
-                if (m < cur.m_valid && nn < cur.n_valid) {
-                  u32x4* dstv = reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(cur.out) + (int64_t)m * cur.ldo + nn);
-                  if (p.nt_out) __builtin_nontemporal_store(val, dstv);
-                  else *dstv = val;
-                }
+                const int m = mrow0 + q * 8 + srow, nn = ncol0 + schunk * 8;
+                __builtin_amdgcn_raw_buffer_store_b128(val[q], orsrc, (m * ldo_b + nn * 2) | ((cur.n_valid - 1 - nn) >> 31), 0, 0);  // nn >= n_valid: offset -1
               }
             } else {  // two blocks of [32 rows][32 columns: f & 1, lq, r] f32
 #pragma unroll
@@ -905,6 +914,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         if constexpr (MODE == 4) {  // act[m][f0 + 64 wv + ..] = bf16(bf16(silu(gate)) * up) on the ROUNDED gate / up values (what pm_swiglu_fwd computes from OUT)
           bf16_t* act = reinterpret_cast<bf16_t*>(p.out2) + ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 / p.ldo) * p.ldo2 +
                         ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 % p.ldo);
+          const int ldo2_b = (int)p.ldo2 * 2;
+          const __amdgpu_buffer_rsrc_t arsrc = out_rsrc(act, cur.m_valid > 0 ? (cur.m_valid - 1) * ldo2_b + 128 * 2 : 0);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int mrow0 = j * 128 + wt * 32;
@@ -920,13 +931,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                 const int ml = g * 16 + lr;
                 *reinterpret_cast<u32x2*>(stg + ml * 128 + (((f * 2 + (lq >> 1)) ^ (ml & 7)) << 4) + (lq & 1) * 8) = u32x2{pack_bf16_hw(o[0], o[1]), pack_bf16_hw(o[2], o[3])};
               }
+            u32x4 val[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int ml = q * 8 + srow;
-              const u32x4 val = *reinterpret_cast<const u32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
-              const int m = mrow0 + ml;
-              if (m < cur.m_valid) *reinterpret_cast<u32x4*>(act + (int64_t)m * p.ldo2 + wv * 64 + schunk * 8) = val;
-            }
+            for (int q = 0; q < 4; ++q) val[q] = *reinterpret_cast<const u32x4*>(stg + (q * 8 + srow) * 128 + ((schunk ^ srow) << 4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(val[q], arsrc, (mrow0 + q * 8 + srow) * ldo2_b + (wv * 64 + schunk * 8) * 2, 0, 0);
           }
         }
       } else {  // ragged column counts: the direct form
