@@ -14,6 +14,24 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _variants_build() -> bool:
+    """Is this a `make VARIANTS=1` library (measured-and-not-adopted A/B builds compiled in)?  Setting the schedule word needs no GPU."""
+    from prime_rl_amd import _lib
+
+    lib = _lib.load()
+    ok = lib.pm_gemm_debug_set_variant(65536 + 7) == 0
+    lib.pm_gemm_debug_set_variant(7)
+    return ok
+
+
+# 3 / 7: the shipped K loop, one workgroup per tile / persistent grid.  Only in a VARIANTS=1 library: 65536 + .: the four-phase loop of rounds 3-4; 64 / 68: the
+# one-wave-per-SIMD kernel (per tile / persistent); 128 / 132: with register staging; 256 / 260: its fine schedule
+AB = _variants_build()
+V_ALL = [3, 7] + ([65536 + 3, 65536 + 7, 64, 68, 128, 132, 256, 260] if AB else [])
+V_SOME = [3, 7] + ([65536 + 7, 64, 68, 132, 260] if AB else [])
+V_FEW = [3, 7] + ([65536 + 7, 68, 132, 260] if AB else [])
+
+
 def _set_variant(v):
     """Select a schedule word of the core; the measured-and-not-adopted builds (four-phase loop, one-wave-per-SIMD kernel) exist only in a
     `make VARIANTS=1` library: skip on the product build."""
@@ -40,7 +58,7 @@ def _check(out, ref, k, bf16_out):
     assert err <= tol, f"max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})"
 
 
-@pytest.mark.parametrize("variant", [3, 7, 65536 + 3, 65536 + 7, 64, 68, 128, 132, 256, 260])  # 3 / 7: the shipped loop, per tile / persistent; VARIANTS=1 builds only: 65536 + .: the four-phase loop of rounds 3-4; 64 / 68: the one-wave-per-SIMD kernel; 128 / 132: with register staging; 256 / 260: its fine schedule
+@pytest.mark.parametrize("variant", V_ALL)
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (300, 520, 384), (1000, 256, 1024), (77, 1000, 128)])
 def test_gemm_forward_layout(m, n, k, variant):
     _set_variant(variant)
@@ -66,7 +84,7 @@ def test_gemm_bias_and_strided_operands():
     assert torch.count_nonzero(out[:, :n]) == 0
 
 
-@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", V_SOME)
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 384, 256), (300, 520, 640), (77, 1024, 128)])
 def test_gemm_dgrad_layout(m, n, k, variant):
     """dx[m, in] = dy[m, out] @ W[out, in]: the weight is read K-major (no transposed copy)."""
@@ -79,7 +97,7 @@ def test_gemm_dgrad_layout(m, n, k, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", V_SOME)
 @pytest.mark.parametrize("tokens,n_out,n_in", [(128, 256, 256), (1024, 512, 384), (1000, 264, 520), (77, 256, 128), (4096, 256, 256)])
 def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
     """dw[out, in] (+)= dy[tok, out]^T @ x[tok, in], f32, any token count (rows past the last token read as zeros)."""
@@ -96,7 +114,7 @@ def test_gemm_wgrad_layout(tokens, n_out, n_in, variant):
         ops.gemm_set_variant(7)
 
 
-@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 68, 132, 260])
+@pytest.mark.parametrize("variant", V_FEW)
 @pytest.mark.parametrize("tokens,n_out,n_in", [(256, 256, 256), (1024, 768, 512), (1000, 264, 520), (2048, 4096, 1024)])
 def test_gemm_wgrad_tile_sumsq(tokens, n_out, n_in, variant):
     """The gradient-norm pass fused into the weight-gradient epilogue: the per-(tile, wave) partials add up to sum(dw^2) of the FINAL values (also
@@ -229,7 +247,7 @@ def test_gemm_identity_with_asymmetric_operand():
     assert torch.equal(ops.gemm(eye, wk.t(), out_dtype=torch.float32), w[:256].float().t().contiguous())
 
 
-@pytest.mark.parametrize("variant", [3, 7, 65536 + 7, 64, 68, 132, 260])
+@pytest.mark.parametrize("variant", V_SOME)
 def test_gemm_many_tiles_per_workgroup(variant):
     """More output tiles than CUs: the persistent form (variant bit 2) walks several tiles per workgroup, staging the next tile's first K-tiles under
     the current tile's last ones; results must equal the one-workgroup-per-tile form bit for bit."""

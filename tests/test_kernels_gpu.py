@@ -18,6 +18,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _attn_variants_build() -> bool:
+    """`make VARIANTS=1` library?  (the A/B builds of the attention kernels exist only there; setting the word needs no GPU)"""
+    from prime_rl_amd import _lib
+
+    lib = _lib.load()
+    ok = lib.pm_attn_debug_set_variant(1, 1) == 0
+    lib.pm_attn_debug_set_variant(1, 0)
+    return ok
+
+
+ATTN_AB = _attn_variants_build()
+
+
 @pytest.fixture(scope="module")
 def ops():
     from prime_rl_amd import ops as _ops
@@ -598,6 +611,7 @@ def test_attention_row_windows(ops, seq_lens, hq, hkv, cp):
 
 @pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([5], 2, 1), ([128], 4, 2), ([129], 4, 2),
                                              ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1), ([255, 257], 8, 2), ([2048] * 3 + [777], 8, 2)])
+@pytest.mark.skipif(not ATTN_AB, reason="the A/B builds of the dK/dV kernel exist only in a `make VARIANTS=1` library")
 def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
     """The dK/dV kernel's build variants (pm_attn_debug_set_variant(1, v): fragment batch, 32 kv rows per wave at one wave per SIMD) walk the
     same q tiles in the same order and feed the same MFMA chains: dk / dv equal the default build bit for bit, full calls and row windows."""
@@ -633,6 +647,7 @@ def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
 
 @pytest.mark.parametrize("seq_lens,hq,hkv", [([200], 4, 2), ([64, 1, 100, 37, 98], 8, 2), ([1024], 4, 1), ([5], 2, 1), ([128], 4, 2), ([129], 4, 2),
                                              ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1), ([255, 257], 8, 2), ([2048] * 3 + [777], 8, 2)])
+@pytest.mark.skipif(not ATTN_AB, reason="the A/B builds of the forward kernel exist only in a `make VARIANTS=1` library")
 def test_attention_fwd_variants_are_bit_identical(ops, seq_lens, hq, hkv):
     """Forward build variants (pm_attn_debug_set_variant(0, v)): the A/B bits of the shipped 4-wave kernel and the 8-wave x 16-row build (47) do the
     same per-row arithmetic over the same kv tiles: out and lse equal the default build bit for bit, full calls and row windows."""
