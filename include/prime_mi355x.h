@@ -507,7 +507,7 @@ int pm_gemm_swiglu_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, int
                         int64_t inter, int64_t k, void* stream);
 int pm_gemm_debug_set_variant(int32_t value); /* one PROCESS-WIDE schedule word around the core's one K loop (setprio around the MFMA clusters, two compute segments
                                                * of 32 MFMAs per K-tile): bit 2 = persistent grid (one workgroup per CU walking its tiles) instead of one workgroup per
-                                               * tile, bit 5 = no split-K of a half-empty last round, bit 9 = non-temporal result stores, bit 10 = the round-3 patch sweep
+                                               * tile, bit 5 = no split-K of a half-empty last round, bit 10 = the round-3 patch sweep
                                                * order; bits 0-1 are accepted and ignored (rounds 3-4 wrote 3 / 7).  Any other bit selects a measured-and-not-adopted build
                                                * that exists only in a `make VARIANTS=1` library (four-phase loop, one-wave-per-SIMD kernel, timing ablations:
                                                * profiles/r04_gemm.md, r05_gemm.md) and returns PM_ERR_UNSUPPORTED otherwise.  Callers that care re-assert their value

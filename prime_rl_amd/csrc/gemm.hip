@@ -70,7 +70,7 @@ struct Params {
   int tiles_m, tiles_n;
   int n_blocks;       // virtual block ids (grid_blocks): a workgroup walks ids blockIdx.x, + gridDim.x, ...
   int out_f32;        // 0: bf16 out; 1: f32 out
-  int nt_out;         // store the result with the non-temporal cache policy (it is not read again by this launch: keeps the operand panels in L2)
+  int nt_out;         // (VARIANTS=1 builds: the one-wave-per-SIMD kernel's non-temporal result stores, A/B)
   int sweep_n;        // patch order of the dense product (tile_of_block): 1 = consecutive patches share their X block and cycle through W
   int accumulate;     // f32 out only: out += product
   // Split-K of the LAST round of tiles (dense f32 products): when the tile count leaves 1-4 of the 8 XCD patch slots of the last round empty, each tail
@@ -845,7 +845,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       const bool wide = f32o ? (p.n % 4 == 0) : (p.n % 8 == 0 && cur.ldo % 8 == 0);
       // the output block as a buffer (bf16 results): rows >= m_valid lie past its end
       const int ldo_b = (int)cur.ldo * 2;
-      const __amdgpu_buffer_rsrc_t orsrc = out_rsrc(cur.out, cur.m_valid > 0 ? (cur.m_valid - 1) * ldo_b + (MODE == 4 ? p.n_first + 128 : cur.n_valid) * 2 : 0);
+      const __amdgpu_buffer_rsrc_t orsrc =
+          out_rsrc(cur.out, cur.m_valid > 0 ? ((cur.m_valid - 1) * ldo_b + (MODE == 4 ? p.n_first + 128 : cur.n_valid) * 2) * (f32o ? 2 : 1) : 0);
       const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
       if (wide) {
 #pragma unroll
@@ -894,17 +895,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                     const int ml = g * 16 + lr;
                     *reinterpret_cast<f32x4*>(stg + ml * 128 + (((fl * 4 + lq) ^ (ml & 7)) << 4)) = s.acc[i][a * 2 + fl][j][g];
                   }
+                // as in the bf16 path: four LDS reads in flight, then branch-free buffer accesses (rows past the block: out of the descriptor's range — stores
+                // dropped, loads return 0; a column past it: offset -1)
+                f32x4 val[4];
+                int off[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                  const int ml = q * 8 + srow;
-                  f32x4 val = *reinterpret_cast<const f32x4*>(stg + ml * 128 + ((schunk ^ srow) << 4));
-                  const int m = mrow0 + ml, nn = ncol0 + a * 32 + schunk * 4;
-                  if (m < cur.m_valid && nn < cur.n_valid) {
-                    float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nn;
-                    if (p.accumulate) val += *reinterpret_cast<const f32x4*>(dst);
-                    if (p.nt_out) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dst));
-                    else *reinterpret_cast<f32x4*>(dst) = val;
-                    if (MODE == 0 && p.sumsq) ss = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], ss))));
+                  val[q] = *reinterpret_cast<const f32x4*>(stg + (q * 8 + srow) * 128 + ((schunk ^ srow) << 4));
+                  const int m = mrow0 + q * 8 + srow, nn = ncol0 + a * 32 + schunk * 4;
+                  off[q] = (m * ldo_b * 2 + nn * 4) | ((cur.n_valid - 1 - nn) >> 31);
+                }
+                if (p.accumulate) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) val[q] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, off[q], 0, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[q]), orsrc, off[q], 0, 0);
+                if (MODE == 0 && p.sumsq) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const bool ok = off[q] != -1 && mrow0 + q * 8 + srow < cur.m_valid;
+                    const float sq = fmaf(val[q][0], val[q][0], fmaf(val[q][1], val[q][1], fmaf(val[q][2], val[q][2], val[q][3] * val[q][3])));
+                    ss += ok ? sq : 0.f;
                   }
                 }
               }
@@ -1669,8 +1681,7 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
 using namespace pm;
 
 // Schedule word of the dense core.  The product library has ONE K loop (kShippedLoop); the word selects around it: bit 2 = persistent grid (one workgroup
-// per CU walking its tiles) instead of one workgroup per tile, bit 5 = no split-K of a half-empty last tile round, bit 9 = non-temporal result stores,
-// bit 10 = the round-3 patch sweep order (A/B); bits 0 / 1 are accepted and ignored (rounds 3-4 wrote 3 / 7 for "per tile" / "persistent").  Every other bit
+// per CU walking its tiles) instead of one workgroup per tile, bit 5 = no split-K of a half-empty last tile round, bit 10 = the round-3 patch sweep order (A/B); bits 0 / 1 are accepted and ignored (rounds 3-4 wrote 3 / 7 for "per tile" / "persistent").  Every other bit
 // selects a build that was measured and not adopted and exists only in a `make VARIANTS=1` library — PM_ERR_UNSUPPORTED otherwise (the GPU tests skip).
 extern "C" int pm_gemm_debug_set_variant(int32_t v) {
 #if !PM_VARIANTS
@@ -1742,7 +1753,7 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
-  p.nt_out = (gm::g_variant & 512) ? 1 : 0;  // bit 9 of the debug variant: non-temporal result stores (A/B)
+  p.nt_out = (gm::g_variant & 512) ? 1 : 0;
   // cycle the smaller operand past the held block of the bigger one (X has m x k elements, W n x k); bit 10 of the debug variant: always the round-3 order (A/B)
   p.sweep_n = (m > n && !(gm::g_variant & 1024)) ? 1 : 0;
   hipStream_t st = as_stream(stream);
@@ -1814,7 +1825,6 @@ extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, in
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)(inter / 128);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = 0; p.accumulate = 0;
-  p.nt_out = (gm::g_variant & 512) ? 1 : 0;
   p.sweep_n = (m > 2 * inter && !(gm::g_variant & 1024)) ? 1 : 0;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
   p.k_chunk = (int)k; p.k_parts = 1;
