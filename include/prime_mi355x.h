@@ -460,6 +460,12 @@ int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf
                        int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream);
 int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
                        int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream);
+/* The experts' down-projection row gradient with the SwiGLU backward in its epilogue (layers/moe.py:181-183 backward): grad_gate_up[m] = [d_gate | d_up] from
+ * (dy[m] . w_down[e(m)]) and the saved gate_up[m]; dy [n_rows, n_dim], w_down [E, n_dim, inter], gate_up / grad_gate_up [n_rows, 2 inter] (may alias).
+ * inter % 256 == 0, n_dim % 128 == 0. */
+int pm_grouped_gemm_nn_swiglu_bwd_supported(int64_t n_rows, int64_t n_dim, int64_t inter);
+int pm_grouped_gemm_nn_swiglu_bwd(const void* dy_bf16, const void* w_down_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
+                                  const void* gate_up_bf16, void* grad_gate_up_bf16, void* stream);
 int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
                        int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, void* stream);
 /* The same with the gradient written (accumulate = 0) or accumulated (1) in f32 straight into a main-gradient buffer [E, n_first, K] / [E, N - n_first, K]
@@ -505,6 +511,14 @@ int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const voi
 int pm_gemm_swiglu_supported(int64_t m, int64_t inter, int64_t k);
 int pm_gemm_swiglu_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, int64_t ldw, void* gate_up_bf16, int64_t ldo, void* act_bf16, int64_t ldo2, int64_t m,
                         int64_t inter, int64_t k, void* stream);
+/* The down projection's row gradient with the SwiGLU backward in its epilogue (the backward of mlp.py:27-29; autograd runs mm, silu_backward, two muls):
+ * d_act[m, inter] = dy[m, k] . w_down[k, inter] (w_down as stored, [hidden, inter], row stride ldw) is rounded to bf16 as pm_gemm_bf16 would store it and
+ * then, still in registers, turned into grad_gate_up[m, 2 inter] = [d_gate | d_up] with the saved gate_up[m, 2 inter] — bit-identical to pm_gemm_bf16
+ * followed by pm_swiglu_bwd, without d_act ever reaching HBM.  grad_gate_up may alias gate_up (every element is read before it is overwritten, by the
+ * same lane).  inter % 8 == 0, k % 128 == 0. */
+int pm_gemm_swiglu_bwd_supported(int64_t m, int64_t inter, int64_t k);
+int pm_gemm_swiglu_bwd_bf16(const void* dy_bf16, int64_t lddy, const void* w_down_bf16, int64_t ldw, const void* gate_up_bf16, int64_t ldgu, void* grad_gate_up_bf16,
+                            int64_t ldo, int64_t m, int64_t inter, int64_t k, void* stream);
 int pm_gemm_debug_set_variant(int32_t value); /* one PROCESS-WIDE schedule word around the core's one K loop (setprio around the MFMA clusters, two compute segments
                                                * of 32 MFMAs per K-tile): bit 2 = persistent grid (one workgroup per CU walking its tiles) instead of one workgroup per
                                                * tile, bit 5 = no split-K of a half-empty last round, bit 10 = the round-3 patch sweep

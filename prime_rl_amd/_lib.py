@@ -139,6 +139,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grouped_gemm_debug_set_variant": (I, [I32]),
     "pm_grouped_gemm_nt": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
     "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
+    "pm_grouped_gemm_nn_swiglu_bwd_supported": (I, [I64, I64, I64]),
+    "pm_grouped_gemm_nn_swiglu_bwd": (I, [P, P, P, I32, I64, I64, I64, P, P, P]),
     "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, P]),
     "pm_grouped_gemm_tn_f32": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
@@ -150,6 +152,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, P]),
     "pm_gemm_swiglu_supported": (I, [I64, I64, I64]),
     "pm_gemm_swiglu_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
+    "pm_gemm_swiglu_bwd_supported": (I, [I64, I64, I64]),
+    "pm_gemm_swiglu_bwd_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
     "pm_gemm_debug_set_variant": (I, [I32]),
 }
 

@@ -60,6 +60,15 @@ __device__ __forceinline__ float swiglu_act(float gate, float up) {
   return round_bf16(s) * up;
 }
 
+// Its gradient on bf16-valued inputs (d = the gradient of act): d_up = d * silu(gate), d_gate = d * up * silu'(gate); the caller rounds both to bf16.
+// ONE definition for pm_swiglu_bwd and the down-projection row-gradient GEMM's fused epilogue (bit-identical by construction).
+__device__ __forceinline__ void swiglu_bwd_pair(float d, float gate, float up, float& d_gate, float& d_up) {
+  const float sig = 1.0f / (1.0f + __expf(-gate));
+  const float s = gate * sig;
+  d_up = d * s;
+  d_gate = d * up * (sig * (1.0f + gate * (1.0f - sig)));
+}
+
 // low / high halves of a packed pair
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

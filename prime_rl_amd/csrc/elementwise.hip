@@ -98,10 +98,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
       unpack8e(dv[j], d);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float sig = 1.0f / (1.0f + __expf(-g[k]));
-        const float s = g[k] * sig;
-        du[k] = d[k] * s;
-        dg[k] = d[k] * u[k] * (sig * (1.0f + g[k] * (1.0f - sig)));
+        swiglu_bwd_pair(d[k], g[k], u[k], dg[k], du[k]);
       }
       u32x4* op = reinterpret_cast<u32x4*>(ggu + (rb + j) * 2 * inter);
       op[c] = pack8e(dg);

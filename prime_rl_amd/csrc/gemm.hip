@@ -85,6 +85,8 @@ struct Params {
   const bf16_t* w2;        // second weight set (the experts' up projection next to the gate projection), or null
   void* out2;              // second output (MODE 3: its weight gradient; MODE 4: act = silu(gate) * up, [M, n_first] bf16, row stride ldo2)
   int64_t ldo2;
+  const bf16_t* gu;        // MODE 5 / 6: the saved [gate | up] of the SwiGLU whose output gradient this product is ([M, 2 n], row stride ldgu); OUT = its gradient
+  int64_t ldgu;
   int n_experts;
   int n_first;             // columns / contraction rows served by the first weight set
 };
@@ -531,8 +533,12 @@ __device__ __forceinline__ bool locate_row_tile(const int32_t* __restrict__ offs
 // MODE 0: the dense product.  1: grouped forward  y[m] = x[m] . [w | w2][e(m)]^T      (x, w K-contiguous; column tiles >= n_first come from w2)
 // 2: grouped row gradient  dx[m] = dy[m, :n_first] . w[e] + dy[m, n_first:] . w2[e]   (dy K-contiguous, weights K-major; two chained parts)
 // 3: grouped weight gradient  dw[e] = dy[rows of e]^T . x[rows of e]                  (both K-major; K = the expert's row count; rows < n_first -> out, else out2)
+// 5 / 6: the tile streams of 0 / 2 (a dense / grouped row gradient through a down projection) with the SwiGLU-backward epilogue: the product is the
+//        gradient of act = silu(gate) * up, and the epilogue turns each value into d_gate and d_up at once (OUT = [d_gate | d_up], gate / up read from p.gu)
 template <int MODE>
 __device__ __forceinline__ constexpr int parts_of() { return MODE == 2 ? 2 : 1; }
+template <int MODE>
+__device__ __forceinline__ constexpr int tile_mode() { return MODE == 5 ? 0 : MODE == 6 ? 2 : MODE; }
 
 template <int MODE, bool XK, bool WK>
 __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, Tile& t) {
@@ -708,12 +714,14 @@ __device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, in
 
 template <int V, bool XK, bool WK, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
+  constexpr int TM = tile_mode<MODE>();          // which tile stream
+  constexpr bool SWB = MODE == 5 || MODE == 6;  // SwiGLU-backward epilogue
   unsigned char* smem = lds_base();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = wave >> 2, wt = wave & 3;  // wv: which 64 W rows of a half (also the ping-pong group), wt: which 32 X rows of a half
   int v = blockIdx.x, part = 0;
   Tile cur;
-  if (!next_unit<MODE, XK, WK>(p, v, part, lane, cur)) return;
+  if (!next_unit<TM, XK, WK>(p, v, part, lane, cur)) return;
 
   Wave s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -782,9 +790,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       for (int t = 0; t < nk; t += 2) {
         if (!(V & 8)) stage<SLOT_W1, 1>(s, smem);  // A(t), first stage: W1(t + 1)
         if (t + 2 >= nk) {
-          advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
+          advance_unit(v_n, part_n, TM == 0 ? p.k_parts : parts_of<TM>());
           Tile nxt;
-          has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+          has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, nxt);
           if (has_next) {
             s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
             s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
@@ -802,9 +810,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       phase<0, 0, V, XK, WK>(s, smem);
       phase<1, 0, V, XK, WK>(s, smem);
       if (t + 2 >= nk) {  // the last pair of this unit: every half-tile staged from here on belongs to the next one
-        advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
+        advance_unit(v_n, part_n, TM == 0 ? p.k_parts : parts_of<TM>());
         Tile nxt;
-        has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+        has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, nxt);
         if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
           s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
           s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
@@ -848,6 +856,18 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       const __amdgpu_buffer_rsrc_t orsrc =
           out_rsrc(cur.out, cur.m_valid > 0 ? ((cur.m_valid - 1) * ldo_b + (MODE == 4 ? p.n_first + 128 : cur.n_valid) * 2) * (f32o ? 2 : 1) : 0);
       const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
+      // SwiGLU-backward epilogue: the tile's block of the gate half of p.gu (same rows and columns as its block of OUT), the up halves p.n columns to the right
+      int ldgu_b = 0;
+      __amdgpu_buffer_rsrc_t grsrc = orsrc, ursrc = orsrc, o2rsrc = orsrc;
+      if constexpr (SWB) {
+        const int64_t eo = (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2;
+        const bf16_t* gt = p.gu + eo / p.ldo * p.ldgu + eo % p.ldo;
+        ldgu_b = (int)p.ldgu * 2;
+        const int gbytes = cur.m_valid > 0 ? (cur.m_valid - 1) * ldgu_b + cur.n_valid * 2 : 0;
+        grsrc = out_rsrc(gt, gbytes);
+        ursrc = out_rsrc(gt + p.n, gbytes);
+        o2rsrc = out_rsrc(reinterpret_cast<bf16_t*>(cur.out) + p.n, cur.m_valid > 0 ? (cur.m_valid - 1) * ldo_b + cur.n_valid * 2 : 0);
+      }
       if (wide) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -880,10 +900,39 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
               u32x4 val[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) val[q] = *reinterpret_cast<const u32x4*>(stg + (q * 8 + srow) * 128 + ((schunk ^ srow) << 4));
+              if constexpr (SWB) {
+                // val = the gradient of act = silu(gate) * up, rounded to bf16 (what the plain product would have stored); gate / up of the same 8
+                // (token, feature) pairs come from the saved projection, and [d_gate | d_up] leave instead (pm_swiglu_bwd's arithmetic: swiglu_bwd_pair)
+                int offo[4];
+                u32x4 gv[4], uv[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int m = mrow0 + q * 8 + srow, nn = ncol0 + schunk * 8;
-                __builtin_amdgcn_raw_buffer_store_b128(val[q], orsrc, (m * ldo_b + nn * 2) | ((cur.n_valid - 1 - nn) >> 31), 0, 0);  // nn >= n_valid: offset -1
+                for (int q = 0; q < 4; ++q) {
+                  const int m = mrow0 + q * 8 + srow, nn = ncol0 + schunk * 8, past = (cur.n_valid - 1 - nn) >> 31;
+                  const int offg = (m * ldgu_b + nn * 2) | past;
+                  offo[q] = (m * ldo_b + nn * 2) | past;
+                  gv[q] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, offg, 0, 0);
+                  uv[q] = __builtin_amdgcn_raw_buffer_load_b128(ursrc, offg, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  u32x4 dgv, duv;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    float dg0, du0, dg1, du1;
+                    swiglu_bwd_pair(bf16lo(val[q][c]), bf16lo(gv[q][c]), bf16lo(uv[q][c]), dg0, du0);
+                    swiglu_bwd_pair(bf16hi(val[q][c]), bf16hi(gv[q][c]), bf16hi(uv[q][c]), dg1, du1);
+                    dgv[c] = pack_bf16_hw(dg0, dg1);
+                    duv[c] = pack_bf16_hw(du0, du1);
+                  }
+                  __builtin_amdgcn_raw_buffer_store_b128(dgv, orsrc, offo[q], 0, 0);
+                  __builtin_amdgcn_raw_buffer_store_b128(duv, o2rsrc, offo[q], 0, 0);
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int m = mrow0 + q * 8 + srow, nn = ncol0 + schunk * 8;
+                  __builtin_amdgcn_raw_buffer_store_b128(val[q], orsrc, (m * ldo_b + nn * 2) | ((cur.n_valid - 1 - nn) >> 31), 0, 0);  // nn >= n_valid: offset -1
+                }
               }
             } else {  // two blocks of [32 rows][32 columns: f & 1, lq, r] f32
 #pragma unroll
@@ -992,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     }
     v = v_n;
     part = part_n;
-    tile_at<MODE, XK, WK>(p, v, part, lane, cur);
+    tile_at<TM, XK, WK>(p, v, part, lane, cur);
   }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
   if (staggered && wv == 0) __builtin_amdgcn_s_barrier();
@@ -1630,6 +1679,7 @@ static void grouped_common(Params& p, const int32_t* offsets, int n_experts, int
   p.n_first = (int)n_first;
   p.w2 = nullptr;
   p.out2 = nullptr;
+  p.gu = nullptr; p.ldgu = 0;
 }
 bool grouped_shapes_ok(int64_t n_first, int64_t n, int64_t k_or_second) { return n_first % 256 == 0 && n % 256 == 0 && k_or_second % 128 == 0; }
 
@@ -1657,6 +1707,21 @@ int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_
   p.tiles_m = 0; p.tiles_n = (int)(k_out / kTile);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
   launch_grouped<false, true, 2>(p, st);
+  return PM_OK;
+}
+// [d_gate | d_up][m] = SwiGLU'(gate_up[m]) applied to (dy[m] . w[e]) : dy [M, n_dim], w [E, n_dim, inter] (the experts' down projection), gate_up and
+// d_gate_up [M, 2 inter] — grouped_nn through one weight set with the SwiGLU-backward epilogue (MODE 6); d_gate_up may be gate_up itself
+int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
+                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st) {
+  Params p;
+  grouped_common(p, offsets, n_experts, n_dim);
+  p.x = dy; p.w = w; p.out = d_gate_up;
+  p.gu = gate_up; p.ldgu = 2 * inter;
+  p.ldx = n_dim; p.ldw = inter; p.ldo = 2 * inter;
+  p.m = (int)n_rows; p.n = (int)inter; p.k = (int)n_dim;
+  p.tiles_m = 0; p.tiles_n = (int)(inter / kTile);
+  p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
+  launch_grouped<false, true, 6>(p, st);
   return PM_OK;
 }
 // dw[e] = dy[rows of e]^T . x[rows of e] : dy [M, n_dim], x [M, k_dim] -> dw [E, n_first, k_dim], dw2 [E, n_dim - n_first, k_dim]
@@ -1746,7 +1811,7 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   PM_REQUIRE(k_chunk == k || (out_dtype == PM_DTYPE_F32 && x_kmajor && w_kmajor && !bias), PM_ERR_UNSUPPORTED,
              "pm_gemm_bf16: a K-major operand beyond 2 GB needs the f32-accumulating wgrad form");
   gm::Params p;
-  p.offsets = nullptr; p.w2 = nullptr; p.out2 = nullptr; p.n_experts = 0; p.n_first = 0;
+  p.offsets = nullptr; p.w2 = nullptr; p.out2 = nullptr; p.n_experts = 0; p.n_first = 0; p.gu = nullptr; p.ldgu = 0;
   p.out = out; p.bias = (const bf16_t*)bias;
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
   p.m = (int)m; p.n = (int)n;
@@ -1817,7 +1882,7 @@ extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, in
   const int64_t kLimit = (1ll << 31) - 4096;
   PM_REQUIRE(256 * ldx * 2 < kLimit && (inter + 128) * ldw * 2 < kLimit, PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bf16: a tile's weight panel (inter + 128 rows) beyond int32 offsets");
   gm::Params p;
-  p.offsets = nullptr; p.w2 = nullptr; p.n_experts = 0; p.bias = nullptr; p.sumsq = nullptr;
+  p.offsets = nullptr; p.w2 = nullptr; p.n_experts = 0; p.bias = nullptr; p.sumsq = nullptr; p.gu = nullptr; p.ldgu = 0;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w;
   p.out = gate_up; p.out2 = act;
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo; p.ldo2 = ldo2;
@@ -1830,5 +1895,42 @@ extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, in
   p.k_chunk = (int)k; p.k_parts = 1;
   gm::launch_grouped<false, false, 4>(p, as_stream(stream));
   PM_CHECK_LAUNCH("gemm_kernel<swiglu>");
+  return PM_OK;
+}
+
+// ---- down-projection row gradient with the SwiGLU-backward epilogue (MODE 5 of the tile stream) -------------------------------------------------------
+// d_act = dy . W_down (W_down [k = hidden, inter] as stored, read K-major) never reaches HBM: each value, rounded to bf16 as the plain product would store
+// it, meets gate / up of its (token, feature) in the epilogue and leaves as d_gate and d_up (pm_swiglu_bwd's arithmetic, bit for bit).
+extern "C" int pm_gemm_swiglu_bwd_supported(int64_t m, int64_t inter, int64_t k) {
+  return pm_gemm_supported(m, inter, k, 0, 1) && inter % 8 == 0 && 2 * inter < (1ll << 31);
+}
+
+extern "C" int pm_gemm_swiglu_bwd_bf16(const void* dy, int64_t lddy, const void* w_down, int64_t ldw, const void* gate_up, int64_t ldgu, void* grad_gate_up, int64_t ldo,
+                                       int64_t m, int64_t inter, int64_t k, void* stream) {
+  if (m == 0 || inter == 0) return PM_OK;
+  PM_REQUIRE(dy && w_down && gate_up && grad_gate_up, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bwd_bf16: null pointer");
+  PM_REQUIRE(pm_gemm_swiglu_bwd_supported(m, inter, k), PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bwd_bf16: unsupported shape (m %lld, inter %lld, k %lld)", (long long)m,
+             (long long)inter, (long long)k);
+  PM_REQUIRE(lddy >= k && ldw >= inter && ldgu >= 2 * inter && ldo >= 2 * inter, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bwd_bf16: leading dimension too small");
+  PM_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldgu % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)w_down & 15) == 0 &&
+                 ((uintptr_t)gate_up & 15) == 0 && ((uintptr_t)grad_gate_up & 15) == 0,
+             PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bwd_bf16: rows must start 16-byte aligned (leading dimensions multiples of 8, 16-byte aligned bases)");
+  const int64_t kLimit = (1ll << 31) - 4096;
+  PM_REQUIRE(256 * lddy * 2 < kLimit && k * ldw * 2 < kLimit && 256 * ldgu * 2 < kLimit && 256 * ldo * 2 < kLimit && m < (1ll << 31), PM_ERR_UNSUPPORTED,
+             "pm_gemm_swiglu_bwd_bf16: sizes beyond int32 offsets");
+  gm::Params p;
+  p.offsets = nullptr; p.w2 = nullptr; p.out2 = nullptr; p.n_experts = 0; p.n_first = 0; p.bias = nullptr; p.sumsq = nullptr;
+  p.x = (const bf16_t*)dy; p.w = (const bf16_t*)w_down;
+  p.out = grad_gate_up; p.gu = (const bf16_t*)gate_up;
+  p.ldx = lddy; p.ldw = ldw; p.ldo = ldo; p.ldo2 = 0; p.ldgu = ldgu;
+  p.m = (int)m; p.n = (int)inter; p.k = (int)k;
+  p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(inter, gm::kTile);
+  p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
+  p.out_f32 = 0; p.accumulate = 0; p.nt_out = 0;
+  p.sweep_n = (m > inter && !(gm::g_variant & 1024)) ? 1 : 0;
+  p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
+  p.k_chunk = (int)k; p.k_parts = 1;
+  gm::launch_grouped<false, true, 5>(p, as_stream(stream));
+  PM_CHECK_LAUNCH("gemm_kernel<swiglu_bwd>");
   return PM_OK;
 }

@@ -618,6 +618,8 @@ int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_
                int64_t k_out, bf16_t* dx, hipStream_t st);
 int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
                int out_f32, int accumulate, hipStream_t st);
+int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
+                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st);
 }  // namespace gm
 }  // namespace pm
 
@@ -682,6 +684,25 @@ extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const
   hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
                      n_experts, n_rows, (int)n_first, (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
   PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
+  return PM_OK;
+}
+
+// [d_gate | d_up][m] = SwiGLU-backward of (dy[m] . w_down[e(m)]) against the saved gate_up[m]: the experts' down-projection row gradient with pm_swiglu_bwd
+// in its epilogue (moe.py:181-183 backward: the gradient of h = silu(x w1^T) * (x w3^T) never reaches HBM).  grad_gate_up may be gate_up (in place).
+extern "C" int pm_grouped_gemm_nn_swiglu_bwd_supported(int64_t n_rows, int64_t n_dim, int64_t inter) {
+  return inter > 0 && n_dim > 0 && inter % 256 == 0 && n_dim % 128 == 0 && gg_shapes_ok(n_rows, n_dim, 2 * inter) ? 1 : 0;
+}
+
+extern "C" int pm_grouped_gemm_nn_swiglu_bwd(const void* dy_bf16, const void* w_down_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
+                                             int64_t inter, const void* gate_up_bf16, void* grad_gate_up_bf16, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn_swiglu_bwd: bad sizes");
+  PM_REQUIRE(w_down_bf16 && offsets && (n_rows == 0 || (dy_bf16 && gate_up_bf16 && grad_gate_up_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn_swiglu_bwd: null pointer");
+  PM_REQUIRE(pm_grouped_gemm_nn_swiglu_bwd_supported(n_rows, n_dim, inter), PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_nn_swiglu_bwd: needs inter %% 256 == 0 and n_dim %% 128 == 0 (n_dim %lld, inter %lld; row tensors < 2 GiB)", (long long)n_dim, (long long)inter);
+  if (n_rows == 0) return PM_OK;
+  gm::grouped_nn_swiglu_bwd((const bf16_t*)dy_bf16, (const bf16_t*)w_down_bf16, offsets, n_experts, n_rows, n_dim, inter, (const bf16_t*)gate_up_bf16,
+                            (bf16_t*)grad_gate_up_bf16, as_stream(stream));
+  PM_CHECK_LAUNCH("pm_grouped_gemm_nn_swiglu_bwd");
   return PM_OK;
 }
 

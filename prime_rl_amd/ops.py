@@ -541,11 +541,15 @@ def swiglu_fwd(gate_up: Tensor, out: Tensor | None = None) -> Tensor:
     return act
 
 
-def swiglu_bwd(grad_act: Tensor, gate_up: Tensor) -> Tensor:
+def swiglu_bwd(grad_act: Tensor, gate_up: Tensor, out: Tensor | None = None) -> Tensor:
     lib = _lib.load()
     _req(grad_act, torch.bfloat16, "grad_act"); _req(gate_up, torch.bfloat16, "gate_up")
     n, two_i = gate_up.shape
-    g = torch.empty_like(gate_up)
+    g = torch.empty_like(gate_up) if out is None else out
+    if out is not None:
+        _req(out, torch.bfloat16, "out")
+        if tuple(out.shape) != tuple(gate_up.shape):
+            raise PrimeMI355XError(f"swiglu_bwd: out {tuple(out.shape)} != gate_up {tuple(gate_up.shape)}")
     check(lib.pm_swiglu_bwd(_p(grad_act), _p(gate_up), n, two_i // 2, _p(g), _stream()), "pm_swiglu_bwd")
     return g
 
@@ -766,6 +770,28 @@ def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = 
     return dx
 
 
+def grouped_gemm_nn_swiglu_bwd_supported(n_rows: int, n_dim: int, inter: int) -> bool:
+    return bool(_lib.load().pm_grouped_gemm_nn_swiglu_bwd_supported(n_rows, n_dim, inter))
+
+
+def grouped_gemm_nn_swiglu_bwd(dy: Tensor, w_down: Tensor, offsets: Tensor, gate_up: Tensor, out: Tensor | None = None) -> Tensor:
+    """grad_gate_up[m] = swiglu_bwd(dy[m] @ w_down[e(m)], gate_up[m]): dy [M, N], w_down [E, N, inter], gate_up [M, 2 inter] -> [M, 2 inter] — equals
+    swiglu_bwd(grouped_gemm_nn(dy, w_down, offsets), gate_up) bit for bit; `out` may be `gate_up`."""
+    lib = _lib.load()
+    _gg_check(dy, w_down, offsets, "dy")
+    e, n, inter = w_down.shape
+    _req(gate_up, torch.bfloat16, "gate_up")
+    if dy.shape[1] != n or tuple(gate_up.shape) != (dy.shape[0], 2 * inter):
+        raise PrimeMI355XError(f"grouped_gemm_nn_swiglu_bwd: dy {tuple(dy.shape)}, w_down {tuple(w_down.shape)}, gate_up {tuple(gate_up.shape)}")
+    if out is None:
+        out = torch.empty_like(gate_up)
+    _req(out, torch.bfloat16, "out")
+    if tuple(out.shape) != tuple(gate_up.shape):
+        raise PrimeMI355XError(f"grouped_gemm_nn_swiglu_bwd: out {tuple(out.shape)} != gate_up {tuple(gate_up.shape)}")
+    check(lib.pm_grouped_gemm_nn_swiglu_bwd(_p(dy), _p(w_down), _p(offsets), e, dy.shape[0], n, inter, _p(gate_up), _p(out), _stream()), "pm_grouped_gemm_nn_swiglu_bwd")
+    return out
+
+
 def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None = None):
     """dw[e] = dy[group e].T @ x[group e]: dy [M, N], x [M, K] -> dw [E, N, K]; with n_first: (dw [E, n_first, K], dw2 [E, N - n_first, K])."""
     lib = _lib.load()
@@ -952,6 +978,37 @@ def gemm_swiglu(x: Tensor, w_gate_up: Tensor, gate_up: Tensor | None = None, act
         check(_lib.load().pm_gemm_swiglu_bf16(_p(x), x.stride(0), _p(w_gate_up), w_gate_up.stride(0), _p(gate_up), gate_up.stride(0), _p(act), act.stride(0), m, inter, k,
                                               _stream()), "pm_gemm_swiglu_bf16")
     return gate_up, act
+
+
+def gemm_swiglu_bwd_supported(dy: Tensor, w_down: Tensor) -> bool:
+    """Can `gemm_swiglu_bwd` take these operands (K-contiguous dy [M, K], the stored w_down [K, inter] with unit column stride, K % 128 == 0, inter % 8 == 0)?"""
+    if dy.dim() != 2 or w_down.dim() != 2 or dy.dtype != torch.bfloat16 or w_down.dtype != torch.bfloat16 or dy.device.type != "cuda":
+        return False
+    if dy.stride(1) != 1 or w_down.stride(1) != 1 or dy.shape[1] != w_down.shape[0]:
+        return False
+    if dy.stride(0) % 8 or w_down.stride(0) % 8 or dy.data_ptr() % 16 or w_down.data_ptr() % 16:
+        return False
+    return bool(_lib.load().pm_gemm_swiglu_bwd_supported(dy.shape[0], w_down.shape[1], dy.shape[1]))
+
+
+def gemm_swiglu_bwd(dy: Tensor, w_down: Tensor, gate_up: Tensor, out: Tensor | None = None, variant: int | None = None) -> Tensor:
+    """grad_gate_up [M, 2 inter] = swiglu_bwd(dy @ w_down, gate_up): the down projection's row gradient with the SwiGLU backward in the GEMM epilogue — equals
+    swiglu_bwd(gemm(dy, w_down.t()), gate_up) bit for bit; the gradient of the activation is never written.  `out` may be `gate_up` (in place)."""
+    _req(dy, torch.bfloat16, "dy", contiguous=False); _req(w_down, torch.bfloat16, "w_down", contiguous=False); _req(gate_up, torch.bfloat16, "gate_up", contiguous=False)
+    if not gemm_swiglu_bwd_supported(dy, w_down):
+        raise PrimeMI355XError(f"gemm_swiglu_bwd: unsupported operands dy {tuple(dy.shape)} {dy.stride()} w_down {tuple(w_down.shape)} {w_down.stride()}")
+    m, k = dy.shape
+    inter = w_down.shape[1]
+    if out is None:
+        out = torch.empty((m, 2 * inter), dtype=torch.bfloat16, device=dy.device)
+    for t, nm in ((gate_up, "gate_up"), (out, "out")):
+        _req(t, torch.bfloat16, nm, contiguous=False)
+        if tuple(t.shape) != (m, 2 * inter) or t.stride(1) != 1 or t.stride(0) % 8:
+            raise PrimeMI355XError(f"gemm_swiglu_bwd: {nm} must be [{m}, {2 * inter}] bf16 with unit column stride and a row stride that is a multiple of 8")
+    with _gemm_variant_scope(variant):
+        check(_lib.load().pm_gemm_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(gate_up), gate_up.stride(0), _p(out), out.stride(0), m, inter, k,
+                                                  _stream()), "pm_gemm_swiglu_bwd_bf16")
+    return out
 
 
 def gemm_sumsq_slots(m: int, n: int) -> int:

@@ -458,7 +458,7 @@ class GRPOEngine:
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
                  shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None, fused_sumsq: bool = True,
-                 embed_split: bool = True):
+                 embed_split: bool = True, fused_swiglu_bwd: bool = True):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -573,6 +573,9 @@ class GRPOEngine:
         self.dgrad_own_below = 7168 if (self.gemm_own and self.gemm_layouts) else 0
         self._dgrad_own_now = "dgrad" in self.gemm_own
         self._fused_sumsq_wanted = fused_sumsq
+        # the SwiGLU backward in the epilogue of the down projection's row-gradient GEMM (ops.gemm_swiglu_bwd) where that GEMM runs on the own core;
+        # `fused_swiglu_bwd=False` is the A/B switch of the tests (GEMM, then pm_swiglu_bwd: identical results)
+        self.fused_swiglu_bwd = fused_swiglu_bwd
         self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and fused_sumsq
         self._fs_plan: dict | None = None
         self._fs_covered: set[str] = set()
@@ -1013,11 +1016,15 @@ class GRPOEngine:
             if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input
                 L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n)
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
-            dact = self._dgrad(dx, i, "mlp.down_proj.weight")
+            w_down = w[p + "mlp.down_proj.weight"]
+            if self.fused_swiglu_bwd and self._dgrad_own_now and not self.gemm_f32 and ops.gemm_swiglu_bwd_supported(dx, w_down):
+                # the SwiGLU backward rides in the row-gradient GEMM's epilogue: d_act never reaches HBM, [d_gate | d_up] overwrite the saved gate | up
+                dgu = ops.gemm_swiglu_bwd(dx, w_down, L["gu"], out=L["gu"], variant=self._gemm_variant)
+            else:
+                dgu = ops.swiglu_bwd(self._dgrad(dx, i, "mlp.down_proj.weight"), L["gu"])
             self._wgrad(dx, act, g[p + "mlp.down_proj.weight"], accumulate, k_contiguous_x=True,
                         final_name=p + "mlp.down_proj.weight" if last_pass else None)
             del act
-            dgu = ops.swiglu_bwd(dact, L["gu"])
             dh2 = self._dgrad(dgu, i, "mlp.gate_up_proj.weight")
             self._wgrad(dgu, L["h2"], g[p + "mlp.gate_up_proj.weight"], accumulate, k_contiguous_x=True,
                         final_name=p + "mlp.gate_up_proj.weight" if last_pass else None)

@@ -133,8 +133,47 @@ class _GroupedSwiGLUFn(torch.autograd.Function):
         return gx, gw1, gw3, None
 
 
+class _GroupedFFNFn(torch.autograd.Function):
+    """The whole expert FFN (moe.py:181-183) as ONE node, so that its backward can run the down projection's row-gradient GEMM with the SwiGLU backward
+    in the epilogue (`pm_grouped_gemm_nn_swiglu_bwd`): the gradient of h is never written, `pm_swiglu_bwd`'s pass over three [rows, hidden] tensors is
+    gone.  Same launches otherwise, same results bit for bit as _GroupedLinearFn(_GroupedSwiGLUFn(x))."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, offsets):
+        gate_up = ops.grouped_gemm_nt(x, w1, offsets, w2=w3)
+        h = ops.swiglu_fwd(gate_up)
+        ctx.save_for_backward(x, w1, w2, w3, offsets, gate_up, h)
+        ctx.main_grads_13, ctx.main_grads_2 = _main_grads(w1, w3), _main_grads(w2)
+        return ops.grouped_gemm_nt(h, w2, offsets)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2, w3, offsets, gate_up, h = ctx.saved_tensors
+        g = g.contiguous()
+        d_gate_up = ops.grouped_gemm_nn_swiglu_bwd(g, w2, offsets, gate_up)
+        gw1 = gw2 = gw3 = None
+        if ctx.needs_input_grad[2]:
+            mg = ctx.main_grads_2
+            if mg is not None and ops.grouped_gemm_tn_f32_supported(w2.shape[1], w2.shape[1], w2.shape[2]):
+                ops.grouped_gemm_tn_f32(g, h, offsets, mg[0][0], None, accumulate=mg[0][1][0])
+                mg[0][1][0] = True
+            else:
+                gw2 = ops.grouped_gemm_tn(g, h, offsets)
+        gx = ops.grouped_gemm_nn(d_gate_up, w1, offsets, w2=w3) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            mg = ctx.main_grads_13
+            if mg is not None and ops.grouped_gemm_tn_f32_supported(w1.shape[1], w1.shape[1] + w3.shape[1], w1.shape[2]):
+                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=mg[0][1][0])
+                mg[0][1][0] = mg[1][1][0] = True
+            else:
+                gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])
+        return gx, gw1, gw2, gw3, None
+
+
 def _experts_grouped_hip(w1, w2, w3, x, offsets):
     """_run_experts_grouped_mm_impl (moe.py:161-188) on pm_grouped_gemm_*: offsets stay on the device, no transposed weight copies."""
+    if ops.grouped_gemm_nn_swiglu_bwd_supported(x.shape[0], w2.shape[1], w2.shape[2]):
+        return _GroupedFFNFn.apply(x, w1, w2, w3, offsets)
     return _GroupedLinearFn.apply(_GroupedSwiGLUFn.apply(x, w1, w3, offsets), w2, offsets)
 
 

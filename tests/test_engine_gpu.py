@@ -629,6 +629,25 @@ def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
     assert (params["1"] != params["0"]).float().mean().item() < 0.01  # an ulp of the clip coefficient may flip a few bf16 roundings
 
 
+def test_swiglu_backward_in_the_gemm_epilogue_is_the_same_step_bit_for_bit():
+    """`fused_swiglu_bwd` (default): the down projection's row-gradient GEMM turns its product into [d_gate | d_up] in the epilogue (ops.gemm_swiglu_bwd,
+    in place over the saved gate | up); with the switch off the GEMM writes d_act and pm_swiglu_bwd reads it back.  Same arithmetic per element: the
+    loss, the gradient buffer and the parameters after two steps are identical."""
+    from prime_rl_amd.trainer.engine import GRPOEngine, ModelDims, OptimConfig, pack_micro_batches
+
+    dims = ModelDims.tiny(layers=2, vocab=1024)
+    mbs = _mbs(dims.vocab_size, 256, 4, True)
+    passes = [pack_micro_batches(mbs[:2], DEV), pack_micro_batches(mbs[2:], DEV)]
+    res = {}
+    for fused in (True, False):
+        eng = GRPOEngine(dims, device=DEV, seed=5, optim=OptimConfig(lr=1e-3, max_norm=1.0), fused_swiglu_bwd=fused)
+        assert "dgrad" in eng.gemm_own and eng.fused_swiglu_bwd == fused
+        out = [eng.step(passes), eng.step(passes[0])]
+        res[fused] = ([float(l) for o in out for l in o["loss"]], [float(o["grad_norm"]) for o in out], eng.store.params.clone())
+    assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
+    assert torch.equal(res[True][2], res[False][2])
+
+
 @pytest.mark.parametrize("own", ["wgrad", "none", "wgrad,dgrad"])
 def test_engine_step_is_the_same_whichever_gemms_run_on_the_own_core(monkeypatch, own):
     """PM_GEMM_OWN selects which of the step's GEMM classes run on csrc/gemm.hip instead of the library: every choice computes the same step — bf16

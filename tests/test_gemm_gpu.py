@@ -286,3 +286,29 @@ def test_gemm_swiglu_epilogue_equals_gemm_then_swiglu(m, inter, k):
     assert torch.count_nonzero(gu2[:, 2 * inter:]) == 0 and torch.count_nonzero(act2[:, inter:]) == 0
     assert not ops.gemm_swiglu_supported(x, _rand(2 * inter + 2, k, 0.05, 13))  # inter must be a multiple of 128
 
+
+@pytest.mark.parametrize("m,inter,k", [(256, 256, 128), (1000, 384, 256), (77, 1096, 640), (2048, 1024, 512), (4096, 12288, 1024), (300, 136, 128)])
+def test_gemm_swiglu_bwd_epilogue_equals_gemm_then_swiglu_bwd(m, inter, k):
+    """pm_gemm_swiglu_bwd_bf16 (the backward of mlp.py:27-29 in the epilogue of the down projection's row-gradient product): [d_gate | d_up] must equal
+    pm_swiglu_bwd on the plain product BIT FOR BIT (the product is rounded to bf16 exactly as it would be stored, then the same function); ragged row and
+    column counts, strided operands, in place over gate_up."""
+    dy, w_down = _rand(m, k, 1.0, 21), _rand(k, inter, 0.05, 22)  # w_down as stored: [hidden, inter]
+    gu = _rand(m, 2 * inter, 1.5, 23)
+    ref = ops.swiglu_bwd(ops.gemm(dy, w_down.t()), gu)
+    got = ops.gemm_swiglu_bwd(dy, w_down, gu)
+    assert torch.equal(got, ref)
+    g = gu[:, :inter].float()
+    d_up = (dy.float() @ w_down.float()) * g * torch.sigmoid(g)  # f32 arithmetic on the same bf16 operands; the kernel rounds the product, then d_up
+    assert ((got[:, inter:].float() - d_up).abs() <= 2.0 ** -7 * d_up.abs() + 2.0 ** -7 * d_up.abs().mean()).all()
+    # strided gate_up / out (row strides beyond the logical width), untouched padding
+    gu2 = torch.zeros(m, 2 * inter + 64, dtype=torch.bfloat16, device=DEV)
+    gu2[:, :2 * inter] = gu
+    out2 = torch.zeros(m, 2 * inter + 8, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_swiglu_bwd(dy, w_down, gu2[:, :2 * inter], out=out2[:, :2 * inter])
+    assert torch.equal(out2[:, :2 * inter], ref) and torch.count_nonzero(out2[:, 2 * inter:]) == 0
+    # in place: every element is read before it is overwritten
+    inplace = gu.clone()
+    assert ops.gemm_swiglu_bwd(dy, w_down, inplace, out=inplace) is inplace
+    assert torch.equal(inplace, ref)
+    assert not ops.gemm_swiglu_bwd_supported(dy, _rand(k, inter + 4, 0.05, 24))  # inter must be a multiple of 8
+

@@ -442,6 +442,48 @@ def test_grouped_gemm_two_weight_sets_equal_two_single_calls():
         o += c
 
 
+@pytest.mark.parametrize("e,inter,n_dim,sizes", [(4, 256, 128, [5, 0, 300, 128]), (8, 768, 2048, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 512, 384, [600, 256, 31]),
+                                                 (2, 256, 256, [0, 0])])
+def test_grouped_row_gradient_with_swiglu_backward_epilogue_equals_two_launches(e, inter, n_dim, sizes):
+    """pm_grouped_gemm_nn_swiglu_bwd = pm_swiglu_bwd(pm_grouped_gemm_nn(dy, w_down), gate_up) bit for bit: ragged and empty groups, an empty batch, in place."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(e * 100 + inter)
+    m = sum(sizes)
+    offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    dy = torch.randn(m, n_dim, generator=g).to(torch.bfloat16).to(DEV)
+    w_down = (torch.randn(e, n_dim, inter, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    gate_up = (torch.randn(m, 2 * inter, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    assert ops.grouped_gemm_nn_swiglu_bwd_supported(m, n_dim, inter)
+    got = ops.grouped_gemm_nn_swiglu_bwd(dy, w_down, offsets, gate_up)
+    if m:
+        ref = ops.swiglu_bwd(ops.grouped_gemm_nn(dy, w_down, offsets), gate_up)
+        assert torch.equal(got, ref)
+        inplace = gate_up.clone()
+        ops.grouped_gemm_nn_swiglu_bwd(dy, w_down, offsets, inplace, out=inplace)
+        assert torch.equal(inplace, ref)
+    assert not ops.grouped_gemm_nn_swiglu_bwd_supported(m, n_dim, inter + 128)  # inter must be a multiple of 256
+
+
+def test_expert_ffn_as_one_autograd_node_equals_the_two_node_form():
+    """_GroupedFFNFn (fused SwiGLU backward) vs _GroupedLinearFn(_GroupedSwiGLUFn(x)): outputs and all four gradients identical."""
+    from prime_rl_amd.trainer.models.layers import moe as M
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    e, dim, hidden, sizes = 6, 256, 512, [300, 0, 129, 1, 700, 64]
+    m = sum(sizes)
+    offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).to(DEV)  # noqa: E731
+    x0, w10, w20, w30, gy = mk(m, dim), mk(e, hidden, dim, s=0.1), mk(e, dim, hidden, s=0.1), mk(e, hidden, dim, s=0.1), mk(m, dim)
+    outs = []
+    for fused in (True, False):
+        x, w1, w2, w3 = (t.clone().requires_grad_(True) for t in (x0, w10, w20, w30))
+        y = M._GroupedFFNFn.apply(x, w1, w2, w3, offsets) if fused else M._GroupedLinearFn.apply(M._GroupedSwiGLUFn.apply(x, w1, w3, offsets), w2, offsets)
+        y.backward(gy)
+        outs.append((y.detach(), x.grad, w1.grad, w2.grad, w3.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_grouped_weight_gradient_in_f32_written_and_accumulated_in_place():
     """pm_grouped_gemm_tn_f32: dw (and dw2) in f32 straight into caller-owned buffers, first call overwrites (garbage in), second accumulates; ragged and
     empty groups; the bf16-output kernel's result is this one rounded once."""

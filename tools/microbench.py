@@ -560,6 +560,28 @@ def main():
         for name, ts in res.items():
             ts.sort()
             out.append(dict(kernel=f"gate|up forward t={t}: {name}", ms=ts[len(ts) // 2] * 1e3, bit_identical_act=same))
+    if which == "gemmswiglubwd":  # the down projection's row gradient of a Qwen3-8B layer + the SwiGLU backward: two launches against the fused epilogue
+        t, inter, k = int(sys.argv[2]) if len(sys.argv) > 2 else 16384, 12288, 4096
+        dy = torch.randn(t, k, device=DEV).to(torch.bfloat16)
+        wd = (torch.randn(k, inter, device=DEV) * 0.02).to(torch.bfloat16)
+        gu = torch.randn(t, 2 * inter, device=DEV).to(torch.bfloat16)
+        dact = torch.empty(t, inter, dtype=torch.bfloat16, device=DEV)
+        dgu = torch.empty(t, 2 * inter, dtype=torch.bfloat16, device=DEV)
+        wdt = wd.t().contiguous()
+        cases = {"library GEMM (K-contiguous weight copy) + pm_swiglu_bwd": lambda: ops.swiglu_bwd(torch.mm(dy, wdt.t(), out=dact), gu, out=dgu),
+                 "own GEMM + pm_swiglu_bwd": lambda: ops.swiglu_bwd(ops.gemm(dy, wd.t(), out=dact), gu, out=dgu),
+                 "own GEMM alone": lambda: ops.gemm(dy, wd.t(), out=dact), "pm_swiglu_bwd alone": lambda: ops.swiglu_bwd(dact, gu, out=dgu),
+                 "pm_gemm_swiglu_bwd_bf16 (fused epilogue)": lambda: ops.gemm_swiglu_bwd(dy, wd, gu, out=dgu)}
+        ref = ops.swiglu_bwd(ops.gemm(dy, wd.t()), gu).clone()
+        same = bool(torch.equal(ops.gemm_swiglu_bwd(dy, wd, gu, out=dgu), ref))
+        res = {k2: [] for k2 in cases}
+        for _ in range(5):
+            for name, fn in cases.items():
+                med, _ = timeit(fn, iters=5, warmup=1)
+                res[name].append(med)
+        for name, ts in res.items():
+            ts.sort()
+            out.append(dict(kernel=f"down-projection row gradient + SwiGLU backward t={t}: {name}", ms=ts[len(ts) // 2] * 1e3, bit_identical=same))
     if which == "moegemm":
         bench_moe_gemm_variants(out)
     if which == "moelayer":
