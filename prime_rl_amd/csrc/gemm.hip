@@ -530,6 +530,57 @@ __device__ __forceinline__ bool locate_row_tile(const int32_t* __restrict__ offs
   return false;
 }
 
+// The same lookup from REGISTERS.  A unit switch happens inside the K loop, where the wave has LDS-DMA loads in flight: a lookup that loads `offsets`
+// from memory waits on vmcnt(0) — i.e. for the whole staging queue — and does so twice per unit (as the next unit when the staging switches to it, as the
+// current one at its own turn); with the short contractions of expert products (12-32 K-tiles per unit) that was 1-2 us out of every 10-27.  So every wave
+// reads the offsets ONCE, when the workgroup starts: lane l of set s keeps expert 64 s + l's rows and the inclusive tile count up to it, and a lookup
+// is a ballot and three v_readlane.  Up to 64 * kTabSets experts (12 registers); more fall back to the memory form.
+constexpr int kTabSets = 4;
+struct RowTab {
+  int lo[kTabSets], hi[kTabSets], incl[kTabSets];
+  bool use;
+};
+__device__ __forceinline__ void build_row_tab(const int32_t* __restrict__ offsets, int n_experts, int lane, RowTab& rt) {
+  rt.use = n_experts <= 64 * kTabSets;
+  int base = 0;
+#pragma unroll
+  for (int s = 0; s < kTabSets; ++s) {
+    const int e = s * 64 + lane;
+    int lo = 0, hi = 0;
+    if (rt.use && e < n_experts) {
+      lo = offsets[e];
+      hi = offsets[e + 1];
+    }
+    int incl = (hi - lo + kTile - 1) / kTile;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    rt.lo[s] = lo;
+    rt.hi[s] = hi;
+    rt.incl[s] = base + incl;
+    base += __builtin_amdgcn_readlane(incl, 63);
+  }
+}
+template <int S>
+__device__ __forceinline__ bool locate_in_set(const RowTab& rt, int t, int& expert, int& row0, int& row_end) {
+  if constexpr (S >= kTabSets) {
+    return false;
+  } else {
+    const unsigned long long hit = __ballot(rt.incl[S] > t);
+    if (!hit) return locate_in_set<S + 1>(rt, t, expert, row0, row_end);
+    const int src = __ffsll((long long)hit) - 1;
+    const int lo = __builtin_amdgcn_readlane(rt.lo[S], src), hi = __builtin_amdgcn_readlane(rt.hi[S], src);
+    const int first_tile = __builtin_amdgcn_readlane(rt.incl[S], src) - (hi - lo + kTile - 1) / kTile;
+    expert = S * 64 + src;
+    row0 = lo + (t - first_tile) * kTile;
+    row_end = hi;
+    return true;
+  }
+}
+__device__ __forceinline__ bool locate_row_tile(const RowTab& rt, int t, int& expert, int& row0, int& row_end) { return locate_in_set<0>(rt, t, expert, row0, row_end); }
+
 // MODE 0: the dense product.  1: grouped forward  y[m] = x[m] . [w | w2][e(m)]^T      (x, w K-contiguous; column tiles >= n_first come from w2)
 // 2: grouped row gradient  dx[m] = dy[m, :n_first] . w[e] + dy[m, n_first:] . w2[e]   (dy K-contiguous, weights K-major; two chained parts)
 // 3: grouped weight gradient  dw[e] = dy[rows of e]^T . x[rows of e]                  (both K-major; K = the expert's row count; rows < n_first -> out, else out2)
@@ -541,7 +592,7 @@ template <int MODE>
 __device__ __forceinline__ constexpr int tile_mode() { return MODE == 5 ? 0 : MODE == 6 ? 2 : MODE; }
 
 template <int MODE, bool XK, bool WK>
-__device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, Tile& t) {
+__device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, const RowTab& rtab, Tile& t) {
   t.first = t.last = true;
   if (MODE == 0) {
     int tm, tn, kpart = 0, vv = v;
@@ -606,7 +657,7 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
     const int ncol = p.tiles_n;
     const int rt = (q / ncol) * 8 + xcd, ct = q % ncol;
     int e, row0, row_end;
-    if (!locate_row_tile(p.offsets, p.n_experts, rt, lane, e, row0, row_end)) return false;
+    if (!(rtab.use ? locate_row_tile(rtab, rt, e, row0, row_end) : locate_row_tile(p.offsets, p.n_experts, rt, lane, e, row0, row_end))) return false;
     const int c0 = ct * kTile;
     t.m_valid = row_end - row0 < kTile ? row_end - row0 : kTile;
     t.ldo = p.ldo;
@@ -640,9 +691,18 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
   }
   // MODE 3: per expert (n_dim / 256) x (k_dim / 256) tiles; X = dy [M, n_dim] K-major (M-side = n), W = x [M, k_dim] K-major (N-side = k)
   const int per = p.tiles_m * p.tiles_n;
-  const int e = (q / per) * 8 + xcd, tile = q % per;
+  const int e = __builtin_amdgcn_readfirstlane((q / per) * 8 + xcd), tile = q % per;
   if (e >= p.n_experts) return false;
-  const int lo = p.offsets[e], hi = p.offsets[e + 1];
+  // a SCALAR load (the address is uniform; hipcc emits a vector load because the kernel also stores): a vector load here makes the unit switch wait on
+  // vmcnt(0), i.e. for every LDS-DMA piece in flight (see RowTab)
+  int lo, hi;
+  {
+    typedef int int2_t __attribute__((ext_vector_type(2)));
+    int2_t lh;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lh) : "s"(p.offsets + e) : "memory");
+    lo = lh[0];
+    hi = lh[1];
+  }
   const int tmn = tile / p.tiles_n, tk = tile % p.tiles_n;
   const int n0 = tmn * kTile, k0 = tk * kTile;
   t.xb = p.x + (int64_t)lo * p.ldx + n0;
@@ -662,9 +722,9 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
 
 // the next unit of this workgroup's stream at or after (v, part); false when the stream is exhausted
 template <int MODE, bool XK, bool WK>
-__device__ __forceinline__ bool next_unit(const Params& p, int& v, int& part, int lane, Tile& t) {
+__device__ __forceinline__ bool next_unit(const Params& p, int& v, int& part, int lane, const RowTab& rtab, Tile& t) {
   for (; v < p.n_blocks;) {
-    if (tile_at<MODE, XK, WK>(p, v, part, lane, t)) return true;
+    if (tile_at<MODE, XK, WK>(p, v, part, lane, rtab, t)) return true;
     part = 0;
     v += gridDim.x;
   }
@@ -721,7 +781,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   const int wv = wave >> 2, wt = wave & 3;  // wv: which 64 W rows of a half (also the ping-pong group), wt: which 32 X rows of a half
   int v = blockIdx.x, part = 0;
   Tile cur;
-  if (!next_unit<TM, XK, WK>(p, v, part, lane, cur)) return;
+  RowTab rtab;
+  rtab.use = false;
+  if constexpr (TM == 1 || TM == 2) build_row_tab(p.offsets, p.n_experts, lane, rtab);  // the expert offsets, once, into registers
+  if (!next_unit<TM, XK, WK>(p, v, part, lane, rtab, cur)) return;
 
   Wave s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -792,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         if (t + 2 >= nk) {
           advance_unit(v_n, part_n, TM == 0 ? p.k_parts : parts_of<TM>());
           Tile nxt;
-          has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, nxt);
+          has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, rtab, nxt);
           if (has_next) {
             s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
             s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
@@ -812,7 +875,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       if (t + 2 >= nk) {  // the last pair of this unit: every half-tile staged from here on belongs to the next one
         advance_unit(v_n, part_n, TM == 0 ? p.k_parts : parts_of<TM>());
         Tile nxt;
-        has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, nxt);
+        has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, rtab, nxt);
         if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
           s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
           s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
@@ -1041,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
     }
     v = v_n;
     part = part_n;
-    tile_at<TM, XK, WK>(p, v, part, lane, cur);
+    tile_at<TM, XK, WK>(p, v, part, lane, rtab, cur);
   }  // units
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) half-tiles must have landed before this workgroup's LDS is handed on
   if (staggered && wv == 0) __builtin_amdgcn_s_barrier();
@@ -1327,7 +1390,9 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
   const int wv = wave >> 1, wt = wave & 1;
   int v = blockIdx.x, part = 0;
   Tile cur;
-  if (!next_unit<MODE, XK, WK>(p, v, part, lane, cur)) return;
+  RowTab rtab;
+  rtab.use = false;
+  if (!next_unit<MODE, XK, WK>(p, v, part, lane, rtab, cur)) return;
 
   Wave4 s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -1398,7 +1463,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
       if (t + 2 >= nk) {  // the last pair of this unit: both K-tiles staged in this iteration belong to the next one
         advance_unit(v_n, part_n, MODE == 0 ? p.k_parts : parts_of<MODE>());
         Tile nxt;
-        has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, nxt);
+        has_next = next_unit<MODE, XK, WK>(p, v_n, part_n, lane, rtab, nxt);
         if (has_next) {
           s.wr = panel_rsrc<WK>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
           s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
@@ -1528,7 +1593,7 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(const Params p) {
     if (!has_next) break;
     v = v_n;
     part = part_n;
-    tile_at<MODE, XK, WK>(p, v, part, lane, cur);
+    tile_at<MODE, XK, WK>(p, v, part, lane, rtab, cur);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) K-tiles must have landed before this workgroup's LDS is handed on
 }

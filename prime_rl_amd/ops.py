@@ -889,6 +889,12 @@ def gemm_supported(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: t
     return bool(_lib.load().pm_gemm_supported(m, n, k, int(xk), int(wk)))
 
 
+def gemm_shape_supported(m: int, n: int, k: int, x_kmajor: bool, w_kmajor: bool) -> bool:
+    """pm_gemm_supported for contiguous operands of these logical sizes (K-major = stored [K, rows]); 16-byte alignment of the bases is the caller's."""
+    ldx, ldw = (m if x_kmajor else k), (n if w_kmajor else k)
+    return ldx % 8 == 0 and ldw % 8 == 0 and n % 4 == 0 and bool(_lib.load().pm_gemm_supported(m, n, k, int(x_kmajor), int(w_kmajor)))
+
+
 _gemm_variant_word = 7  # what pm_gemm_debug_set_variant currently holds (the library's default)
 
 

@@ -243,6 +243,34 @@ class _RouterFn(torch.autograd.Function):
         return g.to(dtype), None, None, None, None, None, None
 
 
+class _GateLinearFn(torch.autograd.Function):
+    """logits = x @ w_gate^T (the router's nn.Linear, moe.py:674-680) with the weight gradient on the hand-written core: dw[E, dim] = g^T x contracts over
+    ALL tokens into 128 x 2048 outputs — 8 tiles; the library runs it without a K split on 16 workgroups (177 us at 16k tokens), the core splits the
+    contraction over the XCDs (pm_gemm_bf16_ws).  f32 accumulation, one rounding to the weight's dtype, like the library's."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.mm(x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.mm(g, w) if ctx.needs_input_grad[0] else None
+        gw = ops.gemm(g.t(), x.t(), out_dtype=torch.float32).to(w.dtype) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def _gate_linear(gate: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    w = gate.weight
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and gate.bias is None and x.is_contiguous() and torch.is_grad_enabled()
+            and w.requires_grad):
+        if ops.gemm_shape_supported(w.shape[0], w.shape[1], x.shape[0], True, True) and x.data_ptr() % 16 == 0:  # dw = g^T x: both operands token-major
+            return _GateLinearFn.apply(x, w)
+    return gate(x)
+
+
 class TokenChoiceTopKRouter(nn.Module):
     def __init__(self, dim: int, num_experts: int, top_k: int, score_func: str, route_norm: bool, route_scale: float):
         super().__init__()
@@ -256,7 +284,7 @@ class TokenChoiceTopKRouter(nn.Module):
         """-> (top_scores [N,k] f32, selected_experts_indices [N,k] i32, num_tokens_per_expert [E] i32, routing_confidence_sum)."""
         if routed_experts is not None and routed_experts.shape[-1] != self.top_k:
             raise AssertionError(f"routed_experts shape: {routed_experts.shape}, top_k: {self.top_k}")
-        logits = self.gate(x.to(torch.float32)) if self.fp32_gate else self.gate(x)
+        logits = self.gate(x.to(torch.float32)) if self.fp32_gate else _gate_linear(self.gate, x)
         forced = None if routed_experts is None else routed_experts.reshape(-1, self.top_k).to(torch.int32).contiguous()
         if forced is None and self.force_balanced:
             n = logits.shape[0]

@@ -383,7 +383,9 @@ def test_expert_parallel_dispatch_on_the_device_equals_local_experts():
 
 @pytest.mark.parametrize("e,n_out,k,sizes", [(4, 128, 128, [5, 0, 300, 128]), (8, 256, 384, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 768, 2048, [1000, 24, 513]),
                                              (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16), (5, 512, 256, [300, 0, 257, 255, 1]),
-                                             (3, 256, 768, [600, 256, 31])])
+                                             (3, 256, 768, [600, 256, 31]),
+                                             # the row-tile lookup: 200 experts = four register sets of the table, 300 = the memory form (csrc/gemm.hip RowTab)
+                                             (200, 256, 256, [3, 0, 300, 1] * 50), (300, 256, 256, [2, 0, 270] * 100)])
 @pytest.mark.parametrize("variant", [0, 1])  # 0: 256 x 256 tiles where the shape allows; 1: 128 x 128 tiles everywhere
 def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes, variant):
     """pm_grouped_gemm_nt / nn / tn vs a per-expert f32 matmul of the same bf16 operands: ragged groups, empty groups, groups that are not
@@ -525,6 +527,32 @@ def test_grouped_gemm_rejects_unsupported_shapes_loudly():
     w = torch.zeros(2, 128, 96, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(PrimeMI355XError, match="multiples of 128"):
         ops.grouped_gemm_nt(x, w, torch.tensor([0, 4, 8], dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize("n,e,dim", [(1000, 128, 256), (16384, 128, 2048), (777, 256, 384)])
+def test_router_gate_weight_gradient_on_the_own_core_matches_autograd(n, e, dim):
+    """_gate_linear (the router's nn.Linear with the split-K weight-gradient product of csrc/gemm.hip) vs the plain module under autograd: same logits bit
+    for bit (same library product), row gradient identical, weight gradient = one bf16 rounding of the f32-accumulated g^T x."""
+    from prime_rl_amd.trainer.models.layers import moe as M
+
+    torch.manual_seed(1)
+    gate = torch.nn.Linear(dim, e, bias=False).to(DEV).to(torch.bfloat16)
+    x = torch.randn(n, dim, device=DEV).to(torch.bfloat16)
+    g = torch.randn(n, e, device=DEV).to(torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = M._gate_linear(gate, xa)
+    assert ya.grad_fn is not None and "GateLinear" in type(ya.grad_fn).__name__
+    ya.backward(g)
+    gwa, gate.weight.grad = gate.weight.grad.clone(), None
+    yb = gate(xb)
+    yb.backward(g)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    ref = g.float().t() @ x.float()
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * float(ref.abs().mean())
+    assert ((gwa.float() - ref).abs() <= tol).all()
+    assert ((gate.weight.grad.float() - ref).abs() <= 2 * tol).all()  # (the library's own rounding of the same sum)
+    small = torch.nn.Linear(dim, 8, bias=False).to(DEV).to(torch.bfloat16)  # 8 experts: below the core's K-major row minimum -> the module itself
+    assert "GateLinear" not in type(M._gate_linear(small, xa).grad_fn).__name__
 
 
 def test_moe_layer_on_the_mfma_grouped_gemms_matches_the_loop_path():

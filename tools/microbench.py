@@ -442,7 +442,7 @@ def bench_moe_gemm_variants(out, variants=(7, 32773), n=16384, e=128, k=8, h=204
         out.append(rec)
 
 
-def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=5):
+def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=int(os.environ.get("PM_MOE_ITERS", "5"))):
     """One Qwen3-30B-A3B MoE layer, forward + backward (for rocprofv3 --kernel-trace)."""
     from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
 
