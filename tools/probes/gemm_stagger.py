@@ -1,4 +1,5 @@
-"""EXPERIMENT: the dense core with its workgroups started in four phases a quarter of a tile apart (schedule word bit 9) against the lock-step start, on the
+"""EXPERIMENT (measured, not adopted; the kernel hook it drove was removed again — see profiles/r05_gemm.md section 7 for the patch and the result): the dense core with its
+workgroups started in four phases a quarter of a tile apart (schedule word bit 9) against the lock-step start, on the
 products of one Qwen3-8B layer at 16 384 tokens; interleaved in one process."""
 import json
 import os
