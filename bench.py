@@ -223,19 +223,24 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
                 p_.grad = None
             layer(x).backward(gy)
 
-        fb()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+        for _ in range(3):  # (the caching allocator and the clocks settle: the first passes after the 8 B engine's step allocate fresh blocks)
             fb()
-        e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
+        per_iter = []
+        for _ in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fb()
+            e1.record()
+            e1.synchronize()
+            per_iter.append(e0.elapsed_time(e1))
+        ms = sorted(per_iter)[len(per_iter) // 2]
         flop = 3 * 3 * 2.0 * n * k * hidden_dim * inter  # three expert GEMMs, forward + two gradients each
         extra["moe_layer"] = {"shape": f"{n} tokens, {e} experts top-{k}, hidden {hidden_dim}, expert intermediate {inter} (Qwen3-30B-A3B layer), forward + backward",
-                              "ms": round(ms, 3), "expert_gemm_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1),
-                              "note": "router, stable sort, gather, grouped MFMA GEMMs (pm_grouped_gemm_nt/nn/tn on the gemm.hip core), combine; per-kernel numbers in profiles/r02_moe.md, r03_gemm.md"}
+                              "ms": round(ms, 3), "ms_mean": round(sum(per_iter) / len(per_iter), 3), "ms_min": round(min(per_iter), 3), "iters": len(per_iter),
+                              "expert_gemm_TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1),
+                              "note": "median of 12 passes (HIP events around each); router, stable sort, gather, grouped MFMA GEMMs on the gemm.hip core (the SwiGLU backward in the "
+                                      "down row gradient's epilogue, expert offsets held in registers), combine; per-kernel numbers in profiles/r05_moe_layer.md"}
         del layer, x, gy
     except Exception as ex:  # pragma: no cover
         extra["moe_layer"] = {"error": repr(ex)[:300]}
