@@ -460,6 +460,13 @@ int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf
                        int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream);
 int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
                        int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream);
+/* The experts' gate and up projections with the SwiGLU activation in the epilogue (layers/moe.py:181-182: F.silu(x @ w1^T) * (x @ w3^T); the reference runs two
+ * grouped GEMMs, silu and mul): gate_up[n_rows, 2 inter] exactly as pm_grouped_gemm_nt(w_gate, w_up) writes it and act[n_rows, inter] = pm_swiglu_fwd(gate_up),
+ * bit for bit, in one launch.  Both weight tensors [E, inter, k_dim] are read through one buffer descriptor: w_up must lie above w_gate within 2 GiB
+ * (parameters of one flat buffer do) — PM_ERR_UNSUPPORTED otherwise, and the caller keeps the two-launch form.  inter % 128 == 0, k_dim % 128 == 0. */
+int pm_grouped_gemm_nt_swiglu_supported(int64_t n_rows, int64_t inter, int64_t k_dim);
+int pm_grouped_gemm_nt_swiglu(const void* x_bf16, const void* w_gate_bf16, const void* w_up_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t inter,
+                              int64_t k_dim, void* gate_up_bf16, void* act_bf16, void* stream);
 /* The experts' down-projection row gradient with the SwiGLU backward in its epilogue (layers/moe.py:181-183 backward): grad_gate_up[m] = [d_gate | d_up] from
  * (dy[m] . w_down[e(m)]) and the saved gate_up[m]; dy [n_rows, n_dim], w_down [E, n_dim, inter], gate_up / grad_gate_up [n_rows, 2 inter] (may alias).
  * inter % 256 == 0, n_dim % 128 == 0. */

@@ -139,6 +139,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grouped_gemm_debug_set_variant": (I, [I32]),
     "pm_grouped_gemm_nt": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
     "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
+    "pm_grouped_gemm_nt_swiglu_supported": (I, [I64, I64, I64]),
+    "pm_grouped_gemm_nt_swiglu": (I, [P, P, P, P, I32, I64, I64, I64, P, P, P]),
     "pm_grouped_gemm_nn_swiglu_bwd_supported": (I, [I64, I64, I64]),
     "pm_grouped_gemm_nn_swiglu_bwd": (I, [P, P, P, I32, I64, I64, I64, P, P, P]),
     "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, P]),

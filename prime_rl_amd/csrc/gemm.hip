@@ -653,6 +653,27 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
   // grouped: block v runs on XCD v % 8; the `ncol` column tiles of one row tile (MODE 1, 2) / the tiles of one expert (MODE 3) are consecutive ids of ONE
   // XCD, so the rows they share leave HBM once
   const int xcd = v & 7, q = v >> 3;
+  if (MODE == 7) {
+    // grouped forward of the experts' gate and up projections with the SwiGLU epilogue (MODE 4's tile on MODE 1's rows): a tile = one 256-row tile of the
+    // expert-sorted rows x 128 FEATURES; W^0 = 128 rows of w[e] (gate), W^1 = the same rows of w2[e] (up) — two tensors of the same shape, so the half-tile
+    // step of the DMA is the byte distance between them (the entry point requires 0 < w2 - w < 2 GiB)
+    const int ncol = p.tiles_n;
+    const int rt = (q / ncol) * 8 + xcd, ct = q % ncol;
+    int e, row0, row_end;
+    if (!(rtab.use ? locate_row_tile(rtab, rt, e, row0, row_end) : locate_row_tile(p.offsets, p.n_experts, rt, lane, e, row0, row_end))) return false;
+    const int f0 = ct * 128;
+    t.xb = p.x + (int64_t)row0 * p.ldx;
+    t.x_rows = row_end - row0;
+    t.wb = p.w + ((int64_t)e * p.n_first + f0) * p.ldw;
+    t.w_rows = (int)((p.w2 - p.w) / p.ldw) + 128;  // rows from the panel base to the end of the up half-tile (panel_rsrc<.., false>)
+    t.k = p.k;
+    t.out = reinterpret_cast<unsigned char*>(p.out) + ((int64_t)row0 * p.ldo + f0) * 2;
+    t.ldo = p.ldo;
+    t.m_valid = row_end - row0 < kTile ? row_end - row0 : kTile;
+    t.n_valid = p.n_first + 128;
+    t.nk = k_tiles(p.k);
+    return true;
+  }
   if (MODE == 1 || MODE == 2) {
     const int ncol = p.tiles_n;
     const int rt = (q / ncol) * 8 + xcd, ct = q % ncol;
@@ -783,15 +804,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   Tile cur;
   RowTab rtab;
   rtab.use = false;
-  if constexpr (TM == 1 || TM == 2) build_row_tab(p.offsets, p.n_experts, lane, rtab);  // the expert offsets, once, into registers
+  if constexpr (TM == 1 || TM == 2 || TM == 7) build_row_tab(p.offsets, p.n_experts, lane, rtab);  // the expert offsets, once, into registers
   if (!next_unit<TM, XK, WK>(p, v, part, lane, rtab, cur)) return;
 
   Wave s;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   setup_operand<WK>(p.ldw, wave, lane, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
   if (MODE == 4) s.wstep = (int)(p.n_first * p.ldw * 2);  // W^1 = the up rows of the same features
+  if (MODE == 7) s.wstep = (int)((p.w2 - p.w) * 2);  // W^1 = the same rows of the second weight tensor
   setup_operand<XK>(p.ldx, wave, lane, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);  // the X window is the second 64 KiB of the ring
-  s.wr = panel_rsrc<WK, MODE != 4>(cur.wb, p.ldw, cur.w_rows, cur.k);
+  s.wr = panel_rsrc<WK, MODE != 4 && MODE != 7>(cur.wb, p.ldw, cur.w_rows, cur.k);
   s.xr = panel_rsrc<XK>(cur.xb, p.ldx, cur.x_rows, cur.k);
   s.piece_lds = wave * 2048;
   if (V & 16) {  // timing ablation: fragments are never read; give them defined (non-zero) contents
@@ -830,7 +852,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       setup_operand<WK>(p.ldw, wave, lane_o, wv * 64, lds0, s.vw, s.wstep, s.wk, s.aw);
-      if (MODE == 4) s.wstep = (int)(p.n_first * p.ldw * 2);
+      if (MODE == 4) s.wstep = (int)(p.n_first * p.ldw * 2);  // W^1 = the up rows of the same features
+      if (MODE == 7) s.wstep = (int)((p.w2 - p.w) * 2);
       setup_operand<XK>(p.ldx, wave, lane_o, wt * 32, lds0 + 4 * kSlot, s.vx, s.xstep, s.xk, s.ax);
     }
     // Only what the epilogue needs of `cur` stays live across the K loop; the NEXT unit is looked up at the point where the staging switches to it,
@@ -857,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
           Tile nxt;
           has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, rtab, nxt);
           if (has_next) {
-            s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+            s.wr = panel_rsrc<WK, MODE != 4 && MODE != 7>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
             s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
           }
           reset_offsets(s);
@@ -877,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         Tile nxt;
         has_next = next_unit<TM, XK, WK>(p, v_n, part_n, lane, rtab, nxt);
         if (has_next) {  // (after the last unit the stream re-stages this unit's first K-tiles: never read, drained before the kernel ends)
-          s.wr = panel_rsrc<WK, MODE != 4>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
+          s.wr = panel_rsrc<WK, MODE != 4 && MODE != 7>(nxt.wb, p.ldw, nxt.w_rows, nxt.k);
           s.xr = panel_rsrc<XK>(nxt.xb, p.ldx, nxt.x_rows, nxt.k);
         }
         reset_offsets(s);
@@ -917,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       // the output block as a buffer (bf16 results): rows >= m_valid lie past its end
       const int ldo_b = (int)cur.ldo * 2;
       const __amdgpu_buffer_rsrc_t orsrc =
-          out_rsrc(cur.out, cur.m_valid > 0 ? ((cur.m_valid - 1) * ldo_b + (MODE == 4 ? p.n_first + 128 : cur.n_valid) * 2) * (f32o ? 2 : 1) : 0);
+          out_rsrc(cur.out, cur.m_valid > 0 ? ((cur.m_valid - 1) * ldo_b + (MODE == 4 || MODE == 7 ? p.n_first + 128 : cur.n_valid) * 2) * (f32o ? 2 : 1) : 0);
       const bf16_t* bias = MODE == 0 && p.bias ? p.bias + (reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / (f32o ? 4 : 2) % p.ldo : nullptr;
       // SwiGLU-backward epilogue: the tile's block of the gate half of p.gu (same rows and columns as its block of OUT), the up halves p.n columns to the right
       int ldgu_b = 0;
@@ -934,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
       if (wide) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int ncol0 = (MODE == 4 ? i * p.n_first : i * 128) + wv * 64;  // MODE 4: the up half sits n_first columns to the right of the gate half
+          const int ncol0 = (MODE == 4 || MODE == 7 ? i * p.n_first : i * 128) + wv * 64;  // MODE 4: the up half sits n_first columns to the right of the gate half
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int mrow0 = j * 128 + wt * 32;
@@ -1035,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
             }
           }
         }
-        if constexpr (MODE == 4) {  // act[m][f0 + 64 wv + ..] = bf16(bf16(silu(gate)) * up) on the ROUNDED gate / up values (what pm_swiglu_fwd computes from OUT)
+        if constexpr (MODE == 4 || MODE == 7) {  // act[m][f0 + 64 wv + ..] = bf16(bf16(silu(gate)) * up) on the ROUNDED gate / up values (what pm_swiglu_fwd computes from OUT)
           bf16_t* act = reinterpret_cast<bf16_t*>(p.out2) + ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 / p.ldo) * p.ldo2 +
                         ((reinterpret_cast<unsigned char*>(cur.out) - reinterpret_cast<unsigned char*>(p.out)) / 2 % p.ldo);
           const int ldo2_b = (int)p.ldo2 * 2;
@@ -1772,6 +1795,19 @@ int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_
   p.tiles_m = 0; p.tiles_n = (int)(k_out / kTile);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
   launch_grouped<false, true, 2>(p, st);
+  return PM_OK;
+}
+// gate_up[m] = x[m] . [w | w2][e(m)]^T and act[m] = silu(gate) * up in ONE launch (MODE 7): x [M, K], w / w2 [E, inter, K], gate_up [M, 2 inter], act [M, inter]
+int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t inter, int64_t k_dim,
+                      bf16_t* gate_up, bf16_t* act, hipStream_t st) {
+  Params p;
+  grouped_common(p, offsets, n_experts, inter);
+  p.x = x; p.w = w; p.w2 = w2; p.out = gate_up; p.out2 = act;
+  p.ldx = k_dim; p.ldw = k_dim; p.ldo = 2 * inter; p.ldo2 = inter;
+  p.m = (int)n_rows; p.n = (int)(2 * inter); p.k = (int)k_dim;
+  p.tiles_m = 0; p.tiles_n = (int)(inter / 128);
+  p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
+  launch_grouped<false, false, 7>(p, st);
   return PM_OK;
 }
 // [d_gate | d_up][m] = SwiGLU'(gate_up[m]) applied to (dy[m] . w[e]) : dy [M, n_dim], w [E, n_dim, inter] (the experts' down projection), gate_up and

@@ -620,6 +620,8 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
                int out_f32, int accumulate, hipStream_t st);
 int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
                           const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st);
+int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t inter, int64_t k_dim,
+                      bf16_t* gate_up, bf16_t* act, hipStream_t st);
 }  // namespace gm
 }  // namespace pm
 
@@ -684,6 +686,32 @@ extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const
   hipLaunchKernelGGL(gg::grouped_nn_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets,
                      n_experts, n_rows, (int)n_first, (int)n_dim, (int)k_out, (bf16_t*)dx_bf16);
   PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
+  return PM_OK;
+}
+
+// gate_up[m] = x[m] . [w_gate | w_up][e(m)]^T and act[m] = silu(gate) * up in one launch (moe.py:181-182: F.silu(x @ w1^T) * (x @ w3^T)): the grouped
+// gate|up forward with pm_swiglu_fwd in its epilogue — gate_up equals pm_grouped_gemm_nt(w, w2), act equals pm_swiglu_fwd(gate_up), bit for bit.  The two weight
+// tensors are read through ONE buffer descriptor (the up half-tile = the gate half-tile's address + the distance between the tensors), so w_up must lie
+// above w_gate within 2 GiB (parameters of one flat buffer do; PM_ERR_UNSUPPORTED otherwise — the caller keeps the two-launch form).
+extern "C" int pm_grouped_gemm_nt_swiglu_supported(int64_t n_rows, int64_t inter, int64_t k_dim) {
+  return inter > 0 && k_dim > 0 && inter % 128 == 0 && k_dim % 128 == 0 && gg_shapes_ok(n_rows, 2 * inter, k_dim) ? 1 : 0;
+}
+
+extern "C" int pm_grouped_gemm_nt_swiglu(const void* x_bf16, const void* w_gate_bf16, const void* w_up_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
+                                         int64_t inter, int64_t k_dim, void* gate_up_bf16, void* act_bf16, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt_swiglu: bad sizes");
+  PM_REQUIRE(w_gate_bf16 && w_up_bf16 && offsets && (n_rows == 0 || (x_bf16 && gate_up_bf16 && act_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt_swiglu: null pointer");
+  PM_REQUIRE(pm_grouped_gemm_nt_swiglu_supported(n_rows, inter, k_dim), PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_nt_swiglu: needs inter %% 128 == 0 and k %% 128 == 0 (inter %lld, k %lld; row tensors < 2 GiB)", (long long)inter, (long long)k_dim);
+  const int64_t delta = (const unsigned char*)w_up_bf16 - (const unsigned char*)w_gate_bf16;
+  const int64_t span = delta + ((int64_t)n_experts * inter) * k_dim * 2;  // from w_gate[0] to the end of w_up: what one descriptor must be able to address from any panel base
+  PM_REQUIRE(delta > 0 && delta % 16 == 0 && delta + 128 * k_dim * 2 < ((int64_t)1 << 31) - 4096, PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_nt_swiglu: w_up must lie above w_gate within 2 GiB (distance %lld bytes)", (long long)delta);
+  (void)span;
+  if (n_rows == 0) return PM_OK;
+  gm::grouped_nt_swiglu((const bf16_t*)x_bf16, (const bf16_t*)w_gate_bf16, (const bf16_t*)w_up_bf16, offsets, n_experts, n_rows, inter, k_dim, (bf16_t*)gate_up_bf16,
+                        (bf16_t*)act_bf16, as_stream(stream));
+  PM_CHECK_LAUNCH("pm_grouped_gemm_nt_swiglu");
   return PM_OK;
 }
 

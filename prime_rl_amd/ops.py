@@ -770,6 +770,34 @@ def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = 
     return dx
 
 
+def grouped_gemm_nt_swiglu_supported(x: Tensor, w_gate: Tensor, w_up: Tensor) -> bool:
+    """Can `grouped_gemm_nt_swiglu` take these operands?  Shapes (inter % 128, K % 128) and the placement of the two weight tensors: one buffer descriptor
+    reads both, so w_up must start above w_gate within 2 GiB."""
+    if w_gate.dim() != 3 or tuple(w_gate.shape) != tuple(w_up.shape) or x.dim() != 2 or x.shape[1] != w_gate.shape[2]:
+        return False
+    if not (x.is_cuda and x.dtype == w_gate.dtype == w_up.dtype == torch.bfloat16 and x.is_contiguous() and w_gate.is_contiguous() and w_up.is_contiguous()):
+        return False
+    delta = w_up.data_ptr() - w_gate.data_ptr()
+    if delta <= 0 or delta % 16 or delta + 128 * w_gate.shape[2] * 2 >= 2**31 - 4096:
+        return False
+    return bool(_lib.load().pm_grouped_gemm_nt_swiglu_supported(x.shape[0], w_gate.shape[1], w_gate.shape[2]))
+
+
+def grouped_gemm_nt_swiglu(x: Tensor, w_gate: Tensor, w_up: Tensor, offsets: Tensor) -> tuple[Tensor, Tensor]:
+    """(gate_up [M, 2 inter], act [M, inter]) = (x[m] @ [w_gate | w_up][e(m)].T, silu(gate) * up) in one launch — equal to grouped_gemm_nt(x, w_gate, offsets,
+    w2=w_up) and swiglu_fwd of it, bit for bit."""
+    lib = _lib.load()
+    _gg_check(x, w_gate, offsets, "x")
+    if not grouped_gemm_nt_swiglu_supported(x, w_gate, w_up):
+        raise PrimeMI355XError(f"grouped_gemm_nt_swiglu: unsupported operands x {tuple(x.shape)}, w {tuple(w_gate.shape)} / {tuple(w_up.shape)} "
+                               f"(w_up - w_gate = {w_up.data_ptr() - w_gate.data_ptr()} bytes)")
+    e, inter, k = w_gate.shape
+    gate_up = torch.empty((x.shape[0], 2 * inter), dtype=torch.bfloat16, device=x.device)
+    act = torch.empty((x.shape[0], inter), dtype=torch.bfloat16, device=x.device)
+    check(lib.pm_grouped_gemm_nt_swiglu(_p(x), _p(w_gate), _p(w_up), _p(offsets), e, x.shape[0], inter, k, _p(gate_up), _p(act), _stream()), "pm_grouped_gemm_nt_swiglu")
+    return gate_up, act
+
+
 def grouped_gemm_nn_swiglu_bwd_supported(n_rows: int, n_dim: int, inter: int) -> bool:
     return bool(_lib.load().pm_grouped_gemm_nn_swiglu_bwd_supported(n_rows, n_dim, inter))
 

@@ -140,8 +140,11 @@ class _GroupedFFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, w3, offsets):
-        gate_up = ops.grouped_gemm_nt(x, w1, offsets, w2=w3)
-        h = ops.swiglu_fwd(gate_up)
+        if ops.grouped_gemm_nt_swiglu_supported(x, w1, w3):  # (w3 above w1 within 2 GiB: parameters of a trainer's flat buffer are)
+            gate_up, h = ops.grouped_gemm_nt_swiglu(x, w1, w3, offsets)
+        else:
+            gate_up = ops.grouped_gemm_nt(x, w1, offsets, w2=w3)
+            h = ops.swiglu_fwd(gate_up)
         ctx.save_for_backward(x, w1, w2, w3, offsets, gate_up, h)
         ctx.main_grads_13, ctx.main_grads_2 = _main_grads(w1, w3), _main_grads(w2)
         return ops.grouped_gemm_nt(h, w2, offsets)
@@ -208,6 +211,19 @@ class GroupedExperts(nn.Module):
         self.use_grouped_mm = use_grouped_mm
         # "auto": the MFMA kernels when the shapes are multiples of 128 (every production MoE), else the library; "hip" / "torch" force one
         self.grouped_impl = "auto"
+
+    def _apply(self, fn, *args, **kwargs):
+        """After any `.to(device)` / `.bfloat16()`: keep w3 directly above w1 in ONE allocation, so that the grouped gate|up forward can read both through one
+        buffer descriptor and run SwiGLU in its epilogue (ops.grouped_gemm_nt_swiglu; a trainer engine that re-homes the parameters in its flat buffer keeps
+        that order by construction).  The parameters stay separate `nn.Parameter`s with the reference's names and shapes."""
+        super()._apply(fn, *args, **kwargs)
+        w1, w3 = self.w1, self.w3
+        if w1.is_cuda and w1.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and w1.shape == w3.shape and w1.device == w3.device and w1.numel() > 0 \
+                and w3.data_ptr() - w1.data_ptr() != w1.numel() * w1.element_size():
+            with torch.no_grad():
+                both = torch.stack([w1.detach(), w3.detach()])
+                self.w1.data, self.w3.data = both[0], both[1]
+        return self
 
     def forward(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
         """x: rows sorted by (local) expert; offsets [E_local + 1] i32 on the device."""

@@ -466,6 +466,27 @@ def test_grouped_row_gradient_with_swiglu_backward_epilogue_equals_two_launches(
     assert not ops.grouped_gemm_nn_swiglu_bwd_supported(m, n_dim, inter + 128)  # inter must be a multiple of 256
 
 
+@pytest.mark.parametrize("e,inter,k,sizes", [(4, 128, 128, [5, 0, 300, 128]), (8, 768, 2048, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 384, 256, [600, 256, 31]),
+                                             (2, 256, 256, [0, 0]), (200, 128, 128, [3, 0, 300, 1] * 50)])
+def test_grouped_gate_up_forward_with_swiglu_epilogue_equals_two_launches(e, inter, k, sizes):
+    """pm_grouped_gemm_nt_swiglu: gate_up = pm_grouped_gemm_nt(x, w_gate, w_up) and act = pm_swiglu_fwd(gate_up), bit for bit; the two weight tensors are read
+    through one descriptor, so the op is offered only when w_up lies above w_gate within 2 GiB."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(e * 10 + inter)
+    m = sum(sizes)
+    offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    both = (torch.randn(2, e, inter, k, generator=g) * 0.1).to(torch.bfloat16).to(DEV)  # one allocation: w_up directly above w_gate
+    w_gate, w_up = both[0], both[1]
+    assert ops.grouped_gemm_nt_swiglu_supported(x, w_gate, w_up)
+    assert not ops.grouped_gemm_nt_swiglu_supported(x, w_up, w_gate)  # the other way round: the caller keeps the two-launch form
+    gate_up, act = ops.grouped_gemm_nt_swiglu(x, w_gate, w_up, offsets)
+    if m:
+        ref = ops.grouped_gemm_nt(x, w_gate, offsets, w2=w_up)
+        assert torch.equal(gate_up, ref)
+        assert torch.equal(act, ops.swiglu_fwd(ref))
+
+
 def test_expert_ffn_as_one_autograd_node_equals_the_two_node_form():
     """_GroupedFFNFn (fused SwiGLU backward) vs _GroupedLinearFn(_GroupedSwiGLUFn(x)): outputs and all four gradients identical."""
     from prime_rl_amd.trainer.models.layers import moe as M
@@ -478,10 +499,12 @@ def test_expert_ffn_as_one_autograd_node_equals_the_two_node_form():
     x0, w10, w20, w30, gy = mk(m, dim), mk(e, hidden, dim, s=0.1), mk(e, dim, hidden, s=0.1), mk(e, hidden, dim, s=0.1), mk(m, dim)
     outs = []
     for fused in (True, False):
-        x, w1, w2, w3 = (t.clone().requires_grad_(True) for t in (x0, w10, w20, w30))
+        x, w2 = (t.clone().requires_grad_(True) for t in (x0, w20))
+        w13 = torch.stack([w10, w30]).requires_grad_(True)  # one allocation (w3 above w1): the fused gate|up forward is used as well
+        w1, w3 = w13[0], w13[1]
         y = M._GroupedFFNFn.apply(x, w1, w2, w3, offsets) if fused else M._GroupedLinearFn.apply(M._GroupedSwiGLUFn.apply(x, w1, w3, offsets), w2, offsets)
         y.backward(gy)
-        outs.append((y.detach(), x.grad, w1.grad, w2.grad, w3.grad))
+        outs.append((y.detach(), x.grad, w13.grad, w2.grad))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
 

@@ -459,7 +459,10 @@ def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=int(os.e
         layer(x).backward(gy)
 
     med, _ = timeit(fb, iters=iters, warmup=2)
-    out.append(dict(kernel=f"MoE layer fwd+bwd [{n} tokens, {e} experts top-{k}, {h}/{hidden}]", ms=med * 1e3))
+    ex = layer.experts
+    out.append(dict(kernel=f"MoE layer fwd+bwd [{n} tokens, {e} experts top-{k}, {h}/{hidden}]", ms=med * 1e3,
+                    fused_gate_up_forward=bool(ops.grouped_gemm_nt_swiglu_supported(x.detach().reshape(-1, h), ex.w1, ex.w3)),
+                    w3_minus_w1_bytes=ex.w3.data_ptr() - ex.w1.data_ptr()))
 
 
 def bench_moe_step(out, layers=8, n_mb=8, seq=2048, steps=3):
