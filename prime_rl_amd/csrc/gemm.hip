@@ -539,6 +539,7 @@ constexpr int kTabSets = 4;
 struct RowTab {
   int lo[kTabSets], hi[kTabSets], incl[kTabSets];
   bool use;
+  int g0, g1;  // MODE 3: this workgroup's XCD owns tiles [g0, g1) of the tile line (expert-major, tiles_m * tiles_n per expert): build_wgrad_range
 };
 __device__ __forceinline__ void build_row_tab(const int32_t* __restrict__ offsets, int n_experts, int lane, RowTab& rt) {
   rt.use = n_experts <= 64 * kTabSets;
@@ -562,6 +563,53 @@ __device__ __forceinline__ void build_row_tab(const int32_t* __restrict__ offset
     rt.incl[s] = base + incl;
     base += __builtin_amdgcn_readlane(incl, 63);
   }
+}
+// MODE 3 (grouped weight gradient): the contraction length of a tile is its expert's ROW COUNT, so tiles differ in cost by the routing's imbalance (a hot
+// expert of a fresh model: 10x the mean).  "Expert e on XCD e % 8" then makes one XCD finish long after the others.  Instead the tile line (expert-major,
+// `per` tiles per expert, cost of a tile = its K-tile count) is cut into 8 contiguous pieces of equal COST, one per XCD: an expert's tiles stay together
+// (its two row panels stay in one L2) except where a cut falls, and with balanced routing the pieces are the 16-expert blocks they always were.  g(B) = the
+// first tile that starts at or after cost position B; computed once per wave when the workgroup starts (one scan over the offsets, nothing kept but g0, g1).
+template <int S>
+__device__ __forceinline__ void first_tile_at(const int (&incl)[kTabSets], const int (&nkv)[kTabSets], int per, long long pos, int n_experts, int& g) {
+  if constexpr (S >= kTabSets) {
+    g = per * n_experts;
+  } else {
+    const unsigned long long hit = __ballot((long long)per * incl[S] > pos);
+    if (!hit) {
+      first_tile_at<S + 1>(incl, nkv, per, pos, n_experts, g);
+    } else {
+      const int src = __ffsll((long long)hit) - 1;
+      const int nk = __builtin_amdgcn_readlane(nkv[S], src);
+      const long long start = (long long)per * (__builtin_amdgcn_readlane(incl[S], src) - nk);  // cost position of the expert's first tile
+      g = per * (S * 64 + src) + (int)((pos - start + nk - 1) / nk);
+    }
+  }
+}
+__device__ __forceinline__ void build_wgrad_range(const int32_t* __restrict__ offsets, int n_experts, int per, int lane, int xcd, RowTab& rt) {
+  rt.use = n_experts <= 64 * kTabSets;
+  rt.g0 = rt.g1 = 0;
+  if (!rt.use) return;
+  int incl[kTabSets], nkv[kTabSets];
+  int base = 0;
+#pragma unroll
+  for (int s = 0; s < kTabSets; ++s) {
+    const int e = s * 64 + lane;
+    int nk = 0;
+    if (e < n_experts) nk = k_tiles(offsets[e + 1] - offsets[e]);
+    int sum = nk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(sum, o, 64);
+      if (lane >= o) sum += up;
+    }
+    nkv[s] = nk;
+    incl[s] = base + sum;
+    base += __builtin_amdgcn_readlane(sum, 63);
+  }
+  const long long total = (long long)per * base;
+  first_tile_at<0>(incl, nkv, per, total * xcd / 8, n_experts, rt.g0);
+  first_tile_at<0>(incl, nkv, per, total * (xcd + 1) / 8, n_experts, rt.g1);
+  if (xcd == 7) rt.g1 = per * n_experts;
 }
 template <int S>
 __device__ __forceinline__ bool locate_in_set(const RowTab& rt, int t, int& expert, int& row0, int& row_end) {
@@ -712,8 +760,17 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
   }
   // MODE 3: per expert (n_dim / 256) x (k_dim / 256) tiles; X = dy [M, n_dim] K-major (M-side = n), W = x [M, k_dim] K-major (N-side = k)
   const int per = p.tiles_m * p.tiles_n;
-  const int e = __builtin_amdgcn_readfirstlane((q / per) * 8 + xcd), tile = q % per;
-  if (e >= p.n_experts) return false;
+  int e, tile;
+  if (rtab.use) {  // this XCD's piece of the cost-balanced tile line (see build_wgrad_range)
+    const int g = rtab.g0 + q;
+    if (g >= rtab.g1) return false;
+    e = __builtin_amdgcn_readfirstlane(g / per);
+    tile = g % per;
+  } else {  // more experts than the table holds: expert e on XCD e % 8
+    e = __builtin_amdgcn_readfirstlane((q / per) * 8 + xcd);
+    tile = q % per;
+    if (e >= p.n_experts) return false;
+  }
   // a SCALAR load (the address is uniform; hipcc emits a vector load because the kernel also stores): a vector load here makes the unit switch wait on
   // vmcnt(0), i.e. for every LDS-DMA piece in flight (see RowTab)
   int lo, hi;
@@ -746,9 +803,11 @@ template <int MODE, bool XK, bool WK>
 __device__ __forceinline__ bool next_unit(const Params& p, int& v, int& part, int lane, const RowTab& rtab, Tile& t) {
   for (; v < p.n_blocks;) {
     if (tile_at<MODE, XK, WK>(p, v, part, lane, rtab, t)) return true;
+    if (MODE == 3 && rtab.use) break;  // the XCD's piece of the tile line is contiguous: the first miss is its end
     part = 0;
     v += gridDim.x;
   }
+  v = p.n_blocks;
   return false;
 }
 __device__ __forceinline__ void advance_unit(int& v, int& part, int parts) {
@@ -805,6 +864,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   RowTab rtab;
   rtab.use = false;
   if constexpr (TM == 1 || TM == 2 || TM == 7) build_row_tab(p.offsets, p.n_experts, lane, rtab);  // the expert offsets, once, into registers
+  if constexpr (TM == 3) build_wgrad_range(p.offsets, p.n_experts, p.tiles_m * p.tiles_n, lane, blockIdx.x & 7, rtab);
   if (!next_unit<TM, XK, WK>(p, v, part, lane, rtab, cur)) return;
 
   Wave s;
@@ -1836,7 +1896,9 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
   p.ldx = n_dim; p.ldw = k_dim; p.ldo = k_dim;
   p.m = (int)n_dim; p.n = (int)k_dim; p.k = 0;
   p.tiles_m = (int)(n_dim / kTile); p.tiles_n = (int)(k_dim / kTile);
-  p.n_blocks = (int)(cdiv(n_experts, 8) * 8 * p.tiles_m * p.tiles_n);
+  // virtual ids: 8 XCD slots x the longest piece an XCD can own.  Up to 256 experts the tile line is cut by cost (build_wgrad_range) and a piece may hold
+  // (nearly) all tiles; a workgroup stops at the first miss, so the surplus ids cost nothing.  More experts: expert e on XCD e % 8.
+  p.n_blocks = (int)((n_experts <= 256 ? (int64_t)n_experts : cdiv(n_experts, 8)) * 8 * p.tiles_m * p.tiles_n);
   launch_grouped<true, true, 3>(p, st);
   return PM_OK;
 }

@@ -385,7 +385,9 @@ def test_expert_parallel_dispatch_on_the_device_equals_local_experts():
                                              (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16), (5, 512, 256, [300, 0, 257, 255, 1]),
                                              (3, 256, 768, [600, 256, 31]),
                                              # the row-tile lookup: 200 experts = four register sets of the table, 300 = the memory form (csrc/gemm.hip RowTab)
-                                             (200, 256, 256, [3, 0, 300, 1] * 50), (300, 256, 256, [2, 0, 270] * 100)])
+                                             (200, 256, 256, [3, 0, 300, 1] * 50), (300, 256, 256, [2, 0, 270] * 100),
+                                             # imbalanced routing: the weight gradient's tile line is cut into 8 XCD pieces by COST (build_wgrad_range)
+                                             (16, 256, 256, [5000, 3, 0, 17] * 4), (9, 512, 256, [0, 0, 0, 0, 0, 0, 0, 0, 4096]), (128, 256, 256, [0] * 127 + [700])])
 @pytest.mark.parametrize("variant", [0, 1])  # 0: 256 x 256 tiles where the shape allows; 1: 128 x 128 tiles everywhere
 def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes, variant):
     """pm_grouped_gemm_nt / nn / tn vs a per-expert f32 matmul of the same bf16 operands: ragged groups, empty groups, groups that are not
