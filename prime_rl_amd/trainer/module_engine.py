@@ -141,6 +141,18 @@ class ModuleEngine:
                 if id(p) in direct_ids and p.dtype == torch.bfloat16:
                     p.main_grad, p.main_grad_written = gv, [False]
                     self._direct.append(p)
+        # The optimizer launch zeroes the gradient it has consumed (zero_grad fused into the update) — except over DIRECT parameters: their first
+        # weight-gradient launch of a step OVERWRITES the slice, so a zero written there (4 of the update's 34 bytes per parameter, over 97 % of an MoE
+        # model) is never read.  Spans of consecutive entries of one kind, in flat-buffer order: (start, end, zero_grad).
+        direct_ids = {id(p) for p in self._direct}
+        self._update_spans: list[tuple[int, int, bool]] = []
+        for i, (pname, p, off) in enumerate(self.entries):
+            end = self.entries[i + 1][2] if i + 1 < len(self.entries) else self.total
+            zero = id(p) not in direct_ids
+            if self._update_spans and self._update_spans[-1][2] == zero:
+                self._update_spans[-1] = (self._update_spans[-1][0], end, zero)
+            else:
+                self._update_spans.append((off if self._update_spans else 0, end, zero))
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
         self._param_readers: list = []
 
@@ -268,6 +280,10 @@ class ModuleEngine:
             for (pname, p, off), gv in zip(self.entries, self._grad_views):
                 if p.grad is None:
                     continue
+                st = getattr(p, "main_grad_written", None)
+                if st is not None and not st[0]:  # a direct parameter whose gradient came through autograd after all (a shape the f32-writing GEMM does not
+                    gv.zero_()                    # take): its slice is not zeroed by the optimizer launch (_update_spans) and still holds the consumed gradient
+                    st[0] = True
                 if p.grad.dtype == torch.bfloat16 and p.numel() % 8 == 0:
                     ops.grad_accumulate(gv.view(-1), p.grad.contiguous().view(-1))
                 else:
@@ -282,6 +298,9 @@ class ModuleEngine:
                 torch.cuda.current_stream().wait_event(ev)
         self._param_readers.clear()
         nr, g = self.n_replicated, self.main_grad
+        for p in self._direct:  # a direct parameter no backward pass of this step wrote (unused / frozen path): its slice still holds the previous step's gradient
+            if not p.main_grad_written[0]:
+                p.main_grad.zero_()
         if self.dp_size > 1:
             if nr:
                 dist.all_reduce(g[:nr], op=dist.ReduceOp.SUM, group=self.dp_group)
@@ -297,10 +316,11 @@ class ModuleEngine:
         total = self._sumsq.sum().reshape(1)
         o = self.optim
         coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)
-        zero.apply_update(ops, o, self.master, self.exp_avg if self.exp_avg.numel() else None, self.exp_avg_sq if self.exp_avg_sq.numel() else None, g,
-                          self.params_bf16, self.step_count, coef, zero_grad=True)
+        for a, b, zero_grad in self._update_spans:
+            zero.apply_update(ops, o, self.master[a:b], self.exp_avg[a:b] if self.exp_avg.numel() else None, self.exp_avg_sq[a:b] if self.exp_avg_sq.numel() else None,
+                              g[a:b], self.params_bf16[a:b], self.step_count, coef, zero_grad=zero_grad)
         for p in self._direct:
-            p.main_grad_written[0] = False  # the buffer is zero again: the next step's first weight-gradient launch may overwrite
+            p.main_grad_written[0] = False  # consumed: the next step's first weight-gradient launch overwrites the slice (it is NOT zeroed, see _update_spans)
         return norm
 
     def step(self, batch: PackedBatch | list[PackedBatch]) -> dict:

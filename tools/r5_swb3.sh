@@ -1,7 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 O=gpurun_out/r5swb; mkdir -p $O
-timeout 900 python -m pytest tests/test_moe_gpu.py tests/test_module_engine_gpu.py -q -x > $O/pytest_moe.txt 2>&1; grep -E "passed|failed|Error|assert" $O/pytest_moe.txt | head -20
-timeout 300 python tools/probes/moe_wgrad_f32.py 2>&1 | grep -v "^\[W"
-PM_MOE_ITERS=30 timeout 300 python tools/microbench.py moelayer 2>&1 | grep -v "^\[W" | tee -a $O/moelayer7.txt
-timeout 600 python tools/microbench.py moestep 2>&1 | grep -v "^\[W" | tee -a $O/moestep7.txt
+timeout 1200 python -m pytest tests/test_moe_gpu.py tests/test_module_engine_gpu.py tests/test_multirank_one_gpu.py -q -x > $O/pytest_moe.txt 2>&1; grep -E "passed|failed|Error|assert" $O/pytest_moe.txt | head -20
+timeout 600 python tools/microbench.py moestep 2>&1 | grep -v "^\[W" | tee -a $O/moestep8.txt
