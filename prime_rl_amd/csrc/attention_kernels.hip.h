@@ -225,6 +225,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
     }
   }
   // k-step outermost: the 2 * KVB * QT/16 accumulators of one batch are independent, so consecutive MFMAs never wait for each other
+  __builtin_amdgcn_s_setprio(1);  // (as in fwd_tile: the matrix phases win the issue slot over the partner wave's exp stream; backward 1.017 -> 0.994 ms)
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     u32x4 qa[QT / 16], da[QT / 16];
@@ -243,6 +244,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
         dp[b][nb] = mfma16(da[nb], vf[b][kk], dp[b][nb]);
       }
   }
+  __builtin_amdgcn_s_setprio(0);
   if (full) {
 #pragma unroll
     for (int b = 0; b < KVB; ++b)
@@ -271,6 +273,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
         }
     }
   }
+  __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int h = 0; h < QT / 32; ++h) {  // 32-row halves of the q tile: one packed P / dS operand per kv block each
     u32x4 pb[KVB], sb[KVB];
@@ -298,6 +301,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
         }
     }
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // The two LDS buffers are two distinct static arrays and the tile loop is unrolled by two, on purpose: hipcc guards every
@@ -758,10 +762,16 @@ __device__ __forceinline__ void fwd_pv(const unsigned char* smV, int bt, const f
 template <int OPT, int CB = 2>  // CB = 16-row q blocks per wave (2: the shipped 4-wave kernel; 1: the 8-wave build)
 __device__ __forceinline__ void fwd_tile(const unsigned char* sm, int kv0, int q0, float sc2, int bq, int bt, int lq, const u32x4 (&qf)[CB][4],
                                          const int (&qi)[CB], const int (&lo)[CB], float (&m)[CB], float (&l)[CB], f32x4 (&ot)[CB][8]) {
+  // s_setprio 1 around the two matrix phases: with two waves per SIMD, the wave that is issuing MFMAs wins the issue slot over the partner's exp / pack
+  // stream, so the matrix pipe is not left waiting behind VALU work (forward 0.354 -> 0.333 ms at 16k tokens, bit-identical; profiles/r05_attention.md)
   f32x4 st[CB][4];
+  __builtin_amdgcn_s_setprio(1);
   fwd_qk<CB>(sm, bq, qf, st);
+  __builtin_amdgcn_s_setprio(0);
   fwd_softmax<OPT, CB>(kv0, q0, sc2, lq, qi, lo, m, l, st, ot);
+  __builtin_amdgcn_s_setprio(1);
   fwd_pv<CB>(sm + 64 * kD * 2, bt, st, ot);
+  __builtin_amdgcn_s_setprio(0);
 }
 
 template <int MINW, int OPT = 0, int CB = 2, int NW = 4>
