@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+DETAIL_DIR = ROOT / "gpurun_out"  # verbose blocks (notes, per-leg parity tables) go to side files here; the JSON line keeps scalars
 HBM_PEAK_BPS = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK = 2.5e15
 
@@ -69,6 +70,14 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
                             "note": "reference benchmark default batch (run_single_benchmark.py:91,187); same engine, same build, measured after the headline"}
     except Exception as e:  # pragma: no cover
         extra["mb2"] = {"error": repr(e)[:300]}
+    # -- BASELINE.json configs[4]: 32 768-token rollouts through the SAME engine with block-level recomputation (VERDICT r5 'next' 3) ---------------------
+    try:
+        if rank == 0 and world == 1 and getattr(args, "long_context", True) and dims.head_dim == dims.kernel_head_dim:
+            extra["long_context"] = long_context_extra(engine, dims, device)
+    except Exception as e:  # pragma: no cover
+        extra["long_context"] = {"error": repr(e)[:300]}
+    finally:
+        torch.cuda.empty_cache()
     # -- the GEMM routing of rounds 3-4 on the SAME engine: library (hipBLASLt) forward + dgrad on [in, out] weight copies, own weight gradients --------
     # (VERDICT r4 'next' 1: "add config.extra.all_own so the hand-written-only step is driver-measured".  Since round 5 the hand-written-only step IS
     # the headline (PM_GEMM_OWN=all); `all_own` repeats its numbers under the name the review asked for and `library_mix` times the old default next to it.)
@@ -249,6 +258,83 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
     return extra
 
 
+def long_context_extra(engine, dims, device, seq: int = 32768, rollouts=(1, 4), steps: int = 2) -> dict:
+    """BASELINE.json configs[4] (32k-token agentic rollouts) on ONE GPU, driver-visible: the policy-update step of the SAME engine on `r` rollouts of `seq`
+    tokens (one document per pass: the causal attention of a pass is seq^2 / 2 per head), `recompute="layer"` (the reference's default model.ac; at 32k
+    tokens the kept activations of 36 layers would be ~140 GB per pass).  Reports ms per step, samples/s, MFU by the reference formula
+    (trainer/perf.py:177-213: 12 L H q T counts the attention as 3 dense N^2 passes) AND by the FLOPs the step executes (causal half; forward twice under
+    recomputation), the attention kernels' share of the step (their stand-alone time at this shape x launches / step time; the kernel trace of the same
+    step is profiles/r06_bench_32k.md), and the peak HBM bytes.  Context-parallel variants (utils/cp.py:140-190, ring_attn.py:99-280) need > 1 GPU:
+    correctness at world 2 on a shared GPU is tests/test_multirank_one_gpu.py."""
+    from prime_rl_amd import ops
+    from prime_rl_amd.trainer.engine import pack_micro_batches
+    from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+    res: dict = {"seq_len": seq, "recompute": "layer"}
+    old = engine.recompute
+    engine.recompute = "layer"
+    try:
+        # the attention kernels stand-alone at this shape (one 32k-token document, all heads)
+        hq, hkv, hd = dims.num_attention_heads, dims.num_key_value_heads, dims.kernel_head_dim
+        q = torch.randn(seq, hq, hd, device=device).to(torch.bfloat16)
+        k = torch.randn(seq, hkv, hd, device=device).to(torch.bfloat16)
+        v = torch.randn(seq, hkv, hd, device=device).to(torch.bfloat16)
+        do = torch.randn(seq, hq, hd, device=device).to(torch.bfloat16)
+        ss = torch.zeros(seq, dtype=torch.int32, device=device)
+        scale = hd**-0.5
+
+        def timed(fn, reps=3):
+            fn()
+            evs = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            return sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+
+        o, lse = ops.attn_varlen_fwd(q, k, v, ss, scale)
+        t_f = timed(lambda: ops.attn_varlen_fwd(q, k, v, ss, scale))
+        t_b = timed(lambda: ops.attn_varlen_bwd(do, q, k, v, o, lse, ss, scale))
+        causal_fwd = 2.0 * seq * seq * hq * dims.head_dim  # QK^T + PV, causal half (SURVEY 8d)
+        res["attn_fwd_ms"], res["attn_bwd_ms"] = round(t_f, 3), round(t_b, 3)
+        res["attn_fwd_frac_of_2.5PF"] = round(causal_fwd / (t_f * 1e-3) / MFMA_BF16_PEAK, 4)
+        res["attn_bwd_frac_of_2.5PF"] = round(2.5 * causal_fwd / (t_b * 1e-3) / MFMA_BF16_PEAK, 4)
+        del q, k, v, do, o, lse
+        L = dims.num_hidden_layers
+        for r in rollouts:
+            try:
+                dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=r), seq_len=seq)
+                bs = [[pack_micro_batches([mb], device) for mb in dl.get_batch()] for _ in range(steps + 1)]
+                torch.cuda.reset_peak_memory_stats()
+                engine.step(bs[0])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in bs[1:]:
+                    engine.step(b)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                tok = r * seq
+                ref_flops = dims.flops_per_token(seq) * tok
+                mm = dims.active_mm_params()
+                head = dims.vocab_size * dims.hidden_size
+                executed = (8.0 * (mm - head) + 6.0 * head) * tok + r * L * (2 + 2.5) * causal_fwd  # layers: fwd + recomputed fwd + 2 x bwd; head: no recompute
+                attn_ms = r * L * (2 * t_f + t_b)
+                res[f"r{r}"] = {"rollouts": r, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(r / dt, 4), "tokens_per_s": round(tok / dt, 1),
+                                "mfu_ref_formula": round(ref_flops / dt / MFMA_BF16_PEAK, 4), "mfu_executed_causal": round(executed / dt / MFMA_BF16_PEAK, 4),
+                                "attention_ms": round(attn_ms, 2), "attention_share": round(attn_ms / (dt * 1e3), 4),
+                                "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+                del bs
+            except Exception as e:  # pragma: no cover
+                res[f"r{r}"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+    finally:
+        engine.recompute = old
+    return res
+
+
 def moe_step_extra(device, layers: int = 8, n_mb: int = 8, seq: int = 2048, steps: int = 3) -> dict:
     """BASELINE.json configs[3] on one GPU, driver-visible (VERDICT r4 'next' 4): the module-engine trainer step (trainer/module_engine.py: forward + loss +
     backward + clip + fused AdamW) of a Qwen3-30B-A3B-width model cut to `layers` of its 48 layers — the full model needs the expert-parallel node (30.5 B
@@ -357,20 +443,27 @@ def parity_block(probe: dict, dims, seq_len: int) -> dict:
     return out
 
 
-def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, prompt_len: int = 256, temperature: float = 0.25, stale_sigma: float = 0.3) -> dict:
-    """ONE extra, untimed forward + loss of the LIVE engine (the weights the timed steps left) on a rollout-like batch, against the oracle's
-    reference-dtype restatement of the scoring forward (oracle B: the reference's bf16 rounding points, exact GEMMs) run with torch on the device —
-    VERDICT r3 'next' 1c.  What makes the batch rollout-like (the FakeDataLoader batches of the timed region are not: ids < 100, log-probs near
-    -11.9, the trust-region mask nowhere near a decision):
-      * input ids uniform over the FULL vocabulary, `prompt_len` masked prompt tokens per rollout, the group-relative advantages of ONE complete group
-        (r - mean(group) = +-0.5: zero mean over the batch, as for every complete group);
+def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, n_rollouts_2l: int = 64, prompt_len: int = 256, temperature: float = 0.25,
+                     stale_sigma: float = 0.3, detail_path=None) -> dict:
+    """Forward + loss of the engine on rollout-like batches, against the oracle's reference-dtype restatement of the scoring forward (oracle B: the
+    reference's bf16 rounding points, exact GEMMs) run with torch on the device — untimed, after the timed region.  What makes a batch rollout-like (the
+    FakeDataLoader batches of the timed region are not: ids < 100, log-probs near -11.9, the trust-region mask nowhere near a decision):
+      * input ids uniform over the FULL vocabulary, `prompt_len` masked prompt tokens per rollout, group-relative advantages of complete groups of 8
+        (r - mean(group) = +-0.5: zero mean over the batch, as for every complete group, orchestrator/algo/grpo.py:27-45);
       * the scored tokens are the policy's own high-probability tokens: labels = argmax of the oracle's logits at T = `temperature` (a sampled token has
         p ~ 0.2-0.9 in RL rollouts; under a random-init model the next input id has p ~ 1e-5 and exp(lp) - exp(lp_inf) can never reach +-0.2);
       * a stale sampling policy: lp_inf = lp_oracle + N(0, `stale_sigma`^2), so a sizeable share of the tokens sits NEAR the DPPO mask threshold
         (loss.py:124-133) and the mask decisions depend on the forward's log-probs.
-    Reported for the 2-layer prefix of the model (a second engine on the live weights' first two layers — small enough for the <= 1e-4 loss gate to be
-    resolvable) and for the live engine at its full depth: loss delta with its paired standard error, mask flips against the oracle next to the flips of
-    the oracle against ITSELF under torch's bf16 GEMMs (the yardstick: what summation order alone does), tokens within 0.02 of the threshold."""
+    Three legs (VERDICT r5 'next' 1):
+      two_layer         2 layers at the model's width on a FIXED seeded weight state (GRPOEngine(seed=0) — independent of --steps / --warmup, so every run of
+                        this script evaluates the same numbers) over `n_rollouts_2l` x seq_len tokens (64 x 2048 -> 114 688 trained tokens: the paired standard
+                        error is <= 1e-4, the north-star tolerance is RESOLVABLE) — THE loss-parity gate: |loss delta to the nearer oracle (B / B_fa)| <= 1e-4 + 2 SE;
+      two_layer_live    the same on the first two layers of the LIVE weights (what the timed steps left), same token count, same gate;
+      full_depth        the live engine at its full depth on `n_rollouts` x seq_len tokens (14 336 trained): a NOISE-LEVEL check only (a 36-layer random-init
+                        network turns every bf16 rounding into a 5e-2 per-token log-prob difference; at 14k tokens the SE of the scalar loss is 2-8e-4) —
+                        gated on the per-token noise level and the mask-flip counts against the reference restatements' own, the loss delta is reported in SE units.
+    Oracles / yardsticks: B = reference dtype, exact GEMMs; B_fa = B + flash-attention's bf16 P; C = torch bf16 GEMMs; D = torch bf16 GEMMs + bf16 P — the
+    reference's own arithmetic on this box (cuBLAS-like GEMMs + flash-attn rounding), the like-for-like yardstick of the engine."""
     import dataclasses
     import math
 
@@ -379,29 +472,28 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
     from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, OptimConfig, pack_micro_batches
 
     lcfg = O.LossConfig()
-    g = torch.Generator().manual_seed(20260924)
-    # ONE group of `n_rollouts` rollouts with half of the rewards 1: adv = r - mean(group) (orchestrator/algo/grpo.py:27-45) = +-0.5, ZERO mean over the batch like
-    # every complete group's — the convexity term -mean(adv) * var(lp noise) / 2 that made round 3's 4-rollout batch look 4e-4 off (profiles/r04_parity.md)
-    # cancels, and the loss delta is a zero-mean quantity with a measurable standard error
-    rewards = torch.zeros(n_rollouts)
-    rewards[torch.randperm(n_rollouts, generator=g)[: n_rollouts // 2]] = 1.0
-    adv_all = rewards - rewards.mean()
     n = seq_len
-    mbs = []
-    for r in range(n_rollouts):
-        mask = torch.ones(1, n, dtype=torch.bool)
-        mask[0, :prompt_len] = False
-        a = float(adv_all[r]) or 0.5
-        mbs.append(dict(input_ids=torch.randint(0, dims.vocab_size, (1, n), generator=g), position_ids=torch.arange(n)[None], advantages=a * mask.float(),
-                        inference_logprobs=torch.zeros(1, n), loss_mask=mask, temperatures=torch.full((1, n), temperature), seq_lens=torch.tensor([n]),
-                        sequence_lengths=[n], env_names=["parity"] * n))
-    live_sd = engine.store.state_dict()  # HF-named views of the live bf16 parameters (no copies)
-    mask = torch.cat([mb["loss_mask"][0] for mb in mbs])
-    adv = torch.cat([mb["advantages"][0] for mb in mbs])
-    n_tr = int(mask.sum())
     pad = math.log(1.0 / dims.vocab_size)
+    GROUP = 8
 
-    def oracle_logprobs(sd, cfg, labels, mm, attn_p_bf16=False):
+    def make_rollouts(count: int, seed: int):
+        g = torch.Generator().manual_seed(seed)
+        mbs = []
+        for g0 in range(0, count, GROUP):
+            gs = min(GROUP, count - g0)
+            rewards = torch.zeros(gs)
+            rewards[torch.randperm(gs, generator=g)[: gs // 2]] = 1.0
+            adv_g = rewards - rewards.mean()  # ZERO mean over every complete group: the convexity term -mean(adv) * var(lp noise) / 2 cancels (profiles/r04_parity.md)
+            for r in range(gs):
+                mask = torch.ones(1, n, dtype=torch.bool)
+                mask[0, :prompt_len] = False
+                a = float(adv_g[r]) or 0.5
+                mbs.append(dict(input_ids=torch.randint(0, dims.vocab_size, (1, n), generator=g), position_ids=torch.arange(n)[None], advantages=a * mask.float(),
+                                inference_logprobs=torch.zeros(1, n), loss_mask=mask, temperatures=torch.full((1, n), temperature), seq_lens=torch.tensor([n]),
+                                sequence_lengths=[n], env_names=["parity"] * n))
+        return mbs
+
+    def oracle_logprobs(sd, cfg, mbs, labels, mm, attn_p_bf16=False):
         """per-token log-prob of `labels` (or, labels None: the greedy tokens, returned as well) under the oracle forward; shifted right per rollout"""
         lps, labs = [], []
         with torch.no_grad():
@@ -417,7 +509,7 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
                 del logits, h
         return torch.cat(lps), labs
 
-    def per_token(lp, inf):
+    def per_token(lp, inf, adv, mask):
         lp, inf, a = lp.double(), inf.double(), adv.double()
         lr = lp - inf
         pd = torch.exp(lp) - torch.exp(inf)
@@ -426,103 +518,217 @@ def realistic_parity(engine, dims, device, seq_len: int, n_rollouts: int = 8, pr
         near = (torch.where(a > 0, (pd - lcfg.dppo_mask_high).abs(), (pd + lcfg.dppo_mask_low).abs()) < 0.02) & mask
         return -(keep * (lcfg.adv_tau * a) * torch.exp(lr)) + lcfg.kl_tau * (mask * lr**2), invalid, near
 
-    def one_depth(eng, n_layers, sigmas):
+    torch_mm = lambda a, w, b=None: torch.nn.functional.linear(a, w, b)  # noqa: E731
+
+    def one_depth(eng, sd, n_layers, mbs, sigmas, chunk=8):
+        """Chunks of `chunk` rollouts: the four oracle forwards per rollout, ONE engine forward per chunk, the loss kernel once per sampling policy and chunk
+        (scale = the trained tokens of the WHOLE leg, so the chunk losses add up to the leg's loss)."""
         cfg = O.TinyQwen3Config(hidden_size=dims.hidden_size, intermediate_size=dims.intermediate_size, num_hidden_layers=n_layers,
                                 num_attention_heads=dims.num_attention_heads, num_key_value_heads=dims.num_key_value_heads, head_dim=dims.head_dim,
                                 vocab_size=dims.vocab_size, rms_norm_eps=dims.rms_norm_eps, rope_theta=dims.rope_theta, qk_norm=dims.qk_norm,
                                 attention_bias=dims.attention_bias, rope_scaling=dims.rope_scaling)
-        lp_b, labels = oracle_logprobs(live_sd, cfg, None, O.exact_mm)                                      # B: reference dtype, exact GEMMs; greedy labels
-        lp_c, _ = oracle_logprobs(live_sd, cfg, labels, lambda a, w, b=None: torch.nn.functional.linear(a, w, b))  # C: same arithmetic, torch bf16 GEMMs
-        lp_f, _ = oracle_logprobs(live_sd, cfg, labels, O.exact_mm, attn_p_bf16=True)  # B_fa: B + the ONE rounding point inside flash-attention (bf16 P into P.V)
-        pb = pack_micro_batches(mbs, device)
-        pb.labels = torch.cat(labels).to(torch.int64)  # the scored tokens: the policy's greedy tokens instead of the next input id
-        ctx = eng.forward(pb)  # ONE forward of the engine; the loss kernel then runs once per sampling policy
-        lp_raw = ctx["logprobs"].cpu()
-        lp_e = torch.cat([torch.cat([lp_raw.new_full((1,), pad), lp_raw[i * n:(i + 1) * n - 1]]) for i in range(n_rollouts)])
+        mask = torch.cat([mb["loss_mask"][0] for mb in mbs])
+        adv = torch.cat([mb["advantages"][0] for mb in mbs])
+        n_tr = int(mask.sum())
+        lp = {k: [] for k in "bcfde"}
+        infs = {name: [] for name, _ in sigmas}
+        k2_loss = {name: 0.0 for name, _ in sigmas}
+        k2_drop = {name: 0 for name, _ in sigmas}
+        gi = torch.Generator().manual_seed(77)
+        for c0 in range(0, len(mbs), chunk):
+            part = mbs[c0:c0 + chunk]
+            lp_b, labels = oracle_logprobs(sd, cfg, part, None, O.exact_mm)               # B: reference dtype, exact GEMMs; greedy labels
+            lp_c, _ = oracle_logprobs(sd, cfg, part, labels, torch_mm)                      # C: same arithmetic, torch bf16 GEMMs
+            lp_f, _ = oracle_logprobs(sd, cfg, part, labels, O.exact_mm, attn_p_bf16=True)  # B_fa: B + the ONE rounding point inside flash-attention (bf16 P into P.V)
+            lp_d, _ = oracle_logprobs(sd, cfg, part, labels, torch_mm, attn_p_bf16=True)    # D: torch bf16 GEMMs + bf16 P = the reference as it runs (like-for-like yardstick)
+            pb = pack_micro_batches(part, device)
+            pb.labels = torch.cat(labels).to(torch.int64)  # the scored tokens: the policy's greedy tokens instead of the next input id
+            ctx = eng.forward(pb)  # ONE forward of the engine per chunk; the loss kernel then runs once per sampling policy
+            lp_raw = ctx["logprobs"].cpu()
+            lp_e = torch.cat([torch.cat([lp_raw.new_full((1,), pad), lp_raw[i * n:(i + 1) * n - 1]]) for i in range(len(part))])
+            for k, v in zip("bcfde", (lp_b, lp_c, lp_f, lp_d, lp_e)):
+                lp[k].append(v)
+            for name, sigma in sigmas:
+                inf = lp_b + sigma * torch.randn(lp_b.shape, generator=gi)
+                infs[name].append(inf)
+                pb.inference_logprobs = inf.to(torch.float32).to(device)
+                eng.loss(ctx, (n_tr, 1, 1))
+                k2_loss[name] += float(ctx["loss"].item())
+                k2_drop[name] += int(ctx["sample_stats"][:, _lib.STAT["RL_N_DROP"]].sum().item())
+            del ctx, pb
+        lp_b, lp_c, lp_f, lp_d, lp_e = (torch.cat(lp[k]) for k in "bcfde")
         p_lab = torch.exp(lp_b[mask])
-        res = {"layers": n_layers, "trained_tokens": n_tr, "logprob_abs_mean": float((lp_e - lp_b)[mask].abs().mean()),
-               "logprob_abs_mean_vs_bfa": float((lp_e - lp_f)[mask].abs().mean()),
-               "yardstick_logprob_abs_mean": float((lp_c - lp_b)[mask].abs().mean()), "yardstick_bfa_logprob_abs_mean": float((lp_f - lp_b)[mask].abs().mean()),
+        am = lambda x, y: float((x - y)[mask].abs().mean())  # noqa: E731
+        res = {"layers": n_layers, "rollouts": len(mbs), "trained_tokens": n_tr, "mean_advantage": float(adv[mask].mean()),
+               "logprob_abs_mean": am(lp_e, lp_b), "logprob_abs_mean_vs_bfa": am(lp_e, lp_f),
+               "logprob_mean_shift": float((lp_e - lp_b)[mask].mean()), "logprob_mean_shift_se": float((lp_e - lp_b)[mask].std() / math.sqrt(n_tr)),
+               "yardstick_logprob_abs_mean": am(lp_c, lp_b), "yardstick_bfa_logprob_abs_mean": am(lp_f, lp_b), "yardstick_d_logprob_abs_mean": am(lp_d, lp_b),
                "label_prob_median": float(p_lab.median()), "label_prob_gt_0.2": float((p_lab > 0.2).float().mean())}
-        # noise LEVEL, the stable statistic: the engine's mean |d log-prob| to its nearest reference restatement (B or B_fa) against the distance between
-        # the reference restatements themselves (C vs B: GEMM summation order; B_fa vs B: flash-attention's bf16 P)
-        res["noise_ratio"] = min(res["logprob_abs_mean"], res["logprob_abs_mean_vs_bfa"]) / max(res["yardstick_logprob_abs_mean"], res["yardstick_bfa_logprob_abs_mean"], 1e-12)
+        # noise LEVEL, like for like (ADVICE r5): the engine (bf16 GEMMs in its own summation order + flash-style bf16 P) against B, over the reference as it
+        # runs (torch bf16 GEMMs + bf16 P = D) against B.  The two single-source ratios are reported next to it.
+        res["noise_ratio"] = res["logprob_abs_mean"] / max(res["yardstick_d_logprob_abs_mean"], 1e-12)
+        res["noise_ratio_vs_c"] = res["logprob_abs_mean"] / max(res["yardstick_logprob_abs_mean"], 1e-12)
+        res["noise_ratio_bfa_pair"] = res["logprob_abs_mean_vs_bfa"] / max(res["yardstick_bfa_logprob_abs_mean"], 1e-12)
         for name, sigma in sigmas:
-            gi = torch.Generator().manual_seed(77)
-            inf = lp_b + sigma * torch.randn(lp_b.shape, generator=gi)
-            pb.inference_logprobs = inf.to(torch.float32).to(device)
-            eng.loss(ctx, (n_tr, 1, 1))
-            loss_k2 = float(ctx["loss"].item())
-            drop_k2 = int(ctx["sample_stats"][:, _lib.STAT["RL_N_DROP"]].sum().item())
-            l_b, inv_b, near_b = per_token(lp_b, inf)
-            l_e, inv_e, _ = per_token(lp_e, inf)
-            l_c, inv_c, _ = per_token(lp_c, inf)
-            l_f, inv_f, _ = per_token(lp_f, inf)
-            d = (l_e - l_b)[mask]
-            dc = (l_c - l_b)[mask]
-            df = (l_e - l_f)[mask]
-            dfb = (l_f - l_b)[mask]
+            inf = torch.cat(infs[name])
+            l_b, inv_b, near_b = per_token(lp_b, inf, adv, mask)
+            l_e, inv_e, _ = per_token(lp_e, inf, adv, mask)
+            l_c, inv_c, _ = per_token(lp_c, inf, adv, mask)
+            l_f, inv_f, _ = per_token(lp_f, inf, adv, mask)
+            l_d, inv_d, _ = per_token(lp_d, inf, adv, mask)
+            d, dc, df, dfb, dd = (l_e - l_b)[mask], (l_c - l_b)[mask], (l_e - l_f)[mask], (l_f - l_b)[mask], (l_d - l_b)[mask]
+            se = lambda x: float(x.std() / math.sqrt(n_tr))  # noqa: E731
             res[name] = {
                 "lp_inf": f"lp_oracle + N(0, {sigma}^2)",
-                "loss_engine": loss_k2, "loss_oracle": float(l_b.sum() / n_tr), "loss_abs_delta": abs(loss_k2 - float(l_b.sum() / n_tr)),
-                "loss_delta_se": float(d.std() / math.sqrt(n_tr)), "loss_engine_host_formula": float(l_e.sum() / n_tr),
-                "yardstick_loss_abs_delta": abs(float(dc.sum() / n_tr)), "yardstick_loss_delta_se": float(dc.std() / math.sqrt(n_tr)),
-                "masked_tokens_oracle": int(inv_b.sum()), "masked_tokens_engine": drop_k2, "masked_tokens_engine_host_formula": int(inv_e.sum()),
+                "loss_engine": k2_loss[name], "loss_oracle": float(l_b.sum() / n_tr), "loss_delta": k2_loss[name] - float(l_b.sum() / n_tr),
+                "loss_abs_delta": abs(k2_loss[name] - float(l_b.sum() / n_tr)),
+                "loss_delta_se": se(d), "loss_engine_host_formula": float(l_e.sum() / n_tr),
+                "yardstick_loss_delta": float(dc.sum() / n_tr), "yardstick_loss_abs_delta": abs(float(dc.sum() / n_tr)), "yardstick_loss_delta_se": se(dc),
+                "yardstick_d_loss_delta": float(dd.sum() / n_tr), "yardstick_d_loss_delta_se": se(dd),
+                "masked_tokens_oracle": int(inv_b.sum()), "masked_tokens_engine": k2_drop[name], "masked_tokens_engine_host_formula": int(inv_e.sum()),
                 "tokens_within_0.02_of_threshold": int(near_b.sum()), "flips": int((inv_e != inv_b).sum()), "yardstick_flips": int((inv_c != inv_b).sum()),
+                "yardstick_d_flips": int((inv_d != inv_b).sum()),
                 # the second oracle column: B_fa = B with flash-attention's bf16 P (the engine's attention rounds P to bf16 as flash-attn does)
-                "loss_oracle_bfa": float(l_f.sum() / n_tr), "loss_abs_delta_vs_bfa": abs(float(df.sum() / n_tr)), "loss_delta_vs_bfa_se": float(df.std() / math.sqrt(n_tr)),
-                "yardstick_bfa_loss_abs_delta": abs(float(dfb.sum() / n_tr)), "yardstick_bfa_loss_delta_se": float(dfb.std() / math.sqrt(n_tr)),
+                "loss_oracle_bfa": float(l_f.sum() / n_tr), "loss_delta_vs_bfa": float(df.sum() / n_tr), "loss_abs_delta_vs_bfa": abs(float(df.sum() / n_tr)),
+                "loss_delta_vs_bfa_se": se(df),
+                "yardstick_bfa_loss_abs_delta": abs(float(dfb.sum() / n_tr)), "yardstick_bfa_loss_delta_se": se(dfb),
                 "masked_tokens_oracle_bfa": int(inv_f.sum()), "masked_tokens_yardstick": int(inv_c.sum()), "flips_vs_bfa": int((inv_e != inv_f).sum()),
                 "yardstick_bfa_flips": int((inv_f != inv_b).sum()),
             }
-        del ctx, pb
+            r = res[name]
+            # the gate's tolerance: north-star 1e-4 + 2 standard errors, the SE from the YARDSTICK pairs (never from the engine under test: ADVICE r4)
+            r["gate_se"] = max(r["yardstick_loss_delta_se"], r["yardstick_bfa_loss_delta_se"], r["yardstick_d_loss_delta_se"])
+            r["gate_tol"] = 1e-4 + 2 * r["gate_se"]
+            r["nearer_oracle_abs_delta"] = min(r["loss_abs_delta"], r["loss_abs_delta_vs_bfa"])
         return res
 
-    out: dict = {"data": f"{n_rollouts} x {seq_len} tokens, ids over the full vocab, {prompt_len} masked prompt tokens, labels = greedy tokens at T={temperature}, "
-                         f"lp_inf = lp_oracle + N(0, sigma^2) with sigma = 0.02 (fresh policy) and {stale_sigma} (stale policy: the DPPO mask is active), group-relative advantages; "
-                         "live weights after the timed steps",
-                 "oracle": "oracle/grpo_oracle.py qwen3_forward with the reference's bf16 rounding points and exact GEMMs (B), and the same with flash-attention's "
-                           "bf16 P (B_fa: the engine's attention rounds P to bf16 as flash-attn does), on the device; yardsticks = the same arithmetic with torch "
-                           "bf16 GEMMs (C) against B, and B_fa against B"}
+    live_sd = engine.store.state_dict()  # HF-named views of the live bf16 parameters (no copies)
+    sig = (("fresh", 0.02), ("stale", stale_sigma))
+    out: dict = {"data": f"rollouts of {seq_len} tokens, ids over the full vocab, {prompt_len} masked prompt tokens, labels = greedy tokens at T={temperature}, "
+                         f"lp_inf = lp_oracle + N(0, sigma^2) with sigma = 0.02 (fresh policy) and {stale_sigma} (stale policy: the DPPO mask is active), "
+                         f"group-relative advantages of complete groups of {GROUP}",
+                 "oracle": "oracle/grpo_oracle.py qwen3_forward on the device: B = reference bf16 rounding points + exact GEMMs; B_fa = B + flash-attention's bf16 P; "
+                           "yardsticks against B: C = torch bf16 GEMMs, D = torch bf16 GEMMs + bf16 P (the reference as it runs)"}
     d2 = dataclasses.replace(dims, num_hidden_layers=min(2, dims.num_hidden_layers))
-    eng2 = GRPOEngine(d2, device=device, optim=OptimConfig(type="sign_sgd"), loss=LossConfig(), seed=0)
+    mbs2 = make_rollouts(n_rollouts_2l, 20260924)
+    eng2 = GRPOEngine(d2, device=device, optim=OptimConfig(type="sign_sgd"), loss=LossConfig(), seed=0)  # FIXED weights: the seeded init, untouched by any step
+    out["two_layer"] = one_depth(eng2, eng2.store.state_dict(), d2.num_hidden_layers, mbs2, sig)
+    out["two_layer"]["weights"] = "fixed: GRPOEngine(seed=0) random init (independent of --steps / --warmup)"
     keep = {k: v for k, v in live_sd.items() if not k.startswith("model.layers.") or int(k.split(".")[2]) < d2.num_hidden_layers}
     eng2.store.load_state_dict(keep)
-    # "fresh": a sampling policy 0.02 away (the trust-region mask stays open, the loss is smooth: the regime the <= 1e-4 tolerance is stated for);
-    # "stale": 0.3 away — hundreds of tokens sit at the mask threshold, the loss jumps by adv * ratio with every decision that differs
-    out["two_layer"] = one_depth(eng2, d2.num_hidden_layers, (("fresh", 0.02), ("stale", stale_sigma)))
+    out["two_layer_live"] = one_depth(eng2, eng2.store.state_dict(), d2.num_hidden_layers, mbs2, sig)
+    out["two_layer_live"]["weights"] = "live: first two layers + embedding + head of the weights the timed steps left"
     del eng2
     torch.cuda.empty_cache()
-    out["full_depth"] = one_depth(engine, dims.num_hidden_layers, (("fresh", 0.02), ("stale", stale_sigma)))
-    t2, tf = out["two_layer"], out["full_depth"]
+    out["full_depth"] = one_depth(engine, live_sd, dims.num_hidden_layers, make_rollouts(n_rollouts, 20260924), sig)
+    out["full_depth"]["weights"] = "live, full depth — noise-level check only (SE of the scalar loss at this token count is 2-8e-4)"
+    t2, tl, tf = out["two_layer"], out["two_layer_live"], out["full_depth"]
 
-    def within(r):
-        """Scalar loss: the engine is within max(1e-4, 3 standard errors) of its nearer oracle (B or B_fa), the standard error taken from the YARDSTICK pairs
-        (C vs B, B_fa vs B: the reference arithmetic against itself), never from the engine under test (a noisier engine must not widen its own
-        tolerance).  The yardstick multiplier of round 4 (2 x |C - B|) is gone from this gate: |E - B| and |C - B| are two draws of the same zero-mean noise,
-        their ratio is not a statistic; the 1.25 x bound sits on the noise LEVELS (noise_ratio) and the flip counts below."""
-        se = max(r["yardstick_loss_delta_se"], r["yardstick_bfa_loss_delta_se"])
-        return min(r["loss_abs_delta"], r["loss_abs_delta_vs_bfa"]) <= max(1e-4, 3 * se)
+    def within(r):  # |loss delta to the nearer oracle (B or B_fa)| <= 1e-4 + 2 SE(yardstick pairs)
+        return r["nearer_oracle_abs_delta"] <= r["gate_tol"]
 
-    def flips_ok(r):  # mask decisions that differ from the nearer oracle: <= 1.25 x the reference restatements' own disagreement (+ 3 sigma of that count)
-        y = max(r["yardstick_flips"], r["yardstick_bfa_flips"])
+    def flips_ok(r):  # mask decisions that differ from the nearer oracle: <= 1.25 x the reference-as-it-runs' own disagreement with B (+ 3 sigma of that count)
+        y = max(r["yardstick_flips"], r["yardstick_bfa_flips"], r["yardstick_d_flips"])
         return min(r["flips"], r["flips_vs_bfa"]) <= 1.25 * y + 3 * math.sqrt(max(y, 1)) + 2
 
-    out["mean_advantage"] = float(adv[mask].mean())
-    out["note"] = ("the <= 1e-4 loss tolerance is asserted where it is resolvable (tests/test_engine_gpu.py: 2 layers 2-4e-5; 229k tokens at full depth with paired "
-                   "standard errors); here T = 0.25 multiplies every logit error by 4 and 14k tokens give a standard error of ~2e-4 (2 layers) / ~8e-4 (36 layers)")
+    for r in (tf["fresh"], tf["stale"]):
+        r["loss_delta_in_gate_se_units"] = r["nearer_oracle_abs_delta"] / max(r["gate_se"], 1e-12)
+    out["note"] = ("two_layer / two_layer_live resolve the north-star tolerance (>= 114k trained tokens: SE <= 1e-4 fresh) and carry the loss gates; full_depth "
+                   "(14k tokens, 36 random-init layers) is a noise-level check: per-token noise and mask flips vs the reference restatements' own; "
+                   "tests/test_engine_gpu.py resolves the full-depth loss on 229k tokens")
     out["gates"] = {
-        "two_layer fresh policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(t2["fresh"]),
-        "two_layer stale policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(t2["stale"]),
-        "full_depth fresh policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(tf["fresh"]),
-        "full_depth stale policy: |loss delta to the nearer oracle| <= max(1e-4, 3 SE of the yardstick pairs)": within(tf["stale"]),
-        "per-token noise level <= 1.25 x the reference restatements' own (both depths)": t2["noise_ratio"] <= 1.25 and tf["noise_ratio"] <= 1.25,
-        "flips <= 1.25 x yardstick + 3 sigma (both depths, stale policy)": flips_ok(t2["stale"]) and flips_ok(tf["stale"]),
-        "mask decisions near the threshold exist": t2["stale"]["tokens_within_0.02_of_threshold"] > 0 and tf["stale"]["tokens_within_0.02_of_threshold"] > 0,
+        "two_layer (fixed weights) fresh: |loss delta to the nearer oracle| <= 1e-4 + 2 SE": within(t2["fresh"]),
+        "two_layer (fixed weights) stale: |loss delta to the nearer oracle| <= 1e-4 + 2 SE": within(t2["stale"]),
+        "two_layer (live weights) fresh: |loss delta to the nearer oracle| <= 1e-4 + 2 SE": within(tl["fresh"]),
+        "two_layer (live weights) stale: |loss delta to the nearer oracle| <= 1e-4 + 2 SE": within(tl["stale"]),
+        "per-token noise level <= 1.25 x the reference-as-it-runs' own (D vs B), all legs": all(r["noise_ratio"] <= 1.25 for r in (t2, tl, tf)),
+        "flips <= 1.25 x yardstick + 3 sigma (all legs, stale policy)": all(flips_ok(r["stale"]) for r in (t2, tl, tf)),
+        "mask decisions near the threshold exist": all(r["stale"]["tokens_within_0.02_of_threshold"] > 0 for r in (t2, tl, tf)),
         "K2 masked count == host formula on the engine's log-probs": all(r[k]["masked_tokens_engine"] == r[k]["masked_tokens_engine_host_formula"]
-                                                                         for r in (t2, tf) for k in ("fresh", "stale")),
+                                                                         for r in (t2, tl, tf) for k in ("fresh", "stale")),
     }
-    return out
+    if detail_path is not None:  # the verbose per-leg blocks go to a side file; the JSON line keeps the gates and one summary row per leg
+        try:
+            Path(detail_path).parent.mkdir(parents=True, exist_ok=True)
+            Path(detail_path).write_text(json.dumps(out, indent=1))
+        except OSError:
+            detail_path = None
+
+    def brief(r):
+        return {"trained_tokens": r["trained_tokens"], "noise_ratio": round(r["noise_ratio"], 3), "logprob_mean_shift": round(r["logprob_mean_shift"], 7),
+                "logprob_mean_shift_se": round(r["logprob_mean_shift_se"], 7),
+                **{f"{k}_{f}": (round(r[k][f], 7) if isinstance(r[k][f], float) else r[k][f]) for k in ("fresh", "stale")
+                   for f in ("loss_delta", "loss_delta_vs_bfa", "gate_se", "gate_tol", "flips", "flips_vs_bfa", "yardstick_d_flips", "masked_tokens_oracle", "masked_tokens_engine")}}
+
+    return {"gates": out["gates"], "two_layer": brief(t2), "two_layer_live": brief(tl), "full_depth_noise_check": brief(tf), "note": out["note"],
+            "detail_file": str(detail_path) if detail_path is not None else None, "_full": out}
+
+
+def finalize_line(result: dict) -> dict:
+    """The driver keeps only SCALAR keys of `config` and the last 8 KB of stdout: hoist every number that matters to a scalar top-level
+    `config` key, write the verbose blocks (notes, shapes, per-leg parity tables) to gpurun_out/bench_detail.json, and keep the printed line small."""
+    cfg = result.get("config", {})
+    extra = cfg.get("extra") or {}
+
+    def _num(v):
+        return v if isinstance(v, (int, float, str, bool)) or v is None else None
+
+    hoist = {
+        "all_own_ms": _dig(extra, ("all_own", "ms_per_step")), "library_mix_ms": _dig(extra, ("library_mix", "ms_per_step")),
+        "forced_collectives_ms": _dig(extra, ("forced_collectives", "ms_per_step")), "fc_delta_ms": _dig(extra, ("forced_collectives", "delta_ms_vs_headline")),
+        "fc_exposed_ms": _dig(extra, ("forced_collectives", "comm", "exposed_ms")), "fc_rs_ms": _dig(extra, ("forced_collectives", "comm", "rs_ms")),
+        "fc_ag_ms": _dig(extra, ("forced_collectives", "comm", "ag_ms")),
+        "mb2_ms": _dig(extra, ("mb2", "ms_per_step")), "mb2_samples_per_s": _dig(extra, ("mb2", "samples_per_s")),
+        "moe_step_ms": _dig(extra, ("moe_step", "ms_per_step")), "moe_step_mfu": _dig(extra, ("moe_step", "mfu_vs_2.5PF_bf16")),
+        "moe_layer_ms": _dig(extra, ("moe_layer", "ms")),
+        "long_context_ms": _dig(extra, ("long_context", "r1", "ms_per_step")), "long_context_mfu_ref": _dig(extra, ("long_context", "r1", "mfu_ref_formula")),
+        "long_context_mfu_executed": _dig(extra, ("long_context", "r1", "mfu_executed_causal")),
+        "long_context_attn_share": _dig(extra, ("long_context", "r1", "attention_share")), "long_context_peak_hbm_gb": _dig(extra, ("long_context", "r1", "peak_hbm_gb")),
+        "long_context_x4_ms": _dig(extra, ("long_context", "r4", "ms_per_step")), "long_context_x4_mfu_executed": _dig(extra, ("long_context", "r4", "mfu_executed_causal")),
+        "long_context_attn_fwd_frac": _dig(extra, ("long_context", "attn_fwd_frac_of_2.5PF")), "long_context_attn_bwd_frac": _dig(extra, ("long_context", "attn_bwd_frac_of_2.5PF")),
+        "j1_frac": _dig(extra, ("j1_roofline", "frac")), "gemm_wgrad_frac": _dig(extra, ("gemm_roofline", "frac")),
+        "weight_push_ms": _dig(extra, ("weight_push", "ms")),
+    }
+    par = result.get("parity") or {}
+    gates = dict(par.get("gates") or {})
+    rgates = dict(_dig(par, ("realistic", "gates")) or {})
+    hoist["parity_gates_all_true"] = (bool(gates) and all(gates.values()) and bool(rgates) and all(rgates.values())) if par else None
+    hoist["parity_kernel_gates_all_true"] = (all(gates.values()) if gates else None)
+    hoist["parity_realistic_gates_all_true"] = (all(rgates.values()) if rgates else None)
+    for leg in ("two_layer", "two_layer_live"):
+        for pol in ("fresh", "stale"):
+            hoist[f"parity_{leg}_{pol}_loss_delta"] = _dig(par, ("realistic", leg, f"{pol}_loss_delta"))
+            hoist[f"parity_{leg}_{pol}_tol"] = _dig(par, ("realistic", leg, f"{pol}_gate_tol"))
+    for k, v in hoist.items():
+        cfg[k] = _num(v)
+    # side file: everything, verbatim
+    try:
+        DETAIL_DIR.mkdir(parents=True, exist_ok=True)
+        (DETAIL_DIR / "bench_detail.json").write_text(json.dumps(result, indent=1))
+        cfg["detail_file"] = "gpurun_out/bench_detail.json"
+    except OSError:
+        cfg["detail_file"] = None
+
+    def strip(d):  # the printed line: drop prose, keep numbers
+        if isinstance(d, dict):
+            return {k: strip(v) for k, v in d.items() if k not in ("note", "pattern", "shape", "model", "kernel", "lp_inf", "traffic_source", "k2_loss_note", "source", "data", "oracle")
+                    or not isinstance(v, str) or len(v) <= 48}
+        return d
+
+    cfg["extra"] = strip(extra)
+    if par:
+        result["parity"] = strip(par)
+    if isinstance(result.get("comm"), dict):
+        result["comm"] = strip(result["comm"])
+    return result
+
+
+def _dig(d, keys):
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
 
 
 def main() -> None:
@@ -541,6 +747,8 @@ def main() -> None:
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in one extra untimed step after the timed region)")
     ap.add_argument("--no-realistic-parity", action="store_true", help="skip parity.realistic (one extra untimed step on rollout-like data vs the oracle forward)")
+    ap.add_argument("--parity-rollouts", type=int, default=64, help="rollouts of the two-layer legs of parity.realistic (64 x 2048 -> 114 688 trained tokens)")
+    ap.add_argument("--no-long-context", dest="long_context", action="store_false", help="skip config.extra.long_context (32k-token rollouts, recompute=layer)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements reported under config.extra (2 micro-batches/GPU line, weight push)")
     args = ap.parse_args()
 
@@ -669,6 +877,7 @@ def main() -> None:
     except Exception:
         rccl["version"] = None
     loss_last = float(sum(l.item() for l in losses[-1]))
+    engine_lm_head, engine_gemm_own = engine.lm_head_impl, sorted(engine.gemm_own)
 
     def assemble(extra: dict) -> dict:
         """The contract's JSON line (rank 0) from the timed region alone; `extra` = whatever extra measurements finished."""
@@ -720,9 +929,9 @@ def main() -> None:
                 "tflop_per_sample": round(flops_per_sample / 1e12, 2),
                 "loss_last": loss_last,
                 "host_enqueue_ms_per_step": round(host_enqueue_empty_queue * 1e3, 1) if host_enqueue_empty_queue is not None else None,
-                "lm_head": engine.lm_head_impl,
-                "gemm_own": sorted(engine.gemm_own),
-                "rccl": rccl,
+                "lm_head": {"library": "stored_logits", "fused": "fused_j1"}.get(engine_lm_head, engine_lm_head),
+                "gemm_own": ",".join(engine_gemm_own) or "none",
+                "rccl_world": rccl["world"], "rccl_backend": rccl["backend"], "rccl_version": rccl["version"],
                 "extra": extra,
             },
         }
@@ -741,10 +950,7 @@ def main() -> None:
                 "rows_per_launch": rows,
                 "launches_timed": len(durs),
                 "mean_launch_ms": round(mean_t * 1e3, 4),
-                "launch_ms": [round(d * 1e3, 4) for d in durs],
-                "note": "in the step K1 starts right behind the LM-head GEMM that wrote its 5 GB of logits: the last 256 MiB of them are still dirty in the Infinity "
-                        "Cache and are written back while K1 streams (+0.04-0.09 ms per launch; tools/microbench.py k1aftergemm, profiles/r05_raw/k1_after_gemm.log: "
-                        "K1 on resident logits 0.74-0.75 ms = 0.83-0.85 of 8 TB/s, behind the own GEMM 0.78-0.84 ms, behind the same GEMM + a 512 MiB flush 0.74 ms)",
+                "min_launch_ms": round(min(durs) * 1e3, 4), "max_launch_ms": round(max(durs) * 1e3, 4),
             }
         else:  # PM_LM_HEAD=fused: no stand-alone log-prob kernel runs; the dominant hand-written kernel is the fused MFMA LM head (J1)
             result["roofline"] = extra.get("j1_roofline")
@@ -762,7 +968,7 @@ def main() -> None:
                 if rank == 0:
                     line = assemble({"error": "an extra measurement did not finish in time; headline and roofline only"})
                     line["cpu_baseline"] = None
-                    print(json.dumps(line), flush=True)
+                    print(json.dumps(finalize_line(line)), flush=True)
                 else:
                     time.sleep(3.0)
                 os._exit(0)
@@ -782,8 +988,11 @@ def main() -> None:
             except Exception as e:  # pragma: no cover - reported, never hidden
                 result["parity"] = {"error": repr(e)[:300]}
             if not args.no_realistic_parity and world == 1 and dims.head_dim == dims.kernel_head_dim:
-                try:  # one extra untimed step on rollout-like data against the oracle's forward (2-layer prefix and full depth)
-                    result["parity"]["realistic"] = realistic_parity(engine, dims, device, args.seq_len, n_rollouts=min(8, args.micro_batches))
+                try:  # rollout-like data against the oracle's forward: 2 layers on fixed + live weights (resolvable loss gates), full depth (noise check)
+                    rp = realistic_parity(engine, dims, device, args.seq_len, n_rollouts=min(8, args.micro_batches), n_rollouts_2l=args.parity_rollouts,
+                                          detail_path=DETAIL_DIR / "bench_parity_realistic.json")
+                    rp.pop("_full", None)
+                    result["parity"]["realistic"] = rp
                 except Exception as e:  # pragma: no cover
                     result["parity"]["realistic"] = {"error": repr(e)[:300]}
         else:
@@ -819,7 +1028,7 @@ def main() -> None:
                 if not fc_done.wait(float(os.environ.get("PM_BENCH_FC_TIMEOUT", "240"))):
                     line = json.loads(headline)
                     line["config"]["extra"]["forced_collectives"] = {"error": "the forced-collectives leg did not finish in time"}
-                    print(json.dumps(line), flush=True)
+                    print(json.dumps(finalize_line(line)), flush=True)
                     os._exit(0)
 
             threading.Thread(target=fc_watchdog, daemon=True).start()
@@ -876,7 +1085,7 @@ def main() -> None:
         import ctypes
 
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(result), flush=True)
+        print(json.dumps(finalize_line(result)), flush=True)
 
 
 if __name__ == "__main__":

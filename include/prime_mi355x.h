@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2
 
 enum { PM_DTYPE_F32 = 0, PM_DTYPE_BF16 = 1, PM_DTYPE_I64 = 2, PM_DTYPE_U8 = 3 /* the last two: pm_comm_* payloads only */ };
 
@@ -455,31 +455,32 @@ int pm_moe_ep_row_map(const int32_t* recv_counts, int32_t ep_size, int32_t n_loc
  * the experts' gate and up projections (w1, w3 of GroupedExperts, moe.py:436-440) run as one product whose output is the gate|up layout
  * pm_swiglu_fwd consumes, their row gradients as one contraction over both, and their weight gradients as one launch with two outputs. */
 int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim);
-int pm_grouped_gemm_debug_set_variant(int32_t value); /* in-process A/B (tools/microbench.py): 0 = default tiling, 1 = force 128 x 128 tiles in the forward kernel */
+int pm_grouped_gemm_debug_set_variant(int32_t value); /* `make VARIANTS=1` libraries only: process-wide override of PM_GROUPED_SCHED_* (see `sched` below) */
 int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
-                       int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream);
+                       int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, int32_t sched, void* stream);
 int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16 /* nullable */, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
-                       int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream);
+                       int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, int32_t sched, void* stream);
 /* The experts' gate and up projections with the SwiGLU activation in the epilogue (layers/moe.py:181-182: F.silu(x @ w1^T) * (x @ w3^T); the reference runs two
  * grouped GEMMs, silu and mul): gate_up[n_rows, 2 inter] exactly as pm_grouped_gemm_nt(w_gate, w_up) writes it and act[n_rows, inter] = pm_swiglu_fwd(gate_up),
  * bit for bit, in one launch.  Both weight tensors [E, inter, k_dim] are read through one buffer descriptor: w_up must lie above w_gate within 2 GiB
- * (parameters of one flat buffer do) — PM_ERR_UNSUPPORTED otherwise, and the caller keeps the two-launch form.  inter % 128 == 0, k_dim % 128 == 0. */
+ * and a whole number of weight rows (k_dim elements) away (parameters of one flat buffer are) — PM_ERR_UNSUPPORTED otherwise, and the caller keeps the two-launch
+ * form.  inter % 128 == 0, k_dim % 128 == 0. */
 int pm_grouped_gemm_nt_swiglu_supported(int64_t n_rows, int64_t inter, int64_t k_dim);
 int pm_grouped_gemm_nt_swiglu(const void* x_bf16, const void* w_gate_bf16, const void* w_up_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t inter,
-                              int64_t k_dim, void* gate_up_bf16, void* act_bf16, void* stream);
+                              int64_t k_dim, void* gate_up_bf16, void* act_bf16, int32_t sched, void* stream);
 /* The experts' down-projection row gradient with the SwiGLU backward in its epilogue (layers/moe.py:181-183 backward): grad_gate_up[m] = [d_gate | d_up] from
  * (dy[m] . w_down[e(m)]) and the saved gate_up[m]; dy [n_rows, n_dim], w_down [E, n_dim, inter], gate_up / grad_gate_up [n_rows, 2 inter] (may alias).
  * inter % 256 == 0, n_dim % 128 == 0. */
 int pm_grouped_gemm_nn_swiglu_bwd_supported(int64_t n_rows, int64_t n_dim, int64_t inter);
 int pm_grouped_gemm_nn_swiglu_bwd(const void* dy_bf16, const void* w_down_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
-                                  const void* gate_up_bf16, void* grad_gate_up_bf16, void* stream);
+                                  const void* gate_up_bf16, void* grad_gate_up_bf16, int32_t sched, void* stream);
 int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
-                       int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, void* stream);
+                       int64_t k_dim, void* dw_bf16, void* dw2_bf16 /* nullable */, int32_t sched, void* stream);
 /* The same with the gradient written (accumulate = 0) or accumulated (1) in f32 straight into a main-gradient buffer [E, n_first, K] / [E, N - n_first, K]
  * (gradient accumulation in f32: configs/trainer.py:233-237; the reference's autograd adds bf16 `.grad`s that FSDP then reduces in f32).  n_first, N, K
  * multiples of 256. */
 int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
-                           int64_t k_dim, float* dw_f32, float* dw2_f32 /* nullable */, int32_t accumulate, void* stream);
+                           int64_t k_dim, float* dw_f32, float* dw2_f32 /* nullable */, int32_t accumulate, int32_t sched, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Dense bf16 GEMM of the scoring model (csrc/gemm.hip): OUT[M, N] = sum_K X[M, K] * W[N, K] (+ bias[N]), f32 accumulation on the MFMA units,
@@ -494,14 +495,14 @@ int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_
 int pm_gemm_supported(int64_t m, int64_t n, int64_t k, int32_t x_kmajor, int32_t w_kmajor);
 int pm_gemm_bf16(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                  int32_t out_dtype /* PM_DTYPE_BF16 | PM_DTYPE_F32 */, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n,
-                 int64_t k, void* stream);
+                 int64_t k, int32_t sched, void* stream);
 /* The weight-gradient form with the gradient-norm pass fused into its epilogue (the reference clips the GLOBAL gradient norm before the optimizer step,
  * trainer/rl/train.py:557-570 `clip_grad_norm_`; here every wave adds up the squares of the FINAL f32 values it stores and writes the sum to
  * tile_sumsq[tile * 8 + wave] — pm_gemm_sumsq_slots(m, n) floats, deterministic, slots of tiles that do not exist are left untouched).  Summing the
  * slots (pm_sum_partials) gives sum(out^2) without reading the 4-byte-per-parameter gradient again. */
 int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n);
 int pm_gemm_bf16_sumsq(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, float* out_f32, int64_t ldo,
-                       int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream);
+                       int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, int32_t sched, void* stream);
 /* The general form: optional per-tile sums of squares (as pm_gemm_bf16_sumsq) and an optional workspace of pm_gemm_workspace_bytes(m, n, k) bytes.  With the
  * workspace, an f32 product without bias whose tile count leaves at most half of the LAST round of 256 tiles occupied (e.g. the q|k|v weight gradient of
  * Qwen3-8B: 384 tiles = 1.5 rounds) computes that round split along K — 2 or 4 workgroups per tile on different XCDs, partial tiles in the workspace, a small
@@ -509,7 +510,7 @@ int pm_gemm_bf16_sumsq(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const 
 int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const void* w_bf16, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
                     int32_t out_dtype, const void* bias_bf16 /* nullable */, int32_t accumulate, int64_t m, int64_t n, int64_t k,
-                    float* tile_sumsq /* nullable */, int64_t tile_sumsq_len, void* workspace /* nullable */, int64_t workspace_bytes, void* stream);
+                    float* tile_sumsq /* nullable */, int64_t tile_sumsq_len, void* workspace /* nullable */, int64_t workspace_bytes, int32_t sched, void* stream);
 /* The fused gate|up projection of the MLP with the SwiGLU activation in its epilogue (mlp.py:27-29: down_proj(act_fn(gate_proj(x)) * up_proj(x)); the
  * reference runs two F.linear, F.silu and a multiply as separate kernels): w = [gate rows ; up rows] ([2 inter, k], row stride ldw, the HF order of a
  * concatenated gate_proj / up_proj), gate_up[m, 2 inter] = x . w^T exactly as pm_gemm_bf16 writes it (kept for the backward pass), and
@@ -517,7 +518,7 @@ int pm_gemm_bf16_ws(const void* x_bf16, int64_t ldx, int32_t x_kmajor, const voi
  * reading gate_up back from HBM: a tile holds 128 features' gate and up columns in the same lanes.  inter % 128 == 0, k % 128 == 0. */
 int pm_gemm_swiglu_supported(int64_t m, int64_t inter, int64_t k);
 int pm_gemm_swiglu_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, int64_t ldw, void* gate_up_bf16, int64_t ldo, void* act_bf16, int64_t ldo2, int64_t m,
-                        int64_t inter, int64_t k, void* stream);
+                        int64_t inter, int64_t k, int32_t sched, void* stream);
 /* The down projection's row gradient with the SwiGLU backward in its epilogue (the backward of mlp.py:27-29; autograd runs mm, silu_backward, two muls):
  * d_act[m, inter] = dy[m, k] . w_down[k, inter] (w_down as stored, [hidden, inter], row stride ldw) is rounded to bf16 as pm_gemm_bf16 would store it and
  * then, still in registers, turned into grad_gate_up[m, 2 inter] = [d_gate | d_up] with the saved gate_up[m, 2 inter] — bit-identical to pm_gemm_bf16
@@ -525,14 +526,24 @@ int pm_gemm_swiglu_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, int
  * same lane).  inter % 8 == 0, k % 128 == 0. */
 int pm_gemm_swiglu_bwd_supported(int64_t m, int64_t inter, int64_t k);
 int pm_gemm_swiglu_bwd_bf16(const void* dy_bf16, int64_t lddy, const void* w_down_bf16, int64_t ldw, const void* gate_up_bf16, int64_t ldgu, void* grad_gate_up_bf16,
-                            int64_t ldo, int64_t m, int64_t inter, int64_t k, void* stream);
-int pm_gemm_debug_set_variant(int32_t value); /* one PROCESS-WIDE schedule word around the core's one K loop (setprio around the MFMA clusters, two compute segments
-                                               * of 32 MFMAs per K-tile): bit 2 = persistent grid (one workgroup per CU walking its tiles) instead of one workgroup per
-                                               * tile, bit 5 = no split-K of a half-empty last round, bit 10 = the round-3 patch sweep
-                                               * order; bits 0-1 are accepted and ignored (rounds 3-4 wrote 3 / 7).  Any other bit selects a measured-and-not-adopted build
-                                               * that exists only in a `make VARIANTS=1` library (four-phase loop, one-wave-per-SIMD kernel, timing ablations:
-                                               * profiles/r04_gemm.md, r05_gemm.md) and returns PM_ERR_UNSUPPORTED otherwise.  Callers that care re-assert their value
-                                               * before a launch (GRPOEngine._own_gemm). */
+                            int64_t ldo, int64_t m, int64_t inter, int64_t k, int32_t sched, void* stream);
+/* `sched` — the schedule word of a launch, passed WITH EVERY CALL of the eleven entry points above (the library keeps no schedule state):
+ * PM_GEMM_SCHED_DEFAULT (-1) = the library default (PM_GEMM_SCHED_PERSISTENT | 3), or a combination of PM_GEMM_SCHED_PERSISTENT (bit 2: one workgroup per CU walking
+ * its tiles instead of one workgroup per tile — what an engine that shares the GPU with RCCL kernels clears), PM_GEMM_SCHED_NO_SPLITK (bit 5),
+ * PM_GEMM_SCHED_NT_OUT (bit 9: non-temporal result stores of pm_gemm_bf16*), PM_GEMM_SCHED_SWEEP_R3 (bit 10: the round-3 patch sweep order); bits 0-1 are accepted
+ * and ignored (rounds 3-4 wrote 3 / 7).  The grouped entry points additionally read PM_GROUPED_SCHED_SMALL / _BIG (bits 16-17: the 128 x 128 / 256 x 256
+ * kernels of csrc/grouped_gemm.hip instead of the gemm.hip tile stream — the A/B references of the GPU tests).  Any other bit selects a measured-and-not-adopted
+ * build that exists only in a `make VARIANTS=1` library (profiles/r04_gemm.md, r05_gemm.md): PM_ERR_UNSUPPORTED in the product library.
+ * pm_gemm_debug_set_variant / pm_grouped_gemm_debug_set_variant: a process-wide OVERRIDE of every launch's word, for the A/B tools of `make VARIANTS=1`
+ * libraries only (value >= 0 sets, -1 clears); the product library has no such state and returns PM_ERR_UNSUPPORTED for any value >= 0. */
+#define PM_GEMM_SCHED_DEFAULT (-1)
+#define PM_GEMM_SCHED_PERSISTENT 4
+#define PM_GEMM_SCHED_NO_SPLITK 32
+#define PM_GEMM_SCHED_NT_OUT 512
+#define PM_GEMM_SCHED_SWEEP_R3 1024
+#define PM_GROUPED_SCHED_SMALL (1 << 16)
+#define PM_GROUPED_SCHED_BIG (2 << 16)
+int pm_gemm_debug_set_variant(int32_t value);
 
 /* --------------------------------------------------------------------------------------------
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.

@@ -137,25 +137,25 @@ SIGNATURES: dict[str, tuple] = {
     "pm_moe_ep_row_map": (I, [P, I32, I32, P, P, P, P]),
     "pm_grouped_gemm_supported": (I, [I64, I64, I64]),
     "pm_grouped_gemm_debug_set_variant": (I, [I32]),
-    "pm_grouped_gemm_nt": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
-    "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, P]),
+    "pm_grouped_gemm_nt": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, I32, P]),
+    "pm_grouped_gemm_nn": (I, [P, P, P, P, I32, I64, I64, I64, I64, P, I32, P]),
     "pm_grouped_gemm_nt_swiglu_supported": (I, [I64, I64, I64]),
-    "pm_grouped_gemm_nt_swiglu": (I, [P, P, P, P, I32, I64, I64, I64, P, P, P]),
+    "pm_grouped_gemm_nt_swiglu": (I, [P, P, P, P, I32, I64, I64, I64, P, P, I32, P]),
     "pm_grouped_gemm_nn_swiglu_bwd_supported": (I, [I64, I64, I64]),
-    "pm_grouped_gemm_nn_swiglu_bwd": (I, [P, P, P, I32, I64, I64, I64, P, P, P]),
-    "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, P]),
-    "pm_grouped_gemm_tn_f32": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, P]),
+    "pm_grouped_gemm_nn_swiglu_bwd": (I, [P, P, P, I32, I64, I64, I64, P, P, I32, P]),
+    "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, P]),
+    "pm_grouped_gemm_tn_f32": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, I32, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
     "pm_gemm_supported": (I, [I64, I64, I64, I32, I32]),
-    "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P]),
+    "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, I32, P]),
     "pm_gemm_sumsq_slots": (I64, [I64, I64]),
     "pm_gemm_workspace_bytes": (I64, [I64, I64, I64]),
-    "pm_gemm_bf16_ws": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P, I64, P, I64, P]),
-    "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, P]),
+    "pm_gemm_bf16_ws": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, P, I64, P, I64, I32, P]),
+    "pm_gemm_bf16_sumsq": (I, [P, I64, I32, P, I64, I32, P, I64, I32, I64, I64, I64, P, I64, I32, P]),
     "pm_gemm_swiglu_supported": (I, [I64, I64, I64]),
-    "pm_gemm_swiglu_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
+    "pm_gemm_swiglu_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, I32, P]),
     "pm_gemm_swiglu_bwd_supported": (I, [I64, I64, I64]),
-    "pm_gemm_swiglu_bwd_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P]),
+    "pm_gemm_swiglu_bwd_bf16": (I, [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, I32, P]),
     "pm_gemm_debug_set_variant": (I, [I32]),
 }
 
@@ -198,8 +198,8 @@ def load() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     got = lib.pm_abi_version()
-    if got != 1:
-        raise PrimeMI355XError(f"ABI version mismatch: library {got}, binding 1")
+    if got != 2:
+        raise PrimeMI355XError(f"ABI version mismatch: library {got}, binding 2")
     _lib = lib
     return lib
 

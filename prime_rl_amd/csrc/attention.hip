@@ -107,29 +107,35 @@ static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
 // workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
 constexpr int kFwdDefaultOpt = 15;  // 1 | 2 | 4 (row-max reduction as one asm block) | 8 (16-byte epilogue stores)
+#if PM_VARIANTS  // the A/B selectors are process-wide state of `make VARIANTS=1` libraries only; the product library holds constants (no mutable globals)
 static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.hip.h); -1 = the default build
 static int g_dkdv_var = 0;
 static int g_dq_var = 0;
+#else
+constexpr int g_fwd_var = -1, g_dkdv_var = 0, g_dq_var = 0;
+#endif
 }  // namespace pm
 
 using namespace pm;
 
 // Product library: only the shipped builds (value <= 0).  Every other value selects an A/B build of a `make VARIANTS=1` library.
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
-#if !PM_VARIANTS
   PM_REQUIRE(kernel >= 0 && kernel <= 2, PM_ERR_INVALID_ARG, "pm_attn_debug_set_variant: kernel %d", (int)kernel);
+#if !PM_VARIANTS
+  // no state to set: the default of each kernel (value <= 0; 15 = the forward's default option word) is accepted as a no-op
   PM_REQUIRE(value <= 0 || (kernel == 0 && value == 15), PM_ERR_UNSUPPORTED, "pm_attn_debug_set_variant(%d, %d): this build exists only in a `make VARIANTS=1` library",
              (int)kernel, (int)value);
-#endif
+  return PM_OK;
+#else
   if (kernel == 0) {
     if (value > 15 && value < 64 && value != 47) return PM_ERR_INVALID_ARG;  // 47 = 15 + 32: eight waves x 16 q rows  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
     g_fwd_var = value;
     return PM_OK;
   }
   if (kernel == 1) g_dkdv_var = value < 0 ? 0 : value;
-  else if (kernel == 2) g_dq_var = value < 0 ? 0 : value;
-  else return PM_ERR_INVALID_ARG;
+  else g_dq_var = value < 0 ? 0 : value;
   return PM_OK;
+#endif
 }
 
 extern "C" int pm_mfma_probe_16x16x32(const void* a, const void* b, float* c, void* stream) {

@@ -58,7 +58,18 @@ enum { SLOT_W0 = 0, SLOT_W1 = 1, SLOT_X0 = 2, SLOT_X1 = 3 };
 __host__ __device__ constexpr int slot_in_window(int buf, int slot) { return (buf * 2 + (slot & 1)) * kSlot; }            // offset inside the operand's 64 KiB window
 __host__ __device__ constexpr int slot_offset(int buf, int slot) { return (slot >= SLOT_X0 ? 4 * kSlot : 0) + slot_in_window(buf, slot); }
 
-static int g_variant = 7;  // bit 2: persistent grid; the other bits: pm_gemm_debug_set_variant
+// The schedule word travels WITH EVERY CALL (the `sched` argument of the pm_gemm_* / pm_grouped_gemm_* entry points; include/prime_mi355x.h): the product
+// library holds no mutable schedule state.  Only a `make VARIANTS=1` library keeps a process-wide override for its A/B builds (pm_gemm_debug_set_variant).
+constexpr int kDefaultSched = 7;  // bit 2: persistent grid (one workgroup per CU walking its tiles)
+#if PM_VARIANTS
+static int g_variant_override = -1;
+#endif
+static inline int eff_sched(int sched) {
+#if PM_VARIANTS
+  if (g_variant_override >= 0) return g_variant_override;
+#endif
+  return sched < 0 ? kDefaultSched : sched;
+}
 
 struct Params {
   const bf16_t* x;    // M-side operand: [M, K] (K-contiguous) or [K, M] (K-major), row stride ldx (elements)
@@ -1713,7 +1724,7 @@ static void launch_v(const Params& p, hipStream_t st, dim3 grid) {
 constexpr int kShippedLoop = 1 | 256 | 1024;
 
 template <bool XK, bool WK>
-static void launch(const Params& p, hipStream_t st) {
+static void launch(const Params& p, hipStream_t st, int g_variant) {
   // bit 2 of the variant: one persistent workgroup per CU walking its tiles (the next tile's first K-tiles are staged under the current tile's last
   // ones); otherwise one workgroup per tile.  n_blocks is a multiple of 256, so both grids keep "block b runs on XCD b % 8".
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
@@ -1758,7 +1769,7 @@ static void launch(const Params& p, hipStream_t st) {
 }
 // grouped products: the shipped loop; persistent unless the debug variant clears bit 2
 template <bool XK, bool WK, int MODE>
-static void launch_grouped(const Params& p, hipStream_t st) {
+static void launch_grouped(const Params& p, hipStream_t st, int g_variant) {
   const dim3 grid((g_variant & 4) ? std::min(p.n_blocks, 256) : p.n_blocks);
 #if PM_VARIANTS
   if (g_variant & 65536) { launch_v<3, XK, WK, MODE>(p, st, grid); return; }
@@ -1833,7 +1844,7 @@ bool grouped_shapes_ok(int64_t n_first, int64_t n, int64_t k_or_second) { return
 
 // y[m] = x[m] . [w | w2][e(m)]^T : x [M, K], w [E, n_first, K], w2 [E, N - n_first, K] -> y [M, N]
 int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_out,
-               int64_t k_dim, bf16_t* y, hipStream_t st) {
+               int64_t k_dim, bf16_t* y, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, n_first);
   p.x = x; p.w = w; p.w2 = w2; p.out = y;
@@ -1841,12 +1852,12 @@ int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t
   p.m = (int)n_rows; p.n = (int)n_out; p.k = (int)k_dim;
   p.tiles_m = 0; p.tiles_n = (int)(n_out / kTile);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
-  launch_grouped<false, false, 1>(p, st);
+  launch_grouped<false, false, 1>(p, st, eff_sched(sched));
   return PM_OK;
 }
 // dx[m] = dy[m, :n_first] . w[e] + dy[m, n_first:] . w2[e] : dy [M, n_dim], w [E, n_first, k_out], w2 [E, n_dim - n_first, k_out] -> dx [M, k_out]
 int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
-               int64_t k_out, bf16_t* dx, hipStream_t st) {
+               int64_t k_out, bf16_t* dx, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, n_first);
   p.x = dy; p.w = w; p.w2 = w2; p.out = dx;
@@ -1854,12 +1865,12 @@ int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_
   p.m = (int)n_rows; p.n = (int)k_out; p.k = (int)n_dim;
   p.tiles_m = 0; p.tiles_n = (int)(k_out / kTile);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
-  launch_grouped<false, true, 2>(p, st);
+  launch_grouped<false, true, 2>(p, st, eff_sched(sched));
   return PM_OK;
 }
 // gate_up[m] = x[m] . [w | w2][e(m)]^T and act[m] = silu(gate) * up in ONE launch (MODE 7): x [M, K], w / w2 [E, inter, K], gate_up [M, 2 inter], act [M, inter]
 int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t inter, int64_t k_dim,
-                      bf16_t* gate_up, bf16_t* act, hipStream_t st) {
+                      bf16_t* gate_up, bf16_t* act, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, inter);
   p.x = x; p.w = w; p.w2 = w2; p.out = gate_up; p.out2 = act;
@@ -1867,13 +1878,13 @@ int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const 
   p.m = (int)n_rows; p.n = (int)(2 * inter); p.k = (int)k_dim;
   p.tiles_m = 0; p.tiles_n = (int)(inter / 128);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
-  launch_grouped<false, false, 7>(p, st);
+  launch_grouped<false, false, 7>(p, st, eff_sched(sched));
   return PM_OK;
 }
 // [d_gate | d_up][m] = SwiGLU'(gate_up[m]) applied to (dy[m] . w[e]) : dy [M, n_dim], w [E, n_dim, inter] (the experts' down projection), gate_up and
 // d_gate_up [M, 2 inter] — grouped_nn through one weight set with the SwiGLU-backward epilogue (MODE 6); d_gate_up may be gate_up itself
 int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
-                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st) {
+                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, n_dim);
   p.x = dy; p.w = w; p.out = d_gate_up;
@@ -1882,12 +1893,12 @@ int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offs
   p.m = (int)n_rows; p.n = (int)inter; p.k = (int)n_dim;
   p.tiles_m = 0; p.tiles_n = (int)(inter / kTile);
   p.n_blocks = (int)(cdiv(cdiv(n_rows, kTile) + n_experts, 8) * 8 * p.tiles_n);
-  launch_grouped<false, true, 6>(p, st);
+  launch_grouped<false, true, 6>(p, st, eff_sched(sched));
   return PM_OK;
 }
 // dw[e] = dy[rows of e]^T . x[rows of e] : dy [M, n_dim], x [M, k_dim] -> dw [E, n_first, k_dim], dw2 [E, n_dim - n_first, k_dim]
 int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
-               int out_f32, int accumulate, hipStream_t st) {
+               int out_f32, int accumulate, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, n_first);
   p.out_f32 = out_f32;
@@ -1899,7 +1910,7 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
   // virtual ids: 8 XCD slots x the longest piece an XCD can own.  Up to 256 experts the tile line is cut by cost (build_wgrad_range) and a piece may hold
   // (nearly) all tiles; a workgroup stops at the first miss, so the surplus ids cost nothing.  More experts: expert e on XCD e % 8.
   p.n_blocks = (int)((n_experts <= 256 ? (int64_t)n_experts : cdiv(n_experts, 8)) * 8 * p.tiles_m * p.tiles_n);
-  launch_grouped<true, true, 3>(p, st);
+  launch_grouped<true, true, 3>(p, st, eff_sched(sched));
   return PM_OK;
 }
 
@@ -1908,15 +1919,18 @@ int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_
 
 using namespace pm;
 
-// Schedule word of the dense core.  The product library has ONE K loop (kShippedLoop); the word selects around it: bit 2 = persistent grid (one workgroup
+// Schedule word of the dense core — the `sched` argument of every launch (-1 = the library default, 7).  The product library has ONE K loop (kShippedLoop); the word selects around it: bit 2 = persistent grid (one workgroup
 // per CU walking its tiles) instead of one workgroup per tile, bit 5 = no split-K of a half-empty last tile round, bit 10 = the round-3 patch sweep order (A/B); bits 0 / 1 are accepted and ignored (rounds 3-4 wrote 3 / 7 for "per tile" / "persistent").  Every other bit
 // selects a build that was measured and not adopted and exists only in a `make VARIANTS=1` library — PM_ERR_UNSUPPORTED otherwise (the GPU tests skip).
 extern "C" int pm_gemm_debug_set_variant(int32_t v) {
-#if !PM_VARIANTS
-  PM_REQUIRE((v & ~(1 | 2 | 4 | 32 | 512 | 1024)) == 0, PM_ERR_UNSUPPORTED, "pm_gemm_debug_set_variant(%d): this schedule exists only in a `make VARIANTS=1` build", (int)v);
-#endif
-  gm::g_variant = v;
+#if PM_VARIANTS
+  gm::g_variant_override = v;  // >= 0: every launch of this process runs under this word, whatever the caller passes; -1: back to the per-call words
   return PM_OK;
+#else
+  PM_REQUIRE(v < 0, PM_ERR_UNSUPPORTED, "pm_gemm_debug_set_variant(%d): the product library holds no schedule state — pass the word as the `sched` argument of the "
+             "launch (a process-wide override exists only in a `make VARIANTS=1` build)", (int)v);
+  return PM_OK;
+#endif
 }
 
 // K-contiguous operands need K % 128 == 0 (a K-tile past the end of a row would read the next row); two K-major operands take any K
@@ -1936,23 +1950,28 @@ extern "C" int64_t pm_gemm_sumsq_slots(int64_t m, int64_t n) {
 
 static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
                      const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* workspace, int64_t workspace_bytes,
-                     void* stream);
+                     int32_t sched, void* stream);
 
 extern "C" int pm_gemm_bf16(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo,
-                            int32_t out_dtype, const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, void* stream) {
-  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, nullptr, nullptr, 0, stream);
+                            int32_t out_dtype, const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, int32_t sched, void* stream) {
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, nullptr, nullptr, 0, sched, stream);
 }
 
 extern "C" int pm_gemm_bf16_sumsq(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, float* out, int64_t ldo,
-                                  int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* stream) {
+                                  int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, int32_t sched, void* stream) {
   PM_REQUIRE(tile_sumsq && tile_sumsq_len >= pm_gemm_sumsq_slots(m, n), PM_ERR_WORKSPACE, "pm_gemm_bf16_sumsq: tile_sumsq needs pm_gemm_sumsq_slots(m, n) floats");
-  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, PM_DTYPE_F32, nullptr, accumulate, m, n, k, tile_sumsq, nullptr, 0, stream);
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, PM_DTYPE_F32, nullptr, accumulate, m, n, k, tile_sumsq, nullptr, 0, sched, stream);
 }
 
 static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
                      const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, void* workspace, int64_t workspace_bytes,
-                     void* stream) {
+                     int32_t sched, void* stream) {
   if (m == 0 || n == 0) return PM_OK;
+#if !PM_VARIANTS
+  PM_REQUIRE(sched < 0 || (sched & ~(1 | 2 | 4 | 32 | 512 | 1024)) == 0, PM_ERR_UNSUPPORTED, "pm_gemm_bf16: schedule word %d selects a build that exists only in a `make VARIANTS=1` library",
+             (int)sched);
+#endif
+  const int g_variant = gm::eff_sched(sched);
   PM_REQUIRE(x && w && out, PM_ERR_INVALID_ARG, "pm_gemm_bf16: null pointer");
   PM_REQUIRE(pm_gemm_supported(m, n, k, x_kmajor, w_kmajor), PM_ERR_UNSUPPORTED,
              "pm_gemm_bf16: unsupported shape / layout (m %lld, n %lld, k %lld, x_kmajor %d, w_kmajor %d)", (long long)m, (long long)n, (long long)k, x_kmajor, w_kmajor);
@@ -1981,15 +2000,15 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(n, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = out_dtype == PM_DTYPE_F32;
-  p.nt_out = (gm::g_variant & 512) ? 1 : 0;
+  p.nt_out = (g_variant & 512) ? 1 : 0;
   // cycle the smaller operand past the held block of the bigger one (X has m x k elements, W n x k); bit 10 of the debug variant: always the round-3 order (A/B)
-  p.sweep_n = (m > n && !(gm::g_variant & 1024)) ? 1 : 0;
+  p.sweep_n = (m > n && !(g_variant & 1024)) ? 1 : 0;
   hipStream_t st = as_stream(stream);
   // split-K of the last round (see Params): f32 results without bias, the whole contraction in one launch, a workspace from the caller
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
   {
     const gm::SplitPlan sp = gm::plan_split(p.tiles_m, p.tiles_n, k);
-    if (sp.s > 1 && !(gm::g_variant & 32) && p.out_f32 && !bias && k_chunk == k && workspace && workspace_bytes >= sp.ws_bytes) {  // (bit 5 of the debug variant: no split)
+    if (sp.s > 1 && !(g_variant & 32) && p.out_f32 && !bias && k_chunk == k && workspace && workspace_bytes >= sp.ws_bytes) {  // (bit 5 of the debug variant: no split)
       p.split_s = sp.s; p.split_rp = sp.rp; p.split_v0 = p.n_blocks - 256; p.split_k = sp.k_part; p.split_ws = (float*)workspace;
       if (accumulate) (void)hipMemsetAsync(workspace, 0, (size_t)sp.ws_bytes, st);  // parts >= 1 then add their product onto zeros
     }
@@ -2003,9 +2022,9 @@ static int gemm_impl(const void* x, int64_t ldx, int32_t x_kmajor, const void* w
   p.k_parts = (int)cdiv(k, k_chunk);
   p.accumulate = accumulate ? 1 : 0;
   p.sumsq = tile_sumsq;
-  if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st);
-  else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st);
-  else gm::launch<true, true>(p, st);
+  if (!x_kmajor && !w_kmajor) gm::launch<false, false>(p, st, g_variant);
+  else if (!x_kmajor && w_kmajor) gm::launch<false, true>(p, st, g_variant);
+  else gm::launch<true, true>(p, st, g_variant);
   PM_CHECK_LAUNCH("gemm_kernel");
   if (p.split_s > 1) {
     hipLaunchKernelGGL(gm::splitk_reduce_kernel, dim3((unsigned)(p.split_rp * 32 * 8)), dim3(256), 0, st, p);
@@ -2021,10 +2040,10 @@ extern "C" int64_t pm_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 
 extern "C" int pm_gemm_bf16_ws(const void* x, int64_t ldx, int32_t x_kmajor, const void* w, int64_t ldw, int32_t w_kmajor, void* out, int64_t ldo, int32_t out_dtype,
                                const void* bias, int32_t accumulate, int64_t m, int64_t n, int64_t k, float* tile_sumsq, int64_t tile_sumsq_len, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+                               int64_t workspace_bytes, int32_t sched, void* stream) {
   PM_REQUIRE(!tile_sumsq || (out_dtype == PM_DTYPE_F32 && !bias && tile_sumsq_len >= pm_gemm_sumsq_slots(m, n)), PM_ERR_WORKSPACE,
              "pm_gemm_bf16_ws: tile_sumsq needs an f32 output, no bias and pm_gemm_sumsq_slots(m, n) floats");
-  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, tile_sumsq, workspace, workspace_bytes, stream);
+  return gemm_impl(x, ldx, x_kmajor, w, ldw, w_kmajor, out, ldo, out_dtype, bias, accumulate, m, n, k, tile_sumsq, workspace, workspace_bytes, sched, stream);
 }
 
 // ---- gate|up forward with the SwiGLU epilogue (MODE 4 of the tile stream) ------------------------------------------------------------------------------
@@ -2033,8 +2052,9 @@ extern "C" int pm_gemm_swiglu_supported(int64_t m, int64_t inter, int64_t k) {
 }
 
 extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, void* gate_up, int64_t ldo, void* act, int64_t ldo2, int64_t m, int64_t inter,
-                                   int64_t k, void* stream) {
+                                   int64_t k, int32_t sched, void* stream) {
   if (m == 0 || inter == 0) return PM_OK;
+  const int g_variant = gm::eff_sched(sched);
   PM_REQUIRE(x && w && gate_up && act, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bf16: null pointer");
   PM_REQUIRE(pm_gemm_swiglu_supported(m, inter, k), PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bf16: needs inter %% 128 == 0 and k %% 128 == 0 (m %lld, inter %lld, k %lld)",
              (long long)m, (long long)inter, (long long)k);
@@ -2053,10 +2073,10 @@ extern "C" int pm_gemm_swiglu_bf16(const void* x, int64_t ldx, const void* w, in
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)(inter / 128);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = 0; p.accumulate = 0;
-  p.sweep_n = (m > 2 * inter && !(gm::g_variant & 1024)) ? 1 : 0;
+  p.sweep_n = (m > 2 * inter && !(g_variant & 1024)) ? 1 : 0;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
   p.k_chunk = (int)k; p.k_parts = 1;
-  gm::launch_grouped<false, false, 4>(p, as_stream(stream));
+  gm::launch_grouped<false, false, 4>(p, as_stream(stream), g_variant);
   PM_CHECK_LAUNCH("gemm_kernel<swiglu>");
   return PM_OK;
 }
@@ -2069,8 +2089,9 @@ extern "C" int pm_gemm_swiglu_bwd_supported(int64_t m, int64_t inter, int64_t k)
 }
 
 extern "C" int pm_gemm_swiglu_bwd_bf16(const void* dy, int64_t lddy, const void* w_down, int64_t ldw, const void* gate_up, int64_t ldgu, void* grad_gate_up, int64_t ldo,
-                                       int64_t m, int64_t inter, int64_t k, void* stream) {
+                                       int64_t m, int64_t inter, int64_t k, int32_t sched, void* stream) {
   if (m == 0 || inter == 0) return PM_OK;
+  const int g_variant = gm::eff_sched(sched);
   PM_REQUIRE(dy && w_down && gate_up && grad_gate_up, PM_ERR_INVALID_ARG, "pm_gemm_swiglu_bwd_bf16: null pointer");
   PM_REQUIRE(pm_gemm_swiglu_bwd_supported(m, inter, k), PM_ERR_UNSUPPORTED, "pm_gemm_swiglu_bwd_bf16: unsupported shape (m %lld, inter %lld, k %lld)", (long long)m,
              (long long)inter, (long long)k);
@@ -2090,10 +2111,10 @@ extern "C" int pm_gemm_swiglu_bwd_bf16(const void* dy, int64_t lddy, const void*
   p.tiles_m = (int)cdiv(m, gm::kTile); p.tiles_n = (int)cdiv(inter, gm::kTile);
   p.n_blocks = gm::grid_blocks(p.tiles_m, p.tiles_n);
   p.out_f32 = 0; p.accumulate = 0; p.nt_out = 0;
-  p.sweep_n = (m > inter && !(gm::g_variant & 1024)) ? 1 : 0;
+  p.sweep_n = (m > inter && !(g_variant & 1024)) ? 1 : 0;
   p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
   p.k_chunk = (int)k; p.k_parts = 1;
-  gm::launch_grouped<false, true, 5>(p, as_stream(stream));
+  gm::launch_grouped<false, true, 5>(p, as_stream(stream), g_variant);
   PM_CHECK_LAUNCH("gemm_kernel<swiglu_bwd>");
   return PM_OK;
 }

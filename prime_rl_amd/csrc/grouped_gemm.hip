@@ -613,22 +613,41 @@ namespace pm {
 namespace gm {
 bool grouped_shapes_ok(int64_t n_first, int64_t n, int64_t k_or_second);
 int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_out,
-               int64_t k_dim, bf16_t* y, hipStream_t st);
+               int64_t k_dim, bf16_t* y, hipStream_t st, int sched);
 int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
-               int64_t k_out, bf16_t* dx, hipStream_t st);
+               int64_t k_out, bf16_t* dx, hipStream_t st, int sched);
 int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
-               int out_f32, int accumulate, hipStream_t st);
+               int out_f32, int accumulate, hipStream_t st, int sched);
 int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
-                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st);
+                          const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st, int sched);
 int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t inter, int64_t k_dim,
-                      bf16_t* gate_up, bf16_t* act, hipStream_t st);
+                      bf16_t* gate_up, bf16_t* act, hipStream_t st, int sched);
 }  // namespace gm
 }  // namespace pm
 
-static int g_nt_variant = 0;  // debug A/B (pm_grouped_gemm_debug_set_variant): 0 = the gemm.hip core where the shape allows, 2 = this file's 256 x 256 kernels, 1 = 128 x 128 tiles everywhere
+// Which kernels run a grouped product travels in the launch's `sched` word (no process-wide state): bits 16-17 = 0: the gemm.hip core where the shape allows,
+// 2 (PM_GROUPED_SCHED_BIG): this file's 256 x 256 kernels, 1 (PM_GROUPED_SCHED_SMALL): 128 x 128 tiles everywhere — the A/B references of the GPU tests;
+// the low bits are the dense core's schedule word (-1 = default).  pm_grouped_gemm_debug_set_variant keeps a process-wide override in `make VARIANTS=1`
+// builds only.
+#if PM_VARIANTS
+static int g_nt_override = -1;
+#endif
+static inline int nt_variant_of(int sched) {
+#if PM_VARIANTS
+  if (g_nt_override >= 0) return g_nt_override;
+#endif
+  return sched < 0 ? 0 : (sched >> 16) & 3;
+}
+static inline int core_sched_of(int sched) { return sched < 0 ? -1 : (sched & 0xffff); }
 extern "C" int pm_grouped_gemm_debug_set_variant(int32_t value) {
-  g_nt_variant = value;
+#if PM_VARIANTS
+  g_nt_override = value;
   return PM_OK;
+#else
+  PM_REQUIRE(value < 0, PM_ERR_UNSUPPORTED, "pm_grouped_gemm_debug_set_variant(%d): the product library holds no variant state — pass PM_GROUPED_SCHED_* in the launch's "
+             "`sched` word", (int)value);
+  return PM_OK;
+#endif
 }
 
 static bool gg_shapes_ok(int64_t m, int64_t n, int64_t k) { return n % 128 == 0 && k % 128 == 0 && m * (n > k ? n : k) * 2 < ((int64_t)1 << 31); }
@@ -636,7 +655,9 @@ static bool gg_shapes_ok(int64_t m, int64_t n, int64_t k) { return n % 128 == 0 
 extern "C" int pm_grouped_gemm_supported(int64_t n_rows, int64_t n_out, int64_t k_dim) { return gg_shapes_ok(n_rows, n_out, k_dim) ? 1 : 0; }
 
 extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const void* w2_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
-                                  int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, void* stream) {
+                                  int64_t n_first, int64_t n_out, int64_t k_dim, void* y_bf16, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: bad sizes");
   PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (x_bf16 && y_bf16)) && (n_first == n_out || w2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: null pointer");
   PM_REQUIRE(n_first > 0 && n_first <= n_out && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt: n_first must be a multiple of 128 in (0, n_out]");
@@ -644,7 +665,7 @@ extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const 
              (long long)n_out, (long long)k_dim);
   if (n_rows == 0) return PM_OK;
   if (g_nt_variant == 0 && gm::grouped_shapes_ok(n_first, n_out, k_dim) && (n_out - n_first) % 256 == 0) {
-    gm::grouped_nt((const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_out, k_dim, (bf16_t*)y_bf16, as_stream(stream));
+    gm::grouped_nt((const bf16_t*)x_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_out, k_dim, (bf16_t*)y_bf16, as_stream(stream), core_sched_of(sched));
     PM_CHECK_LAUNCH("pm_grouped_gemm_nt");
     return PM_OK;
   }
@@ -663,7 +684,9 @@ extern "C" int pm_grouped_gemm_nt(const void* x_bf16, const void* w_bf16, const 
 }
 
 extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const void* w2_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
-                                  int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, void* stream) {
+                                  int64_t n_first, int64_t n_dim, int64_t k_out, void* dx_bf16, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: bad sizes");
   PM_REQUIRE(w_bf16 && offsets && (n_rows == 0 || (dy_bf16 && dx_bf16)) && (n_first == n_dim || w2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: null pointer");
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn: n_first must be a multiple of 128 in (0, n_dim]");
@@ -671,7 +694,7 @@ extern "C" int pm_grouped_gemm_nn(const void* dy_bf16, const void* w_bf16, const
              (long long)n_dim, (long long)k_out);
   if (n_rows == 0) return PM_OK;
   if (g_nt_variant == 0 && k_out % 256 == 0 && n_first % 128 == 0 && (n_dim - n_first) % 128 == 0) {
-    gm::grouped_nn((const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_dim, k_out, (bf16_t*)dx_bf16, as_stream(stream));
+    gm::grouped_nn((const bf16_t*)dy_bf16, (const bf16_t*)w_bf16, (const bf16_t*)w2_bf16, offsets, n_experts, n_rows, n_first, n_dim, k_out, (bf16_t*)dx_bf16, as_stream(stream), core_sched_of(sched));
     PM_CHECK_LAUNCH("pm_grouped_gemm_nn");
     return PM_OK;
   }
@@ -698,19 +721,24 @@ extern "C" int pm_grouped_gemm_nt_swiglu_supported(int64_t n_rows, int64_t inter
 }
 
 extern "C" int pm_grouped_gemm_nt_swiglu(const void* x_bf16, const void* w_gate_bf16, const void* w_up_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows,
-                                         int64_t inter, int64_t k_dim, void* gate_up_bf16, void* act_bf16, void* stream) {
+                                         int64_t inter, int64_t k_dim, void* gate_up_bf16, void* act_bf16, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt_swiglu: bad sizes");
   PM_REQUIRE(w_gate_bf16 && w_up_bf16 && offsets && (n_rows == 0 || (x_bf16 && gate_up_bf16 && act_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nt_swiglu: null pointer");
   PM_REQUIRE(pm_grouped_gemm_nt_swiglu_supported(n_rows, inter, k_dim), PM_ERR_UNSUPPORTED,
              "pm_grouped_gemm_nt_swiglu: needs inter %% 128 == 0 and k %% 128 == 0 (inter %lld, k %lld; row tensors < 2 GiB)", (long long)inter, (long long)k_dim);
   const int64_t delta = (const unsigned char*)w_up_bf16 - (const unsigned char*)w_gate_bf16;
   const int64_t span = delta + ((int64_t)n_experts * inter) * k_dim * 2;  // from w_gate[0] to the end of w_up: what one descriptor must be able to address from any panel base
-  PM_REQUIRE(delta > 0 && delta % 16 == 0 && delta + 128 * k_dim * 2 < ((int64_t)1 << 31) - 4096, PM_ERR_UNSUPPORTED,
-             "pm_grouped_gemm_nt_swiglu: w_up must lie above w_gate within 2 GiB (distance %lld bytes)", (long long)delta);
+  // a whole number of weight ROWS apart: the tile's descriptor is sized in rows ((w_up - w_gate) / k_dim + 128), so a distance that is not a multiple of the row
+  // pitch would cut the K tail of the last up row of every tile short (separately allocated w1 / w3 can sit at such a distance)
+  PM_REQUIRE(delta > 0 && delta % (k_dim * 2) == 0 && delta + 128 * k_dim * 2 < ((int64_t)1 << 31) - 4096, PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_nt_swiglu: w_up must lie above w_gate, a whole number of %lld-byte weight rows away and within 2 GiB (distance %lld bytes)",
+             (long long)(k_dim * 2), (long long)delta);
   (void)span;
   if (n_rows == 0) return PM_OK;
   gm::grouped_nt_swiglu((const bf16_t*)x_bf16, (const bf16_t*)w_gate_bf16, (const bf16_t*)w_up_bf16, offsets, n_experts, n_rows, inter, k_dim, (bf16_t*)gate_up_bf16,
-                        (bf16_t*)act_bf16, as_stream(stream));
+                        (bf16_t*)act_bf16, as_stream(stream), core_sched_of(sched));
   PM_CHECK_LAUNCH("pm_grouped_gemm_nt_swiglu");
   return PM_OK;
 }
@@ -722,27 +750,31 @@ extern "C" int pm_grouped_gemm_nn_swiglu_bwd_supported(int64_t n_rows, int64_t n
 }
 
 extern "C" int pm_grouped_gemm_nn_swiglu_bwd(const void* dy_bf16, const void* w_down_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_dim,
-                                             int64_t inter, const void* gate_up_bf16, void* grad_gate_up_bf16, void* stream) {
+                                             int64_t inter, const void* gate_up_bf16, void* grad_gate_up_bf16, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn_swiglu_bwd: bad sizes");
   PM_REQUIRE(w_down_bf16 && offsets && (n_rows == 0 || (dy_bf16 && gate_up_bf16 && grad_gate_up_bf16)), PM_ERR_INVALID_ARG, "pm_grouped_gemm_nn_swiglu_bwd: null pointer");
   PM_REQUIRE(pm_grouped_gemm_nn_swiglu_bwd_supported(n_rows, n_dim, inter), PM_ERR_UNSUPPORTED,
              "pm_grouped_gemm_nn_swiglu_bwd: needs inter %% 256 == 0 and n_dim %% 128 == 0 (n_dim %lld, inter %lld; row tensors < 2 GiB)", (long long)n_dim, (long long)inter);
   if (n_rows == 0) return PM_OK;
   gm::grouped_nn_swiglu_bwd((const bf16_t*)dy_bf16, (const bf16_t*)w_down_bf16, offsets, n_experts, n_rows, n_dim, inter, (const bf16_t*)gate_up_bf16,
-                            (bf16_t*)grad_gate_up_bf16, as_stream(stream));
+                            (bf16_t*)grad_gate_up_bf16, as_stream(stream), core_sched_of(sched));
   PM_CHECK_LAUNCH("pm_grouped_gemm_nn_swiglu_bwd");
   return PM_OK;
 }
 
 extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first,
-                                  int64_t n_dim, int64_t k_dim, void* dw_bf16, void* dw2_bf16, void* stream) {
+                                  int64_t n_dim, int64_t k_dim, void* dw_bf16, void* dw2_bf16, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: bad sizes");
   PM_REQUIRE(offsets && dw_bf16 && (n_rows == 0 || (dy_bf16 && x_bf16)) && (n_first == n_dim || dw2_bf16), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: null pointer");
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && n_first % 128 == 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn: n_first must be a multiple of 128 in (0, n_dim]");
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
   if (g_nt_variant == 0 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
-    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_bf16, dw2_bf16, 0, 0, as_stream(stream));
+    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_bf16, dw2_bf16, 0, 0, as_stream(stream), core_sched_of(sched));
     PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
     return PM_OK;
   }
@@ -763,13 +795,15 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
 // The weight gradient written (or accumulated) in f32 straight into a main-gradient buffer — what the dense engine's wgrad GEMMs do (pm_gemm_bf16 with an
 // f32 output): no bf16 gradient tensor, no separate bf16 -> f32 accumulation pass over the expert parameters.  Runs on the gemm.hip core only.
 extern "C" int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first,
-                                      int64_t n_dim, int64_t k_dim, float* dw_f32, float* dw2_f32, int32_t accumulate, void* stream) {
+                                      int64_t n_dim, int64_t k_dim, float* dw_f32, float* dw2_f32, int32_t accumulate, int32_t sched, void* stream) {
+  const int g_nt_variant = nt_variant_of(sched);
+  (void)g_nt_variant;
   PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32: bad sizes");
   PM_REQUIRE(offsets && dw_f32 && (n_rows == 0 || (dy_bf16 && x_bf16)) && (n_first == n_dim || dw2_f32), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32: null pointer");
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && gg_shapes_ok(n_rows, n_dim, k_dim) && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0, PM_ERR_UNSUPPORTED,
              "pm_grouped_gemm_tn_f32: n_first=%lld n=%lld k=%lld must be multiples of 256 (and the row tensors < 2 GiB)", (long long)n_first, (long long)n_dim,
              (long long)k_dim);
-  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, as_stream(stream));
+  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, as_stream(stream), core_sched_of(sched));
   PM_CHECK_LAUNCH("pm_grouped_gemm_tn_f32");
   return PM_OK;
 }

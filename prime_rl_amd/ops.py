@@ -744,7 +744,7 @@ def _gg_second(w: Tensor, w2: Tensor | None):
     return w2.shape[1]
 
 
-def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None) -> Tensor:
+def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None, variant: int | None = None) -> Tensor:
     """y[m] = x[m] @ [w | w2][e(m)].T over expert-sorted rows: x [M, K], w [E, N1, K] (, w2 [E, N2, K]), offsets [E+1] i32 -> y [M, N1 + N2]."""
     lib = _lib.load()
     _gg_check(x, w, offsets, "x")
@@ -753,11 +753,11 @@ def grouped_gemm_nt(x: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = N
     if x.shape[1] != k:
         raise PrimeMI355XError(f"grouped_gemm_nt: x {tuple(x.shape)} vs w {tuple(w.shape)}")
     y = torch.empty((x.shape[0], n + n2), dtype=torch.bfloat16, device=x.device)
-    check(lib.pm_grouped_gemm_nt(_p(x), _p(w), _p(w2), _p(offsets), e, x.shape[0], n, n + n2, k, _p(y), _stream()), "pm_grouped_gemm_nt")
+    check(lib.pm_grouped_gemm_nt(_p(x), _p(w), _p(w2), _p(offsets), e, x.shape[0], n, n + n2, k, _p(y), _sched(variant), _stream()), "pm_grouped_gemm_nt")
     return y
 
 
-def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None) -> Tensor:
+def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = None, variant: int | None = None) -> Tensor:
     """dx[m] = dy[m] @ [w ; w2][e(m)]: dy [M, N1 + N2], w [E, N1, K] (, w2 [E, N2, K]) -> dx [M, K]."""
     lib = _lib.load()
     _gg_check(dy, w, offsets, "dy")
@@ -766,24 +766,25 @@ def grouped_gemm_nn(dy: Tensor, w: Tensor, offsets: Tensor, w2: Tensor | None = 
     if dy.shape[1] != n + n2:
         raise PrimeMI355XError(f"grouped_gemm_nn: dy {tuple(dy.shape)} vs w {tuple(w.shape)} (+ {n2})")
     dx = torch.empty((dy.shape[0], k), dtype=torch.bfloat16, device=dy.device)
-    check(lib.pm_grouped_gemm_nn(_p(dy), _p(w), _p(w2), _p(offsets), e, dy.shape[0], n, n + n2, k, _p(dx), _stream()), "pm_grouped_gemm_nn")
+    check(lib.pm_grouped_gemm_nn(_p(dy), _p(w), _p(w2), _p(offsets), e, dy.shape[0], n, n + n2, k, _p(dx), _sched(variant), _stream()), "pm_grouped_gemm_nn")
     return dx
 
 
 def grouped_gemm_nt_swiglu_supported(x: Tensor, w_gate: Tensor, w_up: Tensor) -> bool:
     """Can `grouped_gemm_nt_swiglu` take these operands?  Shapes (inter % 128, K % 128) and the placement of the two weight tensors: one buffer descriptor
-    reads both, so w_up must start above w_gate within 2 GiB."""
+    reads both, so w_up must start above w_gate, a whole number of weight rows away, within 2 GiB."""
     if w_gate.dim() != 3 or tuple(w_gate.shape) != tuple(w_up.shape) or x.dim() != 2 or x.shape[1] != w_gate.shape[2]:
         return False
     if not (x.is_cuda and x.dtype == w_gate.dtype == w_up.dtype == torch.bfloat16 and x.is_contiguous() and w_gate.is_contiguous() and w_up.is_contiguous()):
         return False
     delta = w_up.data_ptr() - w_gate.data_ptr()
-    if delta <= 0 or delta % 16 or delta + 128 * w_gate.shape[2] * 2 >= 2**31 - 4096:
+    row_bytes = w_gate.shape[2] * 2  # the tile's descriptor is sized in whole weight rows: a distance that is not a multiple of the row pitch would cut the
+    if delta <= 0 or delta % row_bytes or delta + 128 * row_bytes >= 2**31 - 4096:  # K tail of every tile's last up row short (ADVICE r5)
         return False
     return bool(_lib.load().pm_grouped_gemm_nt_swiglu_supported(x.shape[0], w_gate.shape[1], w_gate.shape[2]))
 
 
-def grouped_gemm_nt_swiglu(x: Tensor, w_gate: Tensor, w_up: Tensor, offsets: Tensor) -> tuple[Tensor, Tensor]:
+def grouped_gemm_nt_swiglu(x: Tensor, w_gate: Tensor, w_up: Tensor, offsets: Tensor, variant: int | None = None) -> tuple[Tensor, Tensor]:
     """(gate_up [M, 2 inter], act [M, inter]) = (x[m] @ [w_gate | w_up][e(m)].T, silu(gate) * up) in one launch — equal to grouped_gemm_nt(x, w_gate, offsets,
     w2=w_up) and swiglu_fwd of it, bit for bit."""
     lib = _lib.load()
@@ -794,7 +795,7 @@ def grouped_gemm_nt_swiglu(x: Tensor, w_gate: Tensor, w_up: Tensor, offsets: Ten
     e, inter, k = w_gate.shape
     gate_up = torch.empty((x.shape[0], 2 * inter), dtype=torch.bfloat16, device=x.device)
     act = torch.empty((x.shape[0], inter), dtype=torch.bfloat16, device=x.device)
-    check(lib.pm_grouped_gemm_nt_swiglu(_p(x), _p(w_gate), _p(w_up), _p(offsets), e, x.shape[0], inter, k, _p(gate_up), _p(act), _stream()), "pm_grouped_gemm_nt_swiglu")
+    check(lib.pm_grouped_gemm_nt_swiglu(_p(x), _p(w_gate), _p(w_up), _p(offsets), e, x.shape[0], inter, k, _p(gate_up), _p(act), _sched(variant), _stream()), "pm_grouped_gemm_nt_swiglu")
     return gate_up, act
 
 
@@ -802,7 +803,7 @@ def grouped_gemm_nn_swiglu_bwd_supported(n_rows: int, n_dim: int, inter: int) ->
     return bool(_lib.load().pm_grouped_gemm_nn_swiglu_bwd_supported(n_rows, n_dim, inter))
 
 
-def grouped_gemm_nn_swiglu_bwd(dy: Tensor, w_down: Tensor, offsets: Tensor, gate_up: Tensor, out: Tensor | None = None) -> Tensor:
+def grouped_gemm_nn_swiglu_bwd(dy: Tensor, w_down: Tensor, offsets: Tensor, gate_up: Tensor, out: Tensor | None = None, variant: int | None = None) -> Tensor:
     """grad_gate_up[m] = swiglu_bwd(dy[m] @ w_down[e(m)], gate_up[m]): dy [M, N], w_down [E, N, inter], gate_up [M, 2 inter] -> [M, 2 inter] — equals
     swiglu_bwd(grouped_gemm_nn(dy, w_down, offsets), gate_up) bit for bit; `out` may be `gate_up`."""
     lib = _lib.load()
@@ -816,11 +817,11 @@ def grouped_gemm_nn_swiglu_bwd(dy: Tensor, w_down: Tensor, offsets: Tensor, gate
     _req(out, torch.bfloat16, "out")
     if tuple(out.shape) != tuple(gate_up.shape):
         raise PrimeMI355XError(f"grouped_gemm_nn_swiglu_bwd: out {tuple(out.shape)} != gate_up {tuple(gate_up.shape)}")
-    check(lib.pm_grouped_gemm_nn_swiglu_bwd(_p(dy), _p(w_down), _p(offsets), e, dy.shape[0], n, inter, _p(gate_up), _p(out), _stream()), "pm_grouped_gemm_nn_swiglu_bwd")
+    check(lib.pm_grouped_gemm_nn_swiglu_bwd(_p(dy), _p(w_down), _p(offsets), e, dy.shape[0], n, inter, _p(gate_up), _p(out), _sched(variant), _stream()), "pm_grouped_gemm_nn_swiglu_bwd")
     return out
 
 
-def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None = None):
+def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None = None, variant: int | None = None):
     """dw[e] = dy[group e].T @ x[group e]: dy [M, N], x [M, K] -> dw [E, N, K]; with n_first: (dw [E, n_first, K], dw2 [E, N - n_first, K])."""
     lib = _lib.load()
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(offsets, torch.int32, "offsets")
@@ -831,7 +832,7 @@ def grouped_gemm_tn(dy: Tensor, x: Tensor, offsets: Tensor, n_first: int | None 
     n1 = n if n_first is None else n_first
     dw = torch.empty((e, n1, k), dtype=torch.bfloat16, device=x.device)
     dw2 = torch.empty((e, n - n1, k), dtype=torch.bfloat16, device=x.device) if n1 < n else None
-    check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), _stream()), "pm_grouped_gemm_tn")
+    check(lib.pm_grouped_gemm_tn(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), _sched(variant), _stream()), "pm_grouped_gemm_tn")
     return dw if n_first is None else (dw, dw2)
 
 
@@ -839,7 +840,7 @@ def grouped_gemm_tn_f32_supported(n_first: int, n: int, k: int) -> bool:
     return n_first % 256 == 0 and n % 256 == 0 and k % 256 == 0
 
 
-def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2: Tensor | None = None, accumulate: bool = False) -> None:
+def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2: Tensor | None = None, accumulate: bool = False, variant: int | None = None) -> None:
     """dw[e] (+)= dy[group e, :n_first].T @ x[group e] and dw2[e] (+)= dy[group e, n_first:].T @ x[group e] in f32, written straight into the given
     (main-gradient) buffers: dw [E, n_first, K], dw2 [E, N - n_first, K] or None."""
     lib = _lib.load()
@@ -853,7 +854,7 @@ def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2:
         _req(dw2, torch.float32, "dw2")
         if tuple(dw2.shape) != (e, n - n1, k):
             raise PrimeMI355XError(f"grouped_gemm_tn_f32: dw2 {tuple(dw2.shape)} != {(e, n - n1, k)}")
-    check(lib.pm_grouped_gemm_tn_f32(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _stream()), "pm_grouped_gemm_tn_f32")
+    check(lib.pm_grouped_gemm_tn_f32(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _sched(variant), _stream()), "pm_grouped_gemm_tn_f32")
 
 
 def sgd_step(master: Tensor, momentum_buf: Tensor | None, grad: Tensor, param_bf16: Tensor | None, lr: float, momentum: float, weight_decay: float,
@@ -923,24 +924,16 @@ def gemm_shape_supported(m: int, n: int, k: int, x_kmajor: bool, w_kmajor: bool)
     return ldx % 8 == 0 and ldw % 8 == 0 and n % 4 == 0 and bool(_lib.load().pm_gemm_supported(m, n, k, int(x_kmajor), int(w_kmajor)))
 
 
-_gemm_variant_word = 7  # what pm_gemm_debug_set_variant currently holds (the library's default)
+GEMM_SCHED_DEFAULT = -1  # include/prime_mi355x.h PM_GEMM_SCHED_*: the schedule word is an ARGUMENT of every launch (the library holds no schedule state)
+GEMM_SCHED_PERSISTENT, GEMM_SCHED_NO_SPLITK, GEMM_SCHED_NT_OUT, GEMM_SCHED_SWEEP_R3 = 4, 32, 512, 1024
+GROUPED_SCHED_SMALL, GROUPED_SCHED_BIG = 1 << 16, 2 << 16
 
 
-class _gemm_variant_scope:
-    """`with _gemm_variant_scope(v):` — run launches under schedule word v and restore the previous word (None: leave the word alone)."""
+_default_sched = GEMM_SCHED_DEFAULT  # what a launch with `variant=None` passes; moved only by gemm_set_variant (tests / tools)
 
-    def __init__(self, v: int | None):
-        self.v, self.prev = v, None
 
-    def __enter__(self):
-        if self.v is not None and self.v != _gemm_variant_word:
-            self.prev = _gemm_variant_word
-            gemm_set_variant(self.v)
-
-    def __exit__(self, *exc):
-        if self.prev is not None:
-            gemm_set_variant(self.prev)
-        return False
+def _sched(variant: int | None) -> int:
+    return _default_sched if variant is None else int(variant)
 
 
 def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype = torch.bfloat16, bias: Tensor | None = None, accumulate: bool = False,
@@ -969,15 +962,15 @@ def gemm(x: Tensor, w: Tensor, out: Tensor | None = None, out_dtype: torch.dtype
         _req(tile_sumsq, torch.float32, "tile_sumsq")
         if out.dtype != torch.float32 or bias is not None:
             raise PrimeMI355XError("gemm: tile_sumsq needs an f32 output and no bias")
-    with _gemm_variant_scope(variant):  # `variant`: the schedule word for THIS launch only (the library keeps one process-wide word)
-        if out.dtype == torch.float32 and bias is None:  # the f32 (weight-gradient) form: a workspace lets a half-empty last round of tiles split along K
-            ws_bytes = lib.pm_gemm_workspace_bytes(m, n, k)
-            ws = workspace(ws_bytes, x.device, "gemm_splitk") if ws_bytes else None
-            check(lib.pm_gemm_bf16_ws(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], None, int(accumulate), m, n, k,
-                                      _p(tile_sumsq), tile_sumsq.numel() if tile_sumsq is not None else 0, _p(ws), ws_bytes, _stream()), "pm_gemm_bf16_ws")
-            return out
-        check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _stream()),
-              "pm_gemm_bf16")
+    # `variant`: the schedule word of THIS launch (PM_GEMM_SCHED_*; None = the library default) — an argument of the C call, not process state
+    if out.dtype == torch.float32 and bias is None:  # the f32 (weight-gradient) form: a workspace lets a half-empty last round of tiles split along K
+        ws_bytes = lib.pm_gemm_workspace_bytes(m, n, k)
+        ws = workspace(ws_bytes, x.device, "gemm_splitk") if ws_bytes else None
+        check(lib.pm_gemm_bf16_ws(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], None, int(accumulate), m, n, k,
+                                  _p(tile_sumsq), tile_sumsq.numel() if tile_sumsq is not None else 0, _p(ws), ws_bytes, _sched(variant), _stream()), "pm_gemm_bf16_ws")
+        return out
+    check(lib.pm_gemm_bf16(_p(x), ldx, int(xk), _p(w), ldw, int(wk), _p(out), out.stride(0), _DT[out.dtype], _p(bias), int(accumulate), m, n, k, _sched(variant),
+                           _stream()), "pm_gemm_bf16")
     return out
 
 
@@ -1008,9 +1001,8 @@ def gemm_swiglu(x: Tensor, w_gate_up: Tensor, gate_up: Tensor | None = None, act
         _req(t, torch.bfloat16, nm, contiguous=False)
         if tuple(t.shape) != (m, cols) or t.stride(1) != 1 or t.stride(0) % 8:
             raise PrimeMI355XError(f"gemm_swiglu: {nm} must be [{m}, {cols}] bf16 with unit column stride and a row stride that is a multiple of 8")
-    with _gemm_variant_scope(variant):
-        check(_lib.load().pm_gemm_swiglu_bf16(_p(x), x.stride(0), _p(w_gate_up), w_gate_up.stride(0), _p(gate_up), gate_up.stride(0), _p(act), act.stride(0), m, inter, k,
-                                              _stream()), "pm_gemm_swiglu_bf16")
+    check(_lib.load().pm_gemm_swiglu_bf16(_p(x), x.stride(0), _p(w_gate_up), w_gate_up.stride(0), _p(gate_up), gate_up.stride(0), _p(act), act.stride(0), m, inter, k,
+                                          _sched(variant), _stream()), "pm_gemm_swiglu_bf16")
     return gate_up, act
 
 
@@ -1039,9 +1031,8 @@ def gemm_swiglu_bwd(dy: Tensor, w_down: Tensor, gate_up: Tensor, out: Tensor | N
         _req(t, torch.bfloat16, nm, contiguous=False)
         if tuple(t.shape) != (m, 2 * inter) or t.stride(1) != 1 or t.stride(0) % 8:
             raise PrimeMI355XError(f"gemm_swiglu_bwd: {nm} must be [{m}, {2 * inter}] bf16 with unit column stride and a row stride that is a multiple of 8")
-    with _gemm_variant_scope(variant):
-        check(_lib.load().pm_gemm_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(gate_up), gate_up.stride(0), _p(out), out.stride(0), m, inter, k,
-                                                  _stream()), "pm_gemm_swiglu_bwd_bf16")
+    check(_lib.load().pm_gemm_swiglu_bwd_bf16(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(gate_up), gate_up.stride(0), _p(out), out.stride(0), m, inter, k,
+                                              _sched(variant), _stream()), "pm_gemm_swiglu_bwd_bf16")
     return out
 
 
@@ -1064,7 +1055,14 @@ def sum_partials(partials: Tensor, out_scalar: Tensor) -> None:
 
 
 def gemm_set_variant(v: int) -> None:
-    """The library's process-wide schedule word (include/prime_mi355x.h: pm_gemm_debug_set_variant).  Product code passes `variant=` to gemm() instead."""
-    global _gemm_variant_word
-    check(_lib.load().pm_gemm_debug_set_variant(v), "pm_gemm_debug_set_variant")
-    _gemm_variant_word = v
+    """Tests / tools: the schedule word that launches WITHOUT an explicit `variant=` pass from now on (7 or -1 = the library default).  A Python-side default
+    only — the word still travels as the `sched` argument of every C call; the library holds no schedule state.  Words that select a build of a
+    `make VARIANTS=1` library raise here on the product library, so that callers can skip."""
+    global _default_sched
+    lib = _lib.load()
+    if v >= 0 and (v & ~(1 | 2 | 4 | 32 | 512 | 1024)):
+        rc = lib.pm_gemm_debug_set_variant(0)  # accepted only by a VARIANTS=1 library
+        if rc != 0:
+            raise PrimeMI355XError(f"gemm_set_variant({v}): this schedule exists only in a `make VARIANTS=1` build")
+        lib.pm_gemm_debug_set_variant(-1)
+    _default_sched = GEMM_SCHED_DEFAULT if v in (7, -1) else int(v)

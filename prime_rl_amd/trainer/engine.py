@@ -458,7 +458,7 @@ class GRPOEngine:
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
                  shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None, fused_sumsq: bool = True,
-                 embed_split: bool = True, fused_swiglu_bwd: bool = True):
+                 embed_split: bool = True, fused_swiglu_bwd: bool = True, fused_swiglu_fwd: bool = True):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
             raise PrimeMI355XError(f"gemm_dtype must be 'bf16' or 'f32', got {gemm_dtype!r}")
@@ -561,7 +561,7 @@ class GRPOEngine:
             # Schedule of the own core: one PERSISTENT workgroup per CU walking its tiles (+0-2 %) when this rank's GPU runs nothing beside the step; one
             # workgroup per tile when collectives run on the comm stream — a persistent grid of exactly 256 workgroups that each need a whole CU (160 KiB of
             # LDS) would be cut into two rounds by a handful of CUs held by RCCL kernels, a per-tile grid only loses those CUs' share.
-            # The schedule word is process-wide in the library (pm_gemm_debug_set_variant); this engine passes ITS word with every launch (`_own_gemm`).
+            # The schedule word is an ARGUMENT of every launch (include/prime_mi355x.h `sched`): this engine passes ITS word (`_own_gemm`); the library keeps none.
             self._gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7"))  # (the env override is the in-step A/B hook: + 32 = no split-K)
         # The gradient-norm pass fused into the weight-gradient epilogues (ops.gemm(tile_sumsq=...)): on the LAST backward pass of a step every wgrad GEMM
         # leaves per-tile sums of squares of the final f32 gradient; the optimizer then adds those up together with the few small tensors in between
@@ -576,6 +576,7 @@ class GRPOEngine:
         # the SwiGLU backward in the epilogue of the down projection's row-gradient GEMM (ops.gemm_swiglu_bwd) where that GEMM runs on the own core;
         # `fused_swiglu_bwd=False` is the A/B switch of the tests (GEMM, then pm_swiglu_bwd: identical results)
         self.fused_swiglu_bwd = fused_swiglu_bwd
+        self.fused_swiglu_fwd = fused_swiglu_fwd  # A/B switch: the SwiGLU activation in the gate|up product's epilogue vs GEMM + pm_swiglu_fwd (bit-identical)
         self.fused_sumsq = "wgrad" in self.gemm_own and not self.use_collectives and fused_sumsq
         self._fs_plan: dict | None = None
         self._fs_covered: set[str] = set()
@@ -648,8 +649,8 @@ class GRPOEngine:
             self._gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "3" if self.use_collectives else "7"))
 
     def _own_gemm(self, *args, **kwargs) -> Tensor:
-        """ops.gemm on the hand-written core under THIS engine's schedule word: passed per call (ops.gemm sets it for the launch and puts the previous word
-        back), so that no other caller in the process — the nn.Module LM head, the grouped MoE products, a second engine — inherits or disturbs it."""
+        """ops.gemm on the hand-written core under THIS engine's schedule word: the `sched` argument of the C call, so that no other caller in the process —
+        the nn.Module LM head, the grouped MoE products, a second engine, another thread — inherits or disturbs it (the library holds no schedule state)."""
         return ops.gemm(*args, variant=self._gemm_variant, **kwargs)
 
     def _fwd_mm(self, x: Tensor, w: Tensor, out_f32: bool = False, bias: Tensor | None = None) -> Tensor:
@@ -861,7 +862,7 @@ class GRPOEngine:
         attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
         h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
         wgu = w[p + "mlp.gate_up_proj.weight"]
-        if "fwd" in self.gemm_own and not self.gemm_f32 and ops.gemm_swiglu_supported(h2, wgu):
+        if self.fused_swiglu_fwd and "fwd" in self.gemm_own and not self.gemm_f32 and ops.gemm_swiglu_supported(h2, wgu):
             # the own core writes act = silu(gate) * up from the accumulators of the gate|up product (a tile = 128 features' gate AND up columns): the
             # stand-alone SwiGLU pass (read 2 I, write I bytes x 2 per token) disappears; gu is still written once, for the backward
             gu, act = ops.gemm_swiglu(h2, wgu, variant=self._gemm_variant)

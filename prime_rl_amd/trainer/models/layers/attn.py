@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .... import ops
+from .linear import fused_linear, linear
 from .norms import RMSNorm, RMSNormConfig
 
 
@@ -87,6 +88,41 @@ class _VarlenAttnFn(torch.autograd.Function):
         return gq, gk, gv, None, None
 
 
+class _QKVAttnFn(torch.autograd.Function):
+    """per-head q/k RMSNorm + RoPE + varlen causal attention on the fused projection output `qkv [N, (hq + 2 hkv) d]` as ONE autograd node: its backward
+    writes d(qkv) once — the q | k columns by `pm_qknorm_rope_bwd`, the v columns by the attention backward itself (`grad_v_out`) — instead of autograd
+    assembling it from a zero-filled buffer, a slice copy and an add (three passes over [N, qkv] per layer).  `qw` / `kw` None = RoPE only (Llama, Qwen2)."""
+
+    @staticmethod
+    def forward(ctx, qkv, qw, kw, cos, sin, seq_start, hq, hkv, d, eps, scale):
+        n = qkv.shape[0]
+        q, k, rstd = ops.qknorm_rope_fwd(qkv, qw.contiguous() if qw is not None else None, kw.contiguous() if kw is not None else None, cos, sin, hq, hkv, d, eps)
+        v = qkv[:, (hq + hkv) * d:].view(n, hkv, d)
+        out, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
+        ctx.save_for_backward(qkv, qw, kw, cos, sin, rstd, q, k, out, lse, seq_start)
+        ctx.dims = (hq, hkv, d, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, qw, kw, cos, sin, rstd, q, k, out, lse, seq_start = ctx.saved_tensors
+        hq, hkv, d, scale = ctx.dims
+        n = qkv.shape[0]
+        gqkv = torch.empty_like(qkv)
+        v = qkv[:, (hq + hkv) * d:].view(n, hkv, d)
+        gv_view = gqkv[:, (hq + hkv) * d:].view(n, hkv, d)
+        gq, gk, _ = ops.attn_varlen_bwd(go.contiguous(), q, k, v, out, lse, seq_start, scale, grad_v_out=gv_view)
+        gqw = gkw = None
+        if qw is not None:
+            gqw = torch.zeros(d, dtype=torch.float32, device=qkv.device)
+            gkw = torch.zeros(d, dtype=torch.float32, device=qkv.device)
+            ops.qknorm_rope_bwd(gq, gk, qkv, qw.contiguous(), kw.contiguous(), cos, sin, rstd, gqkv, gqw, gkw, hq, hkv, d)
+            gqw, gkw = gqw.to(qw.dtype), gkw.to(kw.dtype)
+        else:
+            ops.qknorm_rope_bwd(gq, gk, None, None, None, cos, sin, None, gqkv, None, None, hq, hkv, d)
+        return gqkv, gqw, gkw, None, None, None, None, None, None, None, None
+
+
 def varlen_causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor, scale: float,
                             sliding_window: int | None = None) -> torch.Tensor:
     """flash_attn_varlen_func(q, k, v, cu, cu, max, max, causal=True[, window_size=(sliding_window - 1, 0)]) equivalent on packed
@@ -122,18 +158,19 @@ class HipVarlenAttention(nn.Module):
         b, n, _ = hidden_states.shape
         assert b == 1, "packed batches are [1, N, H] (trainer/batch.py)"
         x = hidden_states[0]
-        qkv = torch.cat([self.q_proj(x), self.k_proj(x), self.v_proj(x)], dim=-1)
+        # one q|k|v product on the hand-written core when the three weights lie back to back (a trainer engine's flat buffer); else three + a concatenation
+        qkv = fused_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])
         cos, sin = position_embeddings
         half = self.head_dim // 2
         # accept the reference's cat(f,f) tables too; the kernels read bf16 (the reference casts cos/sin to x.dtype, rotary_emb.py:72-73)
         cos, sin = cos.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous(), sin.reshape(n, -1)[:, :half].to(torch.bfloat16).contiguous()
-        if self.use_qk_norm:
-            q, k = _QKNormRopeFn.apply(qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, self.hq, self.hkv, self.head_dim, self.eps)
-        else:
-            q, k = _RopeFn.apply(qkv, cos, sin, self.hq, self.hkv, self.head_dim)
-        v = qkv[:, (self.hq + self.hkv) * self.head_dim:].view(n, self.hkv, self.head_dim)
-        out = varlen_causal_attention(q, k, v, cu_seqlens, self.scaling, sliding_window=getattr(self, "sliding_window", None))  # attn.py:97-99
-        return self.o_proj(out.view(n, self.hq * self.head_dim)).unsqueeze(0), None
+        seq_start = ops.seq_start_from_cu(cu_seqlens.to(torch.int32).contiguous(), n)
+        sliding_window = getattr(self, "sliding_window", None)  # attn.py:97-99
+        if sliding_window is not None:
+            seq_start = ops.seq_start_with_window(seq_start, sliding_window)
+        qw, kw = (self.q_norm.weight, self.k_norm.weight) if self.use_qk_norm else (None, None)
+        out = _QKVAttnFn.apply(qkv.contiguous(), qw, kw, cos, sin, seq_start, self.hq, self.hkv, self.head_dim, self.eps if self.use_qk_norm else 0.0, self.scaling)
+        return linear(out.view(n, self.hq * self.head_dim), self.o_proj.weight).unsqueeze(0), None
 
 
 ATTN_IMPL2CLASS = {"hip_varlen": HipVarlenAttention}

@@ -97,17 +97,27 @@ class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
         vchunk = min(vocab, VOCAB_CHUNK)
         needs_hidden, needs_weight = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_hidden = torch.zeros_like(hidden) if needs_hidden else None
-        grad_weight = torch.zeros_like(weight) if needs_weight else None
+        grad_weight = None  # allocated on first use (the bf16 form accumulates in f32 on the own core instead)
         g = grad_logprobs.contiguous().float()
+        gw_f32 = None  # the fused (bf16) form accumulates the weight gradient in f32 on the own core and rounds once at the end
         for start in range(0, n, chunk_size):
             end = min(start + chunk_size, n)
             h = hidden[start:end]
             if ctx.fused:  # J1 backward: logits recomputed on the MFMA units, dlogits written once (bf16), then the two gradient GEMMs
                 dl = ops.lmhead_logprob_bwd(h.contiguous(), weight.contiguous(), labels[start:end], inv_t[start:end], logz[start:end], g[start:end])
-                if needs_hidden:
-                    torch.mm(dl, weight, out=grad_hidden[start:end])
+                if needs_hidden:  # the two gradient GEMMs on the hand-written core where it applies (the reference: eager matmuls, lm_head.py:184-191)
+                    if ops.gemm_supported(dl, weight.t(), out=grad_hidden[start:end]):
+                        ops.gemm(dl, weight.t(), out=grad_hidden[start:end])
+                    else:
+                        torch.mm(dl, weight, out=grad_hidden[start:end])
                 if needs_weight:
-                    grad_weight.addmm_(dl.t(), h)
+                    if gw_f32 is None and ops.gemm_supported(dl.t(), h.t()):
+                        gw_f32 = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+                    if gw_f32 is not None:
+                        ops.gemm(dl.t(), h.t(), out=gw_f32, accumulate=True)
+                    else:
+                        grad_weight = torch.zeros_like(weight) if grad_weight is None else grad_weight
+                        grad_weight.addmm_(dl.t(), h)
                 continue
             for v0 in range(0, vocab, vchunk):
                 v1 = min(v0 + vchunk, vocab)
@@ -117,7 +127,10 @@ class _SequenceChunkedLogProbEntropyFn(torch.autograd.Function):
                 if needs_hidden:
                     grad_hidden[start:end].addmm_(dl, w)
                 if needs_weight:
+                    grad_weight = torch.zeros_like(weight) if grad_weight is None else grad_weight
                     grad_weight[v0:v1].addmm_(dl.t(), h)
+        if gw_f32 is not None:
+            grad_weight = gw_f32.to(weight.dtype)
         return grad_hidden, grad_weight, None, None, None
 
 

@@ -1,6 +1,7 @@
 """SwiGLU MLP seam — mirrors `prime_rl.trainer.models.layers.mlp` (src/prime_rl/trainer/models/layers/mlp.py:8-29):
-`MLPConfig`, `MLP` with `gate_proj`, `up_proj`, `down_proj` (state-dict compatible).  `silu(gate) * up` is one HIP kernel
-(`pm_swiglu_fwd/bwd`) on the concatenated gate|up activations; the three projections stay library GEMMs."""
+`MLPConfig`, `MLP` with `gate_proj`, `up_proj`, `down_proj` (state-dict compatible).  the projections run on the hand-written MFMA core (layers/linear.py: `ops.gemm`), `silu(gate) * up`
+in the gate|up product's epilogue and its backward in the down row gradient's epilogue where gate_proj / up_proj are adjacent in memory, else as
+`pm_swiglu_fwd/bwd` on the concatenated gate|up activations."""
 
 from __future__ import annotations
 
@@ -10,6 +11,7 @@ import torch
 from torch import nn
 
 from .... import ops
+from .linear import fused_linear, linear, swiglu_mlp
 
 
 @dataclass
@@ -51,5 +53,10 @@ class MLP(nn.Module):
     def forward(self, x, routed_experts: torch.Tensor | None = None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        gate_up = torch.cat([self.gate_proj(x2), self.up_proj(x2)], dim=-1)
-        return self.down_proj(swiglu(gate_up)).view(*shape[:-1], self.hidden_size)
+        # one node on the hand-written core (gate|up product + SwiGLU epilogue, down product; SwiGLU backward in the down row gradient's epilogue) when
+        # gate_proj / up_proj lie back to back (a trainer engine's flat buffer); else the three projections on the core and the SwiGLU kernel
+        y = swiglu_mlp(x2.contiguous(), self.gate_proj.weight, self.up_proj.weight, self.down_proj.weight) if x2.is_cuda else None
+        if y is None:
+            gate_up = fused_linear(x2, [self.gate_proj.weight, self.up_proj.weight])
+            y = linear(swiglu(gate_up), self.down_proj.weight)
+        return y.view(*shape[:-1], self.hidden_size)

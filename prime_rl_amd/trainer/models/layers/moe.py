@@ -218,11 +218,17 @@ class GroupedExperts(nn.Module):
         that order by construction).  The parameters stay separate `nn.Parameter`s with the reference's names and shapes."""
         super()._apply(fn, *args, **kwargs)
         w1, w3 = self.w1, self.w3
-        if w1.is_cuda and w1.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and w1.shape == w3.shape and w1.device == w3.device and w1.numel() > 0 \
-                and w3.data_ptr() - w1.data_ptr() != w1.numel() * w1.element_size():
-            with torch.no_grad():
-                both = torch.stack([w1.detach(), w3.detach()])
-                self.w1.data, self.w3.data = both[0], both[1]
+        if w1.is_cuda and w1.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and w1.shape == w3.shape and w1.device == w3.device and w1.numel() > 0:
+            # re-stack only when the kernel's REAL placement requirement fails (pm_grouped_gemm_nt_swiglu: w3 above w1, a whole number of weight rows away,
+            # within 2 GiB) — parameters a trainer engine re-homed in its flat buffer (w2 lies between them there) satisfy it and must NOT be moved: a fresh
+            # allocation would detach them from the buffer the optimizer updates and the weight push reads (ADVICE r5)
+            delta, row_bytes = w3.data_ptr() - w1.data_ptr(), w1.shape[2] * w1.element_size()
+            placed = delta > 0 and delta % row_bytes == 0 and delta + 128 * row_bytes < 2**31 - 4096
+            engine_owned = hasattr(w1, "main_grad") or hasattr(w3, "main_grad")
+            if not placed and not engine_owned:
+                with torch.no_grad():
+                    both = torch.stack([w1.detach(), w3.detach()])
+                    self.w1.data, self.w3.data = both[0], both[1]
         return self
 
     def forward(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
@@ -267,14 +273,24 @@ class _GateLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return torch.mm(x, w.t())
+        ctx.main_grads = _main_grads(w)
+        return ops.gemm(x, w) if ops.gemm_supported(x, w) else torch.mm(x, w.t())
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = g.contiguous()
-        gx = torch.mm(g, w) if ctx.needs_input_grad[0] else None
-        gw = ops.gemm(g.t(), x.t(), out_dtype=torch.float32).to(w.dtype) if ctx.needs_input_grad[1] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm(g, w.t()) if ops.gemm_supported(g, w.t()) else torch.mm(g, w)
+        gw = None
+        if ctx.needs_input_grad[1]:
+            mg = ctx.main_grads
+            if mg is not None:  # a trainer engine's f32 main gradient: written / accumulated by the GEMM itself
+                ops.gemm(g.t(), x.t(), out=mg[0][0], accumulate=mg[0][1][0])
+                mg[0][1][0] = True
+            else:
+                gw = ops.gemm(g.t(), x.t(), out_dtype=torch.float32).to(w.dtype)
         return gx, gw
 
 

@@ -16,6 +16,7 @@ from torch import nn
 
 from .... import ops
 from ..layers.attn import ATTN_IMPL2CLASS, AttentionConfig
+from ..layers.linear import add_rms_norm, final_norm
 from ..layers.lm_head import PrimeLmOutput
 from ..layers.mlp import MLP, MLPConfig
 from ..layers.norms import RMSNorm, RMSNormConfig
@@ -68,12 +69,24 @@ class Qwen3DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))
         self.post_attention_layernorm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))
 
-    def forward(self, hidden_states, position_embeddings, cu_seqlens=None, max_seqlen=None):
-        residual = hidden_states
-        hidden_states, _ = self.self_attn(self.input_layernorm(hidden_states), position_embeddings=position_embeddings, cu_seqlens=cu_seqlens,
-                                          max_seqlen=max_seqlen)
-        hidden_states = residual + hidden_states
-        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+    def forward(self, hidden_states, position_embeddings, cu_seqlens=None, max_seqlen=None, pending=None, return_pending: bool = False):
+        """The reference's block (modeling_qwen3.py:65-85).  Both residual adds ride in the RMSNorm that follows them (layers/linear.py add_rms_norm):
+        `pending` = the previous block's MLP output, not yet added to `hidden_states`; with `return_pending` this block returns (residual stream after
+        attention, its own MLP output) and leaves the second add to the next block's / the model's final norm.  Called the reference's way
+        (`pending=None`, `return_pending=False`) it returns the summed hidden states."""
+        if pending is None:
+            h1 = self.input_layernorm(hidden_states)
+        else:
+            h1, hidden_states = add_rms_norm(pending.reshape(-1, pending.shape[-1]), hidden_states.reshape(-1, hidden_states.shape[-1]),
+                                             self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+            h1, hidden_states = h1.view(pending.shape), hidden_states.view(pending.shape)
+        attn_out, _ = self.self_attn(h1, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=max_seqlen)
+        shape = hidden_states.shape
+        h2, hidden_states = add_rms_norm(attn_out.reshape(-1, shape[-1]), hidden_states.reshape(-1, shape[-1]), self.post_attention_layernorm.weight,
+                                         self.post_attention_layernorm.variance_epsilon)
+        mlp_out = self.mlp(h2.view(shape))
+        hidden_states = hidden_states.view(shape)
+        return (hidden_states, mlp_out) if return_pending else hidden_states + mlp_out
 
 
 class Qwen3Model(nn.Module):
@@ -99,10 +112,11 @@ class Qwen3Model(nn.Module):
         cu_seqlens = torch.zeros(seq_lens.numel() + 1, dtype=torch.int32, device=inputs_embeds.device)
         cu_seqlens[1:] = seq_lens.to(inputs_embeds.device).cumsum(0)
         position_embeddings = self.rotary_emb(inputs_embeds, position_ids)
-        hidden_states = inputs_embeds
+        hidden_states, pending = inputs_embeds, None
         for layer in self.layers:
-            hidden_states = layer(hidden_states, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=None)
-        return SimpleNamespace(last_hidden_state=self.norm(hidden_states))
+            hidden_states, pending = layer(hidden_states, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=None, pending=pending,
+                                           return_pending=True)
+        return SimpleNamespace(last_hidden_state=final_norm(self.norm, hidden_states, pending))
 
 
 class Qwen3ForCausalLM(nn.Module):

@@ -19,6 +19,7 @@ import torch.distributed as dist
 from torch import nn
 
 from ..layers.attn import ATTN_IMPL2CLASS, AttentionConfig
+from ..layers.linear import add_rms_norm, final_norm
 from ..layers.lm_head import PrimeLmOutput
 from ..layers.mlp import MLP, MLPConfig
 from ..layers.moe import MoE, MoEArgs
@@ -70,12 +71,22 @@ class Qwen3MoeDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))
         self.post_attention_layernorm = RMSNorm(RMSNormConfig(hidden_size=config.hidden_size, eps=config.rms_norm_eps))
 
-    def forward(self, hidden_states, position_embeddings, cu_seqlens=None, max_seqlen=None, routed_experts=None):
-        residual = hidden_states
-        hidden_states, _ = self.self_attn(self.input_layernorm(hidden_states), position_embeddings=position_embeddings, cu_seqlens=cu_seqlens,
-                                          max_seqlen=max_seqlen)
-        hidden_states = residual + hidden_states
-        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states), routed_experts=routed_experts)
+    def forward(self, hidden_states, position_embeddings, cu_seqlens=None, max_seqlen=None, routed_experts=None, pending=None, return_pending: bool = False):
+        """As Qwen3DecoderLayer.forward (models/qwen3/modeling_qwen3.py): both residual adds ride in the RMSNorm that follows them; `pending` / `return_pending`
+        hand the not-yet-added MLP output from block to block."""
+        if pending is None:
+            h1 = self.input_layernorm(hidden_states)
+        else:
+            h1, hidden_states = add_rms_norm(pending.reshape(-1, pending.shape[-1]), hidden_states.reshape(-1, hidden_states.shape[-1]),
+                                             self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+            h1, hidden_states = h1.view(pending.shape), hidden_states.view(pending.shape)
+        attn_out, _ = self.self_attn(h1, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=max_seqlen)
+        shape = hidden_states.shape
+        h2, hidden_states = add_rms_norm(attn_out.reshape(-1, shape[-1]), hidden_states.reshape(-1, shape[-1]), self.post_attention_layernorm.weight,
+                                         self.post_attention_layernorm.variance_epsilon)
+        mlp_out = self.mlp(h2.view(shape), routed_experts=routed_experts)
+        hidden_states = hidden_states.view(shape)
+        return (hidden_states, mlp_out) if return_pending else hidden_states + mlp_out
 
 
 class Qwen3MoeModel(nn.Module):
@@ -100,12 +111,12 @@ class Qwen3MoeModel(nn.Module):
         cu_seqlens = torch.zeros(seq_lens.numel() + 1, dtype=torch.int32, device=inputs_embeds.device)
         cu_seqlens[1:] = seq_lens.to(inputs_embeds.device).cumsum(0)
         position_embeddings = self.rotary_emb(inputs_embeds, position_ids)
-        hidden_states = inputs_embeds
+        hidden_states, pending = inputs_embeds, None
         for i, layer in enumerate(self.layers):
             layer_routing = routed_experts[:, :, i, :] if routed_experts is not None else None  # modeling_qwen3_moe.py:93 of the reference file
-            hidden_states = layer(hidden_states, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=None,
-                                  routed_experts=layer_routing)
-        return SimpleNamespace(last_hidden_state=self.norm(hidden_states))
+            hidden_states, pending = layer(hidden_states, position_embeddings=position_embeddings, cu_seqlens=cu_seqlens, max_seqlen=None,
+                                           routed_experts=layer_routing, pending=pending, return_pending=True)
+        return SimpleNamespace(last_hidden_state=final_norm(self.norm, hidden_states, pending))
 
 
 class Qwen3MoeForCausalLM(nn.Module):

@@ -135,8 +135,27 @@ class ModuleEngine:
         if self.device.type == "cuda" and os.environ.get("PM_MOE_MAIN_GRAD", "1") != "0":
             from .models.layers.lm_head import FusedOutputLinear
 
+            from .models.layers.attn import HipVarlenAttention
+            from .models.layers.mlp import MLP
+            from .models.layers.moe import TokenChoiceTopKRouter
+
             direct_ids = {id(p) for m in model.modules() if isinstance(m, GroupedExperts) for p in m.parameters(recurse=False)}
             direct_ids |= {id(m.weight) for m in model.modules() if isinstance(m, FusedOutputLinear)}  # the LM head's weight gradient GEMM (stored-logits form)
+            # the dense projections of the layer seams run on the hand-written core as autograd nodes (layers/linear.py) whose weight-gradient GEMM writes /
+            # accumulates in f32 here as well: q / k / v / o_proj, gate / up / down_proj, the router gate — where the core takes the shape (rows and columns
+            # multiples of 8, >= 128); anything else keeps the `.grad` path below
+            for m in model.modules():
+                lins = []
+                if isinstance(m, HipVarlenAttention):
+                    lins = [m.q_proj, m.k_proj, m.v_proj, m.o_proj]
+                elif isinstance(m, MLP):
+                    lins = [m.gate_proj, m.up_proj, m.down_proj]
+                elif isinstance(m, TokenChoiceTopKRouter) and not m.fp32_gate:
+                    lins = [m.gate]
+                for lin in lins:
+                    o, i = lin.weight.shape
+                    if o % 128 == 0 and i % 128 == 0:
+                        direct_ids.add(id(lin.weight))
             for (pname, p, off), gv in zip(self.entries, self._grad_views):
                 if id(p) in direct_ids and p.dtype == torch.bfloat16:
                     p.main_grad, p.main_grad_written = gv, [False]

@@ -373,8 +373,12 @@ def sign_sgd_step(master, grad, param_bf16, lr, weight_decay, grad_scale=1.0, cl
         grad.zero_()
 
 
-def gemm_supported(x, w):
+def gemm_supported(x, w, out=None, out_dtype=torch.bfloat16):
     return False  # the CPU stand-in engine keeps the library (torch) GEMM calls
+
+
+def gemm_shape_supported(m, n, k, x_kmajor, w_kmajor):
+    return False
 
 
 def gemm_sumsq_slots(m, n):
@@ -390,7 +394,7 @@ def sum_partials(partials, out_scalar):
     out_scalar += partials.sum()
 
 
-def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False, tile_sumsq=None):
+def gemm(x, w, out=None, out_dtype=torch.bfloat16, bias=None, accumulate=False, tile_sumsq=None, variant=None):
     y = x.float() @ w.float().t()
     if bias is not None:
         y = y + bias.float()

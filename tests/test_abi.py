@@ -49,7 +49,7 @@ def test_integration_doc_covers_every_entry_point():
 
 
 def test_abi_version_and_error_plumbing(lib):
-    assert lib.pm_abi_version() == 1
+    assert lib.pm_abi_version() == 2
     # argument validation happens before any device work, so it is safe without a GPU
     rc = lib.pm_logprob_entropy_fwd(None, 0, 4, 8, 8, None, None, None, None, None, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.pm_last_error()
@@ -104,3 +104,33 @@ def test_gemm_supported_also_checks_the_result(monkeypatch):
     wide = torch.zeros(256, 1024, dtype=torch.bfloat16)
     assert ops.gemm_supported(x, w_ok, out=wide[:, :512]) and not ops.gemm_supported(x, w_ok, out=wide[:, 4:516])  # strided is fine, a 8-byte-aligned base is not
     assert not ops.gemm_supported(x, w_ok, out=torch.zeros(256, 512, dtype=torch.float16))
+
+
+def test_product_library_holds_no_mutable_schedule_state(lib):
+    """"no mutable globals beyond a once-initialised device-props cache".  The GEMM / grouped-GEMM / attention A/B selectors of rounds 3-5 were
+    process-wide words that product code set and restored around launches; since round 6 the schedule word is the `sched` ARGUMENT of every launch and the
+    product library (`make`, VARIANTS=0) has no such storage: (1) no writable symbol named *variant* / *override* in its data / bss sections, (2) the debug
+    setters refuse every value that would have to be stored, (3) the launch entry points carry the argument (their ctypes signatures end in (..., I32 sched,
+    stream))."""
+    import subprocess
+
+    if (_lib.LIB_PATH.parent / ".linked_variants_1").exists():
+        pytest.skip("a `make VARIANTS=1` library keeps process-wide A/B overrides by design")
+    nm = subprocess.run(["nm", "-C", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    writable = [ln for ln in nm.splitlines() if re.search(r" [bBdD] ", ln) and re.search(r"variant|override|g_fwd_var|g_dkdv_var|g_dq_var", ln)]
+    assert not writable, writable
+    # what IS writable and ours: once-initialised caches only (last-error buffer, per-device attribute flags, the dlopen'ed RCCL table)
+    ours = [ln.split(" ", 2)[2] for ln in nm.splitlines() if re.search(r" [bB] ", ln) and ("pm" in ln or "g_" in ln)]
+    allowed = re.compile(r"attr_done|g_err|g_api|g_ok|g_once|completed")
+    assert all(allowed.search(s) for s in ours), [s for s in ours if not allowed.search(s)]
+    assert lib.pm_gemm_debug_set_variant(7) != 0 and b"no schedule state" in lib.pm_last_error()
+    assert lib.pm_gemm_debug_set_variant(-1) == 0
+    assert lib.pm_grouped_gemm_debug_set_variant(1) != 0 and lib.pm_grouped_gemm_debug_set_variant(-1) == 0
+    assert lib.pm_attn_debug_set_variant(1, 1) != 0 and lib.pm_attn_debug_set_variant(0, -1) == 0
+    for name in ("pm_gemm_bf16", "pm_gemm_bf16_ws", "pm_gemm_bf16_sumsq", "pm_gemm_swiglu_bf16", "pm_gemm_swiglu_bwd_bf16", "pm_grouped_gemm_nt", "pm_grouped_gemm_nn",
+                 "pm_grouped_gemm_nt_swiglu", "pm_grouped_gemm_nn_swiglu_bwd", "pm_grouped_gemm_tn", "pm_grouped_gemm_tn_f32"):
+        args = _lib.SIGNATURES[name][1]
+        assert args[-2] is _lib.I32 and args[-1] is _lib.P, name
+    # a word that selects a VARIANTS-only build is refused at the launch, before any device work
+    rc = lib.pm_gemm_bf16(ctypes.c_void_p(16), 128, 0, ctypes.c_void_p(16), 128, 0, ctypes.c_void_p(16), 256, 1, None, 0, 256, 256, 128, 65536 + 7, None)
+    assert rc != 0 and b"VARIANTS=1" in lib.pm_last_error()

@@ -20,7 +20,7 @@ def _variants_build() -> bool:
 
     lib = _lib.load()
     ok = lib.pm_gemm_debug_set_variant(65536 + 7) == 0
-    lib.pm_gemm_debug_set_variant(7)
+    lib.pm_gemm_debug_set_variant(-1)  # (a VARIANTS=1 library keeps a process-wide override: clear it)
     return ok
 
 

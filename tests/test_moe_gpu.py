@@ -402,13 +402,10 @@ def test_grouped_gemm_kernels_against_per_expert_matmul(e, n_out, k, sizes, vari
     assert ops.grouped_gemm_supported(m, n_out, k)
     from prime_rl_amd import _lib
 
-    _lib.load().pm_grouped_gemm_debug_set_variant(variant)
-    try:
-        y = ops.grouped_gemm_nt(x, w, offsets)
-        dx = ops.grouped_gemm_nn(dy, w, offsets)
-        dw = ops.grouped_gemm_tn(dy, x, offsets)
-    finally:
-        _lib.load().pm_grouped_gemm_debug_set_variant(0)
+    sched = ((variant << 16) | 7) if variant else None  # PM_GROUPED_SCHED_SMALL / _BIG ride in the launch's schedule word (no library state)
+    y = ops.grouped_gemm_nt(x, w, offsets, variant=sched)
+    dx = ops.grouped_gemm_nn(dy, w, offsets, variant=sched)
+    dw = ops.grouped_gemm_tn(dy, x, offsets, variant=sched)
     o = 0
     for i, c in enumerate(sizes):
         xe, de, we = x[o:o + c].float(), dy[o:o + c].float(), w[i].float()

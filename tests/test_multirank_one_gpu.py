@@ -239,7 +239,7 @@ def test_bench_script_launches_itself_when_no_launcher_is_present(tmp_path):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["rccl"]["world"] == 2
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["rccl_world"] == 2
     assert "world=2" in out.stderr
 
 

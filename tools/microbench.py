@@ -380,22 +380,20 @@ def bench_moe(out, n=16384, e=128, k=8, h=2048, hidden=768):
     from prime_rl_amd import _lib as _l
 
     for variant, label in ((1, "128 x 128 tiles"), (2, "256 x 256 tiles, round-2 kernel"), (0, "256 x 256 tiles, ping-pong core")):
-        _l.load().pm_grouped_gemm_debug_set_variant(variant)
+        gsched = ((variant << 16) | 7) if variant else None
         ts = []
         for _ in range(3):
-            med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets), iters=10, warmup=2)
+            med, _ = timeit(lambda: ops.grouped_gemm_nt(y, w1, offsets, variant=gsched), iters=10, warmup=2)
             ts.append(med)
         med = sorted(ts)[1]
         out.append(dict(kernel=f"pm_grouped_gemm_nt [{n * k} x {h}] x [{e} x {hidden} x {h}] ({label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
-    _l.load().pm_grouped_gemm_debug_set_variant(0)
     hmid = ops.grouped_gemm_nt(y, w1, offsets)
     for variant, label in ((1, "128 x 128 tiles"), (2, "256 x 256 tiles, round-2 kernel"), (0, "256 x 256 tiles, ping-pong core")):
-        _l.load().pm_grouped_gemm_debug_set_variant(variant)
-        med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets), iters=10, warmup=2)
+        gsched = ((variant << 16) | 7) if variant else None
+        med, _ = timeit(lambda: ops.grouped_gemm_nn(hmid, w1, offsets, variant=gsched), iters=10, warmup=2)
         out.append(dict(kernel=f"pm_grouped_gemm_nn (row gradient of the same; {label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
-        med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets), iters=10, warmup=2)
+        med, _ = timeit(lambda: ops.grouped_gemm_tn(hmid, y, offsets, variant=gsched), iters=10, warmup=2)
         out.append(dict(kernel=f"pm_grouped_gemm_tn (weight gradient of the same; {label})", ms=med * 1e3, TFLOPs=2 * n * k * h * hidden / med / 1e12))
-    _l.load().pm_grouped_gemm_debug_set_variant(0)
 
 
 def bench_moe_gemm_variants(out, variants=(7, 32773), n=16384, e=128, k=8, h=2048, hidden=768, rounds=5):
