@@ -463,6 +463,12 @@ def bench_moe_layer(out, n=16384, e=128, k=8, h=2048, hidden=768, iters=int(os.e
                     w3_minus_w1_bytes=ex.w3.data_ptr() - ex.w1.data_ptr()))
 
 
+def trace_mark():
+    """One launch of the 16 x 16 x 32 MFMA probe kernel: the marker `tools/rocprof_summary.py --window` cuts a kernel trace at."""
+    a = torch.zeros(16, 32, dtype=torch.bfloat16, device=DEV)
+    ops.mfma_probe(a, a)
+
+
 def bench_moe_step(out, layers=8, n_mb=8, seq=2048, steps=3):
     """The module-engine trainer step (trainer/module_engine.py) on a Qwen3-30B-A3B-width model cut to `layers` layers (the full 48 need the
     expert-parallel node: 30.5 B parameters x 18 B of f32 state): forward + loss + backward + clip + fused AdamW on one GPU."""
@@ -490,11 +496,13 @@ def bench_moe_step(out, layers=8, n_mb=8, seq=2048, steps=3):
     batches = [[pack_micro_batches(dl.get_batch(), DEV)] for _ in range(steps + 1)]
     eng.step(batches[0])
     torch.cuda.synchronize()
+    trace_mark()
     t0 = time.perf_counter()
     for b in batches[1:]:
         eng.step(b)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    trace_mark()
     tok = n_mb * seq
     flops = eng.dims.flops_per_token(seq) * tok
     out.append(dict(kernel=f"module-engine step, Qwen3-30B-A3B width, {layers} of 48 layers, {n_mb} x {seq} tokens", ms=dt * 1e3, tokens_per_s=tok / dt,
