@@ -549,11 +549,12 @@ int pm_gemm_debug_set_variant(int32_t value);
  * Diagnostics used by tests/ to pin the MFMA fragment layouts the attention kernels assume.
  * C[16,16] = A[16,32] @ B[32,16]^T-free form: c = sum_k a[i][k]*b[j][k]  (both operands K-contiguous, bf16). */
 int pm_mfma_probe_16x16x32(const void* a_bf16, const void* b_bf16, float* c_f32, void* stream);
-/* Kernel-variant switch for in-process A/B timing (tools/microbench.py): kernel 0 = attention forward (bits: 1 = asm row max, 2 = skip the O rescale
- * when no row max moved, 4 = row-max reduction as one asm block, 8 = 16-byte epilogue stores; default 15; 64 + OPT = the 8-wave ping-pong experiment of
- * csrc/attention_fwd_pp.hip.h), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles; + 16: 8-byte epilogue stores), 2 = dQ (1: 32 kv rows per
- * barrier; + 16: 8-byte epilogue stores); value <= 0
- * restores the default.  Not part of the training path. */
+/* Kernel-variant switch for in-process A/B timing (tools/microbench.py; selectable builds exist only in a `make VARIANTS=1` library): kernel 0 = attention
+ * forward (default = the three-stage pipelined kernel with the hand-placed tile loop, csrc/attention_fwd_p3.hip.h; 0-15 = option bits of the round-1..5
+ * kernel: 1 = asm row max, 2 = skip the O rescale when no row max moved, 4 = row-max reduction as one asm block, 8 = 16-byte epilogue stores, 15 = its
+ * shipped form; 64 + OPT = the 8-wave ping-pong experiment of csrc/attention_fwd_pp.hip.h; 128 = the pipelined kernel with compiler-scheduled stages;
+ * 129 + V = p3_loop_asm<V>), 1 = dK/dV (1: fragment batch 2, 2: fragment batch 8, 3: 32-row q tiles; + 16: 8-byte epilogue stores), 2 = dQ (1: 32 kv
+ * rows per barrier; + 16: 8-byte epilogue stores); value <= 0 restores the default.  Not part of the training path. */
 int pm_attn_debug_set_variant(int32_t kernel, int32_t value);
 /* gfx950 LDS transpose-read (`ds_read_b64_tr_b16`): one wave, LDS image lds[i] = i (u16, 4096 entries); lane l reads at element
  * index elem_index[l] (device int32[64], multiples of 4) and writes its four 16-bit results to out[4*l .. 4*l+3] (device u16[256]). */

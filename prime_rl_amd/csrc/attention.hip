@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 #include "attention_kernels.hip.h"
+#include "attention_fwd_p3.hip.h"
 #if PM_VARIANTS  // `make VARIANTS=1`: the measured-and-not-adopted builds (profiles/r03_attention.md, r04_attention.md)
 #include "attention_fwd_pp.hip.h"
 #endif
@@ -106,7 +107,6 @@ static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
 // boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
 // workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
-constexpr int kFwdDefaultOpt = 15;  // 1 | 2 | 4 (row-max reduction as one asm block) | 8 (16-byte epilogue stores)
 #if PM_VARIANTS  // the A/B selectors are process-wide state of `make VARIANTS=1` libraries only; the product library holds constants (no mutable globals)
 static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.hip.h); -1 = the default build
 static int g_dkdv_var = 0;
@@ -122,13 +122,16 @@ using namespace pm;
 extern "C" int pm_attn_debug_set_variant(int32_t kernel, int32_t value) {
   PM_REQUIRE(kernel >= 0 && kernel <= 2, PM_ERR_INVALID_ARG, "pm_attn_debug_set_variant: kernel %d", (int)kernel);
 #if !PM_VARIANTS
-  // no state to set: the default of each kernel (value <= 0; 15 = the forward's default option word) is accepted as a no-op
-  PM_REQUIRE(value <= 0 || (kernel == 0 && value == 15), PM_ERR_UNSUPPORTED, "pm_attn_debug_set_variant(%d, %d): this build exists only in a `make VARIANTS=1` library",
+  // no state to set: the default of each kernel (value <= 0) is accepted as a no-op
+  PM_REQUIRE(value <= 0, PM_ERR_UNSUPPORTED, "pm_attn_debug_set_variant(%d, %d): this build exists only in a `make VARIANTS=1` library",
              (int)kernel, (int)value);
   return PM_OK;
 #else
   if (kernel == 0) {
-    if (value > 15 && value < 64 && value != 47) return PM_ERR_INVALID_ARG;  // 47 = 15 + 32: eight waves x 16 q rows  // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h)
+    if (value > 15 && value < 64 && value != 47) return PM_ERR_INVALID_ARG;
+    // -1: the default (= 129).  0-15: option bits of the round-1..5 kernel attn_fwd_kernel (15 = its shipped form); 47 = 15 + 32: eight waves x 16 q rows;
+    // 64 + OPT: the 8-wave ping-pong kernel (attention_fwd_pp.hip.h); 128 / 129: the three-stage pipelined forward (attention_fwd_p3.hip.h) with
+    // compiler-scheduled stages / with the hand-placed tile loop; 130-140: A/B builds and timing ablations of 129 (tools/gen_attn_p3_asm.py VARIANTS)
     g_fwd_var = value;
     return PM_OK;
   }
@@ -182,6 +185,29 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse,  \
                      (int)q_row0)
 #if PM_VARIANTS
+  if (g_fwd_var >= 128 && g_fwd_var <= 140) {
+#define PM_LAUNCH_P3(KERNEL_)                                                                                                                      \
+  hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q, (const bf16_t*)k, \
+                     (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse, (int)q_row0)
+    switch (g_fwd_var) {  // 129 + V: p3_loop_asm<V> (tools/gen_attn_p3_asm.py VARIANTS: 0 product, 1-4 placement A/B, 5-8 timing ablations with wrong results)
+      case 128: PM_LAUNCH_P3(attn_fwd_p3_kernel<2>); break;  // compiler-scheduled stages
+      case 129: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 0>)); break;
+      case 130: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 1>)); break;
+      case 131: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 2>)); break;
+      case 132: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 3>)); break;
+      case 133: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 4>)); break;
+      case 134: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 5>)); break;
+      case 135: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 6>)); break;
+      case 136: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 7>)); break;
+      case 137: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 8>)); break;
+      case 138: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 9>)); break;
+      case 139: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 10>)); break;
+      default: PM_LAUNCH_P3((attn_fwd_p3a_kernel<2, 11>)); break;
+    }
+#undef PM_LAUNCH_P3
+    PM_CHECK_LAUNCH(who);
+    return PM_OK;
+  }
   if (g_fwd_var >= 64) {
     const int group = n_q_heads / n_kv_heads;
     const int by_rows = (group & 1) ? 1 : 0;
@@ -215,8 +241,16 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     return PM_OK;
   }
 #endif
+#define PM_LAUNCH_FWD_P3A()                                                                                                                           \
+  hipLaunchKernelGGL((attn_fwd_p3a_kernel<2, 0>), dim3((unsigned)(cdiv(n_q, 128) * n_q_heads)), dim3(256), 0, as_stream(stream), (const bf16_t*)q,    \
+                     (const bf16_t*)k, (const bf16_t*)v, v_row_stride, seq_start, n, n_q_heads, n_kv_heads, softmax_scale, (bf16_t*)out, lse, (int)q_row0)
 #if PM_VARIANTS
-  switch (g_fwd_var < 0 ? kFwdDefaultOpt : g_fwd_var) {
+  if (g_fwd_var < 0) {  // the default of every build: the three-stage pipelined forward with the hand-placed tile loop (attention_fwd_p3.hip.h)
+    PM_LAUNCH_FWD_P3A();
+    PM_CHECK_LAUNCH(who);
+    return PM_OK;
+  }
+  switch (g_fwd_var) {
     case 0: PM_LAUNCH_FWD(0); break;
     case 1: PM_LAUNCH_FWD(1); break;
     case 2: PM_LAUNCH_FWD(2); break;
@@ -229,8 +263,9 @@ static int attn_fwd_impl(const char* who, const void* q, const void* k, const vo
     default: PM_LAUNCH_FWD(15); break;
   }
 #else
-  PM_LAUNCH_FWD(15);
+  PM_LAUNCH_FWD_P3A();
 #endif
+#undef PM_LAUNCH_FWD_P3A
 #undef PM_LAUNCH_FWD
   PM_CHECK_LAUNCH(who);
   return PM_OK;

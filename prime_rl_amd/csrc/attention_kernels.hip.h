@@ -42,6 +42,9 @@ __device__ __forceinline__ float xrow_sum(float v) {  // across the 4 sixteen-la
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// lse = m ln 2 + ln(sum) from the base-2 running maximum and the row sum, as ONE explicit fma (left to the compiler's contraction choice the two forward
+// kernels — attn_fwd_kernel and attn_fwd_p3_kernel — came out one ulp apart)
+__device__ __forceinline__ float lse_of(float m2, float lsum) { return __builtin_fmaf(m2, 0.69314718055994530942f, logf(lsum)); }
 __device__ __forceinline__ void st8_bf16(bf16_t* p, const f32x4& c, float mul) {
   *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16_hw(c[0] * mul, c[1] * mul), pack_bf16_hw(c[2] * mul, c[3] * mul)};
 }
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn_fwd_kernel(const bf16_t* _
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) st8_bf16(op + nb * 16, ot[cb][nb], inv);
       }
-      if (lq == 0) lse[(int64_t)qh * nq + qi[cb] - q_row0] = m[cb] * 0.69314718055994530942f + logf(lsum);
+      if (lq == 0) lse[(int64_t)qh * nq + qi[cb] - q_row0] = lse_of(m[cb], lsum);
     }
     if constexpr ((OPT & 8) != 0) {
       const int row = qi[cb] < n ? qi[cb] : n - 1;

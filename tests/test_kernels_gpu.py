@@ -649,8 +649,10 @@ def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
                                              ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1), ([255, 257], 8, 2), ([2048] * 3 + [777], 8, 2)])
 @pytest.mark.skipif(not ATTN_AB, reason="the A/B builds of the forward kernel exist only in a `make VARIANTS=1` library")
 def test_attention_fwd_variants_are_bit_identical(ops, seq_lens, hq, hkv):
-    """Forward build variants (pm_attn_debug_set_variant(0, v)): the A/B bits of the shipped 4-wave kernel and the 8-wave x 16-row build (47) do the
-    same per-row arithmetic over the same kv tiles: out and lse equal the default build bit for bit, full calls and row windows."""
+    """Forward build variants (pm_attn_debug_set_variant(0, v)): the default is the three-stage pipelined kernel with the hand-placed tile loop
+    (attention_fwd_p3.hip.h); the round-1..5 kernel (15, 7), its 8-wave x 16-row build (47), the pipelined kernel with compiler-scheduled stages (128) and
+    the placement A/B builds of the hand-placed loop (130-133: no fast path / merged reduction / in-stream DMA) do the same per-row arithmetic over the
+    same kv tiles: out and lse equal the default build bit for bit, full calls and row windows."""
     from prime_rl_amd import _lib
 
     lib = _lib.load()
@@ -666,7 +668,7 @@ def test_attention_fwd_variants_are_bit_identical(ops, seq_lens, hq, hkv):
 
     try:
         base = run()
-        for var in (7, 47):
+        for var in (15, 7, 47, 128, 130, 131, 132, 133):
             rc = lib.pm_attn_debug_set_variant(0, var)
             if rc == -2:
                 pytest.skip("the A/B builds of the forward kernel exist only in a `make VARIANTS=1` library")
