@@ -314,8 +314,8 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
                      n_q_heads, 1.0f / softmax_scale, ndelta, nlse);
   PM_CHECK_LAUNCH(who);
 
-#define PM_LAUNCH_DKDV(MINB_, FB_, QT_, KVB_)                                                                                                     \
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_, KVB_>), dim3((unsigned)(cdiv(n, 64 * KVB_) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, \
+#define PM_LAUNCH_DKDV(MINB_, FB_, QT_, KVB_, ...)                                                                                                \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_, KVB_, ##__VA_ARGS__>), dim3((unsigned)(cdiv(n, 64 * KVB_) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
                      softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0)
 #if PM_VARIANTS
@@ -325,6 +325,10 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   else if ((g_dkdv_var & 15) == 4) PM_LAUNCH_DKDV(1, 4, 64, 2);  // 32 kv rows per wave, one wave per SIMD (accumulators in AGPRs)
   else if ((g_dkdv_var & 15) == 5) PM_LAUNCH_DKDV(1, 8, 64, 2);
   else if ((g_dkdv_var & 15) == 6) PM_LAUNCH_DKDV(1, 4, 32, 2);
+  else if ((g_dkdv_var & 15) == 8) PM_LAUNCH_DKDV(2, 4, 64, 1, 1);   // timing ablations of the shipped build (wrong results): no exp / mask VALU
+  else if ((g_dkdv_var & 15) == 9) PM_LAUNCH_DKDV(2, 4, 64, 1, 2);   // no fragment reads
+  else if ((g_dkdv_var & 15) == 10) PM_LAUNCH_DKDV(2, 4, 64, 1, 4);  // no LDS-DMA
+  else if ((g_dkdv_var & 15) == 11) PM_LAUNCH_DKDV(2, 4, 64, 1, 8);  // no MFMAs
   else
 #endif
   PM_LAUNCH_DKDV(2, 4, 64, 1);

@@ -202,7 +202,7 @@ constexpr int kV5DkdvBufBytes = 2 * QT * kD * 2 + 3 * 64 * 4;
 // dV^T += dO^T . P and dK^T += Q^T . dS through transpose-reads of the same tiles.  The S accumulators start at -lse / scale and the dP
 // accumulators at -delta (rows prepared by attn_delta_kernel and DMA'd next to the tiles), so that P = exp2(acc_S * scale * log2 e) and
 // dS / scale = P * acc_dP: no zero-fill, no per-score subtraction of the row statistics.
-template <int FB, int QT, int KVB>
+template <int FB, int QT, int KVB, int ABL = 0>  // ABL (make VARIANTS=1 only; WRONG results): 1 = no exp / mask VALU, 2 = no fragment reads, 4 = no LDS-DMA, 8 = no MFMAs
 __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int kvb, int kvi, unsigned nk_u, int n, float sc2, int bq, int bt, int lq,
                                           const u32x4 (&kf)[KVB][4], const u32x4 (&vf)[KVB][4], f32x4 (&dkt)[KVB][8], f32x4 (&dvt)[KVB][8]) {
   // KVB = 16-row kv blocks per wave: every Q / dO fragment read from LDS feeds KVB MFMAs (the kernel is bounded by the LDS port at KVB = 1:
@@ -235,20 +235,31 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
 #pragma unroll
     for (int nb = 0; nb < QT / 16; ++nb) {
       const bf16_t* pa = Qt + (bq ^ (kk << 5)) + nb * 16 * kD;
-      qa[nb] = lds16(pa);
-      da[nb] = lds16(pa + kDO);
+      if constexpr (ABL & 2) {
+        qa[nb] = kf[0][kk];
+        da[nb] = vf[0][kk];
+      } else {
+        qa[nb] = lds16(pa);
+        da[nb] = lds16(pa + kDO);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nb = 0; nb < QT / 16; ++nb)
 #pragma unroll
       for (int b = 0; b < KVB; ++b) {
-        s[b][nb] = mfma16(qa[nb], kf[b][kk], s[b][nb]);
-        dp[b][nb] = mfma16(da[nb], vf[b][kk], dp[b][nb]);
+        if constexpr (ABL & 8) {
+          s[b][nb][0] += __uint_as_float(qa[nb].x ^ kf[b][kk].y);
+          dp[b][nb][1] += __uint_as_float(da[nb].z ^ vf[b][kk].w);
+        } else {
+          s[b][nb] = mfma16(qa[nb], kf[b][kk], s[b][nb]);
+          dp[b][nb] = mfma16(da[nb], vf[b][kk], dp[b][nb]);
+        }
       }
   }
   __builtin_amdgcn_s_setprio(0);
-  if (full) {
+  if constexpr (ABL & 1) {
+  } else if (full) {
 #pragma unroll
     for (int b = 0; b < KVB; ++b)
 #pragma unroll
@@ -291,16 +302,26 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
 #pragma unroll
       for (int i = 0; i < FB; ++i) {
         const bf16_t* pt = Qt + (bt ^ ((n0 + i) << 4)) + h * 32 * kD;
-        qa[i] = lds_tr_pair(pt);
-        doa[i] = lds_tr_pair(pt + kDO);
+        if constexpr (ABL & 2) {
+          qa[i] = kf[0][i & 3];
+          doa[i] = vf[0][i & 3];
+        } else {
+          qa[i] = lds_tr_pair(pt);
+          doa[i] = lds_tr_pair(pt + kDO);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < FB; ++i)
 #pragma unroll
         for (int b = 0; b < KVB; ++b) {
-          dvt[b][n0 + i] = mfma16(doa[i], pb[b], dvt[b][n0 + i]);
-          dkt[b][n0 + i] = mfma16(qa[i], sb[b], dkt[b][n0 + i]);
+          if constexpr (ABL & 8) {
+            dvt[b][n0 + i][0] += __uint_as_float(doa[i].x ^ pb[b].y);
+            dkt[b][n0 + i][1] += __uint_as_float(qa[i].z ^ sb[b].w);
+          } else {
+            dvt[b][n0 + i] = mfma16(doa[i], pb[b], dvt[b][n0 + i]);
+            dkt[b][n0 + i] = mfma16(qa[i], sb[b], dkt[b][n0 + i]);
+          }
         }
     }
   }
@@ -311,7 +332,7 @@ __device__ __forceinline__ void dkdv_tile(const unsigned char* sm, int qi0, int 
 // `ds_read_b64_tr_b16` that MAY alias a pending LDS-DMA with `s_waitcnt vmcnt(0)` (plain ds_reads are not guarded), which with one dynamic
 // array made every iteration wait for the NEXT tile's DMA in the middle of its own compute.  With the read buffer and the DMA target in
 // different arrays the alias query is answered at compile time and the prefetch stays in flight.
-template <int MINB, int FB, int QT, int KVB = 1>
+template <int MINB, int FB, int QT, int KVB = 1, int ABL = 0>
 __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t v_stride, const bf16_t* __restrict__ dout,
     const float* __restrict__ nlse, const float* __restrict__ ndelta, const int32_t* __restrict__ seq_start, int64_t n64, int hq, int hkv,
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     const int qi0 = kv0 + QT * c_issue.tile;
     const int qh = kvh * group + c_issue.head;
     const int base = ((qi0 - q_row0) * hq + qh) * (kD * 2);
-    dma_pieces<PPW>(qrsrc, dorsrc, sm + w * PPW * 1024, TILE * 2, voff, voff, base, base);
+    if constexpr ((ABL & 4) == 0) dma_pieces<PPW>(qrsrc, dorsrc, sm + w * PPW * 1024, TILE * 2, voff, voff, base, base);
     const int roff = (qh * nq + qi0 - q_row0 + lane) * 4;
     unsigned char* rows = sm + 2 * TILE * 2;
     if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(lrsrc, (lds_void_ptr)rows, 4, roff, 0, 0, 0);
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkdv_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile j have landed ...
     __syncthreads();                                  // ... so have everyone's, and compute(j-1) is finished everywhere
     if (j + 1 < total_iters) dma(wr);
-    if (active && qi0 + QT - 1 >= kvb) dkdv_tile<FB, QT, KVB>(rd, qi0, kvb, kvi, nk_u, n, sc2, bq, bt, lq, kf, vf, dkt, dvt);
+    if (active && qi0 + QT - 1 >= kvb) dkdv_tile<FB, QT, KVB, ABL>(rd, qi0, kvb, kvi, nk_u, n, sc2, bq, bt, lq, kf, vf, dkt, dvt);
   };
   for (int j = 0; j < total_iters; j += 2) {
     step(smA, smB, j);

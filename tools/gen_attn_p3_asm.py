@@ -579,28 +579,36 @@ VARIANTS = [dict(), dict(fast=False, merged=False, dma_in=False), dict(fast=Fals
             dict(ablate=("nowait",)), dict(ablate=("nobarrier",)), dict(ablate=("nodma",))]
 
 
+def render(vi, opts, want_stats=False):
+    lines = build(opts, want_stats)
+    body = "\\n\\t\"\n      \"".join(l.replace('"', '\\"') for l in lines)
+    outs = [f'[o{i}] "=v"(o[{i}])' for i in range(64)] + [f'[m{c}] "=v"(m[{c}])' for c in (0, 1)] + [f'[l{c}] "=v"(l[{c}])' for c in (0, 1)]
+    ins = ([f'[q{cb}{kk}] "v"(qf[{cb}][{kk}])' for cb in (0, 1) for kk in range(4)] + [f'[ak{k}] "v"(aK[{k}])' for k in range(4)] +
+           [f'[av{k}] "v"(aV[{k}])' for k in range(8)] + [f'[ko{j}] "v"(kop[{j}])' for j in range(4)] + [f'[vo{j}] "v"(vop[{j}])' for j in range(4)] +
+           [f'[qrel{c}] "v"(qrel[{c}])' for c in (0, 1)] + [f'[lrel{c}] "v"(lrel[{c}])' for c in (0, 1)] +
+           ['[krsrc] "s"(krsrc)', '[vrsrc] "s"(vrsrc)', '[sc2] "s"(sc2_bits)', '[nit] "s"(n_iters)', '[ntw] "s"(nt_w)', '[kvsm] "s"(kvsm0)', '[q0] "s"(q0)',
+            '[lomax] "s"(lo_max)', '[krow64] "s"(krow64)', '[vrow64] "s"(vrow64)', '[kbase] "s"(kbase0)', '[vbase] "s"(vbase0)', '[ldsw] "s"(ldsw)'])
+    clob = [f'"v{r}"' for r in range(T_BASE, 256)] + [f'"s{r}"' for r in range(S_I, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+    note = "the product stream" if not opts else str(opts)
+    return (f"template <>\n__device__ __forceinline__ void p3_loop_asm<{vi}>({SIG}) {{  // {note}\n  asm volatile(\n      \"" + body + "\"\n      : " +
+            ", ".join(outs) + "\n      : " + ", ".join(ins) + "\n      : " + ", ".join(clob) + ");\n}\n"), len(lines)
+
+
 def main():
-    fns = []
-    n_lines = 0
-    for vi, opts in enumerate(VARIANTS):
-        lines = build(opts, "--stats" in sys.argv and vi == 0)
-        body = "\\n\\t\"\n      \"".join(l.replace('"', '\\"') for l in lines)
-        outs = [f'[o{i}] "=v"(o[{i}])' for i in range(64)] + [f'[m{c}] "=v"(m[{c}])' for c in (0, 1)] + [f'[l{c}] "=v"(l[{c}])' for c in (0, 1)]
-        ins = ([f'[q{cb}{kk}] "v"(qf[{cb}][{kk}])' for cb in (0, 1) for kk in range(4)] + [f'[ak{k}] "v"(aK[{k}])' for k in range(4)] +
-               [f'[av{k}] "v"(aV[{k}])' for k in range(8)] + [f'[ko{j}] "v"(kop[{j}])' for j in range(4)] + [f'[vo{j}] "v"(vop[{j}])' for j in range(4)] +
-               [f'[qrel{c}] "v"(qrel[{c}])' for c in (0, 1)] + [f'[lrel{c}] "v"(lrel[{c}])' for c in (0, 1)] +
-               ['[krsrc] "s"(krsrc)', '[vrsrc] "s"(vrsrc)', '[sc2] "s"(sc2_bits)', '[nit] "s"(n_iters)', '[ntw] "s"(nt_w)', '[kvsm] "s"(kvsm0)', '[q0] "s"(q0)',
-                '[lomax] "s"(lo_max)', '[krow64] "s"(krow64)', '[vrow64] "s"(vrow64)', '[kbase] "s"(kbase0)', '[vbase] "s"(vbase0)', '[ldsw] "s"(ldsw)'])
-        clob = [f'"v{r}"' for r in range(T_BASE, 256)] + [f'"s{r}"' for r in range(S_I, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
-        guard = "" if vi == 0 else "#if PM_VARIANTS\n"
-        fns.append(guard + f"template <>\n__device__ __forceinline__ void p3_loop_asm<{vi}>({SIG}) {{  // {opts}\n  asm volatile(\n      \"" + body + "\"\n      : " +
-                   ", ".join(outs) + "\n      : " + ", ".join(ins) + "\n      : " + ", ".join(clob) + ");\n}\n" + ("" if vi == 0 else "#endif\n"))
-        if vi == 0:
-            n_lines = len(lines)
-    src = HEADER + DOC + f"template <int V>\n__device__ __forceinline__ void p3_loop_asm({SIG});\n\n" + "\n".join(fns)
-    path = __file__.rsplit("/", 2)[0] + "/prime_rl_amd/csrc/attention_fwd_p3_asm.inc.h"
-    open(path, "w").write(src)
-    print(f"wrote {path}: {n_lines} asm lines in the product stream, {len(VARIANTS)} variants", file=sys.stderr)
+    """attention_fwd_p3_asm.inc.h: the declaration + the product stream (committed).  --variants: also attention_fwd_p3_asm_variants.inc.h with the A/B and
+    ablation builds (generated by `make VARIANTS=1`, not committed).  --out DIR: write there instead of prime_rl_amd/csrc (tests)."""
+    out_dir = __file__.rsplit("/", 2)[0] + "/prime_rl_amd/csrc"
+    if "--out" in sys.argv:
+        out_dir = sys.argv[sys.argv.index("--out") + 1]
+    fn, n_lines = render(0, VARIANTS[0], "--stats" in sys.argv)
+    src = HEADER + DOC + f"template <int V>\n__device__ __forceinline__ void p3_loop_asm({SIG});\n\n" + fn
+    open(out_dir + "/attention_fwd_p3_asm.inc.h", "w").write(src)
+    print(f"wrote {out_dir}/attention_fwd_p3_asm.inc.h: {n_lines} asm lines", file=sys.stderr)
+    if "--variants" in sys.argv:
+        head = ("// attention_fwd_p3_asm_variants.inc.h — GENERATED by tools/gen_attn_p3_asm.py --variants (`make VARIANTS=1`; not committed): the placement A/B builds and the\n"
+                "// timing ablations (WRONG results) of p3_loop_asm, selected by pm_attn_debug_set_variant(0, 129 + V).\n#pragma once\n\n")
+        open(out_dir + "/attention_fwd_p3_asm_variants.inc.h", "w").write(head + "\n".join(render(vi, o)[0] for vi, o in enumerate(VARIANTS) if vi > 0))
+        print(f"wrote {out_dir}/attention_fwd_p3_asm_variants.inc.h: {len(VARIANTS) - 1} variants", file=sys.stderr)
 
 
 if __name__ == "__main__":
