@@ -481,6 +481,14 @@ int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const int32_t* o
  * multiples of 256. */
 int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
                            int64_t k_dim, float* dw_f32, float* dw2_f32 /* nullable */, int32_t accumulate, int32_t sched, void* stream);
+/* ... with the gradient-norm pass fused into its epilogue (the grouped counterpart of pm_gemm_bf16_sumsq; the reference computes the norm with
+ * torch.nn.utils.clip_grad_norm_ over the reduced gradients, trainer/rl/train.py:566-570): every wave also writes the sum of squares of the FINAL f32
+ * values it stored for output tile (expert e, tile t) to tile_sumsq[(e * tiles + t) * 8 + wave]; every tile of every expert is visited by every launch,
+ * so after a step's last accumulating launch sum(tile_sumsq) is the squared norm of dw and dw2.  tile_sumsq_len >= pm_grouped_gemm_tn_sumsq_slots(). */
+int64_t pm_grouped_gemm_tn_sumsq_slots(int32_t n_experts, int64_t n_dim, int64_t k_dim);
+int pm_grouped_gemm_tn_f32_sumsq(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
+                                 int64_t k_dim, float* dw_f32, float* dw2_f32 /* nullable */, int32_t accumulate, float* tile_sumsq, int64_t tile_sumsq_len,
+                                 int32_t sched, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Dense bf16 GEMM of the scoring model (csrc/gemm.hip): OUT[M, N] = sum_K X[M, K] * W[N, K] (+ bias[N]), f32 accumulation on the MFMA units,

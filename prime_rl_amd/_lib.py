@@ -145,6 +145,8 @@ SIGNATURES: dict[str, tuple] = {
     "pm_grouped_gemm_nn_swiglu_bwd": (I, [P, P, P, I32, I64, I64, I64, P, P, I32, P]),
     "pm_grouped_gemm_tn": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, P]),
     "pm_grouped_gemm_tn_f32": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, I32, P]),
+    "pm_grouped_gemm_tn_sumsq_slots": (I64, [I32, I64, I64]),
+    "pm_grouped_gemm_tn_f32_sumsq": (I, [P, P, P, I32, I64, I64, I64, I64, P, P, I32, P, I64, I32, P]),
     "pm_ds_read_tr16_probe": (I, [P, P, P]),
     "pm_gemm_supported": (I, [I64, I64, I64, I32, I32]),
     "pm_gemm_bf16": (I, [P, I64, I32, P, I64, I32, P, I64, I32, P, I32, I64, I64, I64, I32, P]),

@@ -479,6 +479,7 @@ struct Tile {
   int m_valid, n_valid;    // rows / columns of the block that exist
   int nk;                  // K-tiles: even, >= 2
   bool first, last;
+  int slot;                // p.sumsq: the tile's 8 floats start at slot * 8 (MODE 0: the virtual block id; MODE 3: expert * tiles per expert + tile — both stable across launches)
 };
 template <bool KM, bool CLAMP = true>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int64_t ld, int64_t rows_left, int k) {
@@ -653,6 +654,7 @@ __device__ __forceinline__ constexpr int tile_mode() { return MODE == 5 ? 0 : MO
 template <int MODE, bool XK, bool WK>
 __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, const RowTab& rtab, Tile& t) {
   t.first = t.last = true;
+  t.slot = v;
   if (MODE == 0) {
     int tm, tn, kpart = 0, vv = v;
     if (p.split_s > 1 && v >= p.split_v0) {  // last round, split: XCD slot x computes K-part x / rp of tail patch x % rp
@@ -794,6 +796,7 @@ __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int la
   }
   const int tmn = tile / p.tiles_n, tk = tile % p.tiles_n;
   const int n0 = tmn * kTile, k0 = tk * kTile;
+  t.slot = e * per + tile;
   t.xb = p.x + (int64_t)lo * p.ldx + n0;
   t.x_rows = p.m - n0;
   t.wb = p.w + (int64_t)lo * p.ldw + k0;
@@ -1117,7 +1120,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[q]), orsrc, off[q], 0, 0);
-                if (MODE == 0 && p.sumsq) {
+                if ((MODE == 0 || MODE == 3) && p.sumsq) {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) {
                     const bool ok = off[q] != -1 && mrow0 + q * 8 + srow < cur.m_valid;
@@ -1177,17 +1180,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                     float* dst = reinterpret_cast<float*>(cur.out) + (int64_t)m * cur.ldo + nb;
                     if (p.accumulate) val += *dst;
                     *dst = val;
-                    if (MODE == 0 && p.sumsq) ss = fmaf(val, val, ss);
+                    if ((MODE == 0 || MODE == 3) && p.sumsq) ss = fmaf(val, val, ss);
                   } else {
                     reinterpret_cast<bf16_t*>(cur.out)[(int64_t)m * cur.ldo + nb] = f32_to_bf16(val);
                   }
                 }
           }
       }
-      if (MODE == 0 && p.sumsq) {  // wave-uniform
+      if ((MODE == 0 || MODE == 3) && p.sumsq) {  // wave-uniform
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if (lane_e == 0) p.sumsq[(int64_t)v * 8 + wave] = ss;
+        if (lane_e == 0) p.sumsq[(int64_t)cur.slot * 8 + wave] = ss;
       }
     }
     }  // cur.last
@@ -1898,9 +1901,10 @@ int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offs
 }
 // dw[e] = dy[rows of e]^T . x[rows of e] : dy [M, n_dim], x [M, k_dim] -> dw [E, n_first, k_dim], dw2 [E, n_dim - n_first, k_dim]
 int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
-               int out_f32, int accumulate, hipStream_t st, int sched) {
+               int out_f32, int accumulate, float* tile_sumsq, hipStream_t st, int sched) {
   Params p;
   grouped_common(p, offsets, n_experts, n_first);
+  p.sumsq = out_f32 ? tile_sumsq : nullptr;  // [n_experts][tiles per expert][8]: sum of squares of the FINAL f32 values each wave stored (the gradient norm, fused)
   p.out_f32 = out_f32;
   p.accumulate = out_f32 ? accumulate : 0;
   p.x = dy; p.w = x; p.out = dw; p.out2 = dw2;

@@ -617,7 +617,7 @@ int grouped_nt(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t
 int grouped_nn(const bf16_t* dy, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_first, int64_t n_dim,
                int64_t k_out, bf16_t* dx, hipStream_t st, int sched);
 int grouped_tn(const bf16_t* dy, const bf16_t* x, const int32_t* offsets, int n_experts, int64_t n_first, int64_t n_dim, int64_t k_dim, void* dw, void* dw2,
-               int out_f32, int accumulate, hipStream_t st, int sched);
+               int out_f32, int accumulate, float* tile_sumsq, hipStream_t st, int sched);
 int grouped_nn_swiglu_bwd(const bf16_t* dy, const bf16_t* w, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t n_dim, int64_t inter,
                           const bf16_t* gate_up, bf16_t* d_gate_up, hipStream_t st, int sched);
 int grouped_nt_swiglu(const bf16_t* x, const bf16_t* w, const bf16_t* w2, const int32_t* offsets, int n_experts, int64_t n_rows, int64_t inter, int64_t k_dim,
@@ -774,7 +774,7 @@ extern "C" int pm_grouped_gemm_tn(const void* dy_bf16, const void* x_bf16, const
   PM_REQUIRE(gg_shapes_ok(n_rows, n_dim, k_dim), PM_ERR_UNSUPPORTED, "pm_grouped_gemm_tn: n=%lld k=%lld must be multiples of 128 (and the row tensors < 2 GiB)",
              (long long)n_dim, (long long)k_dim);
   if (g_nt_variant == 0 && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0) {
-    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_bf16, dw2_bf16, 0, 0, as_stream(stream), core_sched_of(sched));
+    gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_bf16, dw2_bf16, 0, 0, nullptr, as_stream(stream), core_sched_of(sched));
     PM_CHECK_LAUNCH("pm_grouped_gemm_tn");
     return PM_OK;
   }
@@ -803,8 +803,31 @@ extern "C" int pm_grouped_gemm_tn_f32(const void* dy_bf16, const void* x_bf16, c
   PM_REQUIRE(n_first > 0 && n_first <= n_dim && gg_shapes_ok(n_rows, n_dim, k_dim) && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0, PM_ERR_UNSUPPORTED,
              "pm_grouped_gemm_tn_f32: n_first=%lld n=%lld k=%lld must be multiples of 256 (and the row tensors < 2 GiB)", (long long)n_first, (long long)n_dim,
              (long long)k_dim);
-  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, as_stream(stream), core_sched_of(sched));
+  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, nullptr, as_stream(stream), core_sched_of(sched));
   PM_CHECK_LAUNCH("pm_grouped_gemm_tn_f32");
+  return PM_OK;
+}
+
+// ... and with the gradient-norm pass fused into the epilogue (what pm_gemm_bf16_sumsq is to the dense weight gradients): every wave also writes the sum of
+// squares of the FINAL f32 values it stored for output tile (expert e, tile t of its n_dim / 256 x k_dim / 256) to tile_sumsq[(e * tiles + t) * 8 + wave].
+// Every tile of every expert is visited by every launch (an expert without rows stores zeros, or with accumulate = 1 what was there), so after the LAST
+// accumulating launch of a step sum(tile_sumsq) is the squared norm of both gradients.
+extern "C" int64_t pm_grouped_gemm_tn_sumsq_slots(int32_t n_experts, int64_t n_dim, int64_t k_dim) {
+  return n_experts <= 0 || n_dim <= 0 || k_dim <= 0 ? 0 : (int64_t)n_experts * cdiv(n_dim, 256) * cdiv(k_dim, 256) * 8;
+}
+extern "C" int pm_grouped_gemm_tn_f32_sumsq(const void* dy_bf16, const void* x_bf16, const int32_t* offsets, int32_t n_experts, int64_t n_rows, int64_t n_first,
+                                            int64_t n_dim, int64_t k_dim, float* dw_f32, float* dw2_f32, int32_t accumulate, float* tile_sumsq,
+                                            int64_t tile_sumsq_len, int32_t sched, void* stream) {
+  PM_REQUIRE(n_experts > 0 && n_rows >= 0, PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32_sumsq: bad sizes");
+  PM_REQUIRE(offsets && dw_f32 && (dy_bf16 && x_bf16) && (n_first == n_dim || dw2_f32), PM_ERR_INVALID_ARG, "pm_grouped_gemm_tn_f32_sumsq: null pointer");
+  PM_REQUIRE(n_first > 0 && n_first <= n_dim && gg_shapes_ok(n_rows, n_dim, k_dim) && n_first % 256 == 0 && n_dim % 256 == 0 && k_dim % 256 == 0, PM_ERR_UNSUPPORTED,
+             "pm_grouped_gemm_tn_f32_sumsq: n_first=%lld n=%lld k=%lld must be multiples of 256 (and the row tensors < 2 GiB)", (long long)n_first, (long long)n_dim,
+             (long long)k_dim);
+  PM_REQUIRE(tile_sumsq && tile_sumsq_len >= pm_grouped_gemm_tn_sumsq_slots(n_experts, n_dim, k_dim), PM_ERR_WORKSPACE,
+             "pm_grouped_gemm_tn_f32_sumsq: tile_sumsq needs pm_grouped_gemm_tn_sumsq_slots(n_experts, n_dim, k_dim) floats");
+  gm::grouped_tn((const bf16_t*)dy_bf16, (const bf16_t*)x_bf16, offsets, n_experts, n_first, n_dim, k_dim, dw_f32, dw2_f32, 1, accumulate ? 1 : 0, tile_sumsq,
+                 as_stream(stream), core_sched_of(sched));
+  PM_CHECK_LAUNCH("pm_grouped_gemm_tn_f32_sumsq");
   return PM_OK;
 }
 

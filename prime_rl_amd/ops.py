@@ -840,9 +840,12 @@ def grouped_gemm_tn_f32_supported(n_first: int, n: int, k: int) -> bool:
     return n_first % 256 == 0 and n % 256 == 0 and k % 256 == 0
 
 
-def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2: Tensor | None = None, accumulate: bool = False, variant: int | None = None) -> None:
+def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2: Tensor | None = None, accumulate: bool = False, variant: int | None = None,
+                        tile_sumsq: Tensor | None = None) -> None:
     """dw[e] (+)= dy[group e, :n_first].T @ x[group e] and dw2[e] (+)= dy[group e, n_first:].T @ x[group e] in f32, written straight into the given
-    (main-gradient) buffers: dw [E, n_first, K], dw2 [E, N - n_first, K] or None."""
+    (main-gradient) buffers: dw [E, n_first, K], dw2 [E, N - n_first, K] or None.  `tile_sumsq` (f32, >= grouped_gemm_tn_sumsq_slots(E, N, K) elements):
+    every wave also writes the sum of squares of the FINAL values it stored — after the last accumulating launch of a step `tile_sumsq.sum()` is the
+    squared norm of dw and dw2 (the gradient-norm pass fused into the weight-gradient epilogue)."""
     lib = _lib.load()
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(offsets, torch.int32, "offsets"); _req(dw, torch.float32, "dw")
     e = offsets.numel() - 1
@@ -854,7 +857,16 @@ def grouped_gemm_tn_f32(dy: Tensor, x: Tensor, offsets: Tensor, dw: Tensor, dw2:
         _req(dw2, torch.float32, "dw2")
         if tuple(dw2.shape) != (e, n - n1, k):
             raise PrimeMI355XError(f"grouped_gemm_tn_f32: dw2 {tuple(dw2.shape)} != {(e, n - n1, k)}")
-    check(lib.pm_grouped_gemm_tn_f32(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _sched(variant), _stream()), "pm_grouped_gemm_tn_f32")
+    if tile_sumsq is None:
+        check(lib.pm_grouped_gemm_tn_f32(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _sched(variant), _stream()), "pm_grouped_gemm_tn_f32")
+        return
+    _req(tile_sumsq, torch.float32, "tile_sumsq")
+    check(lib.pm_grouped_gemm_tn_f32_sumsq(_p(dy), _p(x), _p(offsets), e, x.shape[0], n1, n, k, _p(dw), _p(dw2), int(accumulate), _p(tile_sumsq), tile_sumsq.numel(),
+                                           _sched(variant), _stream()), "pm_grouped_gemm_tn_f32_sumsq")
+
+
+def grouped_gemm_tn_sumsq_slots(n_experts: int, n: int, k: int) -> int:
+    return int(_lib.load().pm_grouped_gemm_tn_sumsq_slots(n_experts, n, k))
 
 
 def sgd_step(master: Tensor, momentum_buf: Tensor | None, grad: Tensor, param_bf16: Tensor | None, lr: float, momentum: float, weight_decay: float,

@@ -78,6 +78,17 @@ def _main_grads(*params):
     return out
 
 
+def _main_grad_sumsq(p):
+    """The engine's per-launch workspace for the gradient norm fused into the weight-gradient epilogue (`ops.grouped_gemm_tn_f32(tile_sumsq=)`), hung on
+    the FIRST parameter a launch writes (w1 for the gate|up launch, w2 for the down launch) as `main_grad_sumsq` = (slots tensor, [valid this step?]);
+    None when the engine computes the norm with a pass over the gradients instead."""
+    ws = getattr(p, "main_grad_sumsq", None)
+    if ws is None:
+        return None
+    ws[1][0] = True  # this step's norm of the launch's outputs comes from the slots
+    return ws[0]
+
+
 class _GroupedLinearFn(torch.autograd.Function):
     """y[m] = x[m] @ w[expert of m].T over expert-sorted rows — `torch._grouped_mm(x, w.transpose(-2, -1), offs=...)` (moe.py:181-183) and its
     two gradients on the hand-written MFMA kernels of grouped_gemm.hip (pm_grouped_gemm_nt / nn / tn)."""
@@ -97,7 +108,7 @@ class _GroupedLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             mg = ctx.main_grads
             if mg is not None and ops.grouped_gemm_tn_f32_supported(w.shape[1], w.shape[1], w.shape[2]):
-                ops.grouped_gemm_tn_f32(g, x, offsets, mg[0][0], None, accumulate=mg[0][1][0])
+                ops.grouped_gemm_tn_f32(g, x, offsets, mg[0][0], None, accumulate=mg[0][1][0], tile_sumsq=_main_grad_sumsq(w))
                 mg[0][1][0] = True
             else:
                 gw = ops.grouped_gemm_tn(g, x, offsets)
@@ -126,7 +137,7 @@ class _GroupedSwiGLUFn(torch.autograd.Function):
             mg = ctx.main_grads
             if mg is not None and ops.grouped_gemm_tn_f32_supported(w1.shape[1], w1.shape[1] + w3.shape[1], w1.shape[2]):
                 acc = mg[0][1][0]  # both halves were written by the same launches so far
-                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=acc)
+                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=acc, tile_sumsq=_main_grad_sumsq(w1))
                 mg[0][1][0] = mg[1][1][0] = True
             else:
                 gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])
@@ -158,7 +169,7 @@ class _GroupedFFNFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             mg = ctx.main_grads_2
             if mg is not None and ops.grouped_gemm_tn_f32_supported(w2.shape[1], w2.shape[1], w2.shape[2]):
-                ops.grouped_gemm_tn_f32(g, h, offsets, mg[0][0], None, accumulate=mg[0][1][0])
+                ops.grouped_gemm_tn_f32(g, h, offsets, mg[0][0], None, accumulate=mg[0][1][0], tile_sumsq=_main_grad_sumsq(w2))
                 mg[0][1][0] = True
             else:
                 gw2 = ops.grouped_gemm_tn(g, h, offsets)
@@ -166,7 +177,7 @@ class _GroupedFFNFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
             mg = ctx.main_grads_13
             if mg is not None and ops.grouped_gemm_tn_f32_supported(w1.shape[1], w1.shape[1] + w3.shape[1], w1.shape[2]):
-                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=mg[0][1][0])
+                ops.grouped_gemm_tn_f32(d_gate_up, x, offsets, mg[0][0], mg[1][0], accumulate=mg[0][1][0], tile_sumsq=_main_grad_sumsq(w1))
                 mg[0][1][0] = mg[1][1][0] = True
             else:
                 gw1, gw3 = ops.grouped_gemm_tn(d_gate_up, x, offsets, n_first=w1.shape[1])

@@ -174,6 +174,42 @@ class ModuleEngine:
                 self._update_spans.append((off if self._update_spans else 0, end, zero))
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)
         self._param_readers: list = []
+        # The gradient norm of the expert parameters out of their weight-gradient epilogues (ops.grouped_gemm_tn_f32(tile_sumsq=): every launch leaves the sum
+        # of squares of the FINAL values of every output tile in a small workspace) instead of a pass over 97 % of the gradient buffer — what the flat
+        # engine's `fused_sumsq` is to its dense weight gradients.  Only where the norm is taken over what the launches wrote: a gradient that is summed over
+        # ranks afterwards (dp > 1 replicas of the same experts) has no such partials.  PM_MOE_FUSED_NORM=0 is the A/B switch.
+        self._fused_norm: list[tuple[Tensor, list, int, list[tuple[int, int]]]] = []  # (slots, [valid this step], partition 0 / 1, covered [a, b) ranges)
+        self._norm_rest: list[tuple[int, int, int]] = []  # (a, b, partition): what the pass still reads when every launch's slots are valid
+        if self._direct and os.environ.get("PM_MOE_FUSED_NORM", "1") != "0":
+            offs = {id(p): off for _, p, off in self.entries}
+            direct_ids = {id(p) for p in self._direct}
+            sizes = []
+            for m in model.modules():
+                if not isinstance(m, GroupedExperts) or not all(id(q) in direct_ids for q in (m.w1, m.w2, m.w3)):
+                    continue
+                e, inter, hidden = m.w1.shape
+                part = 1 if offs[id(m.w1)] >= self.n_replicated else 0
+                summed_later = self.dp_size > 1 and (part == 0 or self.ep_size == 1 or self.dp_size > self.ep_size)
+                if summed_later or not (ops.grouped_gemm_tn_f32_supported(inter, 2 * inter, hidden) and ops.grouped_gemm_tn_f32_supported(hidden, hidden, inter)):
+                    continue
+                sizes.append((m.w1, [m.w1, m.w3], ops.grouped_gemm_tn_sumsq_slots(e, 2 * inter, hidden), part))
+                sizes.append((m.w2, [m.w2], ops.grouped_gemm_tn_sumsq_slots(e, hidden, inter), part))
+            if sizes:
+                self._fs_ws = torch.zeros(sum(n for _, _, n, _ in sizes), dtype=torch.float32, device=dev)
+                cur, covered = 0, []
+                for first, ps, n, part in sizes:
+                    rng = [(offs[id(q)], offs[id(q)] + q.numel()) for q in ps]
+                    first.main_grad_sumsq = (self._fs_ws[cur:cur + n], [False])
+                    self._fused_norm.append((self._fs_ws[cur:cur + n], first.main_grad_sumsq[1], part, rng))
+                    covered += rng
+                    cur += n
+                covered.sort()
+                pos = 0
+                for a, b in covered + [(self.total, self.total)]:  # the complement of the covered ranges, cut at the partition boundary
+                    for lo, hi, part in ((pos, min(a, self.n_replicated), 0), (max(pos, self.n_replicated), a, 1)):
+                        if hi > lo:
+                            self._norm_rest.append((lo, hi, part))
+                    pos = max(pos, b)
 
     # -- GRPOEngine-compatible surface used by train() and the weight broadcast -----------------------------------------------------
     def wait_params_ready(self) -> None:
@@ -326,12 +362,24 @@ class ModuleEngine:
             if self.total > nr and (self.ep_size == 1 or self.dp_size > self.ep_size):
                 dist.all_reduce(g[nr:], op=dist.ReduceOp.SUM, group=self.ep_replica_group if self.ep_size > 1 else self.dp_group)
         self._sumsq.zero_()
-        if nr:
-            ops.sumsq_accumulate(g[:nr], self._sumsq[0:1])
-        if self.total > nr:
-            ops.sumsq_accumulate(g[nr:], self._sumsq[1:2])
-            if self.ep_size > 1:
-                dist.all_reduce(self._sumsq[1:2], op=dist.ReduceOp.SUM, group=self.ep_group)
+        if self._fused_norm and all(valid[0] for _, valid, _, _ in self._fused_norm):
+            # every expert weight-gradient launch of this step left its tiles' sums of squares: read those (a few MB) and pass only over the rest
+            for a, b, part in self._norm_rest:
+                ops.sumsq_accumulate(g[a:b], self._sumsq[part:part + 1])
+            for part in (0, 1):
+                sl = [ws for ws, _, pt, _ in self._fused_norm if pt == part]
+                if sl:  # the slots of one partition are one contiguous stretch of the workspace
+                    lo = sl[0].storage_offset()
+                    self._sumsq[part:part + 1] += self._fs_ws[lo:lo + sum(w.numel() for w in sl)].sum()
+        else:
+            if nr:
+                ops.sumsq_accumulate(g[:nr], self._sumsq[0:1])
+            if self.total > nr:
+                ops.sumsq_accumulate(g[nr:], self._sumsq[1:2])
+        for _, valid, _, _ in self._fused_norm:
+            valid[0] = False
+        if self.total > nr and self.ep_size > 1:
+            dist.all_reduce(self._sumsq[1:2], op=dist.ReduceOp.SUM, group=self.ep_group)
         total = self._sumsq.sum().reshape(1)
         o = self.optim
         coef, norm = ops.clip_coef(total, 1.0, o.max_norm if o.max_norm else 0.0)

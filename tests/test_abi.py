@@ -128,7 +128,7 @@ def test_product_library_holds_no_mutable_schedule_state(lib):
     assert lib.pm_grouped_gemm_debug_set_variant(1) != 0 and lib.pm_grouped_gemm_debug_set_variant(-1) == 0
     assert lib.pm_attn_debug_set_variant(1, 1) != 0 and lib.pm_attn_debug_set_variant(0, -1) == 0
     for name in ("pm_gemm_bf16", "pm_gemm_bf16_ws", "pm_gemm_bf16_sumsq", "pm_gemm_swiglu_bf16", "pm_gemm_swiglu_bwd_bf16", "pm_grouped_gemm_nt", "pm_grouped_gemm_nn",
-                 "pm_grouped_gemm_nt_swiglu", "pm_grouped_gemm_nn_swiglu_bwd", "pm_grouped_gemm_tn", "pm_grouped_gemm_tn_f32"):
+                 "pm_grouped_gemm_nt_swiglu", "pm_grouped_gemm_nn_swiglu_bwd", "pm_grouped_gemm_tn", "pm_grouped_gemm_tn_f32", "pm_grouped_gemm_tn_f32_sumsq"):
         args = _lib.SIGNATURES[name][1]
         assert args[-2] is _lib.I32 and args[-1] is _lib.P, name
     # a word that selects a VARIANTS-only build is refused at the launch, before any device work

@@ -165,6 +165,7 @@ def test_expert_gradients_written_in_f32_by_the_weight_gradient_gemm(monkeypatch
         grads[mode] = eng.main_grad.clone()
         if mode == "1":
             assert all(p.grad is None and p.main_grad_written[0] for p in eng._direct)
+            assert len(eng._fused_norm) == 2 * cfg.num_hidden_layers and all(valid[0] for _, valid, _, _ in eng._fused_norm)
         norms[mode] = float(eng.optimizer_step())
         params[mode] = eng.params_bf16.clone()
         if mode == "1":
@@ -174,6 +175,27 @@ def test_expert_gradients_written_in_f32_by_the_weight_gradient_gemm(monkeypatch
             direct = {id(p) for p in eng._direct}
             assert all(float(gv.abs().max()) == 0.0 for (nm, p, off), gv in zip(eng.entries, eng._grad_views) if id(p) not in direct)
             assert [z for _, _, z in eng._update_spans].count(False) >= cfg.num_hidden_layers  # the experts of a layer form one span
+    # the expert parameters' share of the norm came out of the weight-gradient epilogues (ModuleEngine._fused_norm): same number as the pass over the buffer
+    monkeypatch.setenv("PM_MOE_MAIN_GRAD", "1")
+    monkeypatch.setenv("PM_MOE_FUSED_NORM", "0")
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        model = Qwen3MoeForCausalLM(cfg)
+    model = model.to(torch.bfloat16)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.fill_(1.0) if p.dim() == 1 else p.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.05).to(p.dtype))
+    inject_prime_lm_head(model, chunk_size=8192)
+    eng = ModuleEngine(model, DEV, optim=OptimConfig(lr=1e-3))
+    assert not eng._fused_norm
+    scales = eng.global_scales(tuple(sum(p.local_counts[k] for p in passes) for k in range(3)))
+    for p in passes:
+        eng.backward(eng.forward_loss(p, scales))
+    assert torch.equal(eng.main_grad, grads["1"])
+    plain = float(eng.optimizer_step())
+    assert abs(plain - norms["1"]) <= 1e-6 * plain, (plain, norms["1"])
+    assert torch.equal(eng.params_bf16, params["1"]) or (eng.params_bf16 != params["1"]).float().mean().item() < 1e-5
     rel = ((grads["1"] - grads["0"]).norm() / grads["0"].norm()).item()
     assert rel < 4e-3, rel  # the autograd path rounds every pass's expert gradient to bf16 before accumulating
     assert abs(norms["1"] - norms["0"]) <= 2e-3 * norms["0"]

@@ -540,6 +540,33 @@ def test_grouped_weight_gradient_in_f32_written_and_accumulated_in_place():
     assert torch.equal(single, first[:e * n1 * k].view(e, n1, k))
 
 
+def test_grouped_weight_gradient_leaves_its_squared_norm_in_the_tile_slots():
+    """pm_grouped_gemm_tn_f32_sumsq: sum(tile_sumsq) is the squared norm of the FINAL dw and dw2 — after an overwriting launch, after an accumulating one
+    (slots overwritten, not added to), with an empty expert (its tiles hold zeros / what was there) and with different rows per launch; the gradients
+    themselves are those of the plain entry point bit for bit."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(22)
+    e, n1, n2, k = 5, 512, 256, 768
+    ws = torch.full((ops.grouped_gemm_tn_sumsq_slots(e, n1 + n2, k) + 8,), float("nan"), dtype=torch.float32, device=DEV)
+    assert ws.numel() - 8 == e * ((n1 + n2) // 256) * (k // 256) * 8
+    dw, dw2 = torch.empty(e, n1, k, dtype=torch.float32, device=DEV), torch.empty(e, n2, k, dtype=torch.float32, device=DEV)
+    rw, rw2 = torch.empty_like(dw), torch.empty_like(dw2)
+    for step, sizes in enumerate(([300, 0, 1, 255, 513], [0, 700, 64, 0, 3])):
+        m = sum(sizes)
+        offsets = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+        x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+        dy = torch.randn(m, n1 + n2, generator=g).to(torch.bfloat16).to(DEV)
+        ops.grouped_gemm_tn_f32(dy, x, offsets, dw, dw2, accumulate=step > 0, tile_sumsq=ws[:-8])
+        ops.grouped_gemm_tn_f32(dy, x, offsets, rw, rw2, accumulate=step > 0)
+        assert torch.equal(dw, rw) and torch.equal(dw2, rw2)
+        want = (dw.double() ** 2).sum() + (dw2.double() ** 2).sum()
+        got = ws[:-8].double().sum()
+        assert abs(got.item() - want.item()) <= 1e-6 * want.item(), (step, got.item(), want.item())
+        assert torch.isnan(ws[-8:]).all()
+    with pytest.raises(Exception):
+        ops.grouped_gemm_tn_f32(dy, x, offsets, dw, dw2, tile_sumsq=ws[:16])  # too few slots
+
+
 def test_grouped_gemm_rejects_unsupported_shapes_loudly():
     ops = _ops()
     from prime_rl_amd._lib import PrimeMI355XError
