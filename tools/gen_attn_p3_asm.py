@@ -51,7 +51,7 @@ NEG_FLT_MAX = "0xff7fffff"
 NEG_INF = "0xff800000"
 
 # physical scalar registers owned by the stream
-S_I, S_KBASE, S_VBASE, S_KVSM, S_TMP, S_LIMIT, S_RS, S_PAIR = 80, 81, 82, 83, 84, 85, 86, 88  # S_PAIR: s[88:89]
+S_I, S_KBASE, S_VBASE, S_KVSM, S_TMP, S_LIMIT, S_RS, S_KDMA, S_PAIR = 80, 81, 82, 83, 84, 85, 86, 87, 88  # S_PAIR: s[88:89]
 S_LAST = 89
 
 
@@ -275,11 +275,11 @@ def mask_list(Y):
     return L
 
 
-def dma_ins(par, which):
+def dma_ins(par, which, ksrc=S_KBASE):
     """the LDS-DMA of K(i + 1) ("k") or V(i - 1) ("v") into the slots of the other parity: [m0 write, 4 loads]"""
     if which == "k":
         return [salu(f"s_add_u32 m0, %[ldsw], {KOFF0 + (1 - par) * SLOT}")] + [
-            Ins(f"buffer_load_dwordx4 %[ko{j}], %[krsrc], {s(S_KBASE)} offen" + (f" offset:{j * 1024}" if j else "") + " lds", "vmem") for j in range(4)]
+            Ins(f"buffer_load_dwordx4 %[ko{j}], %[krsrc], {s(ksrc)} offen" + (f" offset:{j * 1024}" if j else "") + " lds", "vmem") for j in range(4)]
     return [salu(f"s_add_u32 m0, %[ldsw], {VOFF0 + (1 - par) * SLOT}")] + [
         Ins(f"buffer_load_dwordx4 %[vo{j}], %[vrsrc], {s(S_VBASE)} offen" + (f" offset:{j * 1024}" if j else "") + " lds", "vmem") for j in range(4)]
 
@@ -474,13 +474,18 @@ def build(opts, want_stats=False):
         emit(f"s_cbranch_scc1 {P('generic')}")
         emit(f"s_cmp_lt_i32 {s(S_KVSM)}, %[lomax]")
         emit(f"s_cbranch_scc1 {P('generic')}")
-        if not dma_in and "nosync" not in ablate:  # burst right after the barrier (K(i + 1) past the last tile reads zeros through the range check)
-            for x in pad_hazards(dma_ins(par, "k") + dma_ins(par, "v"), tail_mfma_pad=False):
+        # the block always issues a K DMA: K(i + 1), or — for the last tile of the workgroup — K(i) once more (an address inside the tensor; that slot is not read again)
+        emit(f"s_add_u32 {s(S_TMP)}, {s(S_I)}, 1")
+        emit(f"s_sub_u32 {s(S_KDMA)}, {s(S_KBASE)}, %[krow64]")
+        emit(f"s_cmp_lt_i32 {s(S_TMP)}, %[nit]")
+        emit(f"s_cselect_b32 {s(S_KDMA)}, {s(S_KBASE)}, {s(S_KDMA)}")
+        if not dma_in and "nosync" not in ablate:  # burst right after the barrier
+            for x in pad_hazards(dma_ins(par, "k", S_KDMA) + dma_ins(par, "v"), tail_mfma_pad=False):
                 emit(x)
         rescale()
         extras = None
         if dma_in and "nosync" not in ablate and "nodma" not in ablate:
-            d = dma_ins(par, "k") + dma_ins(par, "v")
+            d = dma_ins(par, "k", S_KDMA) + dma_ins(par, "v")
             extras = {k: [d[k]] for k in range(len(d))}
         novalu = "novalu" in ablate
         pre = [] if novalu else lane_max(Y) + (moved_test(P("fast")) if fast else [])
