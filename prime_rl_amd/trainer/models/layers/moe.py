@@ -20,6 +20,8 @@ NemotronH router."""
 
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import torch
@@ -429,6 +431,42 @@ class MoE(nn.Module):
                 self._buffers[name] = buf.float()
         return self
 
+    def _forward_ep_chunked(self, x: torch.Tensor, routed_experts, chunks: int) -> torch.Tensor:
+        """Expert parallelism with the dispatch / combine all-to-alls hidden under expert compute: the router runs ONCE over all tokens (its gate GEMM must
+        not depend on the chunking: a library GEMM picks its algorithm by row count), then the tokens are cut into `chunks` pieces that are sorted and
+        gathered first (so that ONE exchange of counts and ONE host copy of split sizes serve the layer) and `EP.run_experts_chunked` pipelines dispatch ->
+        experts -> combine over the pieces.  Same output and input gradient as the one-piece path bit for bit: sort, gather and combine are per token, an
+        expert's rows are independent of each other; the weight gradients accumulate the pieces in f32 main-grads (or bf16 `.grad`s like two micro-batches
+        would)."""
+        n = x.shape[0]
+        top_scores, idx, counts, conf = self.router(x, self.expert_bias, routed_experts=routed_experts)
+        with torch.no_grad():  # moe.py:1010-1012
+            self.tokens_per_expert.add_(counts)
+            self.routing_confidence_sum.add_(conf)
+        cuts = [n * i // chunks for i in range(chunks + 1)]
+        pieces, routed = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            xc = x[a:b]
+            if b == a:  # fewer tokens than pieces on this rank: the piece still takes part in every collective, with zero rows
+                routed.append((xc, torch.zeros(self.num_experts, dtype=torch.int32, device=x.device)))  # xc = x[a:a]: zero rows that stay in the autograd graph
+                pieces.append(None)
+                continue
+            dest_of_slot, slot_of_dest, offsets = self.reorderer(top_scores[a:b], idx[a:b].contiguous())
+            scores_flat = top_scores[a:b].reshape(-1)
+            routed.append((_GatherFn.apply(xc, scores_flat if self.score_before_experts else None, slot_of_dest, dest_of_slot, self.top_k),
+                           (offsets[1:] - offsets[:-1]).to(torch.int32)))
+            pieces.append((xc, scores_flat, dest_of_slot, slot_of_dest))
+        outs = EP.run_experts_chunked(self.experts, routed, self.ep_group)
+        res = []
+        for piece, routed_out in zip(pieces, outs):
+            if piece is None:  # zero rows came back; they still belong to the output's graph, so that this rank issues the gradients' all-to-alls as well
+                res.append(routed_out)
+                continue
+            xc, scores_flat, dest_of_slot, slot_of_dest = piece
+            base = self.shared_expert(xc) if self.shared_expert is not None else None
+            res.append(_CombineFn.apply(routed_out.contiguous(), None if self.score_before_experts else scores_flat, base, slot_of_dest, dest_of_slot, self.top_k))
+        return torch.cat(res, dim=0)
+
     def forward(self, x: torch.Tensor, routed_experts: torch.Tensor | None = None) -> torch.Tensor:
         bs, slen, dim = x.shape
         x = x.reshape(-1, dim)
@@ -436,6 +474,12 @@ class MoE(nn.Module):
             raise NotImplementedError("the HIP MoE permutation kernels move bf16 rows (the reference trains in bf16)")
         if routed_experts is not None:
             routed_experts = routed_experts.reshape(-1, routed_experts.shape[-1])
+        if self.ep_size > 1:
+            # PM_EP_OVERLAP_CHUNKS: pieces the layer's tokens are cut into so that the row all-to-alls travel under expert compute (default 2 on a GPU; 1 = the
+            # one-piece synchronous exchange).  Every rank must take the same branch: the decision uses only the environment and the layer's configuration.
+            chunks = int(os.environ.get("PM_EP_OVERLAP_CHUNKS", "2" if x.is_cuda else "1"))
+            if chunks > 1:
+                return self._forward_ep_chunked(x, routed_experts, chunks).reshape(bs, slen, dim)
         top_scores, idx, counts, conf = self.router(x, self.expert_bias, routed_experts=routed_experts)
         with torch.no_grad():  # moe.py:1010-1012
             self.tokens_per_expert.add_(counts)

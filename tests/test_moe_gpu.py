@@ -381,6 +381,56 @@ def test_expert_parallel_dispatch_on_the_device_equals_local_experts():
             dist.destroy_process_group()
 
 
+def test_expert_parallel_layer_with_overlapped_chunked_exchange_on_the_device(monkeypatch):
+    """MoE.forward under expert parallelism (an RCCL group of one rank: the all-to-alls are asynchronous self-copies on the communicator's stream) with
+    the tokens cut into 1 / 2 / 3 pieces (PM_EP_OVERLAP_CHUNKS; 2 is the default on a GPU): the chunked, overlapped exchange gives the one-piece layer's
+    output and input gradient bit for bit, the weight gradients up to the bf16 sum over pieces, and equals the layer without expert parallelism."""
+    import os
+
+    import torch.distributed as dist
+
+    from prime_rl_amd.trainer.models.layers.moe import MoE, MoEArgs
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29542")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        args = MoEArgs(num_experts=8, num_shared_experts=0, score_func="softmax", route_norm=True, route_scale=1.0, score_before_experts=False, top_k=2,
+                       use_grouped_mm=True, load_balance_coeff=None)
+        dim, hidden, n = 256, 256, 777
+        torch.manual_seed(0)
+        plain = MoE(args, dim, hidden).to(DEV)
+        for p in plain.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+        plain = plain.to(torch.bfloat16)
+        ep = MoE(args, dim, hidden, ep_group=dist.group.WORLD).to(DEV).to(torch.bfloat16)
+        ep.ep_size = 2  # take the expert-parallel branch on the one-rank group (ep_size only gates the branch; the group's size does the arithmetic)
+        ep.load_state_dict(plain.state_dict())
+        x = torch.randn(1, n, dim, device=DEV).to(torch.bfloat16)
+        gy = torch.randn_like(x)
+        res = {}
+        for chunks in (0, 1, 2, 3):  # 0: the layer without expert parallelism
+            layer = plain if chunks == 0 else ep
+            monkeypatch.setenv("PM_EP_OVERLAP_CHUNKS", str(max(chunks, 1)))
+            layer.zero_grad()
+            xa = x.clone().requires_grad_(True)
+            y = layer(xa)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[chunks] = (y.detach().clone(), xa.grad.clone(), {k: v.grad.float().clone() for k, v in layer.named_parameters()})
+        for chunks in (1, 2, 3):
+            y, gx, gw = res[chunks]
+            assert torch.equal(y, res[0][0]) and torch.equal(gx, res[0][1]), chunks
+            for k, v in gw.items():
+                ref = res[0][2][k]
+                assert (v - ref).abs().max().item() <= 2.0 ** -6 * max(ref.abs().max().item(), 1e-6), (chunks, k)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("e,n_out,k,sizes", [(4, 128, 128, [5, 0, 300, 128]), (8, 256, 384, [64, 1, 127, 129, 0, 0, 700, 3]), (3, 768, 2048, [1000, 24, 513]),
                                              (2, 128, 256, [0, 0]), (16, 128, 128, [17] * 16), (5, 512, 256, [300, 0, 257, 255, 1]),
                                              (3, 256, 768, [600, 256, 31]),
