@@ -99,14 +99,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 #include "attention_kernels.hip.h"
 #include "attention_fwd_p3.hip.h"
+#include "attention_dkdv_p2.hip.h"
 #if PM_VARIANTS  // `make VARIANTS=1`: the measured-and-not-adopted builds (profiles/r03_attention.md, r04_attention.md)
 #include "attention_fwd_pp.hip.h"
 #endif
 
 static inline int64_t align256(int64_t b) { return cdiv(b, 256) * 256; }
 // Debug-only variant codes (pm_attn_debug_set_variant; tools/microbench.py attnbwd / attndq time them interleaved in ONE process because
-// boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 1 = fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three
-// workgroups per CU.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and the generations they replaced: profiles/r02_attention.md.
+// boxes differ by ~5 %).  0 = the default of each kernel.  dK/dV: 0 = attn_bwd_dkdv_p2_kernel (round 6); 7 = the round-2..5 kernel attn_bwd_dkdv_kernel
+// <2, 4, 64, 1>, 1 = its fragment batch 2, 2 = fragment batch 8, 3 = 32-row q tiles at three workgroups per CU, 4-6 = its 32-kv-rows-per-wave builds with
+// compiler scheduling, 8-11 = its timing ablations; 12 + 32 V = timing ablations of the default.  dQ: 1 = 32 kv rows per barrier.  Measured alternatives and
+// the generations they replaced: profiles/r02_attention.md, r04_attention.md, r06_attention.md.
 #if PM_VARIANTS  // the A/B selectors are process-wide state of `make VARIANTS=1` libraries only; the product library holds constants (no mutable globals)
 static int g_fwd_var = -1;  // forward: A/B bits of fwd_tile (attention_kernels.hip.h); -1 = the default build
 static int g_dkdv_var = 0;
@@ -318,8 +321,29 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<MINB_, FB_, QT_, KVB_, ##__VA_ARGS__>), dim3((unsigned)(cdiv(n, 64 * KVB_) * n_kv_heads)), dim3(256), 0, st, (const bf16_t*)q, \
                      (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
                      softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0)
+#define PM_LAUNCH_DKDV_P2(V_)                                                                                                                        \
+  do {                                                                                                                                               \
+    static bool attr_done = false;                                                                                                                   \
+    if (!attr_done) {                                                                                                                                \
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_p2_kernel<V_>, hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvP2Smem);                       \
+      attr_done = true;                                                                                                                              \
+    }                                                                                                                                                \
+    hipLaunchKernelGGL(attn_bwd_dkdv_p2_kernel<V_>, dim3((unsigned)(cdiv(n, 128) * n_kv_heads)), dim3(256), kDkdvP2Smem, st, (const bf16_t*)q,            \
+                       (const bf16_t*)k, (const bf16_t*)v, v_row_stride, (const bf16_t*)grad_out, nlse, ndelta, seq_start, n, n_q_heads, n_kv_heads, \
+                       softmax_scale, (bf16_t*)grad_k, (bf16_t*)grad_v, grad_v_row_stride, (int)q_row0, (g_dkdv_var & 16) ? 1 : 0);                  \
+  } while (0)
 #if PM_VARIANTS
-  if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64, 1);
+  if ((g_dkdv_var & 15) == 0 || (g_dkdv_var & 15) == 12) {  // the default: 32 kv rows per wave, one wave per SIMD, hand-placed two-stage tile loop
+    switch ((g_dkdv_var & 15) == 12 ? g_dkdv_var >> 5 : 0) {  // (attention_dkdv_p2.hip.h); 12 + 32 V: its timing ablations
+      case 1: PM_LAUNCH_DKDV_P2(1); break;
+      case 2: PM_LAUNCH_DKDV_P2(2); break;
+      case 3: PM_LAUNCH_DKDV_P2(3); break;
+      case 4: PM_LAUNCH_DKDV_P2(4); break;
+      case 5: PM_LAUNCH_DKDV_P2(5); break;
+      default: PM_LAUNCH_DKDV_P2(0); break;
+    }
+  }
+  else if ((g_dkdv_var & 15) == 1) PM_LAUNCH_DKDV(2, 2, 64, 1);
   else if ((g_dkdv_var & 15) == 2) PM_LAUNCH_DKDV(2, 8, 64, 1);
   else if ((g_dkdv_var & 15) == 3) PM_LAUNCH_DKDV(3, 4, 32, 1);
   else if ((g_dkdv_var & 15) == 4) PM_LAUNCH_DKDV(1, 4, 64, 2);  // 32 kv rows per wave, one wave per SIMD (accumulators in AGPRs)
@@ -329,9 +353,11 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   else if ((g_dkdv_var & 15) == 9) PM_LAUNCH_DKDV(2, 4, 64, 1, 2);   // no fragment reads
   else if ((g_dkdv_var & 15) == 10) PM_LAUNCH_DKDV(2, 4, 64, 1, 4);  // no LDS-DMA
   else if ((g_dkdv_var & 15) == 11) PM_LAUNCH_DKDV(2, 4, 64, 1, 8);  // no MFMAs
-  else
+  else PM_LAUNCH_DKDV(2, 4, 64, 1);  // 7: the round-2..5 kernel (16 kv rows per wave, two workgroups per CU)
+#else
+  PM_LAUNCH_DKDV_P2(0);
 #endif
-  PM_LAUNCH_DKDV(2, 4, 64, 1);
+#undef PM_LAUNCH_DKDV_P2
 #undef PM_LAUNCH_DKDV
   PM_CHECK_LAUNCH(who);
 

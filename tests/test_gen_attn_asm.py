@@ -1,5 +1,6 @@
-"""The hand-placed tile loop of the attention forward (csrc/attention_fwd_p3_asm.inc.h) is GENERATED: the committed file must be what
-tools/gen_attn_p3_asm.py writes, and the generator's hazard padding / LDS-queue simulation must catch what hipcc does not pad inside an asm statement."""
+"""The hand-placed tile loops of the attention forward (csrc/attention_fwd_p3_asm.inc.h) and of dK/dV (csrc/attention_dkdv_p2_asm.inc.h) are GENERATED: the
+committed files must be what tools/gen_attn_p3_asm.py / gen_attn_dkdv_asm.py write, and the generators' hazard padding / LDS-queue simulation must catch
+what hipcc does not pad inside an asm statement."""
 import importlib.util
 import subprocess
 import sys
@@ -67,3 +68,35 @@ def test_every_variant_builds_and_streams_have_the_expected_mix():
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
     # per parity: slow 64 + fast 64 + pv 32 + qk 32
     assert n_mfma == 2 * (64 + 64 + 32 + 32)
+
+
+def _gen_dkdv():
+    spec = importlib.util.spec_from_file_location("gen_attn_dkdv_asm", ROOT / "tools" / "gen_attn_dkdv_asm.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_committed_dkdv_stream_is_the_generators_output(tmp_path):
+    subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_dkdv_asm.py"), "--out", str(tmp_path)], check=True, capture_output=True)
+    want = (tmp_path / "attention_dkdv_p2_asm.inc.h").read_text()
+    have = (ROOT / "prime_rl_amd" / "csrc" / "attention_dkdv_p2_asm.inc.h").read_text()
+    assert have == want, "attention_dkdv_p2_asm.inc.h is stale: run python tools/gen_attn_dkdv_asm.py"
+
+
+def test_dkdv_stream_mix_and_accumulator_operands():
+    g = _gen_dkdv()
+    for opts in g.VARIANTS:
+        assert g.build(opts)[-1] == "s_waitcnt lgkmcnt(0)"
+    lines = g.build({})
+    mf = [l for l in lines if l.startswith("v_mfma")]
+    # per parity: the interleaved block and the sequential blocks each hold S / dP (64) and dV / dK (64)
+    assert len(mf) == 2 * (64 + 64 + 64 + 64)
+    # S / dP products: D in the architectural file, B (the K / V fragment) in the accumulator file; dV / dK: D in the accumulator file, B = packed P / dS
+    p1 = [l for l in mf if l.split()[1].startswith("v[")]
+    p2 = [l for l in mf if l.split()[1].startswith("a[")]
+    assert len(p1) == len(p2) == 256
+    assert all(l.split(", ")[2].startswith("a[") for l in p1) and all(l.split(", ")[2].startswith("v[") for l in p2)
+    # a K / V fragment or an accumulator tuple is never written by anything but its own MFMA chain / the prologue
+    writers = [l for l in lines if (l.startswith("ds_read") or l.startswith("v_cvt") or l.startswith("v_mul")) and l.split()[1].startswith("a")]
+    assert not writers

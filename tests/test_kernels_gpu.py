@@ -613,8 +613,10 @@ def test_attention_row_windows(ops, seq_lens, hq, hkv, cp):
                                              ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1), ([255, 257], 8, 2), ([2048] * 3 + [777], 8, 2)])
 @pytest.mark.skipif(not ATTN_AB, reason="the A/B builds of the dK/dV kernel exist only in a `make VARIANTS=1` library")
 def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
-    """The dK/dV kernel's build variants (pm_attn_debug_set_variant(1, v): fragment batch, 32 kv rows per wave at one wave per SIMD) walk the
-    same q tiles in the same order and feed the same MFMA chains: dk / dv equal the default build bit for bit, full calls and row windows."""
+    """The dK/dV kernel's build variants (pm_attn_debug_set_variant(1, v)): the default is attn_bwd_dkdv_p2_kernel (32 kv rows per wave, one wave per SIMD,
+    hand-placed two-stage tile loop); the round-2..5 kernel (7; + 16: 8-byte epilogue stores), its fragment-batch builds (1, 2) and its compiler-scheduled
+    32-kv-rows-per-wave builds (4, 5) walk the same q tiles in the same order and feed the same MFMA chains: dk / dv equal the default build bit for bit,
+    full calls and row windows."""
     from prime_rl_amd import _lib
 
     lib = _lib.load()
@@ -634,7 +636,7 @@ def test_attention_dkdv_variants_are_bit_identical(ops, seq_lens, hq, hkv):
 
     try:
         base = run()
-        for var in (1, 2, 4, 5, 4 + 16):
+        for var in (7, 7 + 16, 1, 2, 4, 5, 4 + 16, 16):
             rc = lib.pm_attn_debug_set_variant(1, var)
             if rc == -2:
                 pytest.skip("the A/B builds of the dK/dV kernel exist only in a `make VARIANTS=1` library")
