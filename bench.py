@@ -330,6 +330,26 @@ def long_context_extra(engine, dims, device, seq: int = 32768, rollouts=(1, 4), 
             except Exception as e:  # pragma: no cover
                 res[f"r{r}"] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
+        # the reference's `ac.mode = "selective"` (norm / attn_proj / mlp re-run, the attention core's output kept): the same step with one attention forward
+        # per layer less; 288 GB hold the kept outputs
+        try:
+            engine.recompute = "selective"
+            dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=1), seq_len=seq)
+            bs = [[pack_micro_batches([mb], device) for mb in dl.get_batch()] for _ in range(steps + 1)]
+            torch.cuda.reset_peak_memory_stats()
+            engine.step(bs[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in bs[1:]:
+                engine.step(b)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            res["r1_selective"] = {"rollouts": 1, "recompute": "selective", "ms_per_step": round(dt * 1e3, 2), "tokens_per_s": round(seq / dt, 1),
+                                   "mfu_ref_formula": round(dims.flops_per_token(seq) * seq / dt / MFMA_BF16_PEAK, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+            del bs
+        except Exception as e:  # pragma: no cover
+            res["r1_selective"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     finally:
         engine.recompute = old
     return res
@@ -687,6 +707,7 @@ def finalize_line(result: dict) -> dict:
         "long_context_ms": _dig(extra, ("long_context", "r1", "ms_per_step")), "long_context_mfu_ref": _dig(extra, ("long_context", "r1", "mfu_ref_formula")),
         "long_context_mfu_executed": _dig(extra, ("long_context", "r1", "mfu_executed_causal")),
         "long_context_attn_share": _dig(extra, ("long_context", "r1", "attention_share")), "long_context_peak_hbm_gb": _dig(extra, ("long_context", "r1", "peak_hbm_gb")),
+        "long_context_selective_ms": _dig(extra, ("long_context", "r1_selective", "ms_per_step")), "long_context_selective_mfu_ref": _dig(extra, ("long_context", "r1_selective", "mfu_ref_formula")),
         "long_context_x4_ms": _dig(extra, ("long_context", "r4", "ms_per_step")), "long_context_x4_mfu_executed": _dig(extra, ("long_context", "r4", "mfu_executed_causal")),
         "long_context_attn_fwd_frac": _dig(extra, ("long_context", "attn_fwd_frac_of_2.5PF")), "long_context_attn_bwd_frac": _dig(extra, ("long_context", "attn_bwd_frac_of_2.5PF")),
         "j1_frac": _dig(extra, ("j1_roofline", "frac")), "gemm_wgrad_frac": _dig(extra, ("gemm_roofline", "frac")),
@@ -760,7 +781,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: at N=1 run the RCCL reduce-scatter/all-gather + comm-stream path on a world_size-1 group (not the headline run)")
-    ap.add_argument("--recompute", default="none", choices=["none", "layer"],
+    ap.add_argument("--recompute", default="none", choices=["none", "layer", "selective"],
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in one extra untimed step after the timed region)")
     ap.add_argument("--no-realistic-parity", action="store_true", help="skip parity.realistic (one extra untimed step on rollout-like data vs the oracle forward)")

@@ -522,9 +522,13 @@ class GRPOEngine:
         # layer's INPUT only (8 KB per token and layer instead of ~130 KB), backward re-runs the layer's forward first.  One extra forward of compute;
         # bit-identical gradients (every kernel on the path is deterministic and the stored input is the already-rounded residual sum).  Off by
         # default: 288 GB holds the activations of 16k-token passes; a 32k-token pass on one GPU needs it.
+        # "selective" (the reference's `ac.mode = "selective"` with targets norm / attn_proj / mlp, models/layers/checkpointing.py:120-147: the projections, norms and
+        # the MLP are re-run, the attention core is NOT): like "layer", but the attention output and its lse (268 + 4 MB per layer and 32k-token pass — 288 GB
+        # hold them for every layer) are kept, so the backward re-runs everything but `pm_attn_varlen_fwd`; bit-identical gradients, one attention forward per
+        # layer less (a quarter of a 32k-token step's attention time).
         self.recompute = recompute or os.environ.get("PM_RECOMPUTE", "none")
-        if self.recompute not in ("none", "layer"):
-            raise PrimeMI355XError(f"recompute must be 'none' or 'layer', got {self.recompute!r}")
+        if self.recompute not in ("none", "layer", "selective"):
+            raise PrimeMI355XError(f"recompute must be 'none', 'layer' or 'selective', got {self.recompute!r}")
         self.step_count = 0
         # a dedicated stream for the collectives — on the GPU; the CPU flavour (tests/test_engine_gloo_cpu.py: the SAME engine code over gloo with
         # stand-in kernels) issues them synchronously
@@ -798,7 +802,12 @@ class GRPOEngine:
         for i in range(d.num_hidden_layers):
             self._wait_gather(f"layer{i}")
             L, x, pending = self._layer_forward(i, x, pending, cos, sin, seq_start, scale, n)
-            ctx["layers"].append({"x": L["x"], "recompute": True} if self.recompute == "layer" else L)
+            if self.recompute == "layer" or (self.recompute == "selective" and cp > 1):  # (under context parallelism the attention state is the exchanged tensors: re-run it)
+                ctx["layers"].append({"x": L["x"], "recompute": True})
+            elif self.recompute == "selective":
+                ctx["layers"].append({"x": L["x"], "recompute": True, "o": L["o"], "lse": L["lse"]})
+            else:
+                ctx["layers"].append(L)
         self._wait_gather("head")
         hf, rstd_f, x_last = ops.rmsnorm_fwd(pending, w["model.norm.weight"], d.rms_norm_eps, residual=x)
         ctx.update(x_last=x_last, rstd_f=rstd_f, hf=hf)
@@ -840,7 +849,8 @@ class GRPOEngine:
             probe.update(logprobs=logprobs.clone(), entropy=entropy.clone(), logz=logz.clone())
         return ctx
 
-    def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int):
+    def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int,
+                       kept_attn: tuple[Tensor, Tensor] | None = None):
         """One decoder layer: (saved activations, residual stream after attention, mlp output whose residual add the NEXT norm fuses).  `pending` = the
         previous layer's mlp output (None for layer 0 and when re-running a layer from its saved, already-summed input)."""
         d, w = self.dims, self.store.w
@@ -853,7 +863,9 @@ class GRPOEngine:
         q, k, rstd_qk = ops.qknorm_rope_fwd(qkv, w.get(p + "self_attn.q_norm.weight"), w.get(p + "self_attn.k_norm.weight"), cos, sin,
                                              d.num_attention_heads, d.num_key_value_heads, d.kernel_head_dim, d.rms_norm_eps)
         v = qkv[:, d.q_dim + d.kv_dim:].view(n, d.num_key_value_heads, d.kernel_head_dim)
-        if self.cp_size == 1:
+        if kept_attn is not None:  # recompute = "selective": the attention output of the forward pass was kept
+            (o, lse), attn_saved = kept_attn, None
+        elif self.cp_size == 1:
             o, lse = ops.attn_varlen_fwd(q, k, v, seq_start, scale)
             attn_saved = None
         else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads); "ring": gathered K / V
@@ -1014,8 +1026,8 @@ class GRPOEngine:
         for i in reversed(range(d.num_hidden_layers)):
             p = f"model.layers.{i}."
             L = ctx["layers"][i]
-            if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input
-                L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n)
+            if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input (and, "selective", its kept attention output)
+                L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n, kept_attn=(L["o"], L["lse"]) if "o" in L else None)
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
             w_down = w[p + "mlp.down_proj.weight"]
             if self.fused_swiglu_bwd and self._dgrad_own_now and not self.gemm_f32 and ops.gemm_swiglu_bwd_supported(dx, w_down):

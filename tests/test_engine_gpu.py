@@ -533,14 +533,15 @@ def test_engine_32k_rollout_parity_with_layer_recompute():
 
 
 def test_layer_recompute_is_bit_identical_at_32k_tokens():
-    """recompute="layer" against recompute="none" on a 32k-token pass (2 layers of Qwen3-8B width fit without recomputation): same loss bits, same gradient bits."""
+    """recompute="layer" and recompute="selective" (the reference's `ac.mode = "selective"`: norms, projections and MLP re-run, the attention output kept) against
+    recompute="none" on a 32k-token pass (2 layers of Qwen3-8B width fit without recomputation): same loss bits, same gradient bits."""
     from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
 
     full = ModelDims.qwen3_8b()
     dims = ModelDims(full.vocab_size, full.hidden_size, full.intermediate_size, 2, full.num_attention_heads, full.num_key_value_heads, full.head_dim, name="qwen3_8b_width")
     mbs = _parity_variant_mbs(dims.vocab_size, 32768, 1, prompt_len=4096)
     grads, losses = [], []
-    for rc in ("none", "layer"):
+    for rc in ("none", "layer", "selective"):
         eng = GRPOEngine(dims, device=DEV, optim=OptimConfig(type="sign_sgd"), loss=LossConfig(), seed=0, recompute=rc)
         pb = pack_micro_batches(mbs, DEV)
         ctx = eng.forward(pb)
@@ -550,8 +551,8 @@ def test_layer_recompute_is_bit_identical_at_32k_tokens():
         grads.append(eng.store.main_grad.clone())
         del eng, ctx, pb
         torch.cuda.empty_cache()
-    assert losses[0] == losses[1]
-    assert torch.equal(grads[0], grads[1])
+    assert losses[0] == losses[1] == losses[2]
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
 

@@ -510,14 +510,14 @@ def bench_moe_step(out, layers=8, n_mb=8, seq=2048, steps=3):
                     peak_mem_GiB=torch.cuda.max_memory_allocated() / 2**30))
 
 
-def bench_step_32k(out, seq=32768, rollouts=1, steps=2):
+def bench_step_32k(out, seq=32768, rollouts=1, steps=2, recompute="layer"):
     """BASELINE.json configs[4] on one GPU: the Qwen3-8B policy-update step on `rollouts` x 32 768-token documents with block-level recomputation (the
     engine configuration of bench.py's extra.long_context), bracketed by trace markers for `rocprof_summary.py --window` (profiles/r06_bench_32k.md)."""
     from prime_rl_amd.trainer.engine import GRPOEngine, LossConfig, ModelDims, OptimConfig, pack_micro_batches
     from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
 
     dims = ModelDims.qwen3_8b()
-    eng = GRPOEngine(dims, device=torch.device(DEV), optim=OptimConfig(), loss=LossConfig(), seed=0, recompute="layer")
+    eng = GRPOEngine(dims, device=torch.device(DEV), optim=OptimConfig(), loss=LossConfig(), seed=0, recompute=recompute)
     dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=rollouts), seq_len=seq)
     bs = [[pack_micro_batches([mb], torch.device(DEV)) for mb in dl.get_batch()] for _ in range(steps + 1)]
     eng.step(bs[0])
@@ -529,7 +529,7 @@ def bench_step_32k(out, seq=32768, rollouts=1, steps=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     trace_mark()
-    out.append(dict(kernel=f"GRPO step, Qwen3-8B, {rollouts} x {seq} tokens, recompute=layer", ms=dt * 1e3, tokens_per_s=rollouts * seq / dt,
+    out.append(dict(kernel=f"GRPO step, Qwen3-8B, {rollouts} x {seq} tokens, recompute={recompute}", ms=dt * 1e3, tokens_per_s=rollouts * seq / dt,
                     mfu_ref_formula=dims.flops_per_token(seq) * rollouts * seq / dt / 2.5e15, peak_mem_GiB=torch.cuda.max_memory_allocated() / 2**30))
 
 
@@ -537,7 +537,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
     if which == "step32k":
-        bench_step_32k(out, rollouts=int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+        bench_step_32k(out, rollouts=int(sys.argv[2]) if len(sys.argv) > 2 else 1, recompute=sys.argv[3] if len(sys.argv) > 3 else "layer")
     if which == "moestep":
         bench_moe_step(out, layers=int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     if which == "attnfwd":
