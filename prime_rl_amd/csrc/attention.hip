@@ -334,12 +334,13 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
   } while (0)
 #if PM_VARIANTS
   if ((g_dkdv_var & 15) == 0 || (g_dkdv_var & 15) == 12) {  // the default: 32 kv rows per wave, one wave per SIMD, hand-placed two-stage tile loop
-    switch ((g_dkdv_var & 15) == 12 ? g_dkdv_var >> 5 : 0) {  // (attention_dkdv_p2.hip.h); 12 + 32 V: its timing ablations
+    switch ((g_dkdv_var & 15) == 12 ? g_dkdv_var >> 5 : 0) {  // (attention_dkdv_p2.hip.h); 12 + 32 V: V = 1 its rotating-slot form (A/B), V >= 2 timing ablations
       case 1: PM_LAUNCH_DKDV_P2(1); break;
       case 2: PM_LAUNCH_DKDV_P2(2); break;
       case 3: PM_LAUNCH_DKDV_P2(3); break;
       case 4: PM_LAUNCH_DKDV_P2(4); break;
       case 5: PM_LAUNCH_DKDV_P2(5); break;
+      case 6: PM_LAUNCH_DKDV_P2(6); break;
       default: PM_LAUNCH_DKDV_P2(0); break;
     }
   }

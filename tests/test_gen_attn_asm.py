@@ -90,12 +90,13 @@ def test_dkdv_stream_mix_and_accumulator_operands():
         assert g.build(opts)[-1] == "s_waitcnt lgkmcnt(0)"
     lines = g.build({})
     mf = [l for l in lines if l.startswith("v_mfma")]
-    # per parity: the interleaved block and the sequential blocks each hold S / dP (64) and dV / dK (64)
-    assert len(mf) == 2 * (64 + 64 + 64 + 64)
+    # per copy of the body (2 score sets x 3 ring slots): the interleaved block and the sequential blocks each hold S / dP (64) and dV / dK (64)
+    assert len(mf) == 6 * (64 + 64 + 64 + 64)
+    assert len([l for l in g.build(dict(unroll6=False)) if l.startswith("v_mfma")]) == 2 * 256  # the rotating-slot form (A/B build)
     # S / dP products: D in the architectural file, B (the K / V fragment) in the accumulator file; dV / dK: D in the accumulator file, B = packed P / dS
     p1 = [l for l in mf if l.split()[1].startswith("v[")]
     p2 = [l for l in mf if l.split()[1].startswith("a[")]
-    assert len(p1) == len(p2) == 256
+    assert len(p1) == len(p2) == 768
     assert all(l.split(", ")[2].startswith("a[") for l in p1) and all(l.split(", ")[2].startswith("v[") for l in p2)
     # a K / V fragment or an accumulator tuple is never written by anything but its own MFMA chain / the prologue
     writers = [l for l in lines if (l.startswith("ds_read") or l.startswith("v_cvt") or l.startswith("v_mul")) and l.split()[1].startswith("a")]

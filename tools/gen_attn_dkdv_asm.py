@@ -67,7 +67,33 @@ def ring(g):
     return FR + (g % 3) * 8
 
 
-def p1_reads(g, par):
+class Addr:
+    """LDS read addresses of an iteration.  Rotating form: per-iteration registers v80.. (slot offsets added at the top of the iteration).  Unrolled form
+    (6 copies of the body = 2 score sets x 3 ring slots): the slot is an immediate on the operand registers; slot 2 (beyond the 16-bit offset field) has its own
+    pre-added operands."""
+
+    def __init__(self, slot1=None, slot2=None):
+        self.s1, self.s2 = slot1, slot2
+
+    def _op(self, name, idx, slot, reg):
+        if slot is None:
+            return v(reg), 0
+        return (f"%[{name}2_{idx}]" if slot == 2 else f"%[{name}{idx}]"), (0 if slot == 2 else slot * SLOTB)
+
+    def q(self, kk):
+        return self._op("aq", kk, self.s1, AQ + kk)
+
+    def t(self, n0):
+        return self._op("at", n0, self.s2, AT + n0)
+
+    def r1(self):
+        return self._op("arow", "", self.s1, AR)
+
+    def r2(self):
+        return self._op("arow", "", self.s2, AR2)
+
+
+def p1_reads(g, par, A=Addr()):
     """Q and dO fragment of (k-step kk, q block nb); with the first k-step also the block's accumulator starts: S at -lse / scale, dP at -delta of its q rows
     (rows 0 / 1 of the slot's statistics block; both kv blocks of the wave start from the same values)"""
     kk, nb = divmod(g, 4)
@@ -76,10 +102,12 @@ def p1_reads(g, par):
     if kk == 0:
         sb, pb = SETS[par]
         for b in (0, 1):
-            out.append(Ins(f"ds_read_b128 {vt(sb + (b * 4 + nb) * 4, 4)}, {v(AR)} offset:{nb * 64}", "ds", writes=R(sb + (b * 4 + nb) * 4, 4)))
-            out.append(Ins(f"ds_read_b128 {vt(pb + (b * 4 + nb) * 4, 4)}, {v(AR)} offset:{256 + nb * 64}", "ds", writes=R(pb + (b * 4 + nb) * 4, 4)))
-    return out + [Ins(f"ds_read_b128 {vt(r, 4)}, {v(AQ + kk)} offset:{nb * 4096}", "ds", writes=R(r, 4)),
-                  Ins(f"ds_read_b128 {vt(r + 4, 4)}, {v(AQ + kk)} offset:{16384 + nb * 4096}", "ds", writes=R(r + 4, 4))]
+            ro, ri = A.r1()
+            out.append(Ins(f"ds_read_b128 {vt(sb + (b * 4 + nb) * 4, 4)}, {ro} offset:{ri + nb * 64}", "ds", writes=R(sb + (b * 4 + nb) * 4, 4)))
+            out.append(Ins(f"ds_read_b128 {vt(pb + (b * 4 + nb) * 4, 4)}, {ro} offset:{ri + 256 + nb * 64}", "ds", writes=R(pb + (b * 4 + nb) * 4, 4)))
+    qo, qi = A.q(kk)
+    return out + [Ins(f"ds_read_b128 {vt(r, 4)}, {qo} offset:{qi + nb * 4096}", "ds", writes=R(r, 4)),
+                  Ins(f"ds_read_b128 {vt(r + 4, 4)}, {qo} offset:{qi + 16384 + nb * 4096}", "ds", writes=R(r + 4, 4))]
 
 
 def p1_mfmas(g, par):
@@ -93,14 +121,15 @@ def p1_mfmas(g, par):
     return out
 
 
-def p2_reads(g):
+def p2_reads(g, A=Addr()):
     h, n0 = divmod(g - 16, 8)
     r = ring(g)
-    o = h * 8192
-    return [Ins(f"ds_read_b64_tr_b16 {vt(r, 2)}, {v(AT + n0)} offset:{16384 + o}", "ds", writes=R(r, 2)),
-            Ins(f"ds_read_b64_tr_b16 {vt(r + 2, 2)}, {v(AT + n0)} offset:{16384 + o + 4096}", "ds", writes=R(r + 2, 2)),
-            Ins(f"ds_read_b64_tr_b16 {vt(r + 4, 2)}, {v(AT + n0)} offset:{o}", "ds", writes=R(r + 4, 2)),
-            Ins(f"ds_read_b64_tr_b16 {vt(r + 6, 2)}, {v(AT + n0)} offset:{o + 4096}", "ds", writes=R(r + 6, 2))]
+    to, ti = A.t(n0)
+    o = ti + h * 8192
+    return [Ins(f"ds_read_b64_tr_b16 {vt(r, 2)}, {to} offset:{16384 + o}", "ds", writes=R(r, 2)),
+            Ins(f"ds_read_b64_tr_b16 {vt(r + 2, 2)}, {to} offset:{16384 + o + 4096}", "ds", writes=R(r + 2, 2)),
+            Ins(f"ds_read_b64_tr_b16 {vt(r + 4, 2)}, {to} offset:{o}", "ds", writes=R(r + 4, 2)),
+            Ins(f"ds_read_b64_tr_b16 {vt(r + 6, 2)}, {to} offset:{o + 4096}", "ds", writes=R(r + 6, 2))]
 
 
 def p2_mfmas(g, par):  # par: the set that holds P / dS of the pair
@@ -146,14 +175,15 @@ def softmax_bwd_list(par):
     return L + pack_list(par)
 
 
-def masked_list(par):
+def masked_list(par, A=Addr()):
     """a pair some score of which is hidden (diagonal, document boundary, rows past the end): score (b, nb, r) = (q row qi0 + nb 16 + 4 lq + r, kv row kvi + 16 b)
     counts iff  (unsigned)(q - kv) < n - kv  and  kv >= seq_start[q]  (dkdv_tile of attention_kernels.hip.h); P = 0 otherwise."""
     sb, pb = SETS[par]
     LO = FR  # the pair's seq_start row values: 16 registers of the (idle) fragment ring
     kvb_, nku, base = TM, TM + 2, TM + 4  # [b]
     tmp = TM + 6
-    L = [Ins(f"ds_read_b128 {vt(LO + nb * 4, 4)}, {v(AR2)} offset:{512 + nb * 64}", "ds", writes=R(LO + nb * 4, 4)) for nb in range(4)]
+    ro, ri = A.r2()
+    L = [Ins(f"ds_read_b128 {vt(LO + nb * 4, 4)}, {ro} offset:{ri + 512 + nb * 64}", "ds", writes=R(LO + nb * 4, 4)) for nb in range(4)]
     for b in (0, 1):
         L.append(valu(f"v_add_u32 {v(kvb_ + b)}, {16 * b}, %[kvi]", [], [kvb_ + b]))
         L.append(valu(f"v_sub_u32 {v(nku + b)}, %[n], {v(kvb_ + b)}", [kvb_ + b], [nku + b]))
@@ -175,14 +205,15 @@ def masked_list(par):
     return L + pack_list(par)
 
 
-def dma_ins():
+def dma_ins(slot=None):
     """LDS-DMA of the NEXT pair's Q and dO tiles (4 one-KiB pieces per wave each) and of its statistics row (wave 0: -lse / scale, 1: -delta, 2 and 3: seq_start)
-    into slot S_ON; source offsets S_DB / S_DR (the next pair's, or this pair's once more after the last)."""
-    out = [salu(f"s_add_u32 m0, %[ldsw], {s(S_ON)}")]
+    into slot S_ON (rotating form) / `slot` (unrolled form); source offsets S_DB / S_DR (the next pair's, or this pair's once more after the last)."""
+    son = s(S_ON) if slot is None else str(slot * SLOTB)
+    out = [salu(f"s_add_u32 m0, %[ldsw], {son}")]
     out += [Ins(f"buffer_load_dwordx4 %[vo{j}], %[qrsrc], {s(S_DB)} offen" + (f" offset:{j * 1024}" if j else "") + " lds", "vmem") for j in range(4)]
     out += [salu("s_add_u32 m0, m0, 16384")]
     out += [Ins(f"buffer_load_dwordx4 %[vo{j}], %[dorsrc], {s(S_DB)} offen" + (f" offset:{j * 1024}" if j else "") + " lds", "vmem") for j in range(4)]
-    out += [salu(f"s_add_u32 m0, %[rowm0], {s(S_ON)}")]
+    out += [salu(f"s_add_u32 m0, %[rowm0], {son}")]
     out += [Ins(f"buffer_load_dword %[lane4], %[rowrsrc], {s(S_DR)} offen lds", "vmem")]
     return out
 
@@ -252,20 +283,27 @@ def build(opts, want_stats=False):
     emit(f"s_mov_b32 {s(S_QN)}, %[qi00]")
     emit(f"s_mov_b32 {s(S_Q1)}, %[qi00]")
     emit(f"s_mov_b32 {s(S_Q2)}, %[qi00]")
-    emit(f"s_mov_b32 {s(S_O1)}, 0")
-    emit(f"s_mov_b32 {s(S_ON)}, 0")  # the first pair lands in slot 0 ...
-    emit(f"s_mov_b32 {s(S_O2)}, {2 * SLOTB}")
+    unroll6 = opts.get("unroll6", True)  # six copies of the body (2 score sets x 3 ring slots): slot offsets are immediates, no per-iteration address registers
+    if not unroll6:
+        emit(f"s_mov_b32 {s(S_O1)}, 0")
+        emit(f"s_mov_b32 {s(S_ON)}, 0")  # the first pair lands in slot 0 ...
+        emit(f"s_mov_b32 {s(S_O2)}, {2 * SLOTB}")
     emit(f"s_mov_b32 {s(S_DB)}, {s(S_BASE)}")
     emit(f"s_mov_b32 {s(S_DR)}, {s(S_ROFF)}")
     emit(f"s_mov_b32 {s(S_LO2)}, 0")
     emit(f"s_mov_b32 {s(S_LOLD)}, 0")
     emit(f"s_cmp_lt_i32 {s(S_J)}, %[total]")
     emit(f"s_cbranch_scc0 {L('done')}")
-    for x in pad_hazards(dma_ins(), tail_mfma_pad=False):
+    for x in pad_hazards(dma_ins(0 if unroll6 else None), tail_mfma_pad=False):
         emit(x)
-    emit(f"s_mov_b32 {s(S_ON)}, {SLOTB}")  # ... the second in slot 1
-    for par in (0, 1):
-        P = lambda nme: L(f"{nme}{par}")
+    if not unroll6:
+        emit(f"s_mov_b32 {s(S_ON)}, {SLOTB}")  # ... the second in slot 1
+    bodies = list(range(6)) if unroll6 else [0, 1]
+    for u in bodies:
+        par = u % 2
+        A = Addr(u % 3, (u + 2) % 3) if unroll6 else Addr()
+        slot_n = (u + 1) % 3 if unroll6 else None
+        P = lambda nme: L(f"{nme}{u}")
         emit(f"{P('top')}:")
         emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
         if "nobarrier" not in abl:
@@ -296,13 +334,13 @@ def build(opts, want_stats=False):
         emit(f"{P('nonext')}:")
         emit(f"s_mov_b32 {s(S_DB)}, {s(S_BASE)}")
         emit(f"s_mov_b32 {s(S_DR)}, {s(S_ROFF)}")
-        # this iteration's LDS read addresses
-        for kk in range(4):
-            emit(f"v_add_u32 {v(AQ + kk)}, {s(S_O1)}, %[aq{kk}]")
-        emit(f"v_add_u32 {v(AR)}, {s(S_O1)}, %[arow]")
-        emit(f"v_add_u32 {v(AR2)}, {s(S_O2)}, %[arow]")
-        for n0 in range(8):
-            emit(f"v_add_u32 {v(AT + n0)}, {s(S_O2)}, %[at{n0}]")
+        if not unroll6:  # this iteration's LDS read addresses
+            for kk in range(4):
+                emit(f"v_add_u32 {v(AQ + kk)}, {s(S_O1)}, %[aq{kk}]")
+            emit(f"v_add_u32 {v(AR)}, {s(S_O1)}, %[arow]")
+            emit(f"v_add_u32 {v(AR2)}, {s(S_O2)}, %[arow]")
+            for n0 in range(8):
+                emit(f"v_add_u32 {v(AT + n0)}, {s(S_O2)}, %[at{n0}]")
         # the interleaved block: pair j and pair j - 1 both computed by this wave, pair j - 1 fully visible
         emit(f"s_cmp_lt_i32 {s(S_J)}, 1")
         emit(f"s_cbranch_scc1 {P('generic')}")
@@ -316,24 +354,24 @@ def build(opts, want_stats=False):
         emit(f"s_cbranch_scc1 {P('generic')}")
         emit(f"s_cmp_gt_i32 {s(S_LO2)}, %[kvb]")
         emit(f"s_cbranch_scc1 {P('generic')}")
-        d = dma_ins()
+        d = dma_ins(slot_n)
         extras = {k: [d[k]] for k in range(len(d))}
-        p1 = pipelined(list(range(16)), lambda g: p1_reads(g, par), lambda g: p1_mfmas(g, par), [], softmax_bwd_list(par ^ 1), extras)
-        p2 = pipelined(list(range(16, 32)), p2_reads, lambda g: p2_mfmas(g, par ^ 1), [], [])
-        emit_block(f"full[{par}] S/dP + softmax-bwd", pad_hazards(p1, tail_mfma_pad=False))
-        emit_block(f"full[{par}] dV/dK", pad_hazards(p2, tail_mfma_pad=False))
+        p1 = pipelined(list(range(16)), lambda g: p1_reads(g, par, A), lambda g: p1_mfmas(g, par), [], softmax_bwd_list(par ^ 1), extras)
+        p2 = pipelined(list(range(16, 32)), lambda g: p2_reads(g, A), lambda g: p2_mfmas(g, par ^ 1), [], [])
+        emit_block(f"full[{u}] S/dP + softmax-bwd", pad_hazards(p1, tail_mfma_pad=False))
+        emit_block(f"full[{u}] dV/dK", pad_hazards(p2, tail_mfma_pad=False))
         emit(f"s_branch {P('end')}")
         emit(f"{P('generic')}:")
         emit(f"s_add_u32 {s(S_TMP)}, {s(S_J)}, 1")
         emit(f"s_cmp_ge_i32 {s(S_TMP)}, %[total]")
         emit(f"s_cbranch_scc1 {P('nodma')}")
         if "nodma" not in abl:
-            for x in pad_hazards(dma_ins(), tail_mfma_pad=False):
+            for x in pad_hazards(dma_ins(slot_n), tail_mfma_pad=False):
                 emit(x)
         emit(f"{P('nodma')}:")
         emit(f"s_cmp_ge_i32 {s(S_J)}, %[ntw]")
         emit(f"s_cbranch_scc1 {P('nop1')}")
-        emit_block(f"p1[{par}]", pad_hazards(pipelined(list(range(16)), lambda g: p1_reads(g, par), lambda g: p1_mfmas(g, par), [], []), tail_mfma_pad=False))
+        emit_block(f"p1[{u}]", pad_hazards(pipelined(list(range(16)), lambda g: p1_reads(g, par, A), lambda g: p1_mfmas(g, par), [], []), tail_mfma_pad=False))
         emit(f"{P('nop1')}:")
         # pair j - 1: 1 <= j <= nt_w
         emit(f"s_cmp_lt_i32 {s(S_J)}, 1")
@@ -348,23 +386,23 @@ def build(opts, want_stats=False):
         emit(f"s_cbranch_scc1 {P('mask')}")
         emit(f"s_cmp_gt_i32 {s(S_LO2)}, %[kvb]")
         emit(f"s_cbranch_scc1 {P('mask')}")
-        emit_block(f"softmax-bwd[{par}]", pad_hazards(softmax_bwd_list(par ^ 1), tail_mfma_pad=False))
+        emit_block(f"softmax-bwd[{u}]", pad_hazards(softmax_bwd_list(par ^ 1), tail_mfma_pad=False))
         emit(f"s_branch {P('p2')}")
         emit(f"{P('mask')}:")
-        emit_block(f"masked[{par}]", pad_hazards(masked_list(par ^ 1), tail_mfma_pad=False))
+        emit_block(f"masked[{u}]", pad_hazards(masked_list(par ^ 1, A), tail_mfma_pad=False))
         emit(f"{P('p2')}:")
-        emit_block(f"p2[{par}]", pad_hazards(pipelined(list(range(16, 32)), p2_reads, lambda g: p2_mfmas(g, par ^ 1), [], []), tail_mfma_pad=False))
+        emit_block(f"p2[{u}]", pad_hazards(pipelined(list(range(16, 32)), lambda g: p2_reads(g, A), lambda g: p2_mfmas(g, par ^ 1), [], []), tail_mfma_pad=False))
         emit(f"{P('end')}:")
-        # rotate the slots and the q-tile origins; next iteration
-        emit(f"s_mov_b32 {s(S_TMP)}, {s(S_O2)}")
-        emit(f"s_mov_b32 {s(S_O2)}, {s(S_O1)}")
-        emit(f"s_mov_b32 {s(S_O1)}, {s(S_ON)}")
-        emit(f"s_mov_b32 {s(S_ON)}, {s(S_TMP)}")
+        if not unroll6:  # rotate the slots
+            emit(f"s_mov_b32 {s(S_TMP)}, {s(S_O2)}")
+            emit(f"s_mov_b32 {s(S_O2)}, {s(S_O1)}")
+            emit(f"s_mov_b32 {s(S_O1)}, {s(S_ON)}")
+            emit(f"s_mov_b32 {s(S_ON)}, {s(S_TMP)}")
         emit(f"s_mov_b32 {s(S_Q2)}, {s(S_Q1)}")
         emit(f"s_mov_b32 {s(S_Q1)}, {s(S_QN)}")
         emit(f"s_add_u32 {s(S_J)}, {s(S_J)}, 1")
         emit(f"s_cmp_gt_i32 {s(S_J)}, %[total]")
-        if par == 0:
+        if u != bodies[-1]:
             emit(f"s_cbranch_scc1 {L('done')}")
         else:
             emit(f"s_cbranch_scc0 {L('top0')}")
@@ -383,19 +421,21 @@ HEADER = '''// attention_dkdv_p2_asm.inc.h — GENERATED by tools/gen_attn_dkdv_
 // hand-placed gfx950 instruction stream: v80-v255, a0-a191, s70-s89 are owned by the stream; hazard distances and counted waits checked by the generator.
 #pragma once
 '''
-SIG = ("const void* kp0, const void* kp1, const void* vp0, const void* vp1, const unsigned (&aQ)[4], const unsigned (&aT)[8], unsigned arow, const int (&vo)[4],\n"
+SIG = ("const void* kp0, const void* kp1, const void* vp0, const void* vp1, const unsigned (&aQ)[4], const unsigned (&aT)[8], unsigned arow, const unsigned (&aQ2)[4],\n"
+       "    const unsigned (&aT2)[8], unsigned arow2, const int (&vo)[4],\n"
        "    int lane4, int kvi, int lq4, unsigned aout, __amdgpu_buffer_rsrc_t qrsrc, __amdgpu_buffer_rsrc_t dorsrc, __amdgpu_buffer_rsrc_t rowrsrc, const int* seqptr,\n"
        "    int sc2_bits, int n, int kvb, int total, int nt_w, int head0, int base0, int roff0, int qi00, int qdt, int rowdh, int rowdt, int ldsw, int rowm0")
 
 
-VARIANTS = [dict(), dict(ablate=("novalu",)), dict(ablate=("nolds",)), dict(ablate=("nomfma",)), dict(ablate=("nodma",)), dict(ablate=("nobarrier",))]
+VARIANTS = [dict(), dict(unroll6=False), dict(ablate=("novalu",)), dict(ablate=("nolds",)), dict(ablate=("nomfma",)), dict(ablate=("nodma",)), dict(ablate=("nobarrier",))]
 
 
 def render(vi, opts, want_stats=False):
     lines = build(opts, want_stats)
     body = "\\n\\t\"\n      \"".join(l.replace('"', '\\"') for l in lines)
     ins = (['[kp0] "v"(kp0)', '[kp1] "v"(kp1)', '[vp0] "v"(vp0)', '[vp1] "v"(vp1)'] + [f'[aq{k}] "v"(aQ[{k}])' for k in range(4)] +
-           [f'[at{k}] "v"(aT[{k}])' for k in range(8)] + ['[arow] "v"(arow)'] + [f'[vo{j}] "v"(vo[{j}])' for j in range(4)] +
+           [f'[at{k}] "v"(aT[{k}])' for k in range(8)] + ['[arow] "v"(arow)'] + [f'[aq2_{k}] "v"(aQ2[{k}])' for k in range(4)] +
+           [f'[at2_{k}] "v"(aT2[{k}])' for k in range(8)] + ['[arow2_] "v"(arow2)'] + [f'[vo{j}] "v"(vo[{j}])' for j in range(4)] +
            ['[lane4] "v"(lane4)', '[kvi] "v"(kvi)', '[lq4] "v"(lq4)', '[aout] "v"(aout)', '[qrsrc] "s"(qrsrc)', '[dorsrc] "s"(dorsrc)', '[rowrsrc] "s"(rowrsrc)',
             '[seqptr] "s"(seqptr)', '[sc2] "s"(sc2_bits)', '[n] "s"(n)', '[kvb] "s"(kvb)', '[total] "s"(total)', '[ntw] "s"(nt_w)', '[head0] "s"(head0)',
             '[base0] "s"(base0)', '[roff0] "s"(roff0)', '[qi00] "s"(qi00)', '[qdt] "s"(qdt)', '[rowdh] "s"(rowdh)', '[rowdt] "s"(rowdt)', '[ldsw] "s"(ldsw)',
