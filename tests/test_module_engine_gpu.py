@@ -202,6 +202,60 @@ def test_expert_gradients_written_in_f32_by_the_weight_gradient_gemm(monkeypatch
     assert (params["1"] != params["0"]).float().mean().item() < 0.02
 
 
+def test_direct_parameters_whose_gradient_arrives_through_autograd_after_all(monkeypatch):
+    """the optimizer launch does not zero the gradient slice of a DIRECT parameter (its first weight-gradient launch of a step overwrites it).  When
+    such a parameter's gradient arrives as a bf16 `.grad` after all — experts whose width the f32-writing grouped GEMM does not take (128 is not a multiple of
+    256) — the engine must zero the slice before accumulating, in EVERY step, or the second step would add to the first step's consumed gradient.  Two optimizer
+    steps with PM_MOE_MAIN_GRAD=1 against the engine that accumulates every gradient from `.grad` (=0): same gradients, norms and parameters."""
+    from prime_rl_amd import ops
+    from prime_rl_amd.trainer.engine import OptimConfig, pack_micro_batches
+    from prime_rl_amd.trainer.models.layers.lm_head import inject_prime_lm_head
+    from prime_rl_amd.trainer.models.qwen3_moe import Qwen3MoeConfig, Qwen3MoeForCausalLM
+    from prime_rl_amd.trainer.module_engine import ModuleEngine
+    from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
+
+    cfg = Qwen3MoeConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, num_experts=8,
+                         num_experts_per_tok=2, moe_intermediate_size=128, norm_topk_prob=True)
+    assert not ops.grouped_gemm_tn_f32_supported(128, 256, 256)
+    dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=2), seq_len=256)
+    steps = []
+    for _ in range(2):
+        mbs = dl.get_batch()
+        for mb in mbs:
+            mb["input_ids"] = mb["input_ids"] % cfg.vocab_size
+        steps.append(pack_micro_batches(mbs, DEV))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PM_MOE_MAIN_GRAD", mode)
+        torch.manual_seed(0)
+        with torch.device(DEV):
+            model = Qwen3MoeForCausalLM(cfg)
+        model = model.to(torch.bfloat16)
+        gen = torch.Generator(device=DEV).manual_seed(0)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.fill_(1.0) if p.dim() == 1 else p.copy_((torch.randn(p.shape, device=DEV, generator=gen) * 0.05).to(p.dtype))
+        inject_prime_lm_head(model, chunk_size=8192)
+        eng = ModuleEngine(model, DEV, optim=OptimConfig(lr=1e-3))
+        if mode == "1":
+            experts = [p for p in eng._direct if p.dim() == 3]
+            assert len(experts) == 3 * cfg.num_hidden_layers and not eng._fused_norm  # direct, but their width keeps them off the f32-writing GEMM
+        norms, grads = [], []
+        for pb in steps:
+            scales = eng.global_scales(tuple(pb.local_counts[k] for k in range(3)))
+            eng.backward(eng.forward_loss(pb, scales))
+            grads.append(eng.main_grad.clone())
+            norms.append(float(eng.optimizer_step()))
+        res[mode] = (norms, grads, eng.params_bf16.clone())
+    # (the LM head and the attention projections take the f32-writing GEMMs in mode 1 and one bf16 rounding per pass in mode 0; a slice that kept the first
+    # step's gradient would be off by its whole norm)
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert abs(a - b) <= 2e-3 * b, (res["1"][0], res["0"][0])
+    for ga, gb in zip(res["1"][1], res["0"][1]):
+        assert ((ga - gb).norm() / gb.norm()).item() < 4e-3
+    assert (res["1"][2] != res["0"][2]).float().mean().item() < 0.02
+
+
 def test_router_replay_through_rollout_files_and_train(tmp_path):
     """`enable_router_replay` end to end (train.py:349-360): rollouts written by the orchestrator-side sender carry `routed_experts` (what vLLM returns
     with --enable-return-routed-experts), travel the msgpack wire, are packed by prepare_batch, reach the MoE layers as forced expert indices.
