@@ -246,6 +246,9 @@ def test_direct_parameters_whose_gradient_arrives_through_autograd_after_all(mon
             eng.backward(eng.forward_loss(pb, scales))
             grads.append(eng.main_grad.clone())
             norms.append(float(eng.optimizer_step()))
+        # a third optimizer step that no backward pass preceded (every direct parameter unwritten: an unused / frozen path): the slices still hold step 2's
+        # consumed gradients and must be zeroed, not applied again
+        assert float(eng.optimizer_step()) == 0.0 and not eng.main_grad.any().item()
         res[mode] = (norms, grads, eng.params_bf16.clone())
     # (the LM head and the attention projections take the f32-writing GEMMs in mode 1 and one bf16 rounding per pass in mode 0; a slice that kept the first
     # step's gradient would be off by its whole norm)
@@ -255,7 +258,9 @@ def test_direct_parameters_whose_gradient_arrives_through_autograd_after_all(mon
         # measured 0.0097 in step 2 (bf16 rounding of every pass's gradient in mode 0, on parameters that already differ by an ulp here and there);
         # a slice that kept step 1's gradient would be off by the experts' share of the whole norm (> 0.3)
         assert ((ga - gb).norm() / gb.norm()).item() < 0.05
-    assert (res["1"][2] != res["0"][2]).float().mean().item() < 0.05
+    # bf16 parameters after three updates whose gradients differ by ~1 %: 5.9 % of the elements round to the neighbouring bf16 value (measured)
+    diff = res["1"][2].float() - res["0"][2].float()
+    assert (diff != 0).float().mean().item() < 0.10 and (diff.abs() <= res["0"][2].float().abs() * 2.0**-7 + 1e-6).all().item()
 
 
 def test_router_replay_through_rollout_files_and_train(tmp_path):
