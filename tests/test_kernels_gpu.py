@@ -534,7 +534,9 @@ def _attn_case(n, seq_lens, hq, hkv, seed):
                                              # tile edges of the LDS-DMA kernels: one token, exactly one 64 / 128-row tile, one row past it, documents
                                              # ending on and straddling tile boundaries, many one- and two-token documents inside one tile
                                              ([1], 2, 2), ([64], 2, 1), ([128], 4, 2), ([129], 4, 2), ([63, 65, 128, 1], 4, 1), ([1, 2] * 45, 2, 1),
-                                             ([255, 257], 8, 2)])
+                                             ([255, 257], 8, 2),
+                                             # query-head groups of 8 (Qwen3-30B-A3B: 32 q / 4 kv heads) and 16 on ragged documents
+                                             ([300, 212], 8, 1), ([513, 3, 140], 16, 2), ([700], 32, 2)])
 def test_attention_forward_backward(ops, seq_lens, hq, hkv):
     n, d = sum(seq_lens), 128
     q, k, v = _attn_case(n, seq_lens, hq, hkv, n)
@@ -799,6 +801,49 @@ def test_attention_long_document_and_ragged_tail(ops):
     total.backward()
     _close(gk[:, 0], kf.grad, 2e-2, 4e-2, "long-doc dk")
     _close(gv[:, 0], vf.grad, 2e-2, 4e-2, "long-doc dv")
+
+
+def test_attention_65k_token_document(ops):
+    """Twice BASELINE.json configs[4]'s rollout length in ONE document (65 536 tokens + a ragged tail document): every byte offset the kernels form for the
+    last q / kv tiles lies beyond 2^24 elements per head row and the tile loops run 1 024 kv tiles.  Checked against an f32 computation on the device that
+    walks the score matrix in 4 096-row blocks (the full matrix would be 17 GB per head): out, lse, dq, dk, dv of both q heads."""
+    torch.manual_seed(13)
+    docs, hq, hkv, d = [65536, 333], 2, 1, 128
+    n, scale = sum(docs), 128**-0.5
+    q = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+    k = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    v = torch.randn(n, hkv, d, device=DEV).to(torch.bfloat16)
+    go = torch.randn(n, hq, d, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(docs)), dtype=torch.int32, device=DEV)
+    ss = ops.seq_start_from_cu(cu, n)
+    out, lse = ops.attn_varlen_fwd(q, k, v, ss, scale)
+    gq, gk, gv = ops.attn_varlen_bwd(go, q, k, v, out, lse, ss, scale)
+    want_o, want_lse, want_dq = torch.empty(n, hq, d, device=DEV), torch.empty(hq, n, device=DEV), torch.empty(n, hq, d, device=DEV)
+    want_dk, want_dv = torch.zeros(n, d, device=DEV), torch.zeros(n, d, device=DEV)
+    kf, vf = k[:, 0].float(), v[:, 0].float()
+    bounds = np.cumsum([0] + docs)
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        for b0 in range(s, e, 4096):
+            b1 = min(b0 + 4096, e)
+            rows = torch.arange(b0, b1, device=DEV)[:, None]
+            hidden = torch.arange(s, b1, device=DEV)[None, :] > rows
+            for h in range(hq):
+                sc = ((q[b0:b1, h].float() @ kf[s:b1].T) * scale).masked_fill(hidden, float("-inf"))
+                want_lse[h, b0:b1] = torch.logsumexp(sc, -1)
+                p = torch.softmax(sc, -1)
+                o = p @ vf[s:b1]
+                want_o[b0:b1, h] = o
+                dof = go[b0:b1, h].float()
+                dp = dof @ vf[s:b1].T
+                ds = p * (dp - (dof * o).sum(-1, keepdim=True)) * scale
+                want_dq[b0:b1, h] = ds @ kf[s:b1]
+                want_dk[s:b1] += ds.T @ q[b0:b1, h].float()
+                want_dv[s:b1] += p.T @ dof
+    _close(out, want_o, 1e-2, 1e-2, "65k forward")
+    _close(lse, want_lse, 1e-4, 2e-4, "65k lse")
+    _close(gq, want_dq, 2e-2, 3e-2, "65k dq")
+    _close(gk[:, 0], want_dk, 2e-2, 4e-2, "65k dk")
+    _close(gv[:, 0], want_dv, 2e-2, 4e-2, "65k dv")
 
 
 # ================================================================================================ optimizer

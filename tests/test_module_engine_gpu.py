@@ -260,7 +260,8 @@ def test_direct_parameters_whose_gradient_arrives_through_autograd_after_all(mon
         assert ((ga - gb).norm() / gb.norm()).item() < 0.05
     # bf16 parameters after three updates whose gradients differ by ~1 %: 5.9 % of the elements round to the neighbouring bf16 value (measured)
     diff = res["1"][2].float() - res["0"][2].float()
-    assert (diff != 0).float().mean().item() < 0.10 and (diff.abs() <= res["0"][2].float().abs() * 2.0**-7 + 1e-6).all().item()
+    # (an element whose tiny gradient changes sign between the two runs moves by lr in opposite directions in each of the three updates)
+    assert (diff != 0).float().mean().item() < 0.10 and diff.abs().max().item() <= 3 * 2 * 1e-3 + 2.0**-7
 
 
 def test_router_replay_through_rollout_files_and_train(tmp_path):
