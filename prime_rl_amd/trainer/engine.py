@@ -605,6 +605,7 @@ class GRPOEngine:
         if self.lm_head_impl == "fused" and (self.gemm_f32 or dims.hidden_size % 64):
             raise PrimeMI355XError("the fused LM head is a bf16 MFMA kernel (hidden size a multiple of 64)")
         self.k1_events: list | None = None
+        self._emb_zero_early = self._emb_zeroed = False  # step(): the embedding gradient's zero fill placed between the LM-head product and the log-prob kernel
         # bench.py's parity block (SURVEY §8d "parity gates in the same harness"): when set to a dict, the NEXT forward/loss leaves device-side copies
         # of what the gates need in it (no host sync inside the step): the embedding-gather and label-gather bit checks over ALL rows, 64 sampled
         # logits rows with their labels / temperatures, the per-token log-probs / entropy / logz, the scalar loss and the K2 statistics.
@@ -824,6 +825,12 @@ class GRPOEngine:
                 chunks.append((s, e, None))
                 continue
             logits = self._fwd_mm(hf[s:e], wh, out_f32=self.gemm_f32)
+            if self._emb_zero_early and s == 0:
+                # The step's one zero fill of the embedding gradient (2.5 GB) goes HERE instead of in front of the embedding backward: the GEMM above leaves
+                # its last 256 MiB of logits dirty in the Infinity Cache, and their write-back costs less under this fill's write stream than under the
+                # log-prob kernel's read stream (tools/microbench.py k1aftergemm, "fill placement": fill + K1 1.121 -> 1.103 ms, K1 0.81 -> 0.83 of 8 TB/s).
+                self.store.g["model.embed_tokens.weight"].zero_()
+                self._emb_zero_early, self._emb_zeroed = False, True
             if self.k1_events is not None:  # HIP events on the launch stream around the log-prob kernel (bench.py roofline)
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -1079,8 +1086,9 @@ class GRPOEngine:
         if split:
             self._embed_rows_to_owners(dx, ids)
             return
-        if not emb_accumulate:
+        if not emb_accumulate and not self._emb_zeroed:
             g["model.embed_tokens.weight"].zero_()
+        self._emb_zeroed = False
         ops.embedding_bwd(dx, ids, g["model.embed_tokens.weight"])
         self._bucket_done("embed", last_pass)
 
@@ -1212,7 +1220,10 @@ class GRPOEngine:
         for idx, p in enumerate(passes):
             if idx == len(passes) - 1:
                 self._embed_dense_early()
+            # first pass of a step whose embedding gradient is a plain local buffer: its zero fill is placed inside forward() (see there)
+            self._emb_zero_early = idx == 0 and self._embed_plan is None and not self.dims.tie_word_embeddings and self.lm_head_impl != "fused"
             ctx = self.forward(p)
+            self._emb_zero_early = False
             self.loss(ctx, scales)
             out["loss"].append(ctx["loss"])
             out["entropy"].append(ctx["entropy"])

@@ -114,7 +114,31 @@ def bench_k1_after_gemm(out, rounds=5):
             torch.cuda.synchronize()
             gem[name].append(e0.elapsed_time(e1))
             res[name].append(e1.elapsed_time(e2))
+    # Where should the step's 2.5 GB zero fill of the embedding gradient go: after K1 (A: the GEMM's dirty lines are written back under K1's reads) or between
+    # the GEMM and K1 (B: under the fill's writes)?  Time from the end of the GEMM to the end of both, orders interleaved.
+    emb = torch.empty(151936 * 4096, dtype=torch.float32, device=DEV)
+    order = {"A: GEMM, K1, fill": [], "B: GEMM, fill, K1": []}
+    k1_in = {k: [] for k in order}
+    for _ in range(rounds + 2):
+        for name in order:
+            e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+            ops.gemm(hid, w, out=logits, variant=7)
+            e0.record()
+            if name.startswith("B"):
+                emb.zero_()
+            e1.record()
+            ops.logprob_entropy_fwd(logits, labels, inv_t)
+            e2.record()
+            if name.startswith("A"):
+                emb.zero_()
+            e3.record()
+            torch.cuda.synchronize()
+            order[name].append(e0.elapsed_time(e3))
+            k1_in[name].append(e1.elapsed_time(e2))
     nbytes = n * (2 * v + 20)
+    for name in order:
+        ts, ks = sorted(order[name]), sorted(k1_in[name])
+        out.append(dict(kernel=f"fill placement {name}", k1_plus_fill_ms=ts[len(ts) // 2], k1_ms=ks[len(ks) // 2], k1_frac_hbm=nbytes / (ks[len(ks) // 2] * 1e-3) / HBM_PEAK))
     for name in producers:
         ts, gs = sorted(res[name]), sorted(gem[name])
         med = ts[len(ts) // 2] * 1e-3
