@@ -81,12 +81,15 @@ def _worker(rank, world, port, out_dir, cp, cp_style, tied, seq):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cp,cp_style,tied", [(2, 1, "ulysses", False), (2, 1, "ulysses", True), (2, 2, "ulysses", False), (2, 2, "ring", False),
-                                                    (4, 2, "ring", False)])
-def test_multi_rank_engine_on_one_gpu_equals_single_process(tmp_path, world, cp, cp_style, tied):
+@pytest.mark.parametrize("world,cp,cp_style,tied,seq", [(2, 1, "ulysses", False, 128), (2, 1, "ulysses", True, 128), (2, 2, "ulysses", False, 128),
+                                                        (2, 2, "ring", False, 256),  # the row-window kernels take 128-token multiples per cp rank
+                                                        (4, 2, "ring", False, 256),
+                                                        # BASELINE.json configs[4]'s rollout length through both context-parallel styles: every pass is ONE
+                                                        # 32 768-token sample, cp rank 1's window starts at row 16 384
+                                                        (2, 2, "ulysses", False, 32768), (2, 2, "ring", False, 32768)])
+def test_multi_rank_engine_on_one_gpu_equals_single_process(tmp_path, world, cp, cp_style, tied, seq):
     from prime_rl_amd.trainer.engine import GRPOEngine, OptimConfig, ParamStore, pack_micro_batches
 
-    seq = 256 if cp_style == "ring" else 128  # the row-window kernels take 128-token multiples per cp rank
     dp = world // cp
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), cp, cp_style, tied, seq), nprocs=world, join=True, start_method="spawn")
     r = [torch.load(tmp_path / f"r{k}.pt") for k in range(world)]
