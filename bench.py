@@ -181,7 +181,7 @@ def measure_extras(args, engine, loader, device, world, rank, barrier) -> dict:
             torch.cuda.synchronize()
             ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
             flop = 2.0 * n * dims.vocab_size * dims.hidden_size
-            extra["j1_roofline"] = {"kernel": "lmhead_kernel<fwd> (J1: fused MFMA LM head, GEMM + log-prob epilogue, logits never in HBM)", "bound": "mfma",
+            extra["j1_roofline"] = {"kernel": "gemm_kernel<..., MODE 8> + lmhead_finalize_parts_kernel (J1: fused MFMA LM head = the GEMM core's tile stream with the log-prob epilogue, logits never in HBM)", "bound": "mfma",
                                     "achieved": round(flop / (ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                                     "frac": round(flop / (ms * 1e-3) / MFMA_BF16_PEAK, 4), "traffic": None, "flops_per_launch": flop, "tokens_per_launch": n,
                                     "mean_launch_ms": round(ms, 3)}

@@ -106,7 +106,12 @@ int pm_logprob_chunk_bwd(const void* logits_chunk, int dtype, int64_t n_rows, in
  *          row stride logits_ld — for callers that prefer keeping logits to recomputing them in backward.
  *     bwd: dlogits[n, v] = grad_logprobs[n] * inv_temp[n] * ([v == label[n]] - exp(l[n, v] * inv_temp[n] - logz[n])) as bf16 with
  *          row stride dlogits_ld (a multiple of 4); logits are recomputed on the fly.
- *     workspace (fwd): pm_lmhead_workspace_bytes(n_tokens, vocab): per-token partial online-softmax states.
+ *     workspace (fwd): pm_lmhead_workspace_bytes(n_tokens, vocab): per-token partial online-softmax states (32 B per token and
+ *          256-column vocab tile from 1024 tokens up: 311 MB at 16 384 tokens x 151 936 — against 5 GB of logits).
+ *     Two builds behind these entry points: from 1024 tokens, with round_logits_bf16 != 0, hidden % 128 == 0 and no logits_out (bwd: vocab and
+ *          dlogits_ld multiples of 8, 16-byte aligned dlogits), the passes run as MODE 8 / 9 of the GEMM core's tile stream (csrc/gemm.hip: the product of
+ *          pm_gemm_bf16 with the log-prob epilogue in place of the result store); otherwise lmhead_kernel (csrc/lmhead.hip).  Same results to f32
+ *          summation order over the vocabulary; each build is bitwise reproducible.
  * ------------------------------------------------------------------------------------------ */
 int64_t pm_lmhead_workspace_bytes(int64_t n_tokens, int64_t vocab);
 int pm_lmhead_logprob_fwd(const void* hidden_bf16, const void* weight_bf16, int64_t n_tokens, int64_t hidden, int64_t vocab,

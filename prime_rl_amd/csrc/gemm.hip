@@ -100,6 +100,14 @@ struct Params {
   int64_t ldgu;
   int n_experts;
   int n_first;             // columns / contraction rows served by the first weight set
+  // MODE 8 / 9: the fused LM head (lmhead.hip, pm_lmhead_logprob_fwd / _bwd) on this tile stream — X = hidden [tokens, H], W = head weight [vocab, H];
+  // per-token inputs, and (MODE 8) the per-(vocab tile, wave group) partial softmax states [2 tiles_n][m] x {max, sum, sum p l, target} merged by lmhead.hip
+  const int64_t* lm_labels;
+  const float* lm_inv_temp;
+  const float* lm_logz;    // MODE 9
+  const float* lm_grad;    // MODE 9: d loss / d log-prob
+  float* lm_partial;       // MODE 8
+  int lm_round;            // logits rounded to bf16 before the softmax (the reference's bf16 logits chunk, lm_head.py:133)
 };
 
 // v_mfma_f32_16x16x32_bf16, not 32x32x16: the chip is POWER-limited on dense GEMMs and the 16x16x32 form moves less register data per MAC (its
@@ -646,10 +654,12 @@ __device__ __forceinline__ bool locate_row_tile(const RowTab& rt, int t, int& ex
 // 3: grouped weight gradient  dw[e] = dy[rows of e]^T . x[rows of e]                  (both K-major; K = the expert's row count; rows < n_first -> out, else out2)
 // 5 / 6: the tile streams of 0 / 2 (a dense / grouped row gradient through a down projection) with the SwiGLU-backward epilogue: the product is the
 //        gradient of act = silu(gate) * up, and the epilogue turns each value into d_gate and d_up at once (OUT = [d_gate | d_up], gate / up read from p.gu)
+// 8 / 9: the tile stream of 0 on (hidden, head weight) with the log-prob epilogues of the fused LM head (lm_head.py:89-202): 8 = forward, the tile's logits
+//        leave as per-token partial softmax states and never reach HBM; 9 = backward, the recomputed tile leaves as dlogits = g inv_T (onehot - p)
 template <int MODE>
 __device__ __forceinline__ constexpr int parts_of() { return MODE == 2 ? 2 : 1; }
 template <int MODE>
-__device__ __forceinline__ constexpr int tile_mode() { return MODE == 5 ? 0 : MODE == 6 ? 2 : MODE; }
+__device__ __forceinline__ constexpr int tile_mode() { return (MODE == 5 || MODE == 8 || MODE == 9) ? 0 : MODE == 6 ? 2 : MODE; }
 
 template <int MODE, bool XK, bool WK>
 __device__ __forceinline__ bool tile_at(const Params& p, int v, int part, int lane, const RowTab& rtab, Tile& t) {
@@ -866,6 +876,78 @@ __device__ __forceinline__ void setup_operand(int64_t ld, int wave, int lane, in
   }
 }
 
+// MODE 8 epilogue: the tile's logits leave as partial softmax states (lm_head.py:76-86, 140-148).  acc[i][f][j][g][r] is the logit of token row
+// j * 128 + wt * 32 + g * 16 + lr and vocab column i * 128 + wv * 64 + f * 16 + lq * 4 + r of the tile, so a lane holds 32 logits of each of its 4 token
+// rows: (max, sum exp, sum exp * l, target) per lane, merged over the 4 lanes (lq) that share a token row with two shuffles; one float4 per (token, vocab
+// tile, wave group) goes to p.lm_partial[(2 tn + wv) * m + token], 16 tokens = 256 contiguous bytes per store.  Logits are rounded to bf16 first (what the
+// stored-logits path writes and K1 reads), scaled by 1 / T in f32, columns past the vocabulary masked (last vocab tile only).
+__device__ __forceinline__ void lm_fwd_epilogue(const Params& p, int tm, int tn, f32x4 (&acc)[2][4][2][2], int wv, int wt, int lr, int lq) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  constexpr float kLog2e = 1.4426950408889634f, kNegBig = -3.0e38f;
+  const int col0 = tn * kTile + wv * 64 + lq * 4;  // + i * 128 + f * 16 + r
+  const bool ragged = (tn + 1) * kTile > p.n;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int tok = tm * kTile + j * 128 + wt * 32 + g * 16 + lr;
+      const bool live = tok < p.m;
+      const float inv_t = live ? p.lm_inv_temp[tok] : 1.f;
+      const int rel = live ? (int)p.lm_labels[tok] - col0 : -1;
+      f32x2 x[2][4][2];
+      float mx = kNegBig;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const f32x4 c = acc[i][f][j][g];
+          const uint32_t u0 = pack_bf16_hw(c[0], c[1]), u1 = pack_bf16_hw(c[2], c[3]);
+          f32x2 a = f32x2{bf16lo(u0), bf16hi(u0)} * inv_t, b = f32x2{bf16lo(u1), bf16hi(u1)} * inv_t;
+          if (ragged) {
+            const int cc = col0 + i * 128 + f * 16;
+            a[0] = cc < p.n ? a[0] : kNegBig; a[1] = cc + 1 < p.n ? a[1] : kNegBig;
+            b[0] = cc + 2 < p.n ? b[0] : kNegBig; b[1] = cc + 3 < p.n ? b[1] : kNegBig;
+          }
+          x[i][f][0] = a; x[i][f][1] = b;
+          mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(b[0], b[1]));
+        }
+      float tg = kNegBig;
+      if (rel >= 0 && rel < 256 && (rel & 0x4c) == 0) {  // the label is one of this lane's 32 columns (one lane in ~1000 per tile)
+        const int sel = ((rel >> 7) << 4) | (((rel >> 4) & 3) << 2) | (rel & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tg = sel == ((i << 4) | (f << 2) | r) ? x[i][f][r >> 1][r & 1] : tg;
+      }
+      f32x2 s2 = f32x2{0.f, 0.f}, t2 = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 xx = x[i][f][h], d = (xx - mx) * kLog2e;
+            const f32x2 e = f32x2{__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};  // exp(-huge) = 0 for masked columns
+            s2 += e;
+            t2 += e * (ragged ? f32x2{xx[0] > kNegBig ? xx[0] : 0.f, xx[1] > kNegBig ? xx[1] : 0.f} : xx);
+          }
+      float m = mx, sm = s2[0] + s2[1], tt = t2[0] + t2[1];
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float m2 = __shfl_xor(m, o, 64), sb = __shfl_xor(sm, o, 64), tb = __shfl_xor(tt, o, 64), g2 = __shfl_xor(tg, o, 64);
+        const float mn = fmaxf(m, m2);
+        const float e1 = __builtin_amdgcn_exp2f((m - mn) * kLog2e), e2 = __builtin_amdgcn_exp2f((m2 - mn) * kLog2e);
+        sm = sm * e1 + sb * e2;
+        tt = tt * e1 + tb * e2;
+        m = mn;
+        tg = fmaxf(tg, g2);
+      }
+      if (lq == 0 && live) *reinterpret_cast<f32x4*>(p.lm_partial + ((int64_t)(tn * 2 + wv) * p.m + tok) * 4) = f32x4{m, sm, tt, tg};
+    }
+}
+
 template <int V, bool XK, bool WK, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
   constexpr int TM = tile_mode<MODE>();          // which tile stream
@@ -1028,6 +1110,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
         ursrc = out_rsrc(gt + p.n, gbytes);
         o2rsrc = out_rsrc(reinterpret_cast<bf16_t*>(cur.out) + p.n, cur.m_valid > 0 ? (cur.m_valid - 1) * ldo_b + cur.n_valid * 2 : 0);
       }
+      int lm_tm = 0, lm_tn = 0;  // MODE 8 / 9: the tile's place in the (token, vocab) grid
+      if constexpr (MODE == 8 || MODE == 9) (void)tile_of_block(cur.slot, p.tiles_m, p.tiles_n, p.sweep_n, lm_tm, lm_tn);
+      if constexpr (MODE == 8) {
+        lm_fwd_epilogue(p, lm_tm, lm_tn, s.acc, wv, wt, lr, lq);
+      } else
       if (wide) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1086,6 +1173,35 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const Params p) {
                   }
                   __builtin_amdgcn_raw_buffer_store_b128(dgv, orsrc, offo[q], 0, 0);
                   __builtin_amdgcn_raw_buffer_store_b128(duv, o2rsrc, offo[q], 0, 0);
+                }
+              } else if constexpr (MODE == 9) {
+                // val = 8 recomputed logits of one token, rounded to bf16; out goes dl = g inv_T (onehot(label) - exp(l inv_T - logz)) (lm_head.py:184-191,
+                // the arithmetic of lmhead_kernel<BWD>); the label's column is patched in by the one lane in ~19 000 that holds it
+                constexpr float kLog2e = 1.4426950408889634f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int m = mrow0 + q * 8 + srow, nn = ncol0 + schunk * 8;
+                  const int tok = lm_tm * kTile + m;
+                  const bool live = m < cur.m_valid;
+                  const float inv_t = live ? p.lm_inv_temp[tok] : 1.f, lz = live ? p.lm_logz[tok] : 0.f;
+                  const float gsc = live ? p.lm_grad[tok] * inv_t : 0.f;
+                  const int rel = live ? (int)p.lm_labels[tok] - (lm_tn * kTile + nn) : -1;
+                  float d[8];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    const float p0 = __builtin_amdgcn_exp2f((bf16lo(val[q][c]) * inv_t - lz) * kLog2e), p1 = __builtin_amdgcn_exp2f((bf16hi(val[q][c]) * inv_t - lz) * kLog2e);
+                    d[2 * c] = gsc * (0.f - p0);
+                    d[2 * c + 1] = gsc * (0.f - p1);
+                  }
+                  if ((unsigned)rel < 8u) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                      const float l = (c & 1) ? bf16hi(val[q][c >> 1]) : bf16lo(val[q][c >> 1]);
+                      d[c] = rel == c ? gsc * (1.f - __builtin_amdgcn_exp2f((l * inv_t - lz) * kLog2e)) : d[c];
+                    }
+                  }
+                  const u32x4 dv = u32x4{pack_bf16_hw(d[0], d[1]), pack_bf16_hw(d[2], d[3]), pack_bf16_hw(d[4], d[5]), pack_bf16_hw(d[6], d[7])};
+                  __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, (m * ldo_b + nn * 2) | ((cur.n_valid - 1 - nn) >> 31), 0, 0);
                 }
               } else {
 #pragma unroll
@@ -2122,3 +2238,46 @@ extern "C" int pm_gemm_swiglu_bwd_bf16(const void* dy, int64_t lddy, const void*
   PM_CHECK_LAUNCH("gemm_kernel<swiglu_bwd>");
   return PM_OK;
 }
+
+// ---- the fused LM head on the tile stream (MODE 8 / 9; entry points pm_lmhead_logprob_fwd / _bwd in lmhead.hip) ---------------------------------------
+namespace pm {
+namespace gm {
+bool lmhead_tiles_supported(const void* hidden, const void* weight, int64_t n, int64_t h, int64_t v) {
+  const int64_t kLimit = (1ll << 31) - 4096;
+  return pm_gemm_supported(n, v, h, 0, 0) && h % 8 == 0 && ((uintptr_t)hidden & 15) == 0 && ((uintptr_t)weight & 15) == 0 && 256 * h * 2 < kLimit && n < (1ll << 31) &&
+         v < (1ll << 31) - 256;
+}
+int64_t lmhead_tiles_partial_floats(int64_t n, int64_t v) { return n * 2 * cdiv(v, (int64_t)kTile) * 4; }
+
+static void lmhead_params(Params& p, const bf16_t* hidden, const bf16_t* weight, int64_t n, int64_t h, int64_t v, const int64_t* labels, const float* inv_temp) {
+  p.offsets = nullptr; p.w2 = nullptr; p.out2 = nullptr; p.n_experts = 0; p.n_first = 0; p.gu = nullptr; p.ldgu = 0; p.bias = nullptr; p.sumsq = nullptr;
+  p.x = hidden; p.w = weight; p.out = nullptr;
+  p.ldx = h; p.ldw = h; p.ldo = v; p.ldo2 = 0;
+  p.m = (int)n; p.n = (int)v; p.k = (int)h;
+  p.tiles_m = (int)cdiv(n, (int64_t)kTile); p.tiles_n = (int)cdiv(v, (int64_t)kTile);
+  p.n_blocks = grid_blocks(p.tiles_m, p.tiles_n);
+  p.out_f32 = 0; p.accumulate = 0; p.nt_out = 0;
+  p.sweep_n = n > v ? 1 : 0;  // cycle the smaller operand past the held block of the bigger one (gemm_impl)
+  p.split_s = 1; p.split_rp = 0; p.split_v0 = 0; p.split_k = 0; p.split_ws = nullptr;
+  p.k_chunk = (int)h; p.k_parts = 1;
+  p.lm_labels = labels; p.lm_inv_temp = inv_temp; p.lm_logz = nullptr; p.lm_grad = nullptr; p.lm_partial = nullptr;
+}
+
+void lmhead_fwd_tiles(const bf16_t* hidden, const bf16_t* weight, int64_t n, int64_t h, int64_t v, const int64_t* labels, const float* inv_temp, float* partial,
+                      hipStream_t st) {
+  Params p;
+  lmhead_params(p, hidden, weight, n, h, v, labels, inv_temp);
+  p.lm_partial = partial;
+  launch_grouped<false, false, 8>(p, st, kDefaultSched);
+}
+
+void lmhead_bwd_tiles(const bf16_t* hidden, const bf16_t* weight, int64_t n, int64_t h, int64_t v, const int64_t* labels, const float* inv_temp, const float* logz,
+                      const float* grad, bf16_t* dlogits, int64_t ld, hipStream_t st) {
+  Params p;
+  lmhead_params(p, hidden, weight, n, h, v, labels, inv_temp);
+  p.out = dlogits; p.ldo = ld;
+  p.lm_logz = logz; p.lm_grad = grad;
+  launch_grouped<false, false, 9>(p, st, kDefaultSched);
+}
+}  // namespace gm
+}  // namespace pm

@@ -334,6 +334,14 @@ def bench_lmhead(out, n=16384, h=4096, v=151936):
 
     med, best = timeit(lib, iters=8, warmup=2)
     out.append(dict(kernel="library: hipBLASLt logits + K1", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    def own():
+        ops.gemm(hidden, weight, out=store)
+        return ops.logprob_entropy_fwd(store, labels, inv_t)
+
+    med, best = timeit(own, iters=8, warmup=2)
+    out.append(dict(kernel="stored logits: own GEMM core + K1 (the step's default)", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
+    med, best = timeit(lambda: ops.gemm(hidden, weight, out=store), iters=8, warmup=2)
+    out.append(dict(kernel="own GEMM core, logits only", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
     med, best = timeit(lambda: torch.mm(hidden, weight.t(), out=store), iters=8, warmup=2)
     out.append(dict(kernel="library: hipBLASLt logits only", ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flop / med / 1e12, frac_mfma=flop / med / 2.5e15))
     med, best = timeit(lambda: ops.logprob_bwd(store, labels, inv_t, logz, g, out=store), iters=8, warmup=2)
