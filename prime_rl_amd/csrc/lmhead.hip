@@ -337,16 +337,33 @@ __global__ void lmhead_finalize_kernel(const float* __restrict__ partial, int n,
   entropy[tok] = lzv - tt / s;
 }
 
-// merge of the tile stream's partial states (MODE 8 of gemm.hip): [parts][n] float4, one thread per token, coalesced over tokens; online over the parts
-__global__ void lmhead_finalize_parts_kernel(const float* __restrict__ partial, int n, int parts, float* __restrict__ logprobs, float* __restrict__ entropy,
-                                             float* __restrict__ logz) {
-  const int tok = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tok >= n) return;
-  const lm_f32x4* p = reinterpret_cast<const lm_f32x4*>(partial) + tok;
+// merge of the tile stream's partial states (MODE 8 of gemm.hip): [parts][n] float4.  A workgroup = 64 tokens x 4 part streams (wave w merges parts w, w + 4,
+// ... online, 1 KiB coalesced per row), then wave 0 merges the four streams in a fixed order through LDS.
+__global__ __launch_bounds__(256) void lmhead_finalize_parts_kernel(const float* __restrict__ partial, int n, int parts, float* __restrict__ logprobs,
+                                                                    float* __restrict__ entropy, float* __restrict__ logz) {
+  __shared__ lm_f32x4 sm[4][64];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int tok = blockIdx.x * 64 + lane;
   float m = kNegBig, tg = kNegBig, s = 0.f, tt = 0.f;
+  if (tok < n) {
+    const lm_f32x4* p = reinterpret_cast<const lm_f32x4*>(partial) + tok;
 #pragma unroll 4
-  for (int i = 0; i < parts; ++i) {
-    const lm_f32x4 v = p[(int64_t)i * n];
+    for (int i = sub; i < parts; i += 4) {
+      const lm_f32x4 v = p[(int64_t)i * n];
+      const float mn = fmaxf(m, v[0]);
+      const float e1 = __builtin_amdgcn_exp2f((m - mn) * kLog2e), e2 = __builtin_amdgcn_exp2f((v[0] - mn) * kLog2e);
+      s = fmaf(s, e1, v[1] * e2);
+      tt = fmaf(tt, e1, v[2] * e2);
+      m = mn;
+      tg = fmaxf(tg, v[3]);
+    }
+  }
+  sm[sub][lane] = lm_f32x4{m, s, tt, tg};
+  __syncthreads();
+  if (sub != 0 || tok >= n) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const lm_f32x4 v = sm[w][lane];
     const float mn = fmaxf(m, v[0]);
     const float e1 = __builtin_amdgcn_exp2f((m - mn) * kLog2e), e2 = __builtin_amdgcn_exp2f((v[0] - mn) * kLog2e);
     s = fmaf(s, e1, v[1] * e2);
@@ -442,7 +459,7 @@ extern "C" int pm_lmhead_logprob_fwd(const void* hidden_bf16, const void* weight
   if (!logits_out_bf16 && on_tile_stream(hidden_bf16, weight_bf16, n_tokens, hidden, vocab, round_logits_bf16)) {
     gm::lmhead_fwd_tiles(a.x, a.w, n_tokens, hidden, vocab, labels, inv_temp, a.partial, st);
     PM_CHECK_LAUNCH("gemm_kernel<lmhead fwd>");
-    hipLaunchKernelGGL(lmhead_finalize_parts_kernel, dim3((unsigned)cdiv(n_tokens, 256)), dim3(256), 0, st, a.partial, a.n, (int)(2 * cdiv(vocab, 256)), logprobs, entropy,
+    hipLaunchKernelGGL(lmhead_finalize_parts_kernel, dim3((unsigned)cdiv(n_tokens, 64)), dim3(256), 0, st, a.partial, a.n, (int)(2 * cdiv(vocab, 256)), logprobs, entropy,
                        logz);
     PM_CHECK_LAUNCH("lmhead_finalize_parts_kernel");
     return PM_OK;
