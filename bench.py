@@ -271,8 +271,8 @@ def long_context_extra(engine, dims, device, seq: int = 32768, rollouts=(1, 4), 
     from prime_rl_amd.trainer.rl.data import FakeDataLoader, FakeDataLoaderConfig
 
     res: dict = {"seq_len": seq, "recompute": "layer"}
-    old = engine.recompute
-    engine.recompute = "layer"
+    old, old_freq = engine.recompute, engine.recompute_freq
+    engine.recompute, engine.recompute_freq = "layer", 1
     try:
         # the attention kernels stand-alone at this shape (one 32k-token document, all heads)
         hq, hkv, hd = dims.num_attention_heads, dims.num_key_value_heads, dims.kernel_head_dim
@@ -331,27 +331,29 @@ def long_context_extra(engine, dims, device, seq: int = 32768, rollouts=(1, 4), 
                 res[f"r{r}"] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
         # the reference's `ac.mode = "selective"` (norm / attn_proj / mlp re-run, the attention core's output kept): the same step with one attention forward
-        # per layer less; 288 GB hold the kept outputs
-        try:
-            engine.recompute = "selective"
-            dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=1), seq_len=seq)
-            bs = [[pack_micro_batches([mb], device) for mb in dl.get_batch()] for _ in range(steps + 1)]
-            torch.cuda.reset_peak_memory_stats()
-            engine.step(bs[0])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for b in bs[1:]:
-                engine.step(b)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-            res["r1_selective"] = {"rollouts": 1, "recompute": "selective", "ms_per_step": round(dt * 1e3, 2), "tokens_per_s": round(seq / dt, 1),
-                                   "mfu_ref_formula": round(dims.flops_per_token(seq) * seq / dt / MFMA_BF16_PEAK, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
-            del bs
-        except Exception as e:  # pragma: no cover
-            res["r1_selective"] = {"error": repr(e)[:200]}
-        torch.cuda.empty_cache()
+        # per layer less; 288 GB hold the kept outputs.  Then with `ac.freq = 2` (trainer/model.py:1151: only every second layer is checkpointed, the others
+        # keep their activations: 253 GB peak, half the recompute)
+        for key, freq in (("r1_selective", 1), ("r1_selective_freq2", 2)):
+            try:
+                engine.recompute, engine.recompute_freq = "selective", freq
+                dl = FakeDataLoader(FakeDataLoaderConfig(batch_size=1), seq_len=seq)
+                bs = [[pack_micro_batches([mb], device) for mb in dl.get_batch()] for _ in range(steps + 1)]
+                torch.cuda.reset_peak_memory_stats()
+                engine.step(bs[0])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in bs[1:]:
+                    engine.step(b)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                res[key] = {"rollouts": 1, "recompute": "selective", "recompute_freq": freq, "ms_per_step": round(dt * 1e3, 2), "tokens_per_s": round(seq / dt, 1),
+                            "mfu_ref_formula": round(dims.flops_per_token(seq) * seq / dt / MFMA_BF16_PEAK, 4), "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+                del bs
+            except Exception as e:  # pragma: no cover
+                res[key] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
     finally:
-        engine.recompute = old
+        engine.recompute, engine.recompute_freq = old, old_freq
     return res
 
 
@@ -708,6 +710,8 @@ def finalize_line(result: dict) -> dict:
         "long_context_mfu_executed": _dig(extra, ("long_context", "r1", "mfu_executed_causal")),
         "long_context_attn_share": _dig(extra, ("long_context", "r1", "attention_share")), "long_context_peak_hbm_gb": _dig(extra, ("long_context", "r1", "peak_hbm_gb")),
         "long_context_selective_ms": _dig(extra, ("long_context", "r1_selective", "ms_per_step")), "long_context_selective_mfu_ref": _dig(extra, ("long_context", "r1_selective", "mfu_ref_formula")),
+        "long_context_selective_freq2_ms": _dig(extra, ("long_context", "r1_selective_freq2", "ms_per_step")),
+        "long_context_selective_freq2_mfu_ref": _dig(extra, ("long_context", "r1_selective_freq2", "mfu_ref_formula")),
         "long_context_x4_ms": _dig(extra, ("long_context", "r4", "ms_per_step")), "long_context_x4_mfu_executed": _dig(extra, ("long_context", "r4", "mfu_executed_causal")),
         "long_context_attn_fwd_frac": _dig(extra, ("long_context", "attn_fwd_frac_of_2.5PF")), "long_context_attn_bwd_frac": _dig(extra, ("long_context", "attn_bwd_frac_of_2.5PF")),
         "j1_frac": _dig(extra, ("j1_roofline", "frac")), "gemm_wgrad_frac": _dig(extra, ("gemm_roofline", "frac")),
@@ -783,6 +787,7 @@ def main() -> None:
                     help="diagnostic: at N=1 run the RCCL reduce-scatter/all-gather + comm-stream path on a world_size-1 group (not the headline run)")
     ap.add_argument("--recompute", default="none", choices=["none", "layer", "selective"],
                     help="layer = block-level activation recomputation (the reference's default model.ac): keep layer inputs only, re-run each layer's forward in backward")
+    ap.add_argument("--recompute-freq", type=int, default=1, help="the reference's ac.freq: recompute only every N-th layer, the others keep their activations")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (device copies taken in one extra untimed step after the timed region)")
     ap.add_argument("--no-realistic-parity", action="store_true", help="skip parity.realistic (one extra untimed step on rollout-like data vs the oracle forward)")
     ap.add_argument("--parity-rollouts", type=int, default=64, help="rollouts of the two-layer legs of parity.realistic (64 x 2048 -> 114 688 trained tokens)")
@@ -833,7 +838,7 @@ def main() -> None:
     dims = {"qwen3-8b": ModelDims.qwen3_8b, "qwen3-0.6b": ModelDims.qwen3_0_6b, "qwen2.5-1.5b": ModelDims.qwen2_5_1_5b, "qwen2.5-0.5b": ModelDims.qwen2_5_0_5b,
             "tiny": ModelDims.tiny}[args.model]()
     engine = GRPOEngine(dims, device=device, optim=OptimConfig(), loss=LossConfig(), seed=0, force_collectives=args.force_collectives and world == 1,
-                        recompute=args.recompute)
+                        recompute=args.recompute, recompute_freq=args.recompute_freq)
     loader = FakeDataLoader(FakeDataLoaderConfig(batch_size=args.micro_batches * world), seq_len=args.seq_len, dp_world_size=world, dp_rank=rank)
 
     per_pass = max(args.tokens_per_pass // args.seq_len, 1)

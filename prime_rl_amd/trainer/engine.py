@@ -457,7 +457,8 @@ class GRPOEngine:
                  dp_group: dist.ProcessGroup | None = None, seed: int = 0, lm_head_token_chunk: int = 16384, recompute_act: bool = False,
                  force_collectives: bool = False, gemm_layouts: bool = True, gemm_dtype: str = "bf16", dp_size: int | None = None,
                  cp_group: dist.ProcessGroup | None = None, cp_size: int = 1, lm_head_impl: str | None = None,
-                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None, fused_sumsq: bool = True,
+                 shard_group: dist.ProcessGroup | None = None, cp_style: str = "ulysses", recompute: str | None = None, recompute_freq: int | None = None,
+                 fused_sumsq: bool = True,
                  embed_split: bool = True, fused_swiglu_bwd: bool = True, fused_swiglu_fwd: bool = True):
         self.dims, self.device = dims, torch.device(device)
         if gemm_dtype not in ("bf16", "f32"):
@@ -529,6 +530,11 @@ class GRPOEngine:
         self.recompute = recompute or os.environ.get("PM_RECOMPUTE", "none")
         if self.recompute not in ("none", "layer", "selective"):
             raise PrimeMI355XError(f"recompute must be 'none', 'layer' or 'selective', got {self.recompute!r}")
+        # the reference's `ac.freq` (trainer/model.py:1151: `layer_id % freq != 0` -> not checkpointed): only every freq-th layer is recomputed, the others keep
+        # their activations (~120 KB per token and layer) — at one 32 768-token rollout freq = 2 still fits the 288 GB and halves the recompute
+        self.recompute_freq = int(recompute_freq if recompute_freq is not None else os.environ.get("PM_RECOMPUTE_FREQ", "1"))
+        if self.recompute_freq < 1:
+            raise PrimeMI355XError(f"recompute_freq must be >= 1, got {self.recompute_freq}")
         self.step_count = 0
         # a dedicated stream for the collectives — on the GPU; the CPU flavour (tests/test_engine_gloo_cpu.py: the SAME engine code over gloo with
         # stand-in kernels) issues them synchronously
@@ -803,7 +809,9 @@ class GRPOEngine:
         for i in range(d.num_hidden_layers):
             self._wait_gather(f"layer{i}")
             L, x, pending = self._layer_forward(i, x, pending, cos, sin, seq_start, scale, n)
-            if self.recompute == "layer" or (self.recompute == "selective" and cp > 1):  # (under context parallelism the attention state is the exchanged tensors: re-run it)
+            if self.recompute == "none" or i % self.recompute_freq != 0:
+                ctx["layers"].append(L)
+            elif self.recompute == "layer" or (self.recompute == "selective" and cp > 1):  # (under context parallelism the attention state is the exchanged tensors: re-run it)
                 ctx["layers"].append({"x": L["x"], "recompute": True})
             elif self.recompute == "selective":
                 ctx["layers"].append({"x": L["x"], "recompute": True, "o": L["o"], "lse": L["lse"]})

@@ -330,6 +330,20 @@ def setup_module_engine(config, parallel_dims: ParallelDims, device: torch.devic
                         router_replay=bool(config.enable_router_replay))
 
 
+def recompute_from_config(m) -> dict:
+    """`model.ac` (configs/trainer.py ActivationCheckpointConfig; the reference applies it in trainer/model.py:1141-1185) -> the engine's recompute arguments.
+    `full` = block-level recomputation, `selective` = everything of a layer but the attention core (the engine keeps its output and lse: the reference's
+    norm / attn_proj / mlp targets taken together), `freq` = every freq-th layer only.  PM_RECOMPUTE / PM_RECOMPUTE_FREQ override (288 GB hold the activations
+    of 16k-token passes: `PM_RECOMPUTE=none` is what bench.py's headline runs)."""
+    import os
+
+    # A `model.ac` the user wrote is honoured; the schema's DEFAULT (full checkpointing of every layer — sized for 80 GB parts) is not applied: 288 GB hold the
+    # activations of the passes the default configs make, and recomputation costs a forward per layer for nothing.
+    ac = getattr(m, "ac", None) if "ac" in getattr(m, "model_fields_set", ()) else None
+    mode = {"full": "layer", "selective": "selective"}[ac.mode] if ac is not None else "none"
+    return {"recompute": os.environ.get("PM_RECOMPUTE", mode), "recompute_freq": int(os.environ.get("PM_RECOMPUTE_FREQ", ac.freq if ac is not None else 1))}
+
+
 def uses_module_engine(config, parallel_dims: ParallelDims) -> bool:
     return resolve_moe_config(config.model) is not None or parallel_dims.ep_enabled
 
@@ -351,7 +365,7 @@ def setup_engine(config, parallel_dims: ParallelDims, device: torch.device | str
     loss = loss_from_config(config.loss)
     engine = GRPOEngine(dims, device=device, optim=optim, loss=loss, dp_group=parallel_dims.get_group("dp"), seed=config.seed,
                         dp_size=parallel_dims.dp_size, cp_group=parallel_dims.get_group("cp"), cp_size=parallel_dims.cp,
-                        shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style)
+                        shard_group=parallel_dims.get_group("dp_cp"), cp_style=m.cp_style, **recompute_from_config(m))
     sd = _local_safetensors(m.name)
     if sd is not None:
         engine.store.load_state_dict({k: v.to(device) for k, v in sd.items()})

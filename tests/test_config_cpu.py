@@ -208,3 +208,18 @@ def test_ep_auto_resolves_like_the_reference():
     with pytest.raises(ValueError, match="requires ep > 1"):
         resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep_comm_backend="deepep"), 1)
     assert resolve_ep(ModelConfig(name="Qwen/Qwen3-30B-A3B", ep_comm_backend="deepep"), 8) == 8  # (rejected later by validate_supported, not by the resolution)
+
+
+def test_model_ac_maps_onto_the_engine_recompute_arguments(monkeypatch):
+    """`model.ac` (ActivationCheckpointConfig; applied by the reference in trainer/model.py:1141-1185): what the user WROTE is honoured — mode full -> block-level
+    recomputation, selective -> everything but the attention core, `freq` -> every freq-th layer only —, the schema default (checkpoint everything: sized for
+    80 GB parts) is not applied on a 288 GB part; PM_RECOMPUTE / PM_RECOMPUTE_FREQ override either."""
+    from prime_rl_amd.trainer.model import recompute_from_config
+
+    monkeypatch.delenv("PM_RECOMPUTE", raising=False)
+    monkeypatch.delenv("PM_RECOMPUTE_FREQ", raising=False)
+    assert recompute_from_config(TrainerConfig().model) == {"recompute": "none", "recompute_freq": 1}
+    assert recompute_from_config(parse_argv(["--model.ac"]).model) == {"recompute": "layer", "recompute_freq": 1}  # the reference benchmark's bare flag
+    assert recompute_from_config(parse_argv(["--model.ac.mode", "selective", "--model.ac.freq", "2"]).model) == {"recompute": "selective", "recompute_freq": 2}
+    monkeypatch.setenv("PM_RECOMPUTE", "none")
+    assert recompute_from_config(parse_argv(["--model.ac"]).model)["recompute"] == "none"
