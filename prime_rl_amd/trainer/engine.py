@@ -865,7 +865,7 @@ class GRPOEngine:
         return ctx
 
     def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int,
-                       kept_attn: tuple[Tensor, Tensor] | None = None):
+                       kept_attn: tuple[Tensor, Tensor] | None = None, want_out: bool = True):
         """One decoder layer: (saved activations, residual stream after attention, mlp output whose residual add the NEXT norm fuses).  `pending` = the
         previous layer's mlp output (None for layer 0 and when re-running a layer from its saved, already-summed input)."""
         d, w = self.dims, self.store.w
@@ -896,7 +896,8 @@ class GRPOEngine:
         else:
             gu = self._fwd_mm(h2, wgu)
             act = ops.swiglu_fwd(gu)
-        pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"])
+        # (a layer re-run in the backward needs its activations, not its output: the down projection — a quarter of the layer's forward GEMM work — is skipped)
+        pending = self._fwd_mm(act, w[p + "mlp.down_proj.weight"]) if want_out else None
         saved = dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, q=q, k=k, rstd_qk=rstd_qk, o=o, lse=lse, x2=x2, rstd2=rstd2, h2=h2, gu=gu,
                      act=None if self.recompute_act else act, attn_saved=attn_saved)
         return saved, x2, pending
@@ -1042,7 +1043,8 @@ class GRPOEngine:
             p = f"model.layers.{i}."
             L = ctx["layers"][i]
             if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input (and, "selective", its kept attention output)
-                L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n, kept_attn=(L["o"], L["lse"]) if "o" in L else None)
+                L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n, kept_attn=(L["o"], L["lse"]) if "o" in L else None,
+                                              want_out=False)
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
             w_down = w[p + "mlp.down_proj.weight"]
             if self.fused_swiglu_bwd and self._dgrad_own_now and not self.gemm_f32 and ops.gemm_swiglu_bwd_supported(dx, w_down):
