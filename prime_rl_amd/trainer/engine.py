@@ -524,9 +524,10 @@ class GRPOEngine:
         # bit-identical gradients (every kernel on the path is deterministic and the stored input is the already-rounded residual sum).  Off by
         # default: 288 GB holds the activations of 16k-token passes; a 32k-token pass on one GPU needs it.
         # "selective" (the reference's `ac.mode = "selective"` with targets norm / attn_proj / mlp, models/layers/checkpointing.py:120-147: the projections, norms and
-        # the MLP are re-run, the attention core is NOT): like "layer", but the attention output and its lse (268 + 4 MB per layer and 32k-token pass — 288 GB
-        # hold them for every layer) are kept, so the backward re-runs everything but `pm_attn_varlen_fwd`; bit-identical gradients, one attention forward per
-        # layer less (a quarter of a 32k-token step's attention time).
+        # the MLP are re-run, the attention core is NOT): like "layer", but the attention output, its lse and the residual stream behind the output projection
+        # (268 + 4 + 268 MB per layer and 32k-token pass — 288 GB hold them for every layer) are kept, so the backward re-runs everything but
+        # `pm_attn_varlen_fwd` and the output projection; bit-identical gradients, one attention forward per layer less (a quarter of a 32k-token step's
+        # attention time).
         self.recompute = recompute or os.environ.get("PM_RECOMPUTE", "none")
         if self.recompute not in ("none", "layer", "selective"):
             raise PrimeMI355XError(f"recompute must be 'none', 'layer' or 'selective', got {self.recompute!r}")
@@ -814,7 +815,7 @@ class GRPOEngine:
             elif self.recompute == "layer" or (self.recompute == "selective" and cp > 1):  # (under context parallelism the attention state is the exchanged tensors: re-run it)
                 ctx["layers"].append({"x": L["x"], "recompute": True})
             elif self.recompute == "selective":
-                ctx["layers"].append({"x": L["x"], "recompute": True, "o": L["o"], "lse": L["lse"]})
+                ctx["layers"].append({"x": L["x"], "recompute": True, "o": L["o"], "lse": L["lse"], "x2": L["x2"]})
             else:
                 ctx["layers"].append(L)
         self._wait_gather("head")
@@ -865,7 +866,7 @@ class GRPOEngine:
         return ctx
 
     def _layer_forward(self, i: int, x: Tensor, pending: Tensor | None, cos: Tensor, sin: Tensor, seq_start: Tensor, scale: float, n: int,
-                       kept_attn: tuple[Tensor, Tensor] | None = None, want_out: bool = True):
+                       kept_attn: tuple[Tensor, Tensor] | None = None, want_out: bool = True, kept_x2: Tensor | None = None):
         """One decoder layer: (saved activations, residual stream after attention, mlp output whose residual add the NEXT norm fuses).  `pending` = the
         previous layer's mlp output (None for layer 0 and when re-running a layer from its saved, already-summed input)."""
         d, w = self.dims, self.store.w
@@ -886,8 +887,12 @@ class GRPOEngine:
         else:  # Ulysses: heads <-> sequence all-to-all around the unchanged varlen kernel (full pass, 1/cp of the heads); "ring": gathered K / V
             o, attn_saved = (self._ulysses_attn_fwd if self.cp_style == "ulysses" else self._gathered_kv_attn_fwd)(q, k, v, seq_start, scale)
             lse = None
-        attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
-        h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
+        if kept_x2 is not None:  # recompute = "selective": the residual stream after attention was kept too (the already-rounded sum): no output projection
+            h2, rstd2, _ = ops.rmsnorm_fwd(kept_x2, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps)
+            x2 = kept_x2
+        else:
+            attn_out = self._fwd_mm(o.view(n, d.q_dim), w[p + "self_attn.o_proj.weight"])
+            h2, rstd2, x2 = ops.rmsnorm_fwd(attn_out, w[p + "post_attention_layernorm.weight"], d.rms_norm_eps, residual=x)
         wgu = w[p + "mlp.gate_up_proj.weight"]
         if self.fused_swiglu_fwd and "fwd" in self.gemm_own and not self.gemm_f32 and ops.gemm_swiglu_supported(h2, wgu):
             # the own core writes act = silu(gate) * up from the accumulators of the gate|up product (a tile = 128 features' gate AND up columns): the
@@ -1044,7 +1049,7 @@ class GRPOEngine:
             L = ctx["layers"][i]
             if L.get("recompute"):  # block-level recomputation: rebuild this layer's activations from its saved input (and, "selective", its kept attention output)
                 L, _, _ = self._layer_forward(i, L["x"], None, ctx["cos"], ctx["sin"], ctx["seq_start"], scale, n, kept_attn=(L["o"], L["lse"]) if "o" in L else None,
-                                              want_out=False)
+                                              want_out=False, kept_x2=L.get("x2"))
             act = L["act"] if L["act"] is not None else ops.swiglu_fwd(L["gu"])
             w_down = w[p + "mlp.down_proj.weight"]
             if self.fused_swiglu_bwd and self._dgrad_own_now and not self.gemm_f32 and ops.gemm_swiglu_bwd_supported(dx, w_down):
