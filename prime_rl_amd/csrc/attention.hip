@@ -341,6 +341,10 @@ static int attn_bwd_impl(const char* who, const void* grad_out, const void* q, c
       case 4: PM_LAUNCH_DKDV_P2(4); break;
       case 5: PM_LAUNCH_DKDV_P2(5); break;
       case 6: PM_LAUNCH_DKDV_P2(6); break;
+      case 7: PM_LAUNCH_DKDV_P2(7); break;  // v_pk_mul_f32 instead of the scalar multiplies (same bits, 1-2 % slower: profiles/r06_attention.md); 8-10: its other distances
+      case 8: PM_LAUNCH_DKDV_P2(8); break;
+      case 9: PM_LAUNCH_DKDV_P2(9); break;
+      case 10: PM_LAUNCH_DKDV_P2(10); break;
       default: PM_LAUNCH_DKDV_P2(0); break;
     }
   }

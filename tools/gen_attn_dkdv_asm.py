@@ -32,6 +32,10 @@ SLOTB = 33792                               # one LDS slot: Q tile 16 KiB, dO ti
 # scalar registers owned by the stream
 (S_J, S_HEAD, S_BASE, S_ROFF, S_QN, S_Q1, S_Q2, S_ON, S_O1, S_O2, S_LOLD, S_LO2, S_TMP, S_TMP2, S_DB, S_DR, S_P0, S_P1) = range(70, 88)
 S_LAST = 89  # s[88:89] = the compare pair
+S_SC2 = 68   # s[68:69]: sc2 as the (even-aligned) scalar source of the packed multiplies (op_sel_hi broadcasts its low half)
+PK_LAG = (1, 3)
+PK = False   # packed f32 arithmetic (v_pk_mul_f32: two elements per instruction, the same IEEE multiply per element) in the fully visible pairs: 96 instead
+             # of 128 VALU instructions per pair, bit-identical, and 1-2 % SLOWER at every producer-consumer distance tried (profiles/r06_attention.md): off
 
 
 def v(n):
@@ -161,8 +165,25 @@ def softmax_bwd_list(par):
     """fully visible pair: P = exp2(S sc2) (S started at -lse / scale), dS / scale = P * dP (dP started at -delta), both packed to bf16 in place"""
     sb, pb = SETS[par]
     sc = [(sb + k, pb + k) for k in range(32)]
-    ms = [valu(f"v_mul_f32 {v(a)}, %[sc2], {v(a)}", [a], [a]) for a, _ in sc]
     ex = [valu(f"v_exp_f32 {v(a)}, {v(a)}", [a], [a], kind="trans") for a, _ in sc]
+    if PK:
+        # element pairs (2 j, 2 j + 1) are even-aligned register pairs of the score sets: one v_pk_mul_f32 scales two scores (sc2 from s[68:69], low half
+        # for both lanes), one multiplies two probabilities into their dP; the exponentials stay one per element (96 instead of 128 VALU issues per pair)
+        ms = [valu(f"v_pk_mul_f32 {vt(sb + 2 * j, 2)}, {vt(sb + 2 * j, 2)}, s[{S_SC2}:{S_SC2 + 1}] op_sel_hi:[1,0]", [sb + 2 * j, sb + 2 * j + 1], [sb + 2 * j, sb + 2 * j + 1])
+              for j in range(16)]
+        md = [valu(f"v_pk_mul_f32 {vt(pb + 2 * j, 2)}, {vt(pb + 2 * j, 2)}, {vt(sb + 2 * j, 2)}", [pb + 2 * j, pb + 2 * j + 1, sb + 2 * j, sb + 2 * j + 1], [pb + 2 * j, pb + 2 * j + 1])
+              for j in range(16)]
+        L = []
+        d1, d2 = PK_LAG
+        for j in range(16 + d2):  # pair j is scaled, pair j - d1 exponentiated (two instructions), pair j - d2 multiplied into dP
+            if j < 16:
+                L.append(ms[j])
+            if 0 <= j - d1 < 16:
+                L += [ex[2 * (j - d1)], ex[2 * (j - d1) + 1]]
+            if 0 <= j - d2 < 16:
+                L.append(md[j - d2])
+        return L + pack_list(par)
+    ms = [valu(f"v_mul_f32 {v(a)}, %[sc2], {v(a)}", [a], [a]) for a, _ in sc]
     md = [valu(f"v_mul_f32 {v(d)}, {v(d)}, {v(a)}", [d, a], [d]) for a, d in sc]
     L = []
     for k in range(36):
@@ -247,6 +268,9 @@ def pipelined(groups, reads, mfmas, pre, fillers, extras=None):
 
 
 def build(opts, want_stats=False):
+    global PK, PK_LAG
+    PK = opts.get("pk", False)
+    PK_LAG = opts.get("pk_lag", (1, 3))
     lines = []
     abl = set(opts.get("ablate", ()))  # timing ablations (WRONG results): "nolds", "novalu", "nomfma", "nodma", "nobarrier"
 
@@ -276,6 +300,9 @@ def build(opts, want_stats=False):
         for kk in range(4):
             emit(f"global_load_dwordx4 {at(KF + (b * 4 + kk) * 4, 4)}, %[kp{b}], off offset:{kk * 64}")
             emit(f"global_load_dwordx4 {at(VF + (b * 4 + kk) * 4, 4)}, %[vp{b}], off offset:{kk * 64}")
+    if PK:
+        emit(f"v_readfirstlane_b32 {s(S_SC2)}, %[sc2v]")  # (the "s" operand may arrive in a vector register: hipcc does not always prove it uniform)
+        emit(f"s_mov_b32 {s(S_SC2 + 1)}, {s(S_SC2)}")
     emit(f"s_mov_b32 {s(S_J)}, 0")
     emit(f"s_mov_b32 {s(S_HEAD)}, %[head0]")
     emit(f"s_mov_b32 {s(S_BASE)}, %[base0]")
@@ -427,7 +454,9 @@ SIG = ("const void* kp0, const void* kp1, const void* vp0, const void* vp1, cons
        "    int sc2_bits, int n, int kvb, int total, int nt_w, int head0, int base0, int roff0, int qi00, int qdt, int rowdh, int rowdt, int ldsw, int rowm0")
 
 
-VARIANTS = [dict(), dict(unroll6=False), dict(ablate=("novalu",)), dict(ablate=("nolds",)), dict(ablate=("nomfma",)), dict(ablate=("nodma",)), dict(ablate=("nobarrier",))]
+VARIANTS = [dict(), dict(unroll6=False), dict(ablate=("novalu",)), dict(ablate=("nolds",)), dict(ablate=("nomfma",)), dict(ablate=("nodma",)), dict(ablate=("nobarrier",)),
+            dict(pk=True),  # 7: packed multiplies (measured, not adopted)
+            dict(pk=True, pk_lag=(2, 5)), dict(pk=True, pk_lag=(3, 7)), dict(pk=True, pk_lag=(4, 9))]  # 8-10: longer distances between a packed multiply and its consumers
 
 
 def render(vi, opts, want_stats=False):
@@ -437,10 +466,10 @@ def render(vi, opts, want_stats=False):
            [f'[at{k}] "v"(aT[{k}])' for k in range(8)] + ['[arow] "v"(arow)'] + [f'[aq2_{k}] "v"(aQ2[{k}])' for k in range(4)] +
            [f'[at2_{k}] "v"(aT2[{k}])' for k in range(8)] + ['[arow2_] "v"(arow2)'] + [f'[vo{j}] "v"(vo[{j}])' for j in range(4)] +
            ['[lane4] "v"(lane4)', '[kvi] "v"(kvi)', '[lq4] "v"(lq4)', '[aout] "v"(aout)', '[qrsrc] "s"(qrsrc)', '[dorsrc] "s"(dorsrc)', '[rowrsrc] "s"(rowrsrc)',
-            '[seqptr] "s"(seqptr)', '[sc2] "s"(sc2_bits)', '[n] "s"(n)', '[kvb] "s"(kvb)', '[total] "s"(total)', '[ntw] "s"(nt_w)', '[head0] "s"(head0)',
+            '[seqptr] "s"(seqptr)', '[sc2] "s"(sc2_bits)'] + (['[sc2v] "v"(sc2_bits)'] if opts.get("pk") else []) + [ '[n] "s"(n)', '[kvb] "s"(kvb)', '[total] "s"(total)', '[ntw] "s"(nt_w)', '[head0] "s"(head0)',
             '[base0] "s"(base0)', '[roff0] "s"(roff0)', '[qi00] "s"(qi00)', '[qdt] "s"(qdt)', '[rowdh] "s"(rowdh)', '[rowdt] "s"(rowdt)', '[ldsw] "s"(ldsw)',
             '[rowm0] "s"(rowm0)'])
-    clob = [f'"v{r}"' for r in range(80, 256)] + [f'"a{r}"' for r in range(192)] + [f'"s{r}"' for r in range(S_J, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
+    clob = [f'"v{r}"' for r in range(80, 256)] + [f'"a{r}"' for r in range(192)] + [f'"s{r}"' for r in range(S_SC2 if opts.get("pk") else S_J, S_LAST + 1)] + ['"vcc"', '"scc"', '"memory"']
     note = "the product stream" if not opts else str(opts)
     return (f"template <>\n__device__ __forceinline__ void dkdv_p2_loop_asm<{vi}>({SIG}) {{  // {note}\n  asm volatile(\n      \"" + body + "\"\n      :\n      : " +
             ", ".join(ins) + "\n      : " + ", ".join(clob) + ");\n}\n"), len(lines)
