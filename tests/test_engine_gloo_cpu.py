@@ -176,3 +176,32 @@ def test_engine_step_multi_rank_equals_single_process(tmp_path, world, cp, mode,
             assert float(diff.max()) <= 25 * LR and float((diff > 0).float().mean()) < 0.05, (name, float(diff.max()))
     print(f"worst relative gradient difference world-2 vs single process: {worst:.2e}")
     assert all(torch.equal(r[0]["params"], r[k]["params"]) for k in range(1, world))  # replicas in lock-step after the in-place all-gather
+
+
+def test_recompute_modes_and_freq_leave_the_step_unchanged():
+    """Single process, stand-in kernels: `recompute` = none / layer / selective, each with `recompute_freq` 1 and 2 (the reference's `ac.freq`,
+    trainer/model.py:1151), over two optimizer steps of two passes each — the same losses, gradients and parameters to the bit (a re-run layer rebuilds
+    exactly what the forward had computed; it skips its down projection and, in the selective mode, its output projection).  The first pass's embedding
+    gradient is zeroed inside forward() (the fill placed in front of the log-prob kernel), the second pass accumulates."""
+    import dataclasses
+
+    import tests.cpu_standin_ops as standin
+    from prime_rl_amd.trainer import engine as E
+
+    E.ops = standin
+    dims = dataclasses.replace(E.ModelDims.tiny(layers=3, vocab=320))
+    ref = None
+    for rc, freq in (("none", 1), ("layer", 1), ("selective", 1), ("layer", 2), ("selective", 2)):
+        eng = E.GRPOEngine(dims, device="cpu", optim=E.OptimConfig(lr=LR), seed=5, gemm_layouts=False, recompute=rc, recompute_freq=freq)
+        rec = []
+        for step in range(2):
+            mbs = _batches(E, dims, 1, 0, step)
+            out = eng.step([E.pack_micro_batches(mbs[:1], "cpu"), E.pack_micro_batches(mbs[1:], "cpu")])
+            assert not eng._emb_zeroed and not eng._emb_zero_early
+            rec.append((sum(l.item() for l in out["loss"]), out["grad_norm"].item()))
+        got = (rec, eng.store.params.clone(), eng.store.master.clone())
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0], (rc, freq, got[0], ref[0])
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), (rc, freq)
