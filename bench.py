@@ -1007,7 +1007,8 @@ def main() -> None:
         done = threading.Event()
 
         def watchdog():  # extras are best-effort: if one of them wedges (e.g. a collective at N > 1), rank 0 prints the line it already has
-            if not done.wait(float(os.environ.get("PM_BENCH_EXTRA_TIMEOUT", "180"))):  # (headline + roofline) and EVERY rank leaves
+            # (one GPU: no collective can wedge, the budget only guards against a box several times slower than measured — the extras take 75-90 s)
+            if not done.wait(float(os.environ.get("PM_BENCH_EXTRA_TIMEOUT", "360" if world == 1 else "180"))):  # (headline + roofline) and EVERY rank leaves
                 if rank == 0:
                     line = assemble({"error": "an extra measurement did not finish in time; headline and roofline only"})
                     line["cpu_baseline"] = None
@@ -1017,8 +1018,11 @@ def main() -> None:
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
+        t_extra = time.perf_counter()
         extra = measure_extras(args, engine, loader, device, world, rank, barrier)
         done.set()
+        if rank == 0:
+            print(f"[bench] extras took {time.perf_counter() - t_extra:.1f} s", file=sys.stderr, flush=True)
 
     if rank == 0:
         result = assemble(extra)
