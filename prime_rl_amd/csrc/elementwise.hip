@@ -27,8 +27,16 @@ static inline unsigned capped_grid(int64_t work_items, int block) {
   return (unsigned)g;
 }
 
-// Optimizer kernels: grid-stride over 16-byte vectors, at most 256 CUs x 16 workgroups (profiles/r04_adamw_grid_probe.log: 96 % of the achievable
-// streaming rate at every grid size from 256 to 4096 workgroups).
+// Optimizer kernels.  SGD / SignSGD: grid-stride over 16-byte vectors, at most 256 CUs x 16 workgroups (profiles/r04_adamw_grid_probe.log: 96 % of the
+// achievable streaming rate of THAT walk at every grid size from 256 to 4096 workgroups).  AdamW (round 6): contiguous blocks per workgroup, below.
+// adamw_kernel: contiguous blocks per workgroup.  Block = 16 Ki vectors (256 KiB per f32 stream), halved until there are >= 1024 blocks (small spans keep
+// every CU busy: 512 vectors = one double iteration of a workgroup at the least); grid = one workgroup per CU walking them.
+static inline void update_blocks(int64_t n_vec, unsigned& grid, int64_t& blk) {
+  blk = 16384;
+  while (blk > 512 && n_vec / blk < 1024) blk >>= 1;
+  const int64_t nb = cdiv(n_vec, blk);
+  grid = (unsigned)(nb < 1 ? 1 : nb < 512 ? nb : 512);  // (pm_adamw_step on 2 Gi parameters: 256 workgroups 5.6, 512 6.28, 1024 6.04, 2048 6.18, 4096 6.06 TB/s)
+}
 static inline unsigned update_grid(int64_t n_vec) {
   int64_t g = cdiv(n_vec, (int64_t)256);
   if (g > 256 * 16) g = 256 * 16;
@@ -264,10 +272,11 @@ __global__ void clip_coef_kernel(const float* __restrict__ total_sumsq, float gr
   coef[0] = c > 1.0f ? 1.0f : c;
 }
 
+template <bool BLOCKED>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g,
                                                    bf16_t* __restrict__ pb, int64_t n, float lr, float b1, float b2, float eps, float wd,
                                                    float bc1, float bc2_sqrt, float grad_scale, const float* __restrict__ clip_coef,
-                                                   int zero_grad) {
+                                                   int zero_grad, int64_t blk) {
   const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
   const float step_size = lr / bc1;
   const int64_t nvec = n >> 2;
@@ -297,18 +306,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(pb) + i);
     }
   };
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + stride < nvec; i += 2 * stride) {  // two independent vectors of every stream in flight
-    const f32x4v P0 = __builtin_nontemporal_load(pv + i), M0 = __builtin_nontemporal_load(mv + i), V0 = __builtin_nontemporal_load(vv4 + i),
-                 G0 = __builtin_nontemporal_load(gv + i);
-    const f32x4v P1 = __builtin_nontemporal_load(pv + i + stride), M1 = __builtin_nontemporal_load(mv + i + stride),
-                 V1 = __builtin_nontemporal_load(vv4 + i + stride), G1 = __builtin_nontemporal_load(gv + i + stride);
-    update(i, P0, M0, V0, G0);
-    update(i + stride, P1, M1, V1, G1);
+  // A workgroup walks CONTIGUOUS blocks of `blk` vectors of every stream (256 KiB of each f32 array from 4 Mi vectors up), block b, b + gridDim.x, ...:
+  // consecutive iterations touch adjacent 4 KiB pieces of each of the 8 streams instead of pieces a whole grid stride (16 MiB) apart.  Same bytes, same
+  // per-element arithmetic; tools/probes/adamw_stream_probe.hip: 5.7-5.8 -> 6.2-6.3 TB/s on this access pattern (DRAM page / TLB locality); this kernel on
+  // 2 Gi parameters 5.82-5.89 -> 6.19 TB/s in one process, the step -1.8 ms.
+  if constexpr (!BLOCKED) {  // the grid-stride walk of rounds 1-5 (PM_ADAMW_BLOCKED=0: A/B)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < nvec; i += 2 * stride) {
+      const f32x4v P0 = __builtin_nontemporal_load(pv + i), M0 = __builtin_nontemporal_load(mv + i), V0 = __builtin_nontemporal_load(vv4 + i),
+                   G0 = __builtin_nontemporal_load(gv + i);
+      const f32x4v P1 = __builtin_nontemporal_load(pv + i + stride), M1 = __builtin_nontemporal_load(mv + i + stride),
+                   V1 = __builtin_nontemporal_load(vv4 + i + stride), G1 = __builtin_nontemporal_load(gv + i + stride);
+      update(i, P0, M0, V0, G0);
+      update(i + stride, P1, M1, V1, G1);
+    }
+    for (; i < nvec; i += stride)
+      update(i, __builtin_nontemporal_load(pv + i), __builtin_nontemporal_load(mv + i), __builtin_nontemporal_load(vv4 + i), __builtin_nontemporal_load(gv + i));
+  } else
+  for (int64_t b = blockIdx.x; b * blk < nvec; b += gridDim.x) {
+    const int64_t e = (b + 1) * blk < nvec ? (b + 1) * blk : nvec;
+    int64_t i = b * blk + threadIdx.x;
+    for (; i + 256 < e; i += 512) {  // two independent vectors of every stream in flight
+      const f32x4v P0 = __builtin_nontemporal_load(pv + i), M0 = __builtin_nontemporal_load(mv + i), V0 = __builtin_nontemporal_load(vv4 + i),
+                   G0 = __builtin_nontemporal_load(gv + i);
+      const f32x4v P1 = __builtin_nontemporal_load(pv + i + 256), M1 = __builtin_nontemporal_load(mv + i + 256),
+                   V1 = __builtin_nontemporal_load(vv4 + i + 256), G1 = __builtin_nontemporal_load(gv + i + 256);
+      update(i, P0, M0, V0, G0);
+      update(i + 256, P1, M1, V1, G1);
+    }
+    if (i < e)
+      update(i, __builtin_nontemporal_load(pv + i), __builtin_nontemporal_load(mv + i), __builtin_nontemporal_load(vv4 + i), __builtin_nontemporal_load(gv + i));
   }
-  for (; i < nvec; i += stride)
-    update(i, __builtin_nontemporal_load(pv + i), __builtin_nontemporal_load(mv + i), __builtin_nontemporal_load(vv4 + i), __builtin_nontemporal_load(gv + i));
   if (blockIdx.x == 0) {
     for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += 256) {
       const float gr = g[i] * gs;
@@ -586,8 +615,20 @@ extern "C" int pm_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, f
   if (n == 0) return PM_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
-                     (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, clip_coef, zero_grad);
+  unsigned grid;
+  int64_t blk;
+  update_blocks(n >> 2, grid, blk);
+#if PM_VARIANTS
+  static const bool blocked = !(getenv("PM_ADAMW_BLOCKED") && atoi(getenv("PM_ADAMW_BLOCKED")) == 0);  // A/B: the grid-stride walk (5.82-5.89 against 6.19 TB/s in one process)
+#else
+  constexpr bool blocked = true;
+#endif
+  if (blocked)
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
+                       (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, clip_coef, zero_grad, blk);
+  else
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, exp_avg, exp_avg_sq, grad,
+                       (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, clip_coef, zero_grad, blk);
   PM_CHECK_LAUNCH("pm_adamw_step");
   return PM_OK;
 }
