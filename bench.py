@@ -803,9 +803,21 @@ def main() -> None:
         # rendezvous on 127.0.0.1 — the container hostname may not resolve)
         import socket
 
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        import random
+
+        port = None
+        for _ in range(200):  # below the kernel's ephemeral range: a port from bind(0) can be handed to an outgoing connection before the launcher listens
+            cand = random.randrange(20000, 32000)
+            with socket.socket() as sk:
+                sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    sk.bind(("127.0.0.1", cand))
+                except OSError:
+                    continue
+            port = cand
+            break
+        if port is None:
+            raise SystemExit("no free rendezvous port between 20000 and 32000")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                str(Path(__file__).resolve())] + sys.argv[1:]
         print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-launching as `{' '.join(cmd[1:9])} bench.py ...`", file=sys.stderr, flush=True)

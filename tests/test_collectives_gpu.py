@@ -92,9 +92,9 @@ def test_rccl_weight_push_trainer_side_on_device(rccl_world1, tmp_path):
     before = eng.store.params.clone()
     import socket
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from tests._ports import free_port
+
+    port = free_port()
     comm = W.init_push_communicator("127.0.0.1", port, 0, 1, 0, DEV, timeout=60)
     assert (comm.rank, comm.size) == (0, 1)
     step_dir = get_step_path(get_broadcast_dir(tmp_path), 1)
@@ -152,9 +152,9 @@ def test_rccl_weight_push_moves_real_bytes_device_to_device(tmp_path):
 
     dims = ModelDims.tiny(layers=2, vocab=512)
     eng = GRPOEngine(dims, device=DEV, seed=13)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from tests._ports import free_port
+
+    port = free_port()
     raw = W.init_push_communicator("127.0.0.1", port, 0, 1, 0, DEV, timeout=60)
     loop = _Loopback(raw)
     layout = W.build_layout(eng.store)
@@ -202,9 +202,9 @@ def test_train_loop_with_nccl_weight_broadcast_from_the_config_path(tmp_path):
     from prime_rl_amd.configs.trainer import TrainerConfig
     from prime_rl_amd.trainer.rl.train import train
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from tests._ports import free_port
+
+    port = free_port()
     stop = threading.Event()
 
     def pool():

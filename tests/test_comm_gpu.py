@@ -13,9 +13,9 @@ DEV = torch.device("cuda:0")
 
 
 def _port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def test_rccl_communicator_world1_all_ops():

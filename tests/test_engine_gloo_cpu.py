@@ -23,9 +23,9 @@ SEQ, MB_PER_RANK, STEPS, LR = 64, 2, 2, 1e-4
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def _engine(dp_group=None, tied=False, **kw):

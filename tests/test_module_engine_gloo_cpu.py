@@ -21,9 +21,9 @@ SEQ, LR, STEPS = 48, 2e-3, 2
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def _batches(world, rank, step):

@@ -19,9 +19,9 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def _patch_ops():

@@ -56,9 +56,9 @@ def test_five_stats_is_unbiased_and_nan_aware():
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def _worker(rank, world, port, out_dir):

@@ -18,9 +18,9 @@ HQ, D = 8, 16
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 def _full(hkv, seed=0):

@@ -13,9 +13,9 @@ import torch.multiprocessing as mp
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from tests._ports import free_port
+
+    return free_port()
 
 
 N_TR, N_INF = 2, 2
