@@ -27,8 +27,8 @@ static inline unsigned capped_grid(int64_t work_items, int block) {
   return (unsigned)g;
 }
 
-// Optimizer kernels.  SGD / SignSGD: grid-stride over 16-byte vectors, at most 256 CUs x 16 workgroups (profiles/r04_adamw_grid_probe.log: 96 % of the
-// achievable streaming rate of THAT walk at every grid size from 256 to 4096 workgroups).  AdamW (round 6): contiguous blocks per workgroup, below.
+// Optimizer kernels (AdamW, SGD, SignSGD): contiguous blocks per workgroup (round 6; rounds 1-5 walked a grid stride, which profiles/r04_adamw_grid_probe.log
+// had at 96 % of the achievable streaming rate of THAT walk at every grid size).
 // adamw_kernel: contiguous blocks per workgroup.  Block = 16 Ki vectors (256 KiB per f32 stream), halved until there are >= 1024 blocks (small spans keep
 // every CU busy: 512 vectors = one double iteration of a workgroup at the least); grid = one workgroup per CU walking them.
 static inline void update_blocks(int64_t n_vec, unsigned& grid, int64_t& blk) {
@@ -357,7 +357,7 @@ constexpr int kTrTile = 64, kTrLd = 66;  // 2-D transpose tiles (transpose16_ker
 template <bool SIGN>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ buf, float* __restrict__ g, bf16_t* __restrict__ pb,
                                                  int64_t n, float lr, float momentum, float wd, int nesterov, int first_step, float grad_scale,
-                                                 const float* __restrict__ clip_coef, int zero_grad) {
+                                                 const float* __restrict__ clip_coef, int zero_grad, int64_t blk) {
   const float gs = grad_scale * (clip_coef ? clip_coef[0] : 1.0f);
   auto one = [&](float P, float& B, float G) -> float {
     float gr = G * gs;
@@ -379,8 +379,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   f32x4v* pv = reinterpret_cast<f32x4v*>(p);
   f32x4v* bv = reinterpret_cast<f32x4v*>(buf);
   f32x4v* gv = reinterpret_cast<f32x4v*>(g);
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+  for (int64_t b = blockIdx.x; b * blk < nvec; b += gridDim.x)  // contiguous blocks per workgroup, as adamw_kernel
+  for (int64_t i = b * blk + threadIdx.x, e = (b + 1) * blk < nvec ? (b + 1) * blk : nvec; i < e; i += 256) {
     f32x4v P = __builtin_nontemporal_load(pv + i);
     const f32x4v G = __builtin_nontemporal_load(gv + i);
     f32x4v B = {0.f, 0.f, 0.f, 0.f};
@@ -587,8 +587,11 @@ extern "C" int pm_sgd_step(float* master, float* momentum_buf, float* grad, void
                  (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
              PM_ERR_INVALID_ARG, "pm_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
   if (n == 0) return PM_OK;
-  hipLaunchKernelGGL(sgd_kernel<false>, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, momentum_buf, grad, (bf16_t*)param_bf16, n,
-                     lr, momentum, weight_decay, (int)nesterov, (int)(step == 1), grad_scale, clip_coef, (int)zero_grad);
+  unsigned grid;
+  int64_t blk;
+  update_blocks(n >> 2, grid, blk);
+  hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), master, momentum_buf, grad, (bf16_t*)param_bf16, n,
+                     lr, momentum, weight_decay, (int)nesterov, (int)(step == 1), grad_scale, clip_coef, (int)zero_grad, blk);
   PM_CHECK_LAUNCH("pm_sgd_step");
   return PM_OK;
 }
@@ -599,8 +602,11 @@ extern "C" int pm_sign_sgd_step(float* master, float* grad, void* param_bf16, in
   PM_REQUIRE(((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0 && (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0,
              PM_ERR_INVALID_ARG, "pm_sign_sgd_step: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
   if (n == 0) return PM_OK;
-  hipLaunchKernelGGL(sgd_kernel<true>, dim3(update_grid(n >> 2)), dim3(256), 0, as_stream(stream), master, (float*)nullptr, grad, (bf16_t*)param_bf16,
-                     n, lr, 0.f, weight_decay, 0, 0, grad_scale, clip_coef, (int)zero_grad);
+  unsigned grid;
+  int64_t blk;
+  update_blocks(n >> 2, grid, blk);
+  hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), master, (float*)nullptr, grad, (bf16_t*)param_bf16,
+                     n, lr, 0.f, weight_decay, 0, 0, grad_scale, clip_coef, (int)zero_grad, blk);
   PM_CHECK_LAUNCH("pm_sign_sgd_step");
   return PM_OK;
 }
